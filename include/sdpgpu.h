@@ -1,0 +1,245 @@
+/*
+ * sdpgpu.h -- C ABI of the MI355X-native finite-horizon SDP engine.
+ *
+ * This is the drop-in boundary for ONE path of RobinChen121/Stochastic-Inventory:
+ * the backward Bellman recursion of src/sdp (the `getExpectedValue` bodies).  A
+ * host in any language (the reference's Java over JNI, C++, Python ctypes) binds
+ * exactly these entry points.  Plain pointers and sizes only: no JNI, torch or
+ * C++ types cross this line, no exception crosses it, every call returns an int
+ * status (0 = ok) and the text of the last failure is read with
+ * sdpgpu_last_error().
+ *
+ * Reference interface each entry point replaces (paths relative to the reference
+ * checkout):
+ *
+ *   sdpgpu_create            constructors  src/sdp/inventory/Recursion.java:49-63,
+ *                            src/sdp/inventory/LeadtimeRecursion.java:28-45,
+ *                            src/sdp/cash/CashRecursion.java:39-56,
+ *                            src/sdp/cash/CashLeadtimeRecursion.java:28-46,
+ *                            src/capacitated/CLSP.java:22-24.  The three Java lambdas
+ *                            (feasible actions / StateTransitionFunction /
+ *                            ImmediateValueFunction; StateTransition.java:20-22,
+ *                            ImmediateValue.java:23-25) cannot be called from a GPU;
+ *                            they are named by `family` + the scalar parameters the
+ *                            in-scope drivers close over (see sdpgpu_desc).
+ *   sdpgpu_set_pmf           the `double[][][] pmf` constructor argument
+ *                            (Recursion.java:38,54): pmf[t][j] = {demand, prob}.
+ *   sdpgpu_solve             the first `getExpectedValue(initialState)` call
+ *                            (Recursion.java:89-163, CLSP.java:88-138,
+ *                            LeadtimeRecursion.java:47-75, CashRecursion.java:79-140,
+ *                            CashLeadtimeRecursion.java:48-79): fills the value and
+ *                            action maps.  Here: dense backward sweep t = T..1.
+ *   sdpgpu_run_period        one level of that recursion (all states of period t).
+ *   sdpgpu_values            `cacheValues` lookups (Recursion.java:36,90).
+ *   sdpgpu_policy            `cacheActions` lookups / getAction / getCacheActions
+ *                            (Recursion.java:35,160,165-171).
+ *   sdpgpu_eval_states       `getExpectedValue(state)` for a state that is not a
+ *                            grid point (e.g. an off-grid period-1 initial cash,
+ *                            CashConstraint.java:141) and the lazy re-entry of the
+ *                            simulators (Simulation.java:62-63).
+ *   sdpgpu_reachable         the key set of `cacheActions`, i.e. the states the
+ *                            memoised recursion would have visited; getOptTable
+ *                            (Recursion.java:177-186) lists exactly those.
+ *
+ * Numerics contract: all arithmetic fp64, no FMA contraction, demand index
+ * ascending, `acc += p*imm; acc += p*[gamma*]V(next)` in that order, strict </>
+ * arg-opt in ascending action order (lowest action index wins ties), so values
+ * are bit-identical to a literal CPU restatement of the Java loops and the policy
+ * indices are bit-exact.
+ *
+ * Threading: a handle is NOT thread-safe; distinct handles are independent.
+ * Ownership: the caller owns every host buffer; the library copies what it needs
+ * at the call and owns its device tables unless sdpgpu_attach_values is used.
+ */
+#ifndef SDPGPU_H
+#define SDPGPU_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define SDPGPU_ABI_VERSION 1
+
+/* status codes */
+#define SDPGPU_OK 0
+#define SDPGPU_ERR_ARG 1      /* bad descriptor / argument */
+#define SDPGPU_ERR_STATE 2    /* call out of order (e.g. values before solve) */
+#define SDPGPU_ERR_DEVICE 3   /* HIP runtime error (message carries hipGetErrorString) */
+#define SDPGPU_ERR_UNSUPPORTED 4
+
+/* Functor families = the closed-form lambda families of the in-scope drivers. */
+typedef enum sdpgpu_family {
+  /* state (x). CLSP.java:251-272, CLSPTesting.java:78-106, CLSPforDraw.java:86-103,
+   * LevelFitsS.java:85-102.  Backorder, two-ternary clamp, imm on unclamped level. */
+  SDPGPU_FAMILY_BACKORDER = 1,
+  /* state (x, preQ). Leadtime.java:50-81.  Lead time 1, order arrives next period. */
+  SDPGPU_FAMILY_LEADTIME = 2,
+  /* state (x, cash). CashConstraint.java:95-133 (cash_formula 0) and
+   * CashConstraintTesting.java:110-148 (cash_formula 1).  Lost sales, cash-limited orders. */
+  SDPGPU_FAMILY_CASH = 3,
+  /* state (x, cash). CashOverdraft.java:72-118.  Piecewise overdraft interest. */
+  SDPGPU_FAMILY_OVERDRAFT = 4,
+  /* state (x, cash, preQ). SingleProductLeadtime.java:72-119. */
+  SDPGPU_FAMILY_CASH_LEADTIME = 5
+} sdpgpu_family;
+
+/* OptDirection, Recursion.java:44-47 / CashRecursion.java:34-37. */
+typedef enum sdpgpu_direction { SDPGPU_MIN = 0, SDPGPU_MAX = 1 } sdpgpu_direction;
+
+/* kernel selection (0 = let the library choose) */
+#define SDPGPU_KERNEL_AUTO 0
+#define SDPGPU_KERNEL_GATHER 1 /* generic per-cell functor + gather from V_{t+1} in HBM/L2 */
+#define SDPGPU_KERNEL_WINDOW 2 /* F1/F2: LDS-staged {L(l), V(clamp l)} window, register sliding */
+
+/*
+ * Problem descriptor: everything the reference's lambdas close over.  Field names
+ * follow the reference's variable names.  Inventory, action and demand values must
+ * be integer multiples of `step` and `step` itself integer-valued (every in-scope
+ * driver uses stepSize = 1), so that x + a - d is exact in fp64 as it is in Java.
+ */
+typedef struct sdpgpu_desc {
+  int32_t abi_version; /* SDPGPU_ABI_VERSION */
+  int32_t family;      /* sdpgpu_family */
+  int32_t direction;   /* sdpgpu_direction */
+  int32_t periods;     /* T = pmf.length */
+
+  /* inventory axis */
+  double step;               /* stepSize */
+  double min_inventory;      /* minState / minInventory / minInventoryState */
+  double max_inventory;      /* maxState / maxInventory / maxInventoryState */
+  double max_order_quantity; /* maxOrderQuantity: actions 0, step, ... (count (int)(Q/step)+1) */
+  int32_t clamp_inventory;   /* 1: clamp as CLSP.java:257-258; 0: no clamp (Leadtime.java:65-66
+                                has the clamp commented out) -> per-period boxes grown from ini_* */
+  int32_t zero_order_last_period; /* SingleProductLeadtime.java:74-75: maxQ = 0 when period == T */
+
+  /* period-1 initial state: bounding boxes of unclamped families, reachable-set filter */
+  double ini_inventory;
+  double ini_cash;
+  double ini_preq;
+
+  /* cost parameters (F1/F2) */
+  double fixed_order_cost; /* fixedOrderingCost / fixOrderCost (K) */
+  double unit_order_cost;  /* proportionalOrderingCost / variOrderingCost / variCost (v) */
+  double holding_cost;     /* holdingCost (h) */
+  double penalty_cost;     /* penaltyCost: backorder pi (F1/F2); endCash<0 multiplier (F3) */
+
+  /* cash families (F3/F4/F5) */
+  double price;
+  double salvage_value;   /* applied only when period == T */
+  double deposit_rate;    /* depositeRate (F3 formula 0) */
+  double overhead_cost;   /* overheadCost, same every period unless sdpgpu_set_overhead */
+  double overhead_rate;   /* overheadRate (F3 formula 0) */
+  double discount_factor; /* CashRecursion.java:120: p * gamma * V, evaluated (p*gamma)*V */
+  double min_cash;
+  double max_cash;
+  double cash_round_mult; /* Math.round(nextCash * mult) ... */
+  double cash_round_div;  /* ... / div */
+  int32_t cash_round_int_div; /* 1: `/ 10` long division (CashOverdraft.java:116); 0: `/ 10.0` */
+  int32_t cash_formula;       /* F3: 0 CashConstraint.java:103-119, 1 CashConstraintTesting.java:117-132 */
+
+  /* overdraft interest schedule (F4/F5): CashOverdraft.java:86-95 */
+  double r0;
+  double r2;
+  double r3;
+  double overdraft_limit;
+  double interest_free_amount;
+
+  /* execution */
+  int32_t kernel;      /* SDPGPU_KERNEL_* */
+  int32_t device;      /* HIP device ordinal, -1 = current device */
+  int32_t rank;        /* state-axis slab owned by this handle: rank of world_size */
+  int32_t world_size;  /* 1 = whole grid */
+  int32_t store_all_values; /* 1: keep V_t for every t (values query); 0: two ping-pong tables */
+  int32_t reserved0;
+} sdpgpu_desc;
+
+typedef struct sdpgpu_stats {
+  int64_t states_total;     /* sum over periods of grid states (whole grid, all ranks) */
+  int64_t cells_evaluated;  /* sum over periods and THIS rank's states of nA(s) * D_t */
+  int64_t cells_all_ranks;  /* the same over the whole grid */
+  double  solve_ms;         /* HIP-event time of the last sdpgpu_solve on its stream */
+  double  kernel_ms_sum;    /* sum of per-period kernel times when profiling is on, else 0 */
+  int32_t periods_run;
+  int32_t kernel_used;      /* SDPGPU_KERNEL_* actually launched for the last period run */
+} sdpgpu_stats;
+
+typedef struct sdpgpu_handle sdpgpu_handle;
+
+/* Library identity: returns SDPGPU_ABI_VERSION. */
+int sdpgpu_abi_version(void);
+
+/* Fill a descriptor with the defaults the reference drivers use (discount 1,
+ * rounding 10/10.0, clamp on, world 1, store all values, kernel auto). */
+void sdpgpu_desc_init(sdpgpu_desc* d);
+
+/* Validate the descriptor, lay out the per-period grids, allocate device tables. */
+int sdpgpu_create(const sdpgpu_desc* desc, sdpgpu_handle** out);
+void sdpgpu_destroy(sdpgpu_handle* h);
+
+/* Never NULL; empty string when the last call on h succeeded.  h may be NULL to
+ * read the message of a failed sdpgpu_create. */
+const char* sdpgpu_last_error(const sdpgpu_handle* h);
+
+/* pmf[t] for t = 0..T-1 (period t+1): n pairs, demand[j] ascending as in GetPmf.java:119. */
+int sdpgpu_set_pmf(sdpgpu_handle* h, int32_t t, const double* demand, const double* prob, int32_t n);
+
+/* Optional per-period overhead cost (CashOverdraft.java:38-39 keeps an array). */
+int sdpgpu_set_overhead(sdpgpu_handle* h, int32_t t, double overhead_cost);
+
+/* Launch kernels on a caller-owned hipStream_t (NULL = the library's own stream). */
+int sdpgpu_set_stream(sdpgpu_handle* h, void* hip_stream);
+
+/* Record a HIP event pair around every period kernel (read back through sdpgpu_period_ms). */
+int sdpgpu_set_profiling(sdpgpu_handle* h, int32_t on);
+
+/* ---- geometry ---------------------------------------------------------------------------- */
+/* Number of grid states of period t (1-based period, 1..T). */
+int64_t sdpgpu_num_states(const sdpgpu_handle* h, int32_t period);
+/* Padded row length of the V_t table (multiple of world_size) and this rank's slab [lo, hi). */
+int sdpgpu_slab(const sdpgpu_handle* h, int32_t period, int64_t* padded, int64_t* lo, int64_t* hi);
+/* Grid of period t: x = x_lo + i*step (i < nx); cash index ic < nc; preQ index iq < nq.
+ * Flat index = (iq * nx + ix) * nc + ic. */
+int sdpgpu_grid(const sdpgpu_handle* h, int32_t period, double* x_lo, int64_t* nx, int64_t* nc, int64_t* nq);
+/* Cash value of cash index ic (k / div, exactly the double the reference's rounding yields). */
+double sdpgpu_cash_value(const sdpgpu_handle* h, int64_t ic);
+/* Dense index of a state tuple in period t, or -1 if it is not a grid point. */
+int64_t sdpgpu_state_index(const sdpgpu_handle* h, int32_t period, double x, double cash, double preq);
+
+/* ---- solving ----------------------------------------------------------------------------- */
+/* Whole backward sweep t = T..1 on this handle (world_size must be 1).  Asynchronous on the
+ * handle's stream unless `sync` != 0. */
+int sdpgpu_solve(sdpgpu_handle* h, int32_t sync);
+/* One period for this rank's slab, reading the FULL V_{period+1} table.  With world_size > 1
+ * the caller all-gathers V_period (device pointer below) across ranks before the next call. */
+int sdpgpu_run_period(sdpgpu_handle* h, int32_t period);
+/* Device address of the V_period table (padded row, fp64) -- for the in-place all-gather. */
+void* sdpgpu_values_device_ptr(sdpgpu_handle* h, int32_t period);
+/* Use caller-owned device memory for the value tables: `bytes` >= sdpgpu_values_bytes(h). */
+size_t sdpgpu_values_bytes(const sdpgpu_handle* h);
+int sdpgpu_attach_values(sdpgpu_handle* h, void* device_ptr, size_t bytes);
+/* Block until everything queued on the handle's stream has finished. */
+int sdpgpu_synchronize(sdpgpu_handle* h);
+
+/* ---- results ----------------------------------------------------------------------------- */
+/* Copy V_period[0..n) to host (n <= num_states). */
+int sdpgpu_values(sdpgpu_handle* h, int32_t period, double* out, int64_t n);
+/* Copy this rank's slab of the arg-opt action INDEX table (action = index * step). */
+int sdpgpu_policy(sdpgpu_handle* h, int32_t period, int32_t* out, int64_t lo, int64_t n);
+/* Evaluate arbitrary states of period t against V_{t+1}: out_value/out_action_index get n entries. */
+int sdpgpu_eval_states(sdpgpu_handle* h, int32_t period, int64_t n, const double* x, const double* cash,
+                       const double* preq, double* out_value, int32_t* out_action_index);
+/* Reachable-set mask of period t (1 byte per state), forward-propagated from the ini_* state over
+ * all feasible actions and all demands -- the key set the memoised recursion would build. */
+int sdpgpu_reachable(sdpgpu_handle* h, int32_t period, uint8_t* out, int64_t n);
+
+int sdpgpu_stats_get(sdpgpu_handle* h, sdpgpu_stats* out);
+/* Kernel time of period t of the last solve (ms), needs sdpgpu_set_profiling(h, 1). */
+double sdpgpu_period_ms(sdpgpu_handle* h, int32_t period);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* SDPGPU_H */

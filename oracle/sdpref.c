@@ -1,0 +1,888 @@
+/*
+ * sdpref.c -- CPU ORACLE: line-by-line C restatement of the reference's SDP recursion.
+ * TEST INFRASTRUCTURE ONLY (see sdpref.h for the rule and for the parity-pin status).
+ *
+ * Build: gcc -O2 -ffp-contract=off -fno-fast-math (strict IEEE fp64, no FMA), see Makefile.
+ *
+ * Every function cites the reference file:line it follows (paths relative to the reference
+ * checkout).  The restatement keeps the reference's operation ORDER: that is what makes the
+ * values bit-reproducible and the arg-opt indices exact.
+ */
+#include "sdpref.h"
+
+#include <float.h>
+#include <math.h>
+#include <pthread.h>
+#include <stdlib.h>
+#include <string.h>
+
+/* ------------------------------------------------------------------------------------------
+ * Java arithmetic that differs from the C library's.
+ * ---------------------------------------------------------------------------------------- */
+
+/* java.lang.Math.round(double): nearest long, ties toward +infinity (NOT llround, which rounds
+ * halves away from zero; NOT floor(x+0.5), which is wrong for 0.49999999999999994).
+ * Used at CashConstraint.java:131, CashOverdraft.java:116, SingleProductLeadtime.java:117. */
+int64_t sdpref_java_round(double x) {
+  if (x != x) return 0;
+  if (x >= 9223372036854775807.0) return INT64_MAX;
+  if (x <= -9223372036854775808.0) return INT64_MIN;
+  double f = floor(x);
+  double diff = x - f; /* exact in fp64 */
+  return (int64_t)(diff >= 0.5 ? f + 1.0 : f);
+}
+
+/* java.lang.Math.max(double,double): NaN-propagating, max(-0.0, 0.0) = 0.0. */
+double sdpref_java_max(double a, double b) {
+  if (a != a) return a;
+  if (a == 0.0 && b == 0.0 && signbit(a)) return b;
+  return (a >= b) ? a : b;
+}
+
+/* java.lang.Math.min(double,double). */
+double sdpref_java_min(double a, double b) {
+  if (a != a) return a;
+  if (a == 0.0 && b == 0.0 && signbit(b)) return b;
+  return (a <= b) ? a : b;
+}
+
+/* Java (int) cast of a double: NaN -> 0, saturating, truncation toward zero. */
+int32_t sdpref_java_d2i(double x) {
+  if (x != x) return 0;
+  if (x >= 2147483647.0) return INT32_MAX;
+  if (x <= -2147483648.0) return INT32_MIN;
+  return (int32_t)x;
+}
+
+#define jround sdpref_java_round
+#define jmax sdpref_java_max
+#define jmin sdpref_java_min
+#define jd2i sdpref_java_d2i
+
+/* ------------------------------------------------------------------------------------------
+ * State tuple and problem context
+ * ---------------------------------------------------------------------------------------- */
+
+/* State.java:12-19, LeadtimeState.java:10-20, CashState.java:12-18, CashLeadtimeState.java:11-17. */
+typedef struct st {
+  int32_t period;
+  double x, cash, preq;
+} st_t;
+
+typedef struct ctx {
+  const sdpgpu_desc* d;
+  const int32_t* off;
+  const double* pd;
+  const double* pp;
+  const double* oh; /* may be NULL */
+  int32_t T;
+} ctx_t;
+
+static double overhead_at(const ctx_t* c, int32_t period) {
+  return c->oh ? c->oh[period - 1] : c->d->overhead_cost;
+}
+
+static int has_cash(int family) {
+  return family == SDPGPU_FAMILY_CASH || family == SDPGPU_FAMILY_OVERDRAFT ||
+         family == SDPGPU_FAMILY_CASH_LEADTIME;
+}
+static int has_preq(int family) {
+  return family == SDPGPU_FAMILY_LEADTIME || family == SDPGPU_FAMILY_CASH_LEADTIME;
+}
+
+/* Number of order quantities on the full action grid: `new double[(int)(maxOrderQuantity/stepSize)+1]`
+ * (CLSPTesting.java:79, Leadtime.java:51); CLSP.java:252 `limit(maxOrderQuantity + 1)` with step 1. */
+static int32_t full_action_count(const sdpgpu_desc* d) {
+  return jd2i(d->max_order_quantity / d->step) + 1;
+}
+
+/* getFeasibleActions.apply(state).length */
+static int32_t n_actions(const ctx_t* c, const st_t* s) {
+  const sdpgpu_desc* d = c->d;
+  switch (d->family) {
+    case SDPGPU_FAMILY_BACKORDER: /* CLSP.java:251-253, CLSPTesting.java:78-86 */
+    case SDPGPU_FAMILY_LEADTIME:  /* Leadtime.java:50-58 */
+      return full_action_count(d);
+    case SDPGPU_FAMILY_CASH: { /* CashConstraint.java:95-100 */
+      double maxQ = (double)jd2i(
+          jmin(d->max_order_quantity,
+               jmax(0.0, (s->cash - overhead_at(c, s->period) - d->fixed_order_cost) / d->unit_order_cost)));
+      return jd2i(maxQ) + 1; /* limit((int) maxQ + 1) */
+    }
+    case SDPGPU_FAMILY_OVERDRAFT: /* CashOverdraft.java:72-75 */
+      return jd2i(d->max_order_quantity) + 1;
+    case SDPGPU_FAMILY_CASH_LEADTIME: { /* SingleProductLeadtime.java:72-77 */
+      double maxQ = d->max_order_quantity;
+      if (d->zero_order_last_period && s->period == c->T) maxQ = 0;
+      return jd2i(maxQ) + 1;
+    }
+  }
+  return 0;
+}
+
+/* DoubleStream.iterate(0, i -> i + stepSize): element k.  step is integer-valued so the
+ * iterated sum equals k*step exactly. */
+static double action_value(const ctx_t* c, int32_t k) { return (double)k * c->d->step; }
+
+/* Piecewise interest, CashOverdraft.java:87-95 == SingleProductLeadtime.java:88-96. */
+static double overdraft_interest(const sdpgpu_desc* d, double cashBalanceBefore) {
+  double interest = 0;
+  if (cashBalanceBefore >= 0)
+    interest = -d->r0 * cashBalanceBefore;
+  else if (cashBalanceBefore >= -d->interest_free_amount)
+    interest = 0;
+  else if (cashBalanceBefore >= -d->overdraft_limit)
+    interest = d->r2 * (-cashBalanceBefore - d->interest_free_amount);
+  else
+    interest = d->r3 * (-cashBalanceBefore - d->overdraft_limit) +
+               d->r2 * (d->overdraft_limit - d->interest_free_amount);
+  return interest;
+}
+
+/* immediateValue.apply(state, action, randomDemand) */
+static double imm_value(const ctx_t* c, const st_t* s, double action, double randomDemand) {
+  const sdpgpu_desc* d = c->d;
+  switch (d->family) {
+    case SDPGPU_FAMILY_BACKORDER: { /* CLSP.java:263-272 == CLSPTesting.java:97-106 */
+      double fixedCost = action > 0 ? d->fixed_order_cost : 0;
+      double variableCost = d->unit_order_cost * action;
+      double inventoryLevel = s->x + action - randomDemand;
+      double holdingCosts = d->holding_cost * jmax(inventoryLevel, 0);
+      double penaltyCosts = d->penalty_cost * jmax(-inventoryLevel, 0);
+      double totalCosts = fixedCost + variableCost + holdingCosts + penaltyCosts;
+      return totalCosts;
+    }
+    case SDPGPU_FAMILY_LEADTIME: { /* Leadtime.java:71-81 */
+      double fixedCost = action > 0 ? d->fixed_order_cost : 0;
+      double variableCost = d->unit_order_cost * action;
+      double inventoryLevel = s->x + s->preq - randomDemand;
+      double holdingCosts = d->holding_cost * jmax(inventoryLevel, 0);
+      double penaltyCosts = d->penalty_cost * jmax(-inventoryLevel, 0);
+      double totalCosts = fixedCost + variableCost + holdingCosts + penaltyCosts;
+      return totalCosts;
+    }
+    case SDPGPU_FAMILY_CASH: {
+      double revenue = d->price * jmin(s->x + action, randomDemand);
+      double fixedCost = action > 0 ? d->fixed_order_cost : 0;
+      double variableCost = d->unit_order_cost * action;
+      double inventoryLevel = s->x + action - randomDemand;
+      double holdCosts = d->holding_cost * jmax(inventoryLevel, 0);
+      double cashIncrement;
+      if (d->cash_formula == 0) { /* CashConstraint.java:103-119 */
+        double deposite = (s->cash - fixedCost - variableCost) * (1 + d->deposit_rate);
+        cashIncrement = (1 - d->overhead_rate) * revenue + deposite - holdCosts - overhead_at(c, s->period) - s->cash;
+      } else { /* CashConstraintTesting.java:117-132 */
+        cashIncrement = revenue - fixedCost - variableCost - holdCosts - overhead_at(c, s->period);
+      }
+      double salValue = s->period == c->T ? d->salvage_value * jmax(inventoryLevel, 0) : 0;
+      cashIncrement += salValue;
+      double endCash = s->cash + cashIncrement;
+      if (endCash < 0) {
+        cashIncrement += d->penalty_cost * endCash;
+      }
+      return cashIncrement;
+    }
+    case SDPGPU_FAMILY_OVERDRAFT: { /* CashOverdraft.java:80-104 */
+      double revenue = d->price * jmin(s->x + action, randomDemand);
+      double fixedCost = action > 0 ? d->fixed_order_cost : 0;
+      double variableCost = d->unit_order_cost * action;
+      double inventoryLevel = s->x + action - randomDemand;
+      double cashBalanceBefore = s->cash - fixedCost - variableCost - overhead_at(c, s->period);
+      double interest = overdraft_interest(d, cashBalanceBefore);
+      double cashBalanceAfter = cashBalanceBefore - interest + revenue;
+      double cashIncrement = cashBalanceAfter - s->cash;
+      double salValue = s->period == c->T ? d->salvage_value * jmax(inventoryLevel, 0) : 0;
+      cashIncrement += salValue;
+      return cashIncrement;
+    }
+    case SDPGPU_FAMILY_CASH_LEADTIME: { /* SingleProductLeadtime.java:82-104 */
+      double revenue = d->price * jmin(s->x + s->preq, randomDemand);
+      double variableCost = d->unit_order_cost * action;
+      double inventoryLevel = s->x + s->preq - randomDemand;
+      double cashBalanceBefore = s->cash - variableCost - overhead_at(c, s->period);
+      double interest = overdraft_interest(d, cashBalanceBefore);
+      double cashBalanceAfter = cashBalanceBefore - interest + revenue;
+      double cashIncrement = cashBalanceAfter - s->cash;
+      double salValue = s->period == c->T ? d->salvage_value * jmax(inventoryLevel, 0) : 0;
+      cashIncrement += salValue;
+      return cashIncrement;
+    }
+  }
+  return 0;
+}
+
+/* `nextCash = Math.round(nextCash * 10) / 10.0` (CashConstraint.java:131), `/ 10` long division
+ * (CashOverdraft.java:116), `* 100) / 100.0` (SingleProductLeadtime.java:117),
+ * `Math.round(nextCash * 1) / 1` (CashConstraintTesting.java:146: long / int -> long). */
+static double round_cash(const sdpgpu_desc* d, double nextCash) {
+  int64_t r = jround(nextCash * d->cash_round_mult);
+  if (d->cash_round_int_div) return (double)(r / (int64_t)d->cash_round_div); /* truncating */
+  return (double)r / d->cash_round_div;
+}
+
+/* stateTransition.apply(state, action, randomDemand) */
+static void transition(const ctx_t* c, const st_t* s, double action, double randomDemand, st_t* out) {
+  const sdpgpu_desc* d = c->d;
+  out->period = s->period + 1;
+  out->cash = 0;
+  out->preq = 0;
+  switch (d->family) {
+    case SDPGPU_FAMILY_BACKORDER: { /* CLSP.java:255-260 == CLSPTesting.java:89-94 */
+      double nextInventory = s->x + action - randomDemand;
+      if (d->clamp_inventory) {
+        nextInventory = nextInventory > d->max_inventory ? d->max_inventory : nextInventory;
+        nextInventory = nextInventory < d->min_inventory ? d->min_inventory : nextInventory;
+      }
+      out->x = nextInventory;
+      return;
+    }
+    case SDPGPU_FAMILY_LEADTIME: { /* Leadtime.java:61-68 (clamp lines 65-66 are commented out there) */
+      double nextInventory = s->x + s->preq - randomDemand;
+      if (d->clamp_inventory) {
+        nextInventory = nextInventory > d->max_inventory ? d->max_inventory : nextInventory;
+        nextInventory = nextInventory < d->min_inventory ? d->min_inventory : nextInventory;
+      }
+      out->x = nextInventory;
+      out->preq = action;
+      return;
+    }
+    case SDPGPU_FAMILY_CASH:       /* CashConstraint.java:122-133 */
+    case SDPGPU_FAMILY_OVERDRAFT: { /* CashOverdraft.java:107-118 */
+      double nextInventory = jmax(0, s->x + action - randomDemand);
+      double nextCash = s->cash + imm_value(c, s, action, randomDemand);
+      nextCash = nextCash > d->max_cash ? d->max_cash : nextCash;
+      nextCash = nextCash < d->min_cash ? d->min_cash : nextCash;
+      nextInventory = nextInventory > d->max_inventory ? d->max_inventory : nextInventory;
+      nextInventory = nextInventory < d->min_inventory ? d->min_inventory : nextInventory;
+      nextCash = round_cash(d, nextCash);
+      out->x = nextInventory;
+      out->cash = nextCash;
+      return;
+    }
+    case SDPGPU_FAMILY_CASH_LEADTIME: { /* SingleProductLeadtime.java:107-119 */
+      double nextInventory = jmax(0, s->x + s->preq - randomDemand);
+      double nextCash = s->cash + imm_value(c, s, action, randomDemand);
+      double nextPreQ = action;
+      nextCash = nextCash > d->max_cash ? d->max_cash : nextCash;
+      nextCash = nextCash < d->min_cash ? d->min_cash : nextCash;
+      nextInventory = nextInventory > d->max_inventory ? d->max_inventory : nextInventory;
+      nextInventory = nextInventory < d->min_inventory ? d->min_inventory : nextInventory;
+      nextCash = round_cash(d, nextCash);
+      out->x = nextInventory;
+      out->cash = nextCash;
+      out->preq = nextPreQ;
+      return;
+    }
+  }
+}
+
+/* ------------------------------------------------------------------------------------------
+ * The recursion body, Recursion.java:129-161 (== CLSP.java:111-136, LeadtimeRecursion.java:49-73,
+ * CashRecursion.java:98-138, CashLeadtimeRecursion.java:50-77).  `vlook` is what
+ * getExpectedValue(newState) resolves to: a dense-table read or a recursive call.
+ * ---------------------------------------------------------------------------------------- */
+typedef double (*vlook_fn)(void* env, const st_t* next);
+
+static void eval_state(const ctx_t* c, const st_t* s, vlook_fn vlook, void* env, double* val_out,
+                       double* best_out, int32_t* bestk_out, int64_t* cells) {
+  const sdpgpu_desc* d = c->d;
+  int32_t nA = n_actions(c, s);
+  int32_t t = s->period - 1;
+  int32_t n = c->off[t + 1] - c->off[t];
+  const double* dem = c->pd + c->off[t];
+  const double* prob = c->pp + c->off[t];
+  int maxdir = d->direction == SDPGPU_MAX;
+  int cash_loop = d->family == SDPGPU_FAMILY_CASH || d->family == SDPGPU_FAMILY_OVERDRAFT;
+  double val = maxdir ? -DBL_MAX : DBL_MAX; /* Recursion.java:132-133 */
+  double bestOrderQty = 0;                  /* Recursion.java:134 */
+  int32_t bestk = 0;
+  for (int32_t i = 0; i < nA; i++) {
+    double orderQty = action_value(c, i);
+    double thisQValue = 0;
+    for (int32_t j = 0; j < n; j++) {
+      if (cash_loop) { /* CashRecursion.java:113-122 */
+        double randomDemand = dem[j];
+        double thisDValue = imm_value(c, s, orderQty, randomDemand);
+        double dProb = prob[j];
+        thisQValue += dProb * thisDValue;
+        if (s->period < c->T) {
+          st_t newState;
+          transition(c, s, orderQty, dem[j], &newState);
+          thisQValue += prob[j] * d->discount_factor * vlook(env, &newState);
+        }
+      } else { /* Recursion.java:138-144 */
+        thisQValue += prob[j] * imm_value(c, s, orderQty, dem[j]);
+        if (s->period < c->T) {
+          st_t newState;
+          transition(c, s, orderQty, dem[j], &newState);
+          thisQValue += prob[j] * vlook(env, &newState);
+        }
+      }
+    }
+    if (!maxdir) { /* Recursion.java:146-151 */
+      if (thisQValue < val) {
+        val = thisQValue;
+        bestOrderQty = orderQty;
+        bestk = i;
+      }
+    } else { /* Recursion.java:152-157 */
+      if (thisQValue > val) {
+        val = thisQValue;
+        bestOrderQty = orderQty;
+        bestk = i;
+      }
+    }
+  }
+  if (cells) *cells += (int64_t)nA * n;
+  *val_out = val;
+  if (best_out) *best_out = bestOrderQty;
+  if (bestk_out) *bestk_out = bestk;
+}
+
+/* ------------------------------------------------------------------------------------------
+ * Dense layout
+ * ---------------------------------------------------------------------------------------- */
+static int64_t cash_key(const sdpgpu_desc* d, double cash) {
+  if (d->cash_round_int_div) return (int64_t)cash;
+  return jround(cash * d->cash_round_mult);
+}
+static double cash_of_key(const sdpgpu_desc* d, int64_t k) {
+  if (d->cash_round_int_div) return (double)k;
+  return (double)k / d->cash_round_div;
+}
+
+int sdpref_layout(const sdpgpu_desc* d, const int32_t* pmf_off, const double* pmf_d, sdpref_grid* g) {
+  if (!d || d->periods < 1 || !(d->step >= 1) || d->step != floor(d->step)) return 1;
+  int32_t T = d->periods;
+  int64_t nc = 1, k_lo = 0, nq = 1;
+  if (has_cash(d->family)) {
+    if (!d->cash_round_int_div && d->cash_round_mult != d->cash_round_div) return 4;
+    k_lo = cash_key(d, round_cash(d, d->min_cash));
+    int64_t k_hi = cash_key(d, round_cash(d, d->max_cash));
+    nc = k_hi - k_lo + 1;
+  }
+  if (has_preq(d->family)) nq = full_action_count(d);
+  double lo = d->min_inventory, hi = d->max_inventory;
+  if (!d->clamp_inventory) {
+    if (d->family != SDPGPU_FAMILY_BACKORDER && d->family != SDPGPU_FAMILY_LEADTIME) return 4;
+    lo = hi = d->ini_inventory;
+  }
+  for (int32_t t = 0; t < T; t++) {
+    g[t].x_lo = lo;
+    g[t].nx = (int64_t)((hi - lo) / d->step) + 1;
+    g[t].nc = nc;
+    g[t].nq = nq;
+    g[t].k_lo = k_lo;
+    if (!d->clamp_inventory) { /* box of period t+2 grown over all actions and demands */
+      double dmin = pmf_d[pmf_off[t]], dmax = dmin;
+      for (int32_t j = pmf_off[t]; j < pmf_off[t + 1]; j++) {
+        if (pmf_d[j] < dmin) dmin = pmf_d[j];
+        if (pmf_d[j] > dmax) dmax = pmf_d[j];
+      }
+      double qmax = (double)(full_action_count(d) - 1) * d->step;
+      lo = lo - dmax;
+      hi = hi + qmax - dmin;
+    }
+  }
+  return 0;
+}
+
+static int64_t index_of(const sdpgpu_desc* d, const sdpref_grid* g, const st_t* s) {
+  double qx = (s->x - g->x_lo) / d->step;
+  int64_t ix = (int64_t)qx;
+  if ((double)ix != qx || ix < 0 || ix >= g->nx) return -1;
+  int64_t ic = 0, iq = 0;
+  if (has_cash(d->family)) {
+    int64_t k = cash_key(d, s->cash);
+    if (cash_of_key(d, k) != s->cash) return -1;
+    ic = k - g->k_lo;
+    if (ic < 0 || ic >= g->nc) return -1;
+  }
+  if (has_preq(d->family)) {
+    double qq = s->preq / d->step;
+    iq = (int64_t)qq;
+    if ((double)iq != qq || iq < 0 || iq >= g->nq) return -1;
+  }
+  return (iq * g->nx + ix) * g->nc + ic;
+}
+
+static void state_of(const sdpgpu_desc* d, const sdpref_grid* g, int32_t period, int64_t idx, st_t* s) {
+  int64_t ic = idx % g->nc;
+  int64_t ix = (idx / g->nc) % g->nx;
+  int64_t iq = idx / (g->nc * g->nx);
+  s->period = period;
+  s->x = g->x_lo + (double)ix * d->step;
+  s->cash = has_cash(d->family) ? cash_of_key(d, g->k_lo + ic) : 0;
+  s->preq = has_preq(d->family) ? (double)iq * d->step : 0;
+}
+
+typedef struct dense_env {
+  const sdpgpu_desc* d;
+  const sdpref_grid* gnext;
+  const double* vnext;
+  int err;
+} dense_env;
+
+static double dense_look(void* env, const st_t* next) {
+  dense_env* e = (dense_env*)env;
+  int64_t idx = index_of(e->d, e->gnext, next);
+  if (idx < 0) {
+    e->err = 1;
+    return 0;
+  }
+  return e->vnext[idx];
+}
+
+typedef struct job {
+  const ctx_t* c;
+  const sdpref_grid* gcur;
+  const sdpref_grid* gnext;
+  int32_t period;
+  const double* vnext;
+  double* vcur;
+  int32_t* pol;
+  int64_t lo, hi;
+  int64_t cells;
+  int err;
+} job_t;
+
+static void* period_worker(void* arg) {
+  job_t* jb = (job_t*)arg;
+  dense_env env = {jb->c->d, jb->gnext, jb->vnext, 0};
+  for (int64_t idx = jb->lo; idx < jb->hi; idx++) {
+    st_t s;
+    state_of(jb->c->d, jb->gcur, jb->period, idx, &s);
+    double val;
+    int32_t bestk;
+    eval_state(jb->c, &s, dense_look, &env, &val, NULL, &bestk, &jb->cells);
+    jb->vcur[idx] = val;
+    jb->pol[idx] = bestk;
+  }
+  jb->err = env.err;
+  return NULL;
+}
+
+static int run_period(const ctx_t* c, const sdpref_grid* grids, int32_t period, const double* vnext,
+                      double* vcur, int32_t* pol, int64_t lo, int64_t hi, int32_t nthreads, int64_t* cells) {
+  if (nthreads < 1) nthreads = 1;
+  if (nthreads > 256) nthreads = 256;
+  int64_t n = hi - lo;
+  if (n < nthreads) nthreads = n > 0 ? (int32_t)n : 1;
+  job_t jobs[256];
+  pthread_t th[256];
+  for (int32_t i = 0; i < nthreads; i++) {
+    jobs[i].c = c;
+    jobs[i].gcur = &grids[period - 1];
+    jobs[i].gnext = period < c->T ? &grids[period] : NULL;
+    jobs[i].period = period;
+    jobs[i].vnext = vnext;
+    jobs[i].vcur = vcur;
+    jobs[i].pol = pol;
+    jobs[i].lo = lo + n * i / nthreads;
+    jobs[i].hi = lo + n * (i + 1) / nthreads;
+    jobs[i].cells = 0;
+    jobs[i].err = 0;
+  }
+  if (nthreads == 1) {
+    period_worker(&jobs[0]);
+  } else {
+    for (int32_t i = 0; i < nthreads; i++) pthread_create(&th[i], NULL, period_worker, &jobs[i]);
+    for (int32_t i = 0; i < nthreads; i++) pthread_join(th[i], NULL);
+  }
+  int err = 0;
+  for (int32_t i = 0; i < nthreads; i++) {
+    if (cells) *cells += jobs[i].cells;
+    err |= jobs[i].err;
+  }
+  return err ? 5 : 0;
+}
+
+int sdpref_period(const sdpgpu_desc* d, const int32_t* pmf_off, const double* pmf_d, const double* pmf_p,
+                  const double* overhead, int32_t period, const double* v_next, double* v_cur,
+                  int32_t* pol_cur, int64_t lo, int64_t hi, int32_t nthreads, int64_t* cells_out) {
+  if (period < 1 || period > d->periods) return 1;
+  sdpref_grid* grids = (sdpref_grid*)malloc(sizeof(sdpref_grid) * (size_t)d->periods);
+  int rc = sdpref_layout(d, pmf_off, pmf_d, grids);
+  if (rc == 0) {
+    ctx_t c = {d, pmf_off, pmf_d, pmf_p, overhead, d->periods};
+    int64_t cells = 0;
+    rc = run_period(&c, grids, period, v_next, v_cur, pol_cur, lo, hi, nthreads, &cells);
+    if (cells_out) *cells_out = cells;
+  }
+  free(grids);
+  return rc;
+}
+
+int sdpref_solve(const sdpgpu_desc* d, const int32_t* pmf_off, const double* pmf_d, const double* pmf_p,
+                 const double* overhead, double* values, int32_t* policy, const int64_t* values_off,
+                 int32_t nthreads, int64_t* cells_out) {
+  sdpref_grid* grids = (sdpref_grid*)malloc(sizeof(sdpref_grid) * (size_t)d->periods);
+  int rc = sdpref_layout(d, pmf_off, pmf_d, grids);
+  int64_t cells = 0;
+  if (rc == 0) {
+    ctx_t c = {d, pmf_off, pmf_d, pmf_p, overhead, d->periods};
+    for (int32_t period = d->periods; period >= 1 && rc == 0; period--) {
+      const sdpref_grid* g = &grids[period - 1];
+      int64_t S = g->nx * g->nc * g->nq;
+      const double* vnext = period < d->periods ? values + values_off[period] : NULL;
+      rc = run_period(&c, grids, period, vnext, values + values_off[period - 1], policy + values_off[period - 1],
+                      0, S, nthreads, &cells);
+    }
+  }
+  if (cells_out) *cells_out = cells;
+  free(grids);
+  return rc;
+}
+
+int sdpref_eval_states(const sdpgpu_desc* d, const int32_t* pmf_off, const double* pmf_d, const double* pmf_p,
+                       const double* overhead, int32_t period, const double* v_next, int64_t n,
+                       const double* x, const double* cash, const double* preq, double* out_value,
+                       int32_t* out_action) {
+  if (period < 1 || period > d->periods) return 1;
+  sdpref_grid* grids = (sdpref_grid*)malloc(sizeof(sdpref_grid) * (size_t)d->periods);
+  int rc = sdpref_layout(d, pmf_off, pmf_d, grids);
+  if (rc == 0) {
+    ctx_t c = {d, pmf_off, pmf_d, pmf_p, overhead, d->periods};
+    dense_env env = {d, period < d->periods ? &grids[period] : NULL, v_next, 0};
+    for (int64_t i = 0; i < n; i++) {
+      st_t s = {period, x[i], cash ? cash[i] : 0, preq ? preq[i] : 0};
+      double val;
+      int32_t bestk;
+      eval_state(&c, &s, dense_look, &env, &val, NULL, &bestk, NULL);
+      out_value[i] = val;
+      out_action[i] = bestk;
+    }
+    if (env.err) rc = 5;
+  }
+  free(grids);
+  return rc;
+}
+
+/* ------------------------------------------------------------------------------------------
+ * Forward reachable set: the key set of cacheActions after getExpectedValue(initialState).
+ * ---------------------------------------------------------------------------------------- */
+int sdpref_reachable(const sdpgpu_desc* d, const int32_t* pmf_off, const double* pmf_d, const double* pmf_p,
+                     const double* overhead, uint8_t* mask, const int64_t* values_off) {
+  sdpref_grid* grids = (sdpref_grid*)malloc(sizeof(sdpref_grid) * (size_t)d->periods);
+  int rc = sdpref_layout(d, pmf_off, pmf_d, grids);
+  if (rc) {
+    free(grids);
+    return rc;
+  }
+  ctx_t c = {d, pmf_off, pmf_d, pmf_p, overhead, d->periods};
+  int32_t T = d->periods;
+  for (int32_t t = 0; t < T; t++) {
+    const sdpref_grid* g = &grids[t];
+    memset(mask + values_off[t], 0, (size_t)(g->nx * g->nc * g->nq));
+  }
+  st_t ini = {1, d->ini_inventory, has_cash(d->family) ? d->ini_cash : 0, has_preq(d->family) ? d->ini_preq : 0};
+  int64_t i0 = index_of(d, &grids[0], &ini);
+  for (int32_t period = 1; period <= T; period++) {
+    const sdpref_grid* g = &grids[period - 1];
+    int64_t S = g->nx * g->nc * g->nq;
+    /* period 1: the initial state alone (it may lie off the grid) */
+    for (int64_t idx = (period == 1 ? -1 : 0); idx < (period == 1 ? 0 : S); idx++) {
+      st_t s;
+      if (period == 1) {
+        s = ini;
+        if (i0 >= 0) mask[values_off[0] + i0] = 1;
+      } else {
+        if (!mask[values_off[period - 1] + idx]) continue;
+        state_of(d, g, period, idx, &s);
+      }
+      if (period == T) continue;
+      int32_t nA = n_actions(&c, &s);
+      int32_t n = pmf_off[period] - pmf_off[period - 1];
+      for (int32_t i = 0; i < nA; i++)
+        for (int32_t j = 0; j < n; j++) {
+          st_t nx;
+          transition(&c, &s, action_value(&c, i), pmf_d[pmf_off[period - 1] + j], &nx);
+          int64_t ni = index_of(d, &grids[period], &nx);
+          if (ni < 0) {
+            free(grids);
+            return 5;
+          }
+          mask[values_off[period] + ni] = 1;
+        }
+    }
+  }
+  free(grids);
+  return 0;
+}
+
+/* ------------------------------------------------------------------------------------------
+ * Literal memoised recursion (the reference's actual control flow): cacheValues.computeIfAbsent
+ * (Recursion.java:90) with a hash map in place of the skip list (keys compare by exact ==,
+ * State.java:66-71).
+ * ---------------------------------------------------------------------------------------- */
+typedef struct mentry {
+  st_t key;
+  double value, action;
+  int used;
+} mentry;
+
+typedef struct memo {
+  const ctx_t* c;
+  mentry* tab;
+  int64_t cap, n;
+  int64_t cells;
+} memo_t;
+
+static uint64_t hash_st(const st_t* s) {
+  uint64_t h = 1469598103934665603ull;
+  uint64_t w[4];
+  double x = s->x + 0.0, ca = s->cash + 0.0, pq = s->preq + 0.0; /* -0.0 -> +0.0 */
+  w[0] = (uint64_t)s->period;
+  memcpy(&w[1], &x, 8);
+  memcpy(&w[2], &ca, 8);
+  memcpy(&w[3], &pq, 8);
+  for (int i = 0; i < 4; i++) {
+    h ^= w[i];
+    h *= 1099511628211ull;
+    h ^= h >> 29;
+  }
+  return h;
+}
+static int eq_st(const st_t* a, const st_t* b) {
+  return a->period == b->period && a->x == b->x && a->cash == b->cash && a->preq == b->preq;
+}
+
+static mentry* memo_find(memo_t* m, const st_t* s) {
+  uint64_t i = hash_st(s) & (uint64_t)(m->cap - 1);
+  while (m->tab[i].used) {
+    if (eq_st(&m->tab[i].key, s)) return &m->tab[i];
+    i = (i + 1) & (uint64_t)(m->cap - 1);
+  }
+  return &m->tab[i];
+}
+
+static void memo_grow(memo_t* m) {
+  mentry* old = m->tab;
+  int64_t ocap = m->cap;
+  m->cap *= 2;
+  m->tab = (mentry*)calloc((size_t)m->cap, sizeof(mentry));
+  for (int64_t i = 0; i < ocap; i++)
+    if (old[i].used) *memo_find(m, &old[i].key) = old[i];
+  free(old);
+}
+
+static double memo_value(void* env, const st_t* s) {
+  memo_t* m = (memo_t*)env;
+  mentry* e = memo_find(m, s);
+  if (e->used) return e->value;
+  double val, best;
+  eval_state(m->c, s, memo_value, m, &val, &best, NULL, &m->cells);
+  if ((m->n + 1) * 2 > m->cap) memo_grow(m);
+  e = memo_find(m, s); /* the table may have been rebuilt by nested inserts */
+  e->key = *s;
+  e->value = val;
+  e->action = best;
+  e->used = 1;
+  m->n++;
+  return val;
+}
+
+int sdpref_memo(const sdpgpu_desc* d, const int32_t* pmf_off, const double* pmf_d, const double* pmf_p,
+                const double* overhead, double* root_value, double* root_action, int64_t cap,
+                int32_t* out_period, double* out_x, double* out_cash, double* out_preq,
+                double* out_value, double* out_action, int64_t* n_out) {
+  ctx_t c = {d, pmf_off, pmf_d, pmf_p, overhead, d->periods};
+  memo_t m;
+  m.c = &c;
+  m.cap = 1 << 12;
+  m.n = 0;
+  m.cells = 0;
+  m.tab = (mentry*)calloc((size_t)m.cap, sizeof(mentry));
+  st_t ini = {1, d->ini_inventory, has_cash(d->family) ? d->ini_cash : 0, has_preq(d->family) ? d->ini_preq : 0};
+  double v = memo_value(&m, &ini);
+  if (root_value) *root_value = v;
+  if (root_action) *root_action = memo_find(&m, &ini)->action;
+  int rc = 0;
+  if (n_out) *n_out = m.n;
+  if (out_period) {
+    if (m.n > cap) {
+      rc = 6;
+    } else {
+      int64_t k = 0;
+      for (int64_t i = 0; i < m.cap; i++)
+        if (m.tab[i].used) {
+          out_period[k] = m.tab[i].key.period;
+          out_x[k] = m.tab[i].key.x;
+          out_cash[k] = m.tab[i].key.cash;
+          out_preq[k] = m.tab[i].key.preq;
+          out_value[k] = m.tab[i].value;
+          out_action[k] = m.tab[i].action;
+          k++;
+        }
+    }
+  }
+  free(m.tab);
+  return rc;
+}
+
+/* ------------------------------------------------------------------------------------------
+ * KAT family: CashRecursionMultiLead.java:54-90 + MultiProductLeadtime.java:150-223.
+ * ---------------------------------------------------------------------------------------- */
+typedef struct mst {
+  int32_t period;
+  double i1, i2, q1, q2, cash;
+} mst_t;
+
+typedef struct mlentry {
+  mst_t key;
+  double value;
+  int32_t a1, a2;
+  int used;
+} mlentry;
+
+typedef struct mlmemo {
+  const sdpref_multilead* k;
+  mlentry* tab;
+  int64_t cap, n, cells;
+} mlmemo;
+
+static uint64_t hash_mst(const mst_t* s) {
+  uint64_t h = 1469598103934665603ull, w[6];
+  double v[5] = {s->i1 + 0.0, s->i2 + 0.0, s->q1 + 0.0, s->q2 + 0.0, s->cash + 0.0};
+  w[0] = (uint64_t)s->period;
+  memcpy(&w[1], v, 40);
+  for (int i = 0; i < 6; i++) {
+    h ^= w[i];
+    h *= 1099511628211ull;
+    h ^= h >> 29;
+  }
+  return h;
+}
+static mlentry* ml_find(mlmemo* m, const mst_t* s) {
+  uint64_t i = hash_mst(s) & (uint64_t)(m->cap - 1);
+  while (m->tab[i].used) {
+    const mst_t* k = &m->tab[i].key;
+    if (k->period == s->period && k->i1 == s->i1 && k->i2 == s->i2 && k->q1 == s->q1 && k->q2 == s->q2 &&
+        k->cash == s->cash)
+      return &m->tab[i];
+    i = (i + 1) & (uint64_t)(m->cap - 1);
+  }
+  return &m->tab[i];
+}
+static void ml_grow(mlmemo* m) {
+  mlentry* old = m->tab;
+  int64_t ocap = m->cap;
+  m->cap *= 2;
+  m->tab = (mlentry*)calloc((size_t)m->cap, sizeof(mlentry));
+  for (int64_t i = 0; i < ocap; i++)
+    if (old[i].used) *ml_find(m, &old[i].key) = old[i];
+  free(old);
+}
+
+/* MultiProductLeadtime.java:162-199 */
+static double ml_imm(const sdpref_multilead* k, const mst_t* s, int32_t a1, int32_t a2, int32_t dm1, int32_t dm2) {
+  double action1 = a1, action2 = a2, demand1 = dm1, demand2 = dm2;
+  double preQ1 = s->q1, preQ2 = s->q2;
+  double endInventory1 = jmax(0, s->i1 + preQ1 - demand1);
+  double endInventory2 = jmax(0, s->i2 + preQ2 - demand2);
+  double revenue1 = k->price[0] * jmin(demand1, s->i1 + preQ1);
+  double revenue2 = k->price[1] * jmin(s->i2 + preQ2, demand2);
+  double revenue = revenue1 + revenue2;
+  double orderingCost1 = k->vari_cost[0] * action1;
+  double orderingCost2 = k->vari_cost[1] * action2;
+  double orderingCosts = orderingCost1 + orderingCost2;
+  double salValue = 0;
+  if (s->period == k->T) salValue = k->sal_value[0] * endInventory1 + k->sal_value[1] * endInventory2;
+  int t = s->period - 1;
+  double cashBalanceBefore = s->cash - orderingCosts - k->overhead[t];
+  double interest = 0;
+  if (cashBalanceBefore >= 0)
+    interest = -k->r0 * cashBalanceBefore;
+  else if (cashBalanceBefore >= -k->interest_free)
+    interest = 0;
+  else if (cashBalanceBefore >= -k->limit)
+    interest = k->r1 * (-cashBalanceBefore - k->interest_free);
+  else
+    interest = k->r2 * (-cashBalanceBefore - k->limit) + k->r1 * (k->limit - k->interest_free);
+  double cashBalanceAfter = cashBalanceBefore - interest + revenue + salValue;
+  double cashIncrement = cashBalanceAfter - s->cash;
+  return cashIncrement;
+}
+
+/* MultiProductLeadtime.java:203-223 (the one-sided clamps at :217-218 are the reference's). */
+static void ml_trans(const sdpref_multilead* k, const mst_t* s, int32_t a1, int32_t a2, int32_t dm1, int32_t dm2,
+                     mst_t* out) {
+  double nextPreQ1 = a1, nextPreQ2 = a2;
+  double endInventory1 = s->i1 + s->q1 - (double)dm1;
+  endInventory1 = jmax(0, endInventory1);
+  double endInventory2 = s->i2 + s->q2 - (double)dm2;
+  endInventory2 = jmax(0, endInventory2);
+  double nextCash = s->cash + ml_imm(k, s, a1, a2, dm1, dm2);
+  nextCash = nextCash > k->max_cash ? k->max_cash : nextCash;
+  nextCash = nextCash < k->min_cash ? k->min_cash : nextCash;
+  endInventory1 = endInventory1 > k->max_inventory ? k->max_inventory : endInventory1;
+  endInventory2 = endInventory2 < k->min_inventory ? k->min_inventory : endInventory2;
+  endInventory1 = (double)jd2i(endInventory1);
+  endInventory2 = (double)jd2i(endInventory2);
+  out->period = s->period + 1;
+  out->i1 = endInventory1;
+  out->i2 = endInventory2;
+  out->q1 = nextPreQ1;
+  out->q2 = nextPreQ2;
+  out->cash = nextCash;
+}
+
+/* CashRecursionMultiLead.java:54-90 */
+static double ml_value(mlmemo* m, const mst_t* s) {
+  mlentry* e = ml_find(m, s);
+  if (e->used) return e->value;
+  const sdpref_multilead* k = m->k;
+  double val = -DBL_MAX;
+  int32_t b1 = 0, b2 = 0;
+  for (int32_t ai = 0; ai < k->q_bound; ai++)
+    for (int32_t aj = 0; aj < k->q_bound; aj++) { /* buildActionList, MultiProductLeadtime.java:150-158 */
+      double thisActionsValue = 0;
+      for (int32_t i = 0; i < k->n1; i++)
+        for (int32_t j = 0; j < k->n2; j++) { /* GetPmfMulti.java:157-172: index = i*n2 + j */
+          double prob = k->p1[i] * k->p2[j];
+          int32_t dm1 = jd2i(k->v1[i]), dm2 = jd2i(k->v2[j]);
+          thisActionsValue += prob * ml_imm(k, s, ai, aj, dm1, dm2);
+          if (s->period < k->T) {
+            mst_t ns;
+            ml_trans(k, s, ai, aj, dm1, dm2, &ns);
+            thisActionsValue += prob * k->discount * ml_value(m, &ns);
+          }
+          m->cells++;
+        }
+      if (thisActionsValue > val + 0.1) { /* CashRecursionMultiLead.java:82 */
+        val = thisActionsValue;
+        b1 = ai;
+        b2 = aj;
+      }
+    }
+  if ((m->n + 1) * 2 > m->cap) ml_grow(m);
+  e = ml_find(m, s);
+  e->key = *s;
+  e->value = val;
+  e->a1 = b1;
+  e->a2 = b2;
+  e->used = 1;
+  m->n++;
+  return val;
+}
+
+int sdpref_kat_multilead(const sdpref_multilead* k, double* final_value, int32_t* q1, int32_t* q2,
+                         int64_t* states_visited, int64_t* cells) {
+  if (!k || k->T < 1 || k->T > 16 || k->n1 < 1 || k->n1 > 16 || k->n2 < 1 || k->n2 > 16) return 1;
+  mlmemo m;
+  m.k = k;
+  m.cap = 1 << 14;
+  m.n = 0;
+  m.cells = 0;
+  m.tab = (mlentry*)calloc((size_t)m.cap, sizeof(mlentry));
+  mst_t ini = {1, k->ini_i1, k->ini_i2, 0, 0, k->ini_cash}; /* MultiProductLeadtime.java:232 */
+  double v = ml_value(&m, &ini);
+  mlentry* e = ml_find(&m, &ini);
+  if (final_value) *final_value = k->ini_cash + v; /* :234 */
+  if (q1) *q1 = e->a1;
+  if (q2) *q2 = e->a2;
+  if (states_visited) *states_visited = m.n;
+  if (cells) *cells = m.cells;
+  free(m.tab);
+  return 0;
+}

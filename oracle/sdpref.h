@@ -1,0 +1,101 @@
+/*
+ * sdpref.h -- CPU ORACLE for the src/sdp Bellman recursion.  TEST INFRASTRUCTURE ONLY.
+ *
+ * Nothing in the product (stochastic-inventory_amd/, include/) may import, link, call or
+ * execute this.  Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg use it,
+ * and only as the checker / the timed CPU baseline -- never as the thing shipped.
+ *
+ * Parity pin status (see DESIGN.md "Oracle"):
+ *   - loop template (interleaved accumulation, memo recursion, arg-opt scan, interest schedule,
+ *     lead-time transition): PINNED by KAT-1, the reference's own recorded output
+ *     "final optimal cash is -17.800000000000008, Q1 = 40, Q2 = 20"
+ *     (src/cash/overdraft/MultiProductLeadtime.java:41-43), reproduced bit for bit by
+ *     sdpref_kat_multilead() in tests/test_oracle_kat.py.
+ *   - single-item classes (Recursion, CLSP.f, LeadtimeRecursion, CashRecursion,
+ *     CashLeadtimeRecursion): PARITY UNPINNED by the reference -- it stores no outputs for
+ *     them and cannot be run here (no JDK).  They are pinned only against this line-by-line
+ *     restatement, which is itself protected by dense-sweep == literal-memoised-recursion tests
+ *     and hand-computed 1- and 2-period cases.
+ */
+#ifndef SDPREF_H
+#define SDPREF_H
+
+#include <stdint.h>
+
+#include "../include/sdpgpu.h" /* descriptor struct only (data layout, no code) */
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* Per-period grid as the oracle lays it out (independent of the product's layout code). */
+typedef struct sdpref_grid {
+  double x_lo;
+  int64_t nx, nc, nq;
+  int64_t k_lo; /* cash key of cash index 0 */
+} sdpref_grid;
+
+/* pmf is passed flat: pmf_off[t]..pmf_off[t+1] index demand/prob of period t+1, t = 0..T-1.
+ * overhead may be NULL (desc->overhead_cost every period) or T doubles. */
+
+/* grids[0..T-1] for periods 1..T.  Returns 0 or an error code. */
+int sdpref_layout(const sdpgpu_desc* d, const int32_t* pmf_off, const double* pmf_d, sdpref_grid* grids);
+
+/* Dense backward sweep.  values_off[t] = offset of period t+1 inside `values`/`policy`
+ * (caller computes it from sdpref_layout).  nthreads > 1 splits states over pthreads. */
+int sdpref_solve(const sdpgpu_desc* d, const int32_t* pmf_off, const double* pmf_d, const double* pmf_p,
+                 const double* overhead, double* values, int32_t* policy, const int64_t* values_off,
+                 int32_t nthreads, int64_t* cells_out);
+
+/* One period, states [lo, hi) only, reading v_next (NULL for period T). */
+int sdpref_period(const sdpgpu_desc* d, const int32_t* pmf_off, const double* pmf_d, const double* pmf_p,
+                  const double* overhead, int32_t period, const double* v_next, double* v_cur,
+                  int32_t* pol_cur, int64_t lo, int64_t hi, int32_t nthreads, int64_t* cells_out);
+
+/* Literal top-down memoised recursion from (1, ini_inventory, ini_cash, ini_preq): the shape of
+ * Recursion.java:89-163.  Writes every visited state: period/x/cash/preq/value/action (caller
+ * passes capacity `cap`; returns the number visited through *n_out, error if cap too small). */
+int sdpref_memo(const sdpgpu_desc* d, const int32_t* pmf_off, const double* pmf_d, const double* pmf_p,
+                const double* overhead, double* root_value, double* root_action, int64_t cap,
+                int32_t* out_period, double* out_x, double* out_cash, double* out_preq,
+                double* out_value, double* out_action, int64_t* n_out);
+
+/* Evaluate arbitrary states of `period` against a dense v_next table. */
+int sdpref_eval_states(const sdpgpu_desc* d, const int32_t* pmf_off, const double* pmf_d, const double* pmf_p,
+                       const double* overhead, int32_t period, const double* v_next, int64_t n,
+                       const double* x, const double* cash, const double* preq, double* out_value,
+                       int32_t* out_action);
+
+/* Forward reachable-set mask per period (concatenated with values_off). */
+int sdpref_reachable(const sdpgpu_desc* d, const int32_t* pmf_off, const double* pmf_d, const double* pmf_p,
+                     const double* overhead, uint8_t* mask, const int64_t* values_off);
+
+/* KAT family: two-product overdraft with lead time 1, CashRecursionMultiLead.java:54-90 driven by
+ * the lambdas of MultiProductLeadtime.java:150-223 with DiscreteDistribution pmfs
+ * (GetPmfMulti.java:157-172).  n1/n2 demand points per product. */
+typedef struct sdpref_multilead {
+  int32_t T;
+  int32_t q_bound; /* actions i, j in [0, q_bound) */
+  double price[2], vari_cost[2], sal_value[2];
+  double ini_cash, ini_i1, ini_i2;
+  double r0, r1, r2, limit, interest_free;
+  double min_inventory, max_inventory, min_cash, max_cash;
+  double discount;
+  double overhead[16];
+  int32_t n1, n2;
+  double v1[16], p1[16], v2[16], p2[16];
+} sdpref_multilead;
+
+int sdpref_kat_multilead(const sdpref_multilead* k, double* final_value, int32_t* q1, int32_t* q2,
+                         int64_t* states_visited, int64_t* cells);
+
+/* Java arithmetic helpers, exported so tests can probe their corner cases. */
+int64_t sdpref_java_round(double x);
+double sdpref_java_max(double a, double b);
+double sdpref_java_min(double a, double b);
+int32_t sdpref_java_d2i(double x);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

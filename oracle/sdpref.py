@@ -1,0 +1,211 @@
+"""ctypes binding of the CPU oracle (oracle/sdpref.c).  TEST INFRASTRUCTURE ONLY.
+
+Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may import this module;
+nothing under stochastic-inventory_amd/ does.  It borrows the descriptor struct layout from
+the product's ABI module (data layout only) so that both sides are fed the same bytes.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+import subprocess
+import sys
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_ROOT = os.path.dirname(_HERE)
+if _ROOT not in sys.path:
+    sys.path.insert(0, _ROOT)
+
+from stochastic_inventory_amd._abi import SdpgpuDesc  # noqa: E402  (struct layout only)
+
+LIB_PATH = os.path.join(_HERE, "libsdpref.so")
+
+
+def build(force: bool = False) -> str:
+    src = [os.path.join(_HERE, f) for f in ("sdpref.c", "sdpref.h", "Makefile")] + [
+        os.path.join(_ROOT, "include", "sdpgpu.h")]
+    stale = (not os.path.exists(LIB_PATH)) or any(os.path.getmtime(f) > os.path.getmtime(LIB_PATH) for f in src)
+    if force or stale:
+        subprocess.run(["make", "-C", _HERE, "-B" if force else "-s", "libsdpref.so"], check=True)
+    return LIB_PATH
+
+
+class Grid(C.Structure):
+    _fields_ = [("x_lo", C.c_double), ("nx", C.c_int64), ("nc", C.c_int64), ("nq", C.c_int64), ("k_lo", C.c_int64)]
+
+
+class MultiLead(C.Structure):
+    _fields_ = [
+        ("T", C.c_int32), ("q_bound", C.c_int32),
+        ("price", C.c_double * 2), ("vari_cost", C.c_double * 2), ("sal_value", C.c_double * 2),
+        ("ini_cash", C.c_double), ("ini_i1", C.c_double), ("ini_i2", C.c_double),
+        ("r0", C.c_double), ("r1", C.c_double), ("r2", C.c_double), ("limit", C.c_double),
+        ("interest_free", C.c_double),
+        ("min_inventory", C.c_double), ("max_inventory", C.c_double), ("min_cash", C.c_double),
+        ("max_cash", C.c_double), ("discount", C.c_double),
+        ("overhead", C.c_double * 16),
+        ("n1", C.c_int32), ("n2", C.c_int32),
+        ("v1", C.c_double * 16), ("p1", C.c_double * 16), ("v2", C.c_double * 16), ("p2", C.c_double * 16),
+    ]
+
+
+_lib = None
+_DP = C.POINTER(C.c_double)
+_IP = C.POINTER(C.c_int32)
+_LP = C.POINTER(C.c_int64)
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        build()
+        L = C.CDLL(LIB_PATH)
+        L.sdpref_java_round.restype = C.c_int64
+        L.sdpref_java_round.argtypes = [C.c_double]
+        L.sdpref_java_max.restype = C.c_double
+        L.sdpref_java_max.argtypes = [C.c_double, C.c_double]
+        L.sdpref_java_min.restype = C.c_double
+        L.sdpref_java_min.argtypes = [C.c_double, C.c_double]
+        L.sdpref_java_d2i.restype = C.c_int32
+        L.sdpref_java_d2i.argtypes = [C.c_double]
+        _lib = L
+    return _lib
+
+
+def _dp(a):
+    return None if a is None else a.ctypes.data_as(_DP)
+
+
+class Problem:
+    """Descriptor + flat pmf, the way the oracle's C entry points take them."""
+
+    def __init__(self, desc: SdpgpuDesc, pmf, overhead=None):
+        self.desc = desc
+        self.T = desc.periods
+        tiles = [np.asarray(t, dtype=np.float64) for t in pmf]
+        assert len(tiles) == self.T
+        self.off = np.zeros(self.T + 1, dtype=np.int32)
+        for t, tile in enumerate(tiles):
+            self.off[t + 1] = self.off[t] + tile.shape[0]
+        self.pd = np.ascontiguousarray(np.concatenate([t[:, 0] for t in tiles]))
+        self.pp = np.ascontiguousarray(np.concatenate([t[:, 1] for t in tiles]))
+        self.oh = None if overhead is None else np.ascontiguousarray(overhead, dtype=np.float64)
+        self.grids = (Grid * self.T)()
+        rc = lib().sdpref_layout(C.byref(desc), self.off.ctypes.data_as(_IP), _dp(self.pd), self.grids)
+        if rc:
+            raise RuntimeError(f"sdpref_layout failed: {rc}")
+        self.S = [g.nx * g.nc * g.nq for g in self.grids]
+        self.voff = np.zeros(self.T + 1, dtype=np.int64)
+        self.voff[1:] = np.cumsum(self.S)
+
+    def _args(self):
+        return (C.byref(self.desc), self.off.ctypes.data_as(_IP), _dp(self.pd), _dp(self.pp), _dp(self.oh))
+
+    def solve(self, nthreads: int = 1):
+        """Dense backward sweep: returns (values per period, policy per period, cells)."""
+        total = int(self.voff[-1])
+        values = np.zeros(total, dtype=np.float64)
+        policy = np.zeros(total, dtype=np.int32)
+        cells = C.c_int64(0)
+        rc = lib().sdpref_solve(*self._args(), _dp(values), policy.ctypes.data_as(_IP),
+                                self.voff.ctypes.data_as(_LP), nthreads, C.byref(cells))
+        if rc:
+            raise RuntimeError(f"sdpref_solve failed: {rc}")
+        v = [values[self.voff[t]:self.voff[t + 1]] for t in range(self.T)]
+        p = [policy[self.voff[t]:self.voff[t + 1]] for t in range(self.T)]
+        return v, p, cells.value
+
+    def period(self, period: int, v_next, lo: int = 0, hi: int = None, nthreads: int = 1, v_cur=None, pol=None):
+        """One period on states [lo, hi): returns (v_cur, pol, cells) (full-length arrays)."""
+        S = self.S[period - 1]
+        hi = S if hi is None else hi
+        if v_cur is None:
+            v_cur = np.zeros(S, dtype=np.float64)
+        if pol is None:
+            pol = np.zeros(S, dtype=np.int32)
+        vn = None if v_next is None else np.ascontiguousarray(v_next, dtype=np.float64)
+        cells = C.c_int64(0)
+        rc = lib().sdpref_period(*self._args(), period, _dp(vn), _dp(v_cur), pol.ctypes.data_as(_IP),
+                                 C.c_int64(lo), C.c_int64(hi), nthreads, C.byref(cells))
+        if rc:
+            raise RuntimeError(f"sdpref_period failed: {rc}")
+        return v_cur, pol, cells.value
+
+    def memo(self, cap: int = 1 << 22):
+        """Literal memoised recursion from the ini_* state: dict with root value/action + visited states."""
+        rv, ra, n = C.c_double(), C.c_double(), C.c_int64()
+        per = np.zeros(cap, dtype=np.int32)
+        arrs = [np.zeros(cap, dtype=np.float64) for _ in range(5)]
+        rc = lib().sdpref_memo(*self._args(), C.byref(rv), C.byref(ra), C.c_int64(cap), per.ctypes.data_as(_IP),
+                               *[_dp(a) for a in arrs], C.byref(n))
+        if rc:
+            raise RuntimeError(f"sdpref_memo failed: {rc} (visited {n.value})")
+        k = n.value
+        return {"value": rv.value, "action": ra.value, "n": k, "period": per[:k], "x": arrs[0][:k],
+                "cash": arrs[1][:k], "preq": arrs[2][:k], "values": arrs[3][:k], "actions": arrs[4][:k]}
+
+    def eval_states(self, period: int, v_next, x, cash=None, preq=None):
+        x = np.ascontiguousarray(x, dtype=np.float64)
+        n = len(x)
+        ca = None if cash is None else np.ascontiguousarray(cash, dtype=np.float64)
+        pq = None if preq is None else np.ascontiguousarray(preq, dtype=np.float64)
+        vn = None if v_next is None else np.ascontiguousarray(v_next, dtype=np.float64)
+        val = np.zeros(n, dtype=np.float64)
+        act = np.zeros(n, dtype=np.int32)
+        rc = lib().sdpref_eval_states(*self._args(), period, _dp(vn), C.c_int64(n), _dp(x), _dp(ca), _dp(pq),
+                                      _dp(val), act.ctypes.data_as(_IP))
+        if rc:
+            raise RuntimeError(f"sdpref_eval_states failed: {rc}")
+        return val, act
+
+    def reachable(self):
+        total = int(self.voff[-1])
+        mask = np.zeros(total, dtype=np.uint8)
+        rc = lib().sdpref_reachable(*self._args(), mask.ctypes.data_as(C.POINTER(C.c_uint8)),
+                                    self.voff.ctypes.data_as(_LP))
+        if rc:
+            raise RuntimeError(f"sdpref_reachable failed: {rc}")
+        return [mask[self.voff[t]:self.voff[t + 1]].astype(bool) for t in range(self.T)]
+
+    def state_arrays(self, period: int):
+        """(x, cash, preq) value arrays of every grid state of `period`, in flat-index order."""
+        g = self.grids[period - 1]
+        d = self.desc
+        idx = np.arange(g.nx * g.nc * g.nq)
+        ic = idx % g.nc
+        ix = (idx // g.nc) % g.nx
+        iq = idx // (g.nc * g.nx)
+        x = g.x_lo + ix * d.step
+        if d.family in (3, 4, 5):
+            k = (g.k_lo + ic).astype(np.float64)
+            cash = k if d.cash_round_int_div else k / d.cash_round_div
+        else:
+            cash = np.zeros(len(idx))
+        preq = iq * d.step if d.family in (2, 5) else np.zeros(len(idx))
+        return x.astype(np.float64), cash.astype(np.float64), preq.astype(np.float64)
+
+
+def kat_multilead(**kw):
+    """sdpref_kat_multilead: returns (final_value, q1, q2, states_visited, cells)."""
+    k = MultiLead()
+    k.T = kw["T"]
+    k.q_bound = kw["q_bound"]
+    for name in ("price", "vari_cost", "sal_value"):
+        getattr(k, name)[0], getattr(k, name)[1] = kw[name]
+    for name in ("ini_cash", "ini_i1", "ini_i2", "r0", "r1", "r2", "limit", "interest_free", "min_inventory",
+                 "max_inventory", "min_cash", "max_cash", "discount"):
+        setattr(k, name, float(kw[name]))
+    for t, v in enumerate(kw["overhead"]):
+        k.overhead[t] = v
+    k.n1, k.n2 = len(kw["values"][0]), len(kw["values"][1])
+    for i, (v, p) in enumerate(zip(kw["values"][0], kw["probs"][0])):
+        k.v1[i], k.p1[i] = v, p
+    for i, (v, p) in enumerate(zip(kw["values"][1], kw["probs"][1])):
+        k.v2[i], k.p2[i] = v, p
+    fv, q1, q2, ns, nc = C.c_double(), C.c_int32(), C.c_int32(), C.c_int64(), C.c_int64()
+    rc = lib().sdpref_kat_multilead(C.byref(k), C.byref(fv), C.byref(q1), C.byref(q2), C.byref(ns), C.byref(nc))
+    if rc:
+        raise RuntimeError(f"sdpref_kat_multilead failed: {rc}")
+    return fv.value, q1.value, q2.value, ns.value, nc.value

@@ -1,0 +1,21 @@
+"""stochastic-inventory_amd -- MI355X-native engine for the finite-horizon SDP recursion of
+RobinChen121/Stochastic-Inventory's src/sdp (hand-written HIP behind the C ABI of include/sdpgpu.h).
+
+The directory name carries a hyphen (it is fixed by the build contract); import it as
+`stochastic_inventory_amd` through the alias module at the repository root.
+"""
+from . import _abi
+from ._abi import (FAMILY_BACKORDER, FAMILY_CASH, FAMILY_CASH_LEADTIME, FAMILY_LEADTIME, FAMILY_OVERDRAFT,
+                   KERNEL_AUTO, KERNEL_GATHER, KERNEL_WINDOW, SdpgpuDesc, SdpgpuError, SdpgpuStats, desc_defaults)
+from .engine import SdpEngine
+from .functors import (BackorderFunctor, CashFunctor, CashLeadtimeFunctor, LeadtimeFunctor, OverdraftFunctor,
+                       java_round)
+from .recursion import CLSP, CashLeadtimeRecursion, CashRecursion, LeadtimeRecursion, Recursion
+from .states import CashLeadtimeState, CashState, LeadtimeState, OptDirection, State
+
+__all__ = [
+    "SdpEngine", "SdpgpuDesc", "SdpgpuError", "SdpgpuStats", "desc_defaults",
+    "BackorderFunctor", "LeadtimeFunctor", "CashFunctor", "OverdraftFunctor", "CashLeadtimeFunctor",
+    "Recursion", "CLSP", "LeadtimeRecursion", "CashRecursion", "CashLeadtimeRecursion",
+    "State", "LeadtimeState", "CashState", "CashLeadtimeState", "OptDirection", "java_round",
+]

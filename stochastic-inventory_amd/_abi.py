@@ -1,0 +1,174 @@
+"""ctypes binding of the C ABI declared in include/sdpgpu.h.
+
+The shared library `libsdpgpu.so` (hand-written HIP for gfx950, built in-tree by
+`build.py`) is the product.  There is no Python or CPU fallback: if the library is
+missing or no HIP device is present every compute call raises.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libsdpgpu.so")
+
+SDPGPU_ABI_VERSION = 1
+
+FAMILY_BACKORDER = 1
+FAMILY_LEADTIME = 2
+FAMILY_CASH = 3
+FAMILY_OVERDRAFT = 4
+FAMILY_CASH_LEADTIME = 5
+
+MIN = 0
+MAX = 1
+
+KERNEL_AUTO = 0
+KERNEL_GATHER = 1
+KERNEL_WINDOW = 2
+
+
+class SdpgpuDesc(C.Structure):
+    """struct sdpgpu_desc (include/sdpgpu.h), field for field."""
+
+    _fields_ = [
+        ("abi_version", C.c_int32),
+        ("family", C.c_int32),
+        ("direction", C.c_int32),
+        ("periods", C.c_int32),
+        ("step", C.c_double),
+        ("min_inventory", C.c_double),
+        ("max_inventory", C.c_double),
+        ("max_order_quantity", C.c_double),
+        ("clamp_inventory", C.c_int32),
+        ("zero_order_last_period", C.c_int32),
+        ("ini_inventory", C.c_double),
+        ("ini_cash", C.c_double),
+        ("ini_preq", C.c_double),
+        ("fixed_order_cost", C.c_double),
+        ("unit_order_cost", C.c_double),
+        ("holding_cost", C.c_double),
+        ("penalty_cost", C.c_double),
+        ("price", C.c_double),
+        ("salvage_value", C.c_double),
+        ("deposit_rate", C.c_double),
+        ("overhead_cost", C.c_double),
+        ("overhead_rate", C.c_double),
+        ("discount_factor", C.c_double),
+        ("min_cash", C.c_double),
+        ("max_cash", C.c_double),
+        ("cash_round_mult", C.c_double),
+        ("cash_round_div", C.c_double),
+        ("cash_round_int_div", C.c_int32),
+        ("cash_formula", C.c_int32),
+        ("r0", C.c_double),
+        ("r2", C.c_double),
+        ("r3", C.c_double),
+        ("overdraft_limit", C.c_double),
+        ("interest_free_amount", C.c_double),
+        ("kernel", C.c_int32),
+        ("device", C.c_int32),
+        ("rank", C.c_int32),
+        ("world_size", C.c_int32),
+        ("store_all_values", C.c_int32),
+        ("reserved0", C.c_int32),
+    ]
+
+
+class SdpgpuStats(C.Structure):
+    _fields_ = [
+        ("states_total", C.c_int64),
+        ("cells_evaluated", C.c_int64),
+        ("cells_all_ranks", C.c_int64),
+        ("solve_ms", C.c_double),
+        ("kernel_ms_sum", C.c_double),
+        ("periods_run", C.c_int32),
+        ("kernel_used", C.c_int32),
+    ]
+
+
+def desc_defaults() -> SdpgpuDesc:
+    """Python twin of sdpgpu_desc_init (usable without loading the library)."""
+    d = SdpgpuDesc()
+    d.abi_version = SDPGPU_ABI_VERSION
+    d.family = FAMILY_BACKORDER
+    d.direction = MIN
+    d.periods = 1
+    d.step = 1.0
+    d.clamp_inventory = 1
+    d.discount_factor = 1.0
+    d.cash_round_mult = 10.0
+    d.cash_round_div = 10.0
+    d.kernel = KERNEL_AUTO
+    d.device = -1
+    d.rank = 0
+    d.world_size = 1
+    d.store_all_values = 1
+    return d
+
+
+# every symbol include/sdpgpu.h declares: name -> (restype, argtypes)
+_P = C.c_void_p
+_DP = C.POINTER(C.c_double)
+_IP = C.POINTER(C.c_int32)
+_LP = C.POINTER(C.c_int64)
+EXPORTS = {
+    "sdpgpu_abi_version": (C.c_int, []),
+    "sdpgpu_desc_init": (None, [C.POINTER(SdpgpuDesc)]),
+    "sdpgpu_create": (C.c_int, [C.POINTER(SdpgpuDesc), C.POINTER(_P)]),
+    "sdpgpu_destroy": (None, [_P]),
+    "sdpgpu_last_error": (C.c_char_p, [_P]),
+    "sdpgpu_set_pmf": (C.c_int, [_P, C.c_int32, _DP, _DP, C.c_int32]),
+    "sdpgpu_set_overhead": (C.c_int, [_P, C.c_int32, C.c_double]),
+    "sdpgpu_set_stream": (C.c_int, [_P, _P]),
+    "sdpgpu_set_profiling": (C.c_int, [_P, C.c_int32]),
+    "sdpgpu_num_states": (C.c_int64, [_P, C.c_int32]),
+    "sdpgpu_slab": (C.c_int, [_P, C.c_int32, _LP, _LP, _LP]),
+    "sdpgpu_grid": (C.c_int, [_P, C.c_int32, _DP, _LP, _LP, _LP]),
+    "sdpgpu_cash_value": (C.c_double, [_P, C.c_int64]),
+    "sdpgpu_state_index": (C.c_int64, [_P, C.c_int32, C.c_double, C.c_double, C.c_double]),
+    "sdpgpu_solve": (C.c_int, [_P, C.c_int32]),
+    "sdpgpu_run_period": (C.c_int, [_P, C.c_int32]),
+    "sdpgpu_values_device_ptr": (_P, [_P, C.c_int32]),
+    "sdpgpu_values_bytes": (C.c_size_t, [_P]),
+    "sdpgpu_attach_values": (C.c_int, [_P, _P, C.c_size_t]),
+    "sdpgpu_synchronize": (C.c_int, [_P]),
+    "sdpgpu_values": (C.c_int, [_P, C.c_int32, _DP, C.c_int64]),
+    "sdpgpu_policy": (C.c_int, [_P, C.c_int32, _IP, C.c_int64, C.c_int64]),
+    "sdpgpu_eval_states": (C.c_int, [_P, C.c_int32, C.c_int64, _DP, _DP, _DP, _DP, _IP]),
+    "sdpgpu_reachable": (C.c_int, [_P, C.c_int32, C.POINTER(C.c_uint8), C.c_int64]),
+    "sdpgpu_stats_get": (C.c_int, [_P, C.POINTER(SdpgpuStats)]),
+    "sdpgpu_period_ms": (C.c_double, [_P, C.c_int32]),
+}
+
+_lib = None
+
+
+class SdpgpuError(RuntimeError):
+    """A C-ABI call returned a non-zero status (message from sdpgpu_last_error)."""
+
+    def __init__(self, code: int, message: str):
+        super().__init__(f"sdpgpu error {code}: {message}")
+        self.code = code
+        self.message = message
+
+
+def load():
+    """Load libsdpgpu.so and type every export.  Raises if the extension is not built."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise ImportError(
+            f"{LIB_PATH} is missing: build the HIP extension first "
+            "(python -c 'import __graft_entry__ as g; g.build()'); there is no CPU fallback"
+        )
+    lib = C.CDLL(LIB_PATH)
+    for name, (res, args) in EXPORTS.items():
+        fn = getattr(lib, name)  # AttributeError if the library lacks a declared symbol
+        fn.restype = res
+        fn.argtypes = args
+    if lib.sdpgpu_abi_version() != SDPGPU_ABI_VERSION:
+        raise ImportError("libsdpgpu.so ABI version mismatch")
+    _lib = lib
+    return lib

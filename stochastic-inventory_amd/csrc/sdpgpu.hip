@@ -1,0 +1,894 @@
+// sdpgpu.hip -- C-ABI implementation (include/sdpgpu.h) of the MI355X SDP engine.
+//
+// Host side: descriptor validation, per-period grid layout, device tables, launch logic.
+// Device side: sdp_gather.hpp (generic functor + gather kernel), sdp_window.hpp (F1/F2
+// LDS-window kernel).  gfx950 only; there is NO CPU fallback anywhere in this library --
+// without a HIP device every compute entry point fails with SDPGPU_ERR_DEVICE.
+#include "../../include/sdpgpu.h"
+
+#include <hip/hip_runtime.h>
+
+#include <cmath>
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <new>
+#include <string>
+#include <vector>
+
+#include "sdp_device.hpp"
+#include "sdp_gather.hpp"
+#include "sdp_window.hpp"
+
+using sdp::DevParams;
+using sdp::Grid;
+
+namespace {
+
+thread_local std::string g_create_error;
+
+struct PeriodInfo {
+  Grid g{};
+  int64_t S = 0;      // grid states
+  int64_t S_pad = 0;  // padded to a multiple of world_size
+  int64_t lo = 0, hi = 0;  // this rank's slab
+  int32_t nD = 0;
+  size_t pmf_off = 0;   // element offset of this period's demand array inside d_pmf
+  size_t v_off = 0;     // element offset of V_t inside the value arena
+  size_t pol_off = 0;   // element offset of this rank's policy slab
+  double overhead = 0;
+  bool overhead_set = false;
+  int64_t cells_rank = 0, cells_all = 0;
+  hipEvent_t ev0 = nullptr, ev1 = nullptr;
+  bool timed = false;
+  int32_t kernel_used = 0;
+};
+
+}  // namespace
+
+struct sdpgpu_handle {
+  sdpgpu_desc d{};
+  int32_t T = 0;
+  int32_t n_actions_full = 0;
+  std::vector<PeriodInfo> per;  // index period-1
+  std::vector<std::vector<double>> pmf_d, pmf_p;
+  std::vector<char> pmf_set;
+  bool laid_out = false;
+  bool allocated = false;
+  bool pmf_uploaded = false;
+  double* d_pmf = nullptr;
+  double* d_values = nullptr;
+  size_t values_elems = 0;
+  bool values_external = false;
+  int32_t* d_policy = nullptr;
+  size_t policy_elems = 0;
+  hipStream_t stream = nullptr;
+  bool own_stream = false;
+  bool profiling = false;
+  hipEvent_t ev_solve0 = nullptr, ev_solve1 = nullptr;
+  bool solve_timed = false;
+  std::vector<char> period_done;  // V_t valid
+  uint8_t* d_reach = nullptr;      // reachable masks, period t at reach_off[t-1]
+  std::vector<size_t> reach_off;
+  bool reach_done = false;
+  std::string err;
+  int device = -1;
+};
+
+namespace {
+
+int fail(sdpgpu_handle* h, int code, const char* fmt, ...) {
+  char buf[512];
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(buf, sizeof buf, fmt, ap);
+  va_end(ap);
+  if (h)
+    h->err = buf;
+  else
+    g_create_error = buf;
+  return code;
+}
+
+#define HIP_TRY(h, expr)                                                                        \
+  do {                                                                                          \
+    hipError_t e_ = (expr);                                                                     \
+    if (e_ != hipSuccess) return fail(h, SDPGPU_ERR_DEVICE, "%s: %s", #expr, hipGetErrorString(e_)); \
+  } while (0)
+
+bool has_cash(int f) { return f == SDPGPU_FAMILY_CASH || f == SDPGPU_FAMILY_OVERDRAFT || f == SDPGPU_FAMILY_CASH_LEADTIME; }
+bool has_preq(int f) { return f == SDPGPU_FAMILY_LEADTIME || f == SDPGPU_FAMILY_CASH_LEADTIME; }
+
+// Java semantics needed on the host for the layout only.
+int64_t java_round(double x) {
+  double f = std::floor(x);
+  return (int64_t)((x - f >= 0.5) ? f + 1.0 : f);
+}
+int32_t java_d2i(double x) {
+  if (x != x) return 0;
+  if (x >= 2147483647.0) return INT32_MAX;
+  if (x <= -2147483648.0) return INT32_MIN;
+  return (int32_t)x;
+}
+
+int64_t cash_key_of_bound(const sdpgpu_desc& d, double bound) {
+  // key of the grid point the reference's rounding maps `bound` to
+  int64_t r = java_round(bound * d.cash_round_mult);
+  if (d.cash_round_int_div) return r / (int64_t)d.cash_round_div;
+  return r;
+}
+
+bool is_pow2_int(double s) {
+  if (!(s >= 1) || s != std::floor(s) || s > 1073741824.0) return false;
+  int64_t v = (int64_t)s;
+  return (v & (v - 1)) == 0;
+}
+
+int validate(const sdpgpu_desc& d) {
+  if (d.abi_version != SDPGPU_ABI_VERSION) return fail(nullptr, SDPGPU_ERR_ARG, "abi_version %d != %d", d.abi_version, SDPGPU_ABI_VERSION);
+  if (d.family < 1 || d.family > 5) return fail(nullptr, SDPGPU_ERR_ARG, "unknown family %d", d.family);
+  if (d.direction != SDPGPU_MIN && d.direction != SDPGPU_MAX) return fail(nullptr, SDPGPU_ERR_ARG, "bad direction %d", d.direction);
+  if (d.periods < 1 || d.periods > 4096) return fail(nullptr, SDPGPU_ERR_ARG, "periods %d out of range", d.periods);
+  if (!is_pow2_int(d.step)) return fail(nullptr, SDPGPU_ERR_UNSUPPORTED, "step %g: only power-of-two integer step sizes are supported (every in-scope driver uses 1)", d.step);
+  if (!(d.max_order_quantity >= 0) || d.max_order_quantity > 1e9) return fail(nullptr, SDPGPU_ERR_ARG, "max_order_quantity %g", d.max_order_quantity);
+  if (d.world_size < 1 || d.rank < 0 || d.rank >= d.world_size) return fail(nullptr, SDPGPU_ERR_ARG, "rank %d / world_size %d", d.rank, d.world_size);
+  if (d.clamp_inventory) {
+    if (!(d.max_inventory >= d.min_inventory)) return fail(nullptr, SDPGPU_ERR_ARG, "max_inventory < min_inventory");
+    if (std::fmod(d.min_inventory, d.step) != 0 || std::fmod(d.max_inventory, d.step) != 0) return fail(nullptr, SDPGPU_ERR_ARG, "inventory bounds must be multiples of step");
+  } else {
+    if (d.family != SDPGPU_FAMILY_BACKORDER && d.family != SDPGPU_FAMILY_LEADTIME) return fail(nullptr, SDPGPU_ERR_UNSUPPORTED, "clamp_inventory = 0 only for the backorder / lead-time families");
+    if (std::fmod(d.ini_inventory, d.step) != 0) return fail(nullptr, SDPGPU_ERR_ARG, "ini_inventory must be a multiple of step");
+  }
+  if (has_cash(d.family)) {
+    if (!(d.max_cash >= d.min_cash)) return fail(nullptr, SDPGPU_ERR_ARG, "max_cash < min_cash");
+    if (!(d.cash_round_mult > 0) || !(d.cash_round_div > 0)) return fail(nullptr, SDPGPU_ERR_ARG, "cash rounding factors must be positive");
+    if (!d.cash_round_int_div && d.cash_round_mult != d.cash_round_div) return fail(nullptr, SDPGPU_ERR_UNSUPPORTED, "Math.round(c*m)/d with m != d does not map onto a uniform grid");
+    if (d.cash_round_int_div && d.cash_round_div != std::floor(d.cash_round_div)) return fail(nullptr, SDPGPU_ERR_ARG, "integer cash divisor must be integral");
+    if (std::fabs(d.min_cash * d.cash_round_mult) > 2.0e9 || std::fabs(d.max_cash * d.cash_round_mult) > 2.0e9) return fail(nullptr, SDPGPU_ERR_UNSUPPORTED, "cash keys exceed 32 bits");
+  }
+  if ((d.family == SDPGPU_FAMILY_LEADTIME) && d.direction != SDPGPU_MIN) return fail(nullptr, SDPGPU_ERR_ARG, "LeadtimeRecursion is MIN only (LeadtimeRecursion.java:52,66)");
+  if ((d.family == SDPGPU_FAMILY_CASH_LEADTIME) && d.direction != SDPGPU_MAX) return fail(nullptr, SDPGPU_ERR_ARG, "CashLeadtimeRecursion is MAX only (CashLeadtimeRecursion.java:53,70)");
+  return SDPGPU_OK;
+}
+
+int32_t full_action_count(const sdpgpu_desc& d) {
+  if (d.family == SDPGPU_FAMILY_OVERDRAFT || d.family == SDPGPU_FAMILY_CASH_LEADTIME) return java_d2i(d.max_order_quantity) + 1;
+  return java_d2i(d.max_order_quantity / d.step) + 1;
+}
+
+// Per-period grids.  Clamped families: one fixed box.  Unclamped (Leadtime.java:65-66): the box
+// of period t+1 is the image of the period-t box under every action and demand.
+int layout(sdpgpu_handle* h) {
+  if (h->laid_out) return SDPGPU_OK;
+  const sdpgpu_desc& d = h->d;
+  for (int t = 0; t < h->T; ++t)
+    if (!h->pmf_set[t]) return fail(h, SDPGPU_ERR_STATE, "pmf of period %d not set", t + 1);
+  int64_t nc = 1, k_lo = 0, nq = 1;
+  if (has_cash(d.family)) {
+    k_lo = cash_key_of_bound(d, d.min_cash);
+    nc = cash_key_of_bound(d, d.max_cash) - k_lo + 1;
+  }
+  h->n_actions_full = full_action_count(d);
+  if (has_preq(d.family)) nq = java_d2i(d.max_order_quantity / d.step) + 1;
+  double lo = d.min_inventory, hi = d.max_inventory;
+  if (!d.clamp_inventory) lo = hi = d.ini_inventory;
+  size_t v_off = 0, pol_off = 0, pmf_off = 0;
+  int64_t s_pad_max = 0;
+  for (int t = 0; t < h->T; ++t) {
+    PeriodInfo& p = h->per[t];
+    p.g.x_lo = lo;
+    p.g.nx = (int64_t)((hi - lo) / d.step) + 1;
+    p.g.nc = nc;
+    p.g.nq = nq;
+    p.g.k_lo = k_lo;
+    if (p.g.nx >= 2147483647LL || nc >= 2147483647LL) return fail(h, SDPGPU_ERR_UNSUPPORTED, "axis longer than 2^31");
+    p.S = p.g.nx * p.g.nc * p.g.nq;
+    int64_t w = d.world_size;
+    p.S_pad = (p.S + w - 1) / w * w;
+    int64_t slab = p.S_pad / w;
+    p.lo = std::min<int64_t>(p.S, slab * d.rank);
+    p.hi = std::min<int64_t>(p.S, slab * (d.rank + 1));
+    p.nD = (int32_t)h->pmf_d[t].size();
+    p.pmf_off = pmf_off;
+    pmf_off += 2 * (size_t)p.nD;
+    p.v_off = v_off;
+    p.pol_off = pol_off;
+    pol_off += (size_t)slab;
+    if (d.store_all_values) v_off += (size_t)p.S_pad;
+    s_pad_max = std::max(s_pad_max, p.S_pad);
+    if (!p.overhead_set) p.overhead = d.overhead_cost;
+    if (!d.clamp_inventory) {
+      double dmin = h->pmf_d[t][0], dmax = dmin;
+      for (double v : h->pmf_d[t]) {
+        dmin = std::min(dmin, v);
+        dmax = std::max(dmax, v);
+      }
+      double qmax = (double)(h->n_actions_full - 1) * d.step;
+      lo = lo - dmax;
+      hi = hi + qmax - dmin;
+    }
+  }
+  if (!d.store_all_values) {
+    // two ping-pong tables: V_t lives in table (t & 1)
+    for (int t = 0; t < h->T; ++t) h->per[t].v_off = (size_t)((t + 1) & 1) * (size_t)s_pad_max;
+    v_off = 2 * (size_t)s_pad_max;
+  }
+  h->values_elems = v_off;
+  h->policy_elems = pol_off;
+  h->laid_out = true;
+  return SDPGPU_OK;
+}
+
+int ensure_device(sdpgpu_handle* h) {
+  if (h->device >= 0) HIP_TRY(h, hipSetDevice(h->device));
+  return SDPGPU_OK;
+}
+
+int allocate(sdpgpu_handle* h) {
+  if (h->allocated) return SDPGPU_OK;
+  int rc = layout(h);
+  if (rc) return rc;
+  rc = ensure_device(h);
+  if (rc) return rc;
+  int ndev = 0;
+  hipError_t e = hipGetDeviceCount(&ndev);
+  if (e != hipSuccess || ndev < 1)
+    return fail(h, SDPGPU_ERR_DEVICE, "no HIP device available (%s); this library has no CPU path",
+                e == hipSuccess ? "device count 0" : hipGetErrorString(e));
+  if (!h->stream) {
+    HIP_TRY(h, hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking));
+    h->own_stream = true;
+  }
+  if (!h->d_values) {
+    HIP_TRY(h, hipMalloc((void**)&h->d_values, std::max<size_t>(h->values_elems, 1) * sizeof(double)));
+    h->values_external = false;
+  }
+  HIP_TRY(h, hipMalloc((void**)&h->d_policy, std::max<size_t>(h->policy_elems, 1) * sizeof(int32_t)));
+  size_t pmf_elems = 0;
+  for (auto& p : h->per) pmf_elems += 2 * (size_t)p.nD;
+  HIP_TRY(h, hipMalloc((void**)&h->d_pmf, std::max<size_t>(pmf_elems, 1) * sizeof(double)));
+  std::vector<double> host(pmf_elems);
+  for (int t = 0; t < h->T; ++t) {
+    const PeriodInfo& p = h->per[t];
+    std::memcpy(&host[p.pmf_off], h->pmf_d[t].data(), (size_t)p.nD * sizeof(double));
+    std::memcpy(&host[p.pmf_off + p.nD], h->pmf_p[t].data(), (size_t)p.nD * sizeof(double));
+  }
+  HIP_TRY(h, hipMemcpy(h->d_pmf, host.data(), pmf_elems * sizeof(double), hipMemcpyHostToDevice));
+  HIP_TRY(h, hipEventCreate(&h->ev_solve0));
+  HIP_TRY(h, hipEventCreate(&h->ev_solve1));
+  h->allocated = true;
+  return SDPGPU_OK;
+}
+
+DevParams make_params(const sdpgpu_handle* h, int period) {
+  const sdpgpu_desc& d = h->d;
+  const PeriodInfo& p = h->per[period - 1];
+  DevParams P{};
+  P.family = d.family;
+  P.maxdir = d.direction == SDPGPU_MAX;
+  P.is_last = period == h->T;
+  P.n_demand = p.nD;
+  P.clamp_inventory = d.clamp_inventory;
+  P.cash_formula = d.cash_formula;
+  P.cash_round_int_div = d.cash_round_int_div;
+  P.n_actions_full = h->n_actions_full;
+  if (d.family == SDPGPU_FAMILY_CASH_LEADTIME && d.zero_order_last_period && period == h->T) P.n_actions_full = 1;
+  P.step = d.step;
+  P.inv_step = 1.0 / d.step;  // exact: step is a power of two
+  P.min_inventory = d.min_inventory;
+  P.max_inventory = d.max_inventory;
+  P.max_order_quantity = d.max_order_quantity;
+  P.K = d.fixed_order_cost;
+  P.v = d.unit_order_cost;
+  P.h = d.holding_cost;
+  P.pi = d.penalty_cost;
+  P.price = d.price;
+  P.salvage = d.salvage_value;
+  P.one_plus_deposit = 1 + d.deposit_rate;
+  P.overhead = p.overhead;
+  P.one_minus_overhead_rate = 1 - d.overhead_rate;
+  // Recursion / LeadtimeRecursion / CashLeadtimeRecursion have no discount (p * V); p * 1.0 == p
+  // exactly, so one code path serves both loop shapes.
+  bool cash_loop = d.family == SDPGPU_FAMILY_CASH || d.family == SDPGPU_FAMILY_OVERDRAFT;
+  P.gamma = cash_loop ? d.discount_factor : 1.0;
+  P.min_cash = d.min_cash;
+  P.max_cash = d.max_cash;
+  P.round_mult = d.cash_round_mult;
+  P.round_div = d.cash_round_div;
+  P.r0 = d.r0;
+  P.r2 = d.r2;
+  P.r3 = d.r3;
+  P.limit = d.overdraft_limit;
+  P.interest_free = d.interest_free_amount;
+  P.cur = p.g;
+  if (period < h->T) P.next = h->per[period].g;
+  return P;
+}
+
+// ---- launch helpers --------------------------------------------------------------------------
+
+template <int FAM, bool MAXDIR, int SX, bool QUERY>
+hipError_t launch_gather_sx(const DevParams& P, const double* v_next, double* v_cur, int32_t* pol, const double* pmf_d,
+                            const double* pmf_p, int64_t lo, int64_t hi, sdp::QueryStates q, hipStream_t st) {
+  int64_t n = hi - lo;
+  if (n <= 0) return hipSuccess;
+  int64_t blocks = (n + SX - 1) / SX;
+  size_t smem = (size_t)P.n_demand * 16 + 4 * 64 * (sizeof(double) + sizeof(int));
+  hipLaunchKernelGGL((sdp::gather_period_kernel<FAM, MAXDIR, SX, QUERY>), dim3((unsigned)blocks), dim3(256), smem, st, P,
+                     v_next, v_cur, pol, pmf_d, pmf_p, lo, hi, q);
+  return hipGetLastError();
+}
+
+template <int FAM, bool MAXDIR, bool QUERY>
+hipError_t launch_gather_dir(const DevParams& P, const double* v_next, double* v_cur, int32_t* pol, const double* pmf_d,
+                             const double* pmf_p, int64_t lo, int64_t hi, sdp::QueryStates q, hipStream_t st) {
+  // Enough workgroups to fill 256 CUs several times over: shrink the state tile (and widen the
+  // action split) for small grids.
+  int64_t n = hi - lo;
+  if (n >= 64 * 2048) return launch_gather_sx<FAM, MAXDIR, 64, QUERY>(P, v_next, v_cur, pol, pmf_d, pmf_p, lo, hi, q, st);
+  if (n >= 16 * 1024) return launch_gather_sx<FAM, MAXDIR, 16, QUERY>(P, v_next, v_cur, pol, pmf_d, pmf_p, lo, hi, q, st);
+  return launch_gather_sx<FAM, MAXDIR, 4, QUERY>(P, v_next, v_cur, pol, pmf_d, pmf_p, lo, hi, q, st);
+}
+
+template <bool QUERY>
+hipError_t launch_gather(const DevParams& P, const double* v_next, double* v_cur, int32_t* pol, const double* pmf_d,
+                         const double* pmf_p, int64_t lo, int64_t hi, sdp::QueryStates q, hipStream_t st) {
+#define SDP_CASE(F)                                                                                        \
+  case F:                                                                                                  \
+    return P.maxdir ? launch_gather_dir<F, true, QUERY>(P, v_next, v_cur, pol, pmf_d, pmf_p, lo, hi, q, st)  \
+                    : launch_gather_dir<F, false, QUERY>(P, v_next, v_cur, pol, pmf_d, pmf_p, lo, hi, q, st);
+  switch (P.family) {
+    SDP_CASE(sdp::FAM_BACKORDER)
+    SDP_CASE(sdp::FAM_LEADTIME)
+    SDP_CASE(sdp::FAM_CASH)
+    SDP_CASE(sdp::FAM_OVERDRAFT)
+    SDP_CASE(sdp::FAM_CASH_LEADTIME)
+  }
+#undef SDP_CASE
+  return hipErrorInvalidValue;
+}
+
+// cells of one period: sum over states of nA(s) * D  (host arithmetic, no device work)
+void count_cells(sdpgpu_handle* h, int period) {
+  PeriodInfo& p = h->per[period - 1];
+  const sdpgpu_desc& d = h->d;
+  int64_t nD = p.nD;
+  auto range_cells = [&](int64_t lo, int64_t hi) -> int64_t {
+    if (hi <= lo) return 0;
+    if (d.family != SDPGPU_FAMILY_CASH) {
+      int64_t nA = h->n_actions_full;
+      if (d.family == SDPGPU_FAMILY_CASH_LEADTIME && d.zero_order_last_period && period == h->T) nA = 1;
+      return (hi - lo) * nA * nD;
+    }
+    // F3: nA depends on the cash index only; flat = ix * nc + ic
+    int64_t nc = p.g.nc;
+    std::vector<int64_t> pre((size_t)nc + 1, 0);
+    for (int64_t ic = 0; ic < nc; ++ic) {
+      double k = (double)(p.g.k_lo + ic);
+      double cash = d.cash_round_int_div ? k : k / d.cash_round_div;
+      double m = std::fmin(d.max_order_quantity, std::fmax(0.0, (cash - p.overhead - d.fixed_order_cost) / d.unit_order_cost));
+      int64_t nA = (int64_t)java_d2i(m) + 1;
+      pre[(size_t)ic + 1] = pre[(size_t)ic] + nA;
+    }
+    auto upto = [&](int64_t idx) { return (idx / nc) * pre[(size_t)nc] + pre[(size_t)(idx % nc)]; };
+    return (upto(hi) - upto(lo)) * nD;
+  };
+  p.cells_rank = range_cells(p.lo, p.hi);
+  p.cells_all = range_cells(0, p.S);
+}
+
+bool window_eligible(const sdpgpu_handle* h, int period);
+hipError_t launch_window(const sdpgpu_handle* h, const DevParams& P, int period, const double* v_next, double* v_cur,
+                         int32_t* pol, const double* pmf_d, const double* pmf_p, int64_t lo, int64_t hi, hipStream_t st);
+
+int run_period_impl(sdpgpu_handle* h, int period) {
+  int rc = allocate(h);
+  if (rc) return rc;
+  if (period < 1 || period > h->T) return fail(h, SDPGPU_ERR_ARG, "period %d out of 1..%d", period, h->T);
+  if (period < h->T && !h->period_done[period]) return fail(h, SDPGPU_ERR_STATE, "V_%d has not been computed yet (periods run T..1)", period + 1);
+  rc = ensure_device(h);
+  if (rc) return rc;
+  PeriodInfo& p = h->per[period - 1];
+  DevParams P = make_params(h, period);
+  const double* v_next = period < h->T ? h->d_values + h->per[period].v_off : nullptr;
+  double* v_cur = h->d_values + p.v_off;
+  int32_t* pol = h->d_policy + p.pol_off - p.lo;  // kernels index the policy by flat state index
+  const double* pd = h->d_pmf + p.pmf_off;
+  const double* pp = pd + p.nD;
+  if (p.nD > 4000) return fail(h, SDPGPU_ERR_UNSUPPORTED, "pmf with %d points exceeds the LDS tile", p.nD);
+  if (h->profiling) {
+    if (!p.ev0) {
+      HIP_TRY(h, hipEventCreate(&p.ev0));
+      HIP_TRY(h, hipEventCreate(&p.ev1));
+    }
+    HIP_TRY(h, hipEventRecord(p.ev0, h->stream));
+  }
+  bool use_window = false;
+  if (h->d.kernel == SDPGPU_KERNEL_WINDOW) {
+    if (!window_eligible(h, period)) return fail(h, SDPGPU_ERR_UNSUPPORTED, "window kernel needs the backorder / lead-time family with a unit-stride demand grid");
+    use_window = true;
+  } else if (h->d.kernel == SDPGPU_KERNEL_AUTO) {
+    use_window = window_eligible(h, period);
+  }
+  hipError_t e;
+  if (use_window) {
+    e = launch_window(h, P, period, v_next, v_cur, pol, pd, pp, p.lo, p.hi, h->stream);
+    p.kernel_used = SDPGPU_KERNEL_WINDOW;
+  } else {
+    e = launch_gather<false>(P, v_next, v_cur, pol, pd, pp, p.lo, p.hi, sdp::QueryStates{nullptr, nullptr, nullptr}, h->stream);
+    p.kernel_used = SDPGPU_KERNEL_GATHER;
+  }
+  if (e != hipSuccess) return fail(h, SDPGPU_ERR_DEVICE, "period %d kernel launch: %s", period, hipGetErrorString(e));
+  if (h->profiling) {
+    HIP_TRY(h, hipEventRecord(p.ev1, h->stream));
+    p.timed = true;
+  } else {
+    p.timed = false;
+  }
+  h->period_done[period - 1] = 1;
+  if (!h->d.store_all_values && period + 2 <= h->T) h->period_done[period + 1] = 0;  // V_{t+2} was overwritten
+  return SDPGPU_OK;
+}
+
+template <int FAM>
+hipError_t launch_reach_fam(const DevParams& P, const uint8_t* mcur, uint8_t* mnext, const double* pmf_d, int64_t n,
+                            sdp::QueryStates q, bool query, hipStream_t st) {
+  if (n <= 0) return hipSuccess;
+  unsigned blocks = (unsigned)((n + 63) / 64);
+  if (query)
+    hipLaunchKernelGGL((sdp::reach_kernel<FAM, true>), dim3(blocks), dim3(256), 0, st, P, mcur, mnext, pmf_d, n, q);
+  else
+    hipLaunchKernelGGL((sdp::reach_kernel<FAM, false>), dim3(blocks), dim3(256), 0, st, P, mcur, mnext, pmf_d, n, q);
+  return hipGetLastError();
+}
+
+hipError_t launch_reach(const DevParams& P, const uint8_t* mcur, uint8_t* mnext, const double* pmf_d, int64_t n,
+                        sdp::QueryStates q, bool query, hipStream_t st) {
+  switch (P.family) {
+    case sdp::FAM_BACKORDER: return launch_reach_fam<sdp::FAM_BACKORDER>(P, mcur, mnext, pmf_d, n, q, query, st);
+    case sdp::FAM_LEADTIME: return launch_reach_fam<sdp::FAM_LEADTIME>(P, mcur, mnext, pmf_d, n, q, query, st);
+    case sdp::FAM_CASH: return launch_reach_fam<sdp::FAM_CASH>(P, mcur, mnext, pmf_d, n, q, query, st);
+    case sdp::FAM_OVERDRAFT: return launch_reach_fam<sdp::FAM_OVERDRAFT>(P, mcur, mnext, pmf_d, n, q, query, st);
+    case sdp::FAM_CASH_LEADTIME: return launch_reach_fam<sdp::FAM_CASH_LEADTIME>(P, mcur, mnext, pmf_d, n, q, query, st);
+  }
+  return hipErrorInvalidValue;
+}
+
+// Forward propagation from (1, ini_inventory, ini_cash, ini_preq) through every period.
+int compute_reachable(sdpgpu_handle* h) {
+  if (h->reach_done) return SDPGPU_OK;
+  int rc = allocate(h);
+  if (rc) return rc;
+  rc = ensure_device(h);
+  if (rc) return rc;
+  h->reach_off.assign((size_t)h->T, 0);
+  size_t total = 0;
+  for (int t = 0; t < h->T; ++t) {
+    h->reach_off[t] = total;
+    total += (size_t)h->per[t].S;
+  }
+  if (!h->d_reach) HIP_TRY(h, hipMalloc((void**)&h->d_reach, std::max<size_t>(total, 1)));
+  HIP_TRY(h, hipMemsetAsync(h->d_reach, 0, std::max<size_t>(total, 1), h->stream));
+  const sdpgpu_desc& d = h->d;
+  double ini[3] = {d.ini_inventory, has_cash(d.family) ? d.ini_cash : 0.0, has_preq(d.family) ? d.ini_preq : 0.0};
+  int64_t i0 = sdpgpu_state_index(h, 1, ini[0], ini[1], ini[2]);
+  if (i0 >= 0) {
+    uint8_t one = 1;
+    HIP_TRY(h, hipMemcpyAsync(h->d_reach + i0, &one, 1, hipMemcpyHostToDevice, h->stream));
+    HIP_TRY(h, hipStreamSynchronize(h->stream));
+  }
+  double* d_ini = nullptr;
+  HIP_TRY(h, hipMalloc((void**)&d_ini, sizeof ini));
+  hipError_t e = hipMemcpy(d_ini, ini, sizeof ini, hipMemcpyHostToDevice);
+  for (int period = 1; period < h->T && e == hipSuccess; ++period) {
+    DevParams P = make_params(h, period);
+    const PeriodInfo& p = h->per[period - 1];
+    const double* pd = h->d_pmf + p.pmf_off;
+    uint8_t* mnext = h->d_reach + h->reach_off[period];
+    if (period == 1)
+      e = launch_reach(P, nullptr, mnext, pd, 1, sdp::QueryStates{d_ini, d_ini + 1, d_ini + 2}, true, h->stream);
+    else
+      e = launch_reach(P, h->d_reach + h->reach_off[period - 1], mnext, pd, p.S, sdp::QueryStates{nullptr, nullptr, nullptr}, false, h->stream);
+  }
+  if (e == hipSuccess) e = hipStreamSynchronize(h->stream);
+  (void)hipFree(d_ini);
+  if (e != hipSuccess) return fail(h, SDPGPU_ERR_DEVICE, "reachable: %s", hipGetErrorString(e));
+  h->reach_done = true;
+  return SDPGPU_OK;
+}
+
+bool window_eligible(const sdpgpu_handle*, int) { return false; }
+hipError_t launch_window(const sdpgpu_handle*, const DevParams&, int, const double*, double*, int32_t*, const double*,
+                         const double*, int64_t, int64_t, hipStream_t) {
+  return hipErrorNotSupported;
+}
+
+}  // namespace
+
+// =================================================================================================
+// C ABI
+// =================================================================================================
+extern "C" {
+
+int sdpgpu_abi_version(void) { return SDPGPU_ABI_VERSION; }
+
+void sdpgpu_desc_init(sdpgpu_desc* d) {
+  if (!d) return;
+  std::memset(d, 0, sizeof *d);
+  d->abi_version = SDPGPU_ABI_VERSION;
+  d->family = SDPGPU_FAMILY_BACKORDER;
+  d->direction = SDPGPU_MIN;
+  d->periods = 1;
+  d->step = 1;
+  d->clamp_inventory = 1;
+  d->discount_factor = 1;
+  d->cash_round_mult = 10;
+  d->cash_round_div = 10;
+  d->kernel = SDPGPU_KERNEL_AUTO;
+  d->device = -1;
+  d->rank = 0;
+  d->world_size = 1;
+  d->store_all_values = 1;
+}
+
+int sdpgpu_create(const sdpgpu_desc* desc, sdpgpu_handle** out) {
+  g_create_error.clear();
+  if (!desc || !out) return fail(nullptr, SDPGPU_ERR_ARG, "null argument");
+  *out = nullptr;
+  int rc = validate(*desc);
+  if (rc) return rc;
+  sdpgpu_handle* h = new (std::nothrow) sdpgpu_handle();
+  if (!h) return fail(nullptr, SDPGPU_ERR_ARG, "out of host memory");
+  try {
+    h->d = *desc;
+    h->T = desc->periods;
+    h->device = desc->device;
+    h->per.resize((size_t)h->T);
+    h->pmf_d.resize((size_t)h->T);
+    h->pmf_p.resize((size_t)h->T);
+    h->pmf_set.assign((size_t)h->T, 0);
+    h->period_done.assign((size_t)h->T, 0);
+  } catch (...) {
+    delete h;
+    return fail(nullptr, SDPGPU_ERR_ARG, "out of host memory");
+  }
+  *out = h;
+  return SDPGPU_OK;
+}
+
+void sdpgpu_destroy(sdpgpu_handle* h) {
+  if (!h) return;
+  if (h->allocated || h->d_policy || h->d_pmf) {
+    if (h->device >= 0) (void)hipSetDevice(h->device);
+    if (h->stream) (void)hipStreamSynchronize(h->stream);
+  }
+  for (auto& p : h->per) {
+    if (p.ev0) (void)hipEventDestroy(p.ev0);
+    if (p.ev1) (void)hipEventDestroy(p.ev1);
+  }
+  if (h->ev_solve0) (void)hipEventDestroy(h->ev_solve0);
+  if (h->ev_solve1) (void)hipEventDestroy(h->ev_solve1);
+  if (h->d_values && !h->values_external) (void)hipFree(h->d_values);
+  if (h->d_policy) (void)hipFree(h->d_policy);
+  if (h->d_pmf) (void)hipFree(h->d_pmf);
+  if (h->d_reach) (void)hipFree(h->d_reach);
+  if (h->stream && h->own_stream) (void)hipStreamDestroy(h->stream);
+  delete h;
+}
+
+const char* sdpgpu_last_error(const sdpgpu_handle* h) { return h ? h->err.c_str() : g_create_error.c_str(); }
+
+int sdpgpu_set_pmf(sdpgpu_handle* h, int32_t t, const double* demand, const double* prob, int32_t n) {
+  if (!h) return SDPGPU_ERR_ARG;
+  h->err.clear();
+  if (t < 0 || t >= h->T || !demand || !prob || n < 1) return fail(h, SDPGPU_ERR_ARG, "set_pmf: bad argument (t=%d n=%d)", t, n);
+  if (h->allocated) return fail(h, SDPGPU_ERR_STATE, "pmf is frozen once the device tables exist");
+  for (int32_t j = 0; j < n; ++j) {
+    if (std::fmod(demand[j], h->d.step) != 0) return fail(h, SDPGPU_ERR_ARG, "demand %g of period %d is not a multiple of step", demand[j], t + 1);
+    if (j && !(demand[j] > demand[j - 1])) return fail(h, SDPGPU_ERR_ARG, "demands of period %d must be strictly ascending", t + 1);
+  }
+  try {
+    h->pmf_d[t].assign(demand, demand + n);
+    h->pmf_p[t].assign(prob, prob + n);
+  } catch (...) {
+    return fail(h, SDPGPU_ERR_ARG, "out of host memory");
+  }
+  h->pmf_set[t] = 1;
+  h->laid_out = false;
+  return SDPGPU_OK;
+}
+
+int sdpgpu_set_overhead(sdpgpu_handle* h, int32_t t, double overhead_cost) {
+  if (!h) return SDPGPU_ERR_ARG;
+  h->err.clear();
+  if (t < 0 || t >= h->T) return fail(h, SDPGPU_ERR_ARG, "set_overhead: t=%d", t);
+  h->per[t].overhead = overhead_cost;
+  h->per[t].overhead_set = true;
+  return SDPGPU_OK;
+}
+
+int sdpgpu_set_stream(sdpgpu_handle* h, void* hip_stream) {
+  if (!h) return SDPGPU_ERR_ARG;
+  h->err.clear();
+  if (h->stream && h->own_stream) {
+    (void)hipStreamSynchronize(h->stream);
+    (void)hipStreamDestroy(h->stream);
+  }
+  h->stream = (hipStream_t)hip_stream;
+  h->own_stream = false;
+  if (!hip_stream && h->allocated) {
+    HIP_TRY(h, hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking));
+    h->own_stream = true;
+  }
+  return SDPGPU_OK;
+}
+
+int sdpgpu_set_profiling(sdpgpu_handle* h, int32_t on) {
+  if (!h) return SDPGPU_ERR_ARG;
+  h->profiling = on != 0;
+  return SDPGPU_OK;
+}
+
+int64_t sdpgpu_num_states(const sdpgpu_handle* hc, int32_t period) {
+  sdpgpu_handle* h = const_cast<sdpgpu_handle*>(hc);
+  if (!h || period < 1 || period > h->T) return -1;
+  if (layout(h)) return -1;
+  return h->per[period - 1].S;
+}
+
+int sdpgpu_slab(const sdpgpu_handle* hc, int32_t period, int64_t* padded, int64_t* lo, int64_t* hi) {
+  sdpgpu_handle* h = const_cast<sdpgpu_handle*>(hc);
+  if (!h) return SDPGPU_ERR_ARG;
+  if (period < 1 || period > h->T) return fail(h, SDPGPU_ERR_ARG, "period %d", period);
+  int rc = layout(h);
+  if (rc) return rc;
+  const PeriodInfo& p = h->per[period - 1];
+  if (padded) *padded = p.S_pad;
+  if (lo) *lo = p.lo;
+  if (hi) *hi = p.hi;
+  return SDPGPU_OK;
+}
+
+int sdpgpu_grid(const sdpgpu_handle* hc, int32_t period, double* x_lo, int64_t* nx, int64_t* nc, int64_t* nq) {
+  sdpgpu_handle* h = const_cast<sdpgpu_handle*>(hc);
+  if (!h) return SDPGPU_ERR_ARG;
+  if (period < 1 || period > h->T) return fail(h, SDPGPU_ERR_ARG, "period %d", period);
+  int rc = layout(h);
+  if (rc) return rc;
+  const Grid& g = h->per[period - 1].g;
+  if (x_lo) *x_lo = g.x_lo;
+  if (nx) *nx = g.nx;
+  if (nc) *nc = g.nc;
+  if (nq) *nq = g.nq;
+  return SDPGPU_OK;
+}
+
+double sdpgpu_cash_value(const sdpgpu_handle* hc, int64_t ic) {
+  sdpgpu_handle* h = const_cast<sdpgpu_handle*>(hc);
+  if (!h || !has_cash(h->d.family) || layout(h)) return NAN;
+  double k = (double)(h->per[0].g.k_lo + ic);
+  return h->d.cash_round_int_div ? k : k / h->d.cash_round_div;
+}
+
+int64_t sdpgpu_state_index(const sdpgpu_handle* hc, int32_t period, double x, double cash, double preq) {
+  sdpgpu_handle* h = const_cast<sdpgpu_handle*>(hc);
+  if (!h || period < 1 || period > h->T || layout(h)) return -1;
+  const sdpgpu_desc& d = h->d;
+  const Grid& g = h->per[period - 1].g;
+  double qx = (x - g.x_lo) / d.step;
+  int64_t ix = (int64_t)qx;
+  if ((double)ix != qx || ix < 0 || ix >= g.nx) return -1;
+  int64_t ic = 0, iq = 0;
+  if (has_cash(d.family)) {
+    int64_t k = d.cash_round_int_div ? (int64_t)cash : java_round(cash * d.cash_round_mult);
+    double back = d.cash_round_int_div ? (double)k : (double)k / d.cash_round_div;
+    if (back != cash) return -1;
+    ic = k - g.k_lo;
+    if (ic < 0 || ic >= g.nc) return -1;
+  }
+  if (has_preq(d.family)) {
+    double qq = preq / d.step;
+    iq = (int64_t)qq;
+    if ((double)iq != qq || iq < 0 || iq >= g.nq) return -1;
+  }
+  return (iq * g.nx + ix) * g.nc + ic;
+}
+
+size_t sdpgpu_values_bytes(const sdpgpu_handle* hc) {
+  sdpgpu_handle* h = const_cast<sdpgpu_handle*>(hc);
+  if (!h || layout(h)) return 0;
+  return std::max<size_t>(h->values_elems, 1) * sizeof(double);
+}
+
+int sdpgpu_attach_values(sdpgpu_handle* h, void* device_ptr, size_t bytes) {
+  if (!h) return SDPGPU_ERR_ARG;
+  h->err.clear();
+  if (h->allocated) return fail(h, SDPGPU_ERR_STATE, "attach_values must precede the first run");
+  int rc = layout(h);
+  if (rc) return rc;
+  if (!device_ptr || bytes < std::max<size_t>(h->values_elems, 1) * sizeof(double))
+    return fail(h, SDPGPU_ERR_ARG, "attach_values: need %zu bytes", std::max<size_t>(h->values_elems, 1) * sizeof(double));
+  h->d_values = (double*)device_ptr;
+  h->values_external = true;
+  return SDPGPU_OK;
+}
+
+void* sdpgpu_values_device_ptr(sdpgpu_handle* h, int32_t period) {
+  if (!h || period < 1 || period > h->T) return nullptr;
+  if (allocate(h)) return nullptr;
+  return h->d_values + h->per[period - 1].v_off;
+}
+
+int sdpgpu_run_period(sdpgpu_handle* h, int32_t period) {
+  if (!h) return SDPGPU_ERR_ARG;
+  h->err.clear();
+  try {
+    int rc = run_period_impl(h, period);
+    if (rc == SDPGPU_OK) count_cells(h, period);
+    return rc;
+  } catch (const std::exception& e) {
+    return fail(h, SDPGPU_ERR_ARG, "exception: %s", e.what());
+  } catch (...) {
+    return fail(h, SDPGPU_ERR_ARG, "unknown exception");
+  }
+}
+
+int sdpgpu_solve(sdpgpu_handle* h, int32_t sync) {
+  if (!h) return SDPGPU_ERR_ARG;
+  h->err.clear();
+  if (h->d.world_size != 1) return fail(h, SDPGPU_ERR_STATE, "sdpgpu_solve needs world_size 1; sharded handles run period by period with an all-gather in between");
+  try {
+    int rc = allocate(h);
+    if (rc) return rc;
+    std::fill(h->period_done.begin(), h->period_done.end(), 0);
+    HIP_TRY(h, hipEventRecord(h->ev_solve0, h->stream));
+    for (int period = h->T; period >= 1; --period) {
+      rc = run_period_impl(h, period);
+      if (rc) return rc;
+    }
+    HIP_TRY(h, hipEventRecord(h->ev_solve1, h->stream));
+    h->solve_timed = true;
+    for (int period = 1; period <= h->T; ++period)
+      if (h->per[period - 1].cells_all == 0) count_cells(h, period);
+    if (sync) HIP_TRY(h, hipStreamSynchronize(h->stream));
+    return SDPGPU_OK;
+  } catch (const std::exception& e) {
+    return fail(h, SDPGPU_ERR_ARG, "exception: %s", e.what());
+  } catch (...) {
+    return fail(h, SDPGPU_ERR_ARG, "unknown exception");
+  }
+}
+
+int sdpgpu_synchronize(sdpgpu_handle* h) {
+  if (!h) return SDPGPU_ERR_ARG;
+  h->err.clear();
+  if (!h->allocated) return SDPGPU_OK;
+  int rc = ensure_device(h);
+  if (rc) return rc;
+  HIP_TRY(h, hipStreamSynchronize(h->stream));
+  return SDPGPU_OK;
+}
+
+int sdpgpu_values(sdpgpu_handle* h, int32_t period, double* out, int64_t n) {
+  if (!h) return SDPGPU_ERR_ARG;
+  h->err.clear();
+  if (period < 1 || period > h->T || !out) return fail(h, SDPGPU_ERR_ARG, "values: bad argument");
+  if (!h->allocated || !h->period_done[period - 1]) return fail(h, SDPGPU_ERR_STATE, "V_%d has not been computed", period);
+  const PeriodInfo& p = h->per[period - 1];
+  if (n < 0 || n > p.S) return fail(h, SDPGPU_ERR_ARG, "values: n=%lld > %lld states", (long long)n, (long long)p.S);
+  int rc = ensure_device(h);
+  if (rc) return rc;
+  HIP_TRY(h, hipStreamSynchronize(h->stream));
+  HIP_TRY(h, hipMemcpy(out, h->d_values + p.v_off, (size_t)n * sizeof(double), hipMemcpyDeviceToHost));
+  return SDPGPU_OK;
+}
+
+int sdpgpu_policy(sdpgpu_handle* h, int32_t period, int32_t* out, int64_t lo, int64_t n) {
+  if (!h) return SDPGPU_ERR_ARG;
+  h->err.clear();
+  if (period < 1 || period > h->T || !out) return fail(h, SDPGPU_ERR_ARG, "policy: bad argument");
+  if (!h->allocated || !h->period_done[period - 1]) return fail(h, SDPGPU_ERR_STATE, "period %d has not been computed", period);
+  const PeriodInfo& p = h->per[period - 1];
+  if (lo < p.lo || n < 0 || lo + n > p.hi) return fail(h, SDPGPU_ERR_ARG, "policy: [%lld, %lld) outside this rank's slab [%lld, %lld)", (long long)lo, (long long)(lo + n), (long long)p.lo, (long long)p.hi);
+  int rc = ensure_device(h);
+  if (rc) return rc;
+  HIP_TRY(h, hipStreamSynchronize(h->stream));
+  HIP_TRY(h, hipMemcpy(out, h->d_policy + p.pol_off + (lo - p.lo), (size_t)n * sizeof(int32_t), hipMemcpyDeviceToHost));
+  return SDPGPU_OK;
+}
+
+int sdpgpu_eval_states(sdpgpu_handle* h, int32_t period, int64_t n, const double* x, const double* cash,
+                       const double* preq, double* out_value, int32_t* out_action_index) {
+  if (!h) return SDPGPU_ERR_ARG;
+  h->err.clear();
+  if (period < 1 || period > h->T || n < 0 || !x || !out_value || !out_action_index) return fail(h, SDPGPU_ERR_ARG, "eval_states: bad argument");
+  if (has_cash(h->d.family) && !cash) return fail(h, SDPGPU_ERR_ARG, "eval_states: cash array required");
+  if (has_preq(h->d.family) && !preq) return fail(h, SDPGPU_ERR_ARG, "eval_states: preq array required");
+  int rc = allocate(h);
+  if (rc) return rc;
+  if (period < h->T && !h->period_done[period]) return fail(h, SDPGPU_ERR_STATE, "V_%d has not been computed", period + 1);
+  if (n == 0) return SDPGPU_OK;
+  rc = ensure_device(h);
+  if (rc) return rc;
+  double* d_in = nullptr;
+  double* d_val = nullptr;
+  int32_t* d_act = nullptr;
+  size_t nn = (size_t)n;
+  HIP_TRY(h, hipMalloc((void**)&d_in, 3 * nn * sizeof(double)));
+  hipError_t e = hipMalloc((void**)&d_val, nn * sizeof(double));
+  if (e == hipSuccess) e = hipMalloc((void**)&d_act, nn * sizeof(int32_t));
+  if (e == hipSuccess) e = hipMemcpy(d_in, x, nn * sizeof(double), hipMemcpyHostToDevice);
+  if (e == hipSuccess && cash) e = hipMemcpy(d_in + nn, cash, nn * sizeof(double), hipMemcpyHostToDevice);
+  if (e == hipSuccess && preq) e = hipMemcpy(d_in + 2 * nn, preq, nn * sizeof(double), hipMemcpyHostToDevice);
+  if (e == hipSuccess) {
+    DevParams P = make_params(h, period);
+    const PeriodInfo& p = h->per[period - 1];
+    const double* v_next = period < h->T ? h->d_values + h->per[period].v_off : nullptr;
+    const double* pd = h->d_pmf + p.pmf_off;
+    sdp::QueryStates q{d_in, cash ? d_in + nn : nullptr, preq ? d_in + 2 * nn : nullptr};
+    e = launch_gather<true>(P, v_next, d_val, d_act, pd, pd + p.nD, 0, n, q, h->stream);
+  }
+  if (e == hipSuccess) e = hipStreamSynchronize(h->stream);
+  if (e == hipSuccess) e = hipMemcpy(out_value, d_val, nn * sizeof(double), hipMemcpyDeviceToHost);
+  if (e == hipSuccess) e = hipMemcpy(out_action_index, d_act, nn * sizeof(int32_t), hipMemcpyDeviceToHost);
+  (void)hipFree(d_in);
+  (void)hipFree(d_val);
+  (void)hipFree(d_act);
+  if (e != hipSuccess) return fail(h, SDPGPU_ERR_DEVICE, "eval_states: %s", hipGetErrorString(e));
+  return SDPGPU_OK;
+}
+
+int sdpgpu_reachable(sdpgpu_handle* h, int32_t period, uint8_t* out, int64_t n) {
+  if (!h) return SDPGPU_ERR_ARG;
+  h->err.clear();
+  if (period < 1 || period > h->T || !out) return fail(h, SDPGPU_ERR_ARG, "reachable: bad argument");
+  int rc = compute_reachable(h);
+  if (rc) return rc;
+  const PeriodInfo& p = h->per[period - 1];
+  if (n < 0 || n > p.S) return fail(h, SDPGPU_ERR_ARG, "reachable: n=%lld > %lld states", (long long)n, (long long)p.S);
+  HIP_TRY(h, hipMemcpy(out, h->d_reach + h->reach_off[period - 1], (size_t)n, hipMemcpyDeviceToHost));
+  return SDPGPU_OK;
+}
+
+int sdpgpu_stats_get(sdpgpu_handle* h, sdpgpu_stats* out) {
+  if (!h || !out) return SDPGPU_ERR_ARG;
+  h->err.clear();
+  std::memset(out, 0, sizeof *out);
+  if (layout(h)) return SDPGPU_ERR_STATE;
+  for (int t = 0; t < h->T; ++t) {
+    const PeriodInfo& p = h->per[t];
+    out->states_total += p.S;
+    out->cells_evaluated += p.cells_rank;
+    out->cells_all_ranks += p.cells_all;
+    if (h->period_done[t]) out->periods_run++;
+  }
+  out->kernel_used = h->per[0].kernel_used;
+  if (h->allocated) {
+    (void)ensure_device(h);
+    if (h->solve_timed && hipStreamSynchronize(h->stream) == hipSuccess) {
+      float ms = 0;
+      if (hipEventElapsedTime(&ms, h->ev_solve0, h->ev_solve1) == hipSuccess) out->solve_ms = ms;
+    }
+    for (int t = 0; t < h->T; ++t) {
+      const PeriodInfo& p = h->per[t];
+      if (p.timed) {
+        float ms = 0;
+        if (hipEventElapsedTime(&ms, p.ev0, p.ev1) == hipSuccess) out->kernel_ms_sum += ms;
+      }
+    }
+  }
+  return SDPGPU_OK;
+}
+
+double sdpgpu_period_ms(sdpgpu_handle* h, int32_t period) {
+  if (!h || period < 1 || period > h->T) return -1;
+  const PeriodInfo& p = h->per[period - 1];
+  if (!p.timed) return -1;
+  (void)ensure_device(h);
+  if (hipStreamSynchronize(h->stream) != hipSuccess) return -1;
+  float ms = 0;
+  if (hipEventElapsedTime(&ms, p.ev0, p.ev1) != hipSuccess) return -1;
+  return ms;
+}
+
+}  // extern "C"

@@ -1,0 +1,172 @@
+"""Thin object wrapper over one sdpgpu_handle (include/sdpgpu.h).
+
+`pmf` follows the reference's `double[][][] pmf` (Recursion.java:38): pmf[t][j] = [demand, prob].
+"""
+from __future__ import annotations
+
+import ctypes as C
+from typing import Optional, Sequence
+
+import numpy as np
+
+from . import _abi
+from ._abi import SdpgpuDesc, SdpgpuError, SdpgpuStats
+
+
+def _dp(a: np.ndarray):
+    return a.ctypes.data_as(C.POINTER(C.c_double))
+
+
+def _ip(a: np.ndarray):
+    return a.ctypes.data_as(C.POINTER(C.c_int32))
+
+
+def split_pmf(pmf):
+    """pmf[t][j] = (demand, prob) -> list of (demand array, prob array) per period."""
+    out = []
+    for tile in pmf:
+        arr = np.asarray(tile, dtype=np.float64)
+        if arr.ndim != 2 or arr.shape[1] != 2 or arr.shape[0] < 1:
+            raise ValueError("pmf[t] must be an array of [demand, prob] pairs")
+        out.append((np.ascontiguousarray(arr[:, 0]), np.ascontiguousarray(arr[:, 1])))
+    return out
+
+
+class SdpEngine:
+    """One backward-recursion problem on one GPU (or one rank's state slab of it)."""
+
+    def __init__(self, desc: SdpgpuDesc, pmf, overhead: Optional[Sequence[float]] = None):
+        self._lib = _abi.load()
+        self._h = C.c_void_p()
+        self.desc = desc
+        tiles = split_pmf(pmf)
+        if len(tiles) != desc.periods:
+            raise ValueError(f"pmf has {len(tiles)} periods, descriptor says {desc.periods}")
+        rc = self._lib.sdpgpu_create(C.byref(desc), C.byref(self._h))
+        if rc:
+            raise SdpgpuError(rc, self._lib.sdpgpu_last_error(None).decode())
+        try:
+            for t, (d, p) in enumerate(tiles):
+                self._check(self._lib.sdpgpu_set_pmf(self._h, t, _dp(d), _dp(p), len(d)))
+            if overhead is not None:
+                for t, oh in enumerate(overhead):
+                    self._check(self._lib.sdpgpu_set_overhead(self._h, t, float(oh)))
+        except Exception:
+            self.close()
+            raise
+        self.T = desc.periods
+
+    # -- plumbing ---------------------------------------------------------------------------
+    def _check(self, rc: int):
+        if rc:
+            raise SdpgpuError(rc, self._lib.sdpgpu_last_error(self._h).decode())
+
+    def close(self):
+        if getattr(self, "_h", None) is not None and self._h:
+            self._lib.sdpgpu_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        self.close()
+
+    # -- geometry ---------------------------------------------------------------------------
+    def num_states(self, period: int) -> int:
+        n = self._lib.sdpgpu_num_states(self._h, period)
+        if n < 0:
+            raise SdpgpuError(2, self._lib.sdpgpu_last_error(self._h).decode() or "layout not available")
+        return int(n)
+
+    def slab(self, period: int):
+        pad, lo, hi = C.c_int64(), C.c_int64(), C.c_int64()
+        self._check(self._lib.sdpgpu_slab(self._h, period, C.byref(pad), C.byref(lo), C.byref(hi)))
+        return pad.value, lo.value, hi.value
+
+    def grid(self, period: int):
+        x_lo = C.c_double()
+        nx, nc, nq = C.c_int64(), C.c_int64(), C.c_int64()
+        self._check(self._lib.sdpgpu_grid(self._h, period, C.byref(x_lo), C.byref(nx), C.byref(nc), C.byref(nq)))
+        return x_lo.value, nx.value, nc.value, nq.value
+
+    def cash_value(self, ic: int) -> float:
+        return float(self._lib.sdpgpu_cash_value(self._h, ic))
+
+    def state_index(self, period: int, x: float, cash: float = 0.0, preq: float = 0.0) -> int:
+        return int(self._lib.sdpgpu_state_index(self._h, period, float(x), float(cash), float(preq)))
+
+    # -- execution --------------------------------------------------------------------------
+    def set_stream(self, hip_stream: int):
+        self._check(self._lib.sdpgpu_set_stream(self._h, C.c_void_p(hip_stream)))
+
+    def set_profiling(self, on: bool):
+        self._check(self._lib.sdpgpu_set_profiling(self._h, 1 if on else 0))
+
+    def solve(self, sync: bool = True):
+        self._check(self._lib.sdpgpu_solve(self._h, 1 if sync else 0))
+
+    def run_period(self, period: int):
+        self._check(self._lib.sdpgpu_run_period(self._h, period))
+
+    def synchronize(self):
+        self._check(self._lib.sdpgpu_synchronize(self._h))
+
+    def values_bytes(self) -> int:
+        return int(self._lib.sdpgpu_values_bytes(self._h))
+
+    def attach_values(self, device_ptr: int, nbytes: int):
+        self._check(self._lib.sdpgpu_attach_values(self._h, C.c_void_p(device_ptr), nbytes))
+
+    def values_device_ptr(self, period: int) -> int:
+        p = self._lib.sdpgpu_values_device_ptr(self._h, period)
+        if not p:
+            raise SdpgpuError(3, self._lib.sdpgpu_last_error(self._h).decode() or "no device table")
+        return int(p)
+
+    # -- results ----------------------------------------------------------------------------
+    def values(self, period: int) -> np.ndarray:
+        n = self.num_states(period)
+        out = np.empty(n, dtype=np.float64)
+        self._check(self._lib.sdpgpu_values(self._h, period, _dp(out), n))
+        return out
+
+    def policy(self, period: int) -> np.ndarray:
+        """Arg-opt action INDEX of this rank's slab (action = index * step)."""
+        _, lo, hi = self.slab(period)
+        out = np.empty(hi - lo, dtype=np.int32)
+        self._check(self._lib.sdpgpu_policy(self._h, period, _ip(out), lo, hi - lo))
+        return out
+
+    def eval_states(self, period: int, x, cash=None, preq=None):
+        x = np.ascontiguousarray(x, dtype=np.float64)
+        n = len(x)
+        cash_a = None if cash is None else np.ascontiguousarray(cash, dtype=np.float64)
+        preq_a = None if preq is None else np.ascontiguousarray(preq, dtype=np.float64)
+        val = np.empty(n, dtype=np.float64)
+        act = np.empty(n, dtype=np.int32)
+        self._check(
+            self._lib.sdpgpu_eval_states(
+                self._h, period, n, _dp(x), None if cash_a is None else _dp(cash_a),
+                None if preq_a is None else _dp(preq_a), _dp(val), _ip(act)))
+        return val, act
+
+    def reachable(self, period: int) -> np.ndarray:
+        n = self.num_states(period)
+        out = np.empty(n, dtype=np.uint8)
+        self._check(self._lib.sdpgpu_reachable(self._h, period, out.ctypes.data_as(C.POINTER(C.c_uint8)), n))
+        return out.astype(bool)
+
+    def stats(self) -> SdpgpuStats:
+        st = SdpgpuStats()
+        self._check(self._lib.sdpgpu_stats_get(self._h, C.byref(st)))
+        return st
+
+    def period_ms(self, period: int) -> float:
+        return float(self._lib.sdpgpu_period_ms(self._h, period))

@@ -1,0 +1,103 @@
+"""Synthetic workloads = the BASELINE.json configs, as laid out in SURVEY.md section 8(d).
+
+Deterministic, closed-form inputs (no RNG, no data files): a D-point period has support
+d = 0..D-1 with p_d proportional to the Poisson(lambda_t) pmf renormalised over the support
+(the shape GetPmf.java:123-124 produces), lambda_t = (D/2)(1 + 0.25 sin(2 pi t / T)), so every
+period has a distinct PMF tile.
+"""
+from __future__ import annotations
+
+import math
+from dataclasses import dataclass
+from typing import List, Optional
+
+import numpy as np
+
+from .functors import BackorderFunctor, CashFunctor, LeadtimeFunctor
+from .states import OptDirection
+
+
+def truncated_poisson_tile(lam: float, D: int) -> np.ndarray:
+    """[[d, p_d]] for d = 0..D-1, p_d = Poisson(lam) pmf / sum over the support."""
+    d = np.arange(D, dtype=np.float64)
+    logp = -lam + d * math.log(lam) - np.array([math.lgamma(k + 1.0) for k in range(D)])
+    p = np.exp(logp - logp.max())
+    p = p / p.sum()
+    return np.stack([d, p], axis=1)
+
+
+def seasonal_pmf(T: int, D: int) -> List[np.ndarray]:
+    return [truncated_poisson_tile((D / 2.0) * (1.0 + 0.25 * math.sin(2.0 * math.pi * (t + 1) / T)), D)
+            for t in range(T)]
+
+
+@dataclass
+class Workload:
+    name: str
+    functor: object
+    direction: OptDirection
+    pmf: List[np.ndarray]
+    note: str = ""
+
+    @property
+    def T(self) -> int:
+        return len(self.pmf)
+
+    def desc(self):
+        return self.functor.to_desc(self.T, self.direction)
+
+    def overhead(self):
+        return self.functor.overheads(self.T) if hasattr(self.functor, "overheads") else None
+
+
+def cfg1_sS(T: int = 12) -> Workload:
+    """configs[0]: single-item (s,S), Poisson(10) truncated at q = 0.9999 (support 0..24), 200 states."""
+    f = BackorderFunctor(fixedOrderingCost=500, variOrderingCost=0, holdingCost=2, penaltyCost=10,
+                         minInventory=-100, maxInventory=99, maxOrderQuantity=100, iniInventory=0)
+    pmf = [truncated_poisson_tile(10.0, 25) for _ in range(T)]
+    return Workload("cfg1_sS_200x101x25", f, OptDirection.MIN, pmf, "src/sdp Recursion plumbing case")
+
+
+def cfg2_clsp(T: int = 52, S: int = 10000, A: int = 200, D: int = 100) -> Workload:
+    """configs[1]: capacitated lot sizing, 1e4 states x 200 actions x 100 demands, 52 periods."""
+    f = BackorderFunctor(fixedOrderingCost=500, variOrderingCost=1, holdingCost=2, penaltyCost=10,
+                         minInventory=-(S // 2), maxInventory=S - S // 2 - 1, maxOrderQuantity=A - 1,
+                         iniInventory=0)
+    return Workload(f"cfg2_clsp_{S}x{A}x{D}x{T}", f, OptDirection.MIN, seasonal_pmf(T, D),
+                    "src/capacitated CLSP.f")
+
+
+def cfg3_cash(T: int = 6, NX: int = 200, NC: int = 5000, A: int = 300, D: int = 150) -> Workload:
+    """configs[2]: cash-constrained 2-D state (inventory x cash), 1e6 states x <=300 actions x 150."""
+    f = CashFunctor(price=10, fixOrderCost=0, variCost=1, holdingCost=0, depositeRate=0, overheadCost=0,
+                    overheadRate=0, salvageValue=0.5, penaltyCost=0, discountFactor=1.0,
+                    maxOrderQuantity=A - 1, minInventoryState=0, maxInventoryState=NX - 1,
+                    minCashState=0, maxCashState=NC - 1, cashRoundMult=1.0, cashRoundDiv=1.0,
+                    cashRoundIntDiv=True, cashFormula=0, iniInventory=0, iniCash=100)
+    return Workload(f"cfg3_cash_{NX}x{NC}x{A}x{D}x{T}", f, OptDirection.MAX, seasonal_pmf(T, D),
+                    "src/cash CashConstraint via CashRecursion, cash quantum 1")
+
+
+def cfg4_leadtime(T: int = 4, NX: int = 250, A: int = 200, D: int = 100) -> Workload:
+    """configs[3] (lead time 1 shape of Leadtime.java, clamped synthetic grid)."""
+    f = LeadtimeFunctor(fixedOrderingCost=0, variOrderingCost=1, holdingCost=2, penaltyCost=10,
+                        maxOrderQuantity=A - 1, clampInventory=True, minInventory=-50,
+                        maxInventory=NX - 51, iniInventory=0, iniPreQ=0)
+    return Workload(f"cfg4_leadtime_{NX}x{A}q x{A}x{D}x{T}", f, OptDirection.MIN, seasonal_pmf(T, D),
+                    "src/leadtime via LeadtimeRecursion")
+
+
+def cfg5_scaled(S: int, T: int = 3, A: int = 500, D: int = 200) -> Workload:
+    """configs[4] / the north-star target grid: F1 scaled to S states, 500 actions, 200 demands."""
+    f = BackorderFunctor(fixedOrderingCost=500, variOrderingCost=1, holdingCost=2, penaltyCost=10,
+                         minInventory=0, maxInventory=S - 1, maxOrderQuantity=A - 1, iniInventory=0)
+    return Workload(f"cfg5_f1_{S}x{A}x{D}x{T}", f, OptDirection.MIN, seasonal_pmf(T, D), "synthetic scaled F1")
+
+
+def by_name(name: str, **kw) -> Workload:
+    table = {"cfg1": cfg1_sS, "cfg2": cfg2_clsp, "cfg3": cfg3_cash, "cfg4": cfg4_leadtime}
+    if name in table:
+        return table[name](**kw)
+    if name == "cfg5":
+        return cfg5_scaled(**kw)
+    raise KeyError(name)

@@ -1,0 +1,48 @@
+"""Pure-Python literal translation of the reference's memoised recursion (Recursion.java:89-163,
+CashRecursion.java:79-140) over the host-side functor restatements.  Small cases only; a third,
+independent statement of the loop used to cross-check the C oracle."""
+import sys
+
+from stochastic_inventory_amd.states import OptDirection
+
+DBL_MAX = sys.float_info.max
+
+
+def memo_recursion(functor, pmf, direction, ini_state, cash_loop=False, gamma=1.0):
+    T = len(pmf)
+    cache_values, cache_actions = {}, {}
+
+    def get_expected_value(s):
+        if s in cache_values:
+            return cache_values[s]
+        feasible = functor.feasibleActions(s, T)
+        d_and_p = pmf[s.getPeriod() - 1]
+        val = DBL_MAX if direction == OptDirection.MIN else -DBL_MAX
+        best = 0.0
+        for order_qty in feasible:
+            q = 0.0
+            for dp in d_and_p:
+                d, p = float(dp[0]), float(dp[1])
+                if cash_loop:
+                    this_d = functor.immediateValue(s, order_qty, d, T)
+                    q += p * this_d
+                    if s.getPeriod() < T:
+                        ns = functor.stateTransition(s, order_qty, d, T)
+                        q += p * gamma * get_expected_value(ns)
+                else:
+                    q += p * functor.immediateValue(s, order_qty, d, T)
+                    if s.getPeriod() < T:
+                        ns = functor.stateTransition(s, order_qty, d, T)
+                        q += p * get_expected_value(ns)
+            if direction == OptDirection.MIN:
+                if q < val:
+                    val, best = q, order_qty
+            else:
+                if q > val:
+                    val, best = q, order_qty
+        cache_values[s] = val
+        cache_actions[s] = best
+        return val
+
+    root = get_expected_value(ini_state)
+    return root, cache_values, cache_actions
