@@ -1,0 +1,106 @@
+"""State-axis sharding over the GPUs of one node: one process per GPU, torch.distributed over RCCL.
+
+Within a period every state is independent; between periods each rank needs the FULL V_{t+1}
+(the transition can land anywhere on the grid).  So: the flat state index of every period is cut
+into `world_size` equal contiguous slabs (the table row is padded to a multiple of world_size),
+rank r computes V_t and the policy for slab r, then ONE all-gather of the fp64 slabs rebuilds
+the full V_t on every rank, in place in the table the next period reads
+(SURVEY.md section 8(e)).  Policy tables are never exchanged: they stay sharded.
+
+xGMI is point-to-point (7 links per GPU); the message is S/world * 8 B per rank per period
+(1 MB at the 1e6-state grid, 100 MB at 1e8), against seconds of compute per period, so the
+exchange needs no overlap tricks -- it is issued on the compute stream right behind the kernel.
+
+`SlabBackend` is the seam the CPU tests use: the `gloo` world_size-2 tests drive this very
+class with a test double in place of the HIP engine (the product backend below has no CPU path).
+"""
+from __future__ import annotations
+
+from typing import List, Optional
+
+import torch
+import torch.distributed as dist
+
+from .engine import SdpEngine
+
+
+class SlabBackend:
+    """What ShardedSolver needs from a per-rank engine."""
+
+    T: int
+
+    def slab(self, period: int):  # -> (padded, lo, hi)
+        raise NotImplementedError
+
+    def table(self, period: int) -> torch.Tensor:  # the full padded V_period row (this rank's copy)
+        raise NotImplementedError
+
+    def run_period(self, period: int) -> None:  # compute this rank's slab of V_period into table(period)
+        raise NotImplementedError
+
+
+class GpuSlabBackend(SlabBackend):
+    """SdpEngine on one GPU with its value arena held in a torch tensor (so RCCL can address it)."""
+
+    def __init__(self, desc, pmf, overhead=None, device: Optional[torch.device] = None):
+        self.device = device or torch.device("cuda", torch.cuda.current_device())
+        desc.device = self.device.index if self.device.index is not None else -1
+        self.engine = SdpEngine(desc, pmf, overhead)
+        self.T = self.engine.T
+        nbytes = self.engine.values_bytes()
+        self.arena = torch.zeros(nbytes // 8, dtype=torch.float64, device=self.device)
+        self.engine.attach_values(self.arena.data_ptr(), nbytes)
+        self.engine.set_stream(torch.cuda.current_stream(self.device).cuda_stream)
+        self._views = {}
+
+    def slab(self, period: int):
+        return self.engine.slab(period)
+
+    def table(self, period: int) -> torch.Tensor:
+        if period not in self._views:
+            pad, _, _ = self.engine.slab(period)
+            base = (self.engine.values_device_ptr(period) - self.arena.data_ptr()) // 8
+            self._views[period] = self.arena[base: base + pad]
+        return self._views[period]
+
+    def run_period(self, period: int) -> None:
+        self.engine.run_period(period)
+
+    def close(self):
+        self.engine.close()
+
+
+class ShardedSolver:
+    """Backward sweep t = T..1 with one all-gather of V_t between periods."""
+
+    def __init__(self, backend: SlabBackend, group=None):
+        self.backend = backend
+        self.group = group
+        self.world = dist.get_world_size(group) if dist.is_initialized() else 1
+        self.rank = dist.get_rank(group) if dist.is_initialized() else 0
+        self.gathered_bytes = 0
+
+    def exchange(self, period: int) -> None:
+        if self.world == 1:
+            return
+        pad, lo, hi = self.backend.slab(period)
+        full = self.backend.table(period)
+        n = pad // self.world
+        shard = full[self.rank * n: (self.rank + 1) * n]
+        # in place: this rank's shard already sits at its offset inside `full`
+        dist.all_gather_into_tensor(full, shard, group=self.group)
+        self.gathered_bytes += pad * 8
+
+    def solve(self, first_period: int = 1) -> None:
+        for period in range(self.backend.T, first_period - 1, -1):
+            self.backend.run_period(period)
+            if period > first_period:  # V_1 is never read by another period
+                self.exchange(period)
+
+    def gather_policy(self, period: int, local: torch.Tensor) -> Optional[List[torch.Tensor]]:
+        """Collect the per-rank policy slabs on rank 0 (host-side read-out, not on the hot path)."""
+        if self.world == 1:
+            return [local]
+        out = [torch.empty_like(local) for _ in range(self.world)] if self.rank == 0 else None
+        dist.gather(local, out, dst=0, group=self.group)
+        return out

@@ -1,0 +1,144 @@
+"""CPU-side checks of the boundary: the shared library loads, exports every symbol the header
+declares, and the host logic that needs no GPU (validation, layout, error reporting) behaves."""
+import ctypes as C
+import os
+import re
+
+import numpy as np
+import pytest
+
+import cases
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.fixture(scope="module")
+def lib(sia):
+    import __graft_entry__ as g
+    g.build()
+    return sia._abi.load()
+
+
+def test_every_declared_symbol_is_exported(sia, lib):
+    header = open(os.path.join(ROOT, "include", "sdpgpu.h")).read()
+    header = re.sub(r"/\*.*?\*/", "", header, flags=re.S)
+    declared = set(re.findall(r"\b(sdpgpu_[a-z_]+)\s*\(", header))
+    assert declared == set(sia._abi.EXPORTS), declared ^ set(sia._abi.EXPORTS)
+    for name in declared:
+        assert hasattr(lib, name)
+
+
+def test_struct_layout_matches_the_header(sia, lib):
+    d = sia.SdpgpuDesc()
+    lib.sdpgpu_desc_init(C.byref(d))
+    ref = sia.desc_defaults()
+    assert bytes(d) == bytes(ref)
+    # sizeof / offsetof as the C compiler sees the header
+    import subprocess, tempfile
+    fields = [f[0] for f in sia.SdpgpuDesc._fields_]
+    src = '#include <stdio.h>\n#include <stddef.h>\n#include "sdpgpu.h"\nint main(void){printf("%zu", sizeof(sdpgpu_desc));' + \
+        "".join(f'printf(" %zu", offsetof(sdpgpu_desc, {f}));' for f in fields) + \
+        'printf(" %zu", sizeof(sdpgpu_stats)); return 0;}'
+    with tempfile.TemporaryDirectory() as td:
+        open(os.path.join(td, "a.c"), "w").write(src)
+        subprocess.run(["gcc", "-I", os.path.join(ROOT, "include"), "-o", os.path.join(td, "a"), os.path.join(td, "a.c")], check=True)
+        out = subprocess.run([os.path.join(td, "a")], capture_output=True, text=True, check=True).stdout.split()
+    assert int(out[0]) == C.sizeof(sia.SdpgpuDesc)
+    assert [int(v) for v in out[1:-1]] == [getattr(sia.SdpgpuDesc, f).offset for f in fields]
+    assert int(out[-1]) == C.sizeof(sia.SdpgpuStats)
+    assert d.abi_version == 1 and d.discount_factor == 1.0 and d.cash_round_div == 10.0 and d.world_size == 1
+
+
+def test_create_rejects_bad_descriptors(sia, lib):
+    d = sia.desc_defaults()
+    d.family = 9
+    h = C.c_void_p()
+    assert lib.sdpgpu_create(C.byref(d), C.byref(h)) == 1
+    assert b"family" in lib.sdpgpu_last_error(None)
+    d = sia.desc_defaults()
+    d.step = 3.0
+    assert lib.sdpgpu_create(C.byref(d), C.byref(h)) == 4  # unsupported, says why
+    assert b"step" in lib.sdpgpu_last_error(None)
+    d = sia.desc_defaults()
+    d.family, d.direction = sia.FAMILY_LEADTIME, 1
+    assert lib.sdpgpu_create(C.byref(d), C.byref(h)) == 1
+    assert b"MIN only" in lib.sdpgpu_last_error(None)
+
+
+@pytest.mark.parametrize("make", cases.ALL, ids=lambda f: f.__name__)
+def test_layout_agrees_with_the_oracle(sia, oracle, make):
+    """Two independent layout implementations (product C++ vs oracle C) give the same grids."""
+    w = make()
+    P = oracle.Problem(w.desc(), w.pmf, w.overhead())
+    eng = sia.SdpEngine(w.desc(), w.pmf, w.overhead())
+    for period in range(1, w.T + 1):
+        g = P.grids[period - 1]
+        assert eng.grid(period) == (g.x_lo, g.nx, g.nc, g.nq)
+        assert eng.num_states(period) == P.S[period - 1]
+        x, cash, preq = P.state_arrays(period)
+        for idx in (0, len(x) // 3, len(x) - 1):
+            assert eng.state_index(period, x[idx], cash[idx], preq[idx]) == idx
+            if g.nc > 1:
+                assert eng.cash_value(idx % g.nc) == cash[idx]
+    assert eng.state_index(1, 0.5, 0.0, 0.0) == -1
+    eng.close()
+
+
+def test_slabs_partition_the_grid(sia):
+    w = cases.f3_tenths()
+    seen = []
+    for rank in range(3):
+        d = w.desc()
+        d.rank, d.world_size = rank, 3
+        eng = sia.SdpEngine(d, w.pmf, w.overhead())
+        pad, lo, hi = eng.slab(1)
+        assert pad % 3 == 0 and pad >= eng.num_states(1)
+        seen.append((lo, hi))
+        eng.close()
+    assert seen[0][0] == 0 and seen[-1][1] == 11 * 231
+    assert all(seen[i][1] == seen[i + 1][0] for i in range(2))
+
+
+def test_errors_are_reported_not_thrown(sia):
+    w = cases.f1_small()
+    with pytest.raises(ValueError):
+        sia.SdpEngine(w.desc(), w.pmf[:-1])
+    bad = [t.copy() for t in w.pmf]
+    bad[0][:, 0] = bad[0][::-1, 0]  # descending demands
+    with pytest.raises(sia.SdpgpuError) as e:
+        sia.SdpEngine(w.desc(), bad)
+    assert "ascending" in str(e.value)
+    eng = sia.SdpEngine(w.desc(), w.pmf)
+    with pytest.raises(sia.SdpgpuError):
+        eng.values(1)  # nothing solved yet
+    eng.close()
+
+
+def test_compute_fails_loudly_without_a_gpu(sia):
+    """No HIP device in the authoring container: the product must refuse, not fall back to a CPU path."""
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("a GPU is present")
+    w = cases.f1_small()
+    eng = sia.SdpEngine(w.desc(), w.pmf)
+    with pytest.raises(sia.SdpgpuError) as e:
+        eng.solve()
+    assert e.value.code == 3
+    eng.close()
+
+
+def test_host_mirror_keeps_the_reference_api(sia):
+    for cls in (sia.Recursion, sia.CashRecursion, sia.LeadtimeRecursion, sia.CashLeadtimeRecursion):
+        for name in ("getExpectedValue", "getAction", "getCacheActions", "getOptTable",
+                     "getStateTransitionFunction", "getImmediateValueFunction", "setTreeMapCacheAction"):
+            assert callable(getattr(cls, name))
+    s = sia.CashState(2, 3.0, 4.5)
+    assert (s.getPeriod(), s.getIniInventory(), s.getIniCash()) == (2, 3.0, 4.5)
+    assert s == sia.CashState(2, 3.0, 4.5) and s != sia.CashState(2, 3.0, 4.6)
+    assert sia.State(1, 0.0) != sia.LeadtimeState(1, 0.0, 0.0)
+    with pytest.raises(TypeError):
+        sia.Recursion(sia.OptDirection.MIN, cases.f1_small().pmf)  # functor descriptor is mandatory
+
+
+def test_java_round_host(sia):
+    assert sia.java_round(-2.5) == -2 and sia.java_round(2.5) == 3 and sia.java_round(0.49999999999999994) == 0

@@ -1,0 +1,266 @@
+"""Parity tests proper: the HIP path through the C ABI against the CPU oracle, same inputs.
+
+Bar (BASELINE.json north_star): value tables within 1e-9 relative, policy indices bit-exact.
+The kernels keep the reference's operation order, so the values are in fact bit-identical and
+the tests assert exact equality; the 1e-9 tolerance is stated once, in _assert_tables.
+"""
+import numpy as np
+import pytest
+
+import cases
+
+pytestmark = pytest.mark.gpu
+
+REL_TOL = 1e-9  # north_star tolerance for value tables (we hold the stronger bit-for-bit bar)
+
+
+def _assert_tables(gv, gp, ov, op, what):
+    assert gp.dtype == np.int32 and np.array_equal(gp, op), f"{what}: policy indices differ"
+    scale = np.maximum(np.abs(ov), 1e-300)
+    assert np.all(np.abs(gv - ov) <= REL_TOL * scale), f"{what}: values beyond 1e-9 relative"
+    assert np.array_equal(gv, ov), f"{what}: values are within tolerance but not bit-identical"
+
+
+def _solve_both(sia, oracle, w, kernel=0, nthreads=8):
+    desc = w.desc()
+    desc.kernel = kernel
+    eng = sia.SdpEngine(desc, w.pmf, w.overhead())
+    eng.solve(sync=True)
+    P = oracle.Problem(w.desc(), w.pmf, w.overhead())
+    V, pol, cells = P.solve(nthreads=nthreads)
+    return eng, P, V, pol, cells
+
+
+@pytest.mark.parametrize("make", cases.ALL, ids=lambda f: f.__name__)
+@pytest.mark.parametrize("kernel", [0, 1], ids=["auto", "gather"])
+def test_small_cases_bit_exact(sia, oracle, make, kernel):
+    w = make()
+    eng, P, V, pol, cells = _solve_both(sia, oracle, w, kernel)
+    for period in range(1, w.T + 1):
+        _assert_tables(eng.values(period), eng.policy(period), V[period - 1], pol[period - 1], f"{w.name} t={period}")
+    st = eng.stats()
+    assert st.cells_evaluated == cells == st.cells_all_ranks
+    assert st.periods_run == w.T
+    eng.close()
+
+
+def test_clsp_main_instance(sia, oracle):
+    """The instance left in CLSP.java:196-211 (601 states, 61 actions, 4 periods)."""
+    w = cases.f1_clsp_main()
+    eng, P, V, pol, _ = _solve_both(sia, oracle, w)
+    for period in range(1, w.T + 1):
+        _assert_tables(eng.values(period), eng.policy(period), V[period - 1], pol[period - 1], f"clsp t={period}")
+    eng.close()
+
+
+def test_cfg1_full(sia, oracle):
+    from stochastic_inventory_amd import workloads
+    w = workloads.cfg1_sS()
+    eng, P, V, pol, cells = _solve_both(sia, oracle, w)
+    assert cells == 200 * 101 * 25 * 12
+    for period in range(1, w.T + 1):
+        _assert_tables(eng.values(period), eng.policy(period), V[period - 1], pol[period - 1], f"cfg1 t={period}")
+    eng.close()
+
+
+@pytest.mark.parametrize("kernel", [1, 0], ids=["gather", "auto"])
+def test_cfg2_shape_reduced_horizon(sia, oracle, kernel):
+    """configs[1] at full width (1e4 x 200 x 100) for 3 periods: 6e8 cells, seconds on 8 host threads."""
+    from stochastic_inventory_amd import workloads
+    w = workloads.cfg2_clsp(T=3)
+    eng, P, V, pol, _ = _solve_both(sia, oracle, w, kernel)
+    for period in range(1, w.T + 1):
+        _assert_tables(eng.values(period), eng.policy(period), V[period - 1], pol[period - 1], f"cfg2 t={period}")
+    eng.close()
+
+
+def test_cfg3_shape_reduced(sia, oracle):
+    """configs[2] family (2-D inventory x cash, ragged action counts) at 40 x 600 states."""
+    from stochastic_inventory_amd import workloads
+    w = workloads.cfg3_cash(T=3, NX=40, NC=600, A=60, D=30)
+    eng, P, V, pol, cells = _solve_both(sia, oracle, w)
+    assert eng.stats().cells_evaluated == cells
+    for period in range(1, w.T + 1):
+        _assert_tables(eng.values(period), eng.policy(period), V[period - 1], pol[period - 1], f"cfg3 t={period}")
+    eng.close()
+
+
+def test_cfg4_shape_reduced(sia, oracle):
+    from stochastic_inventory_amd import workloads
+    w = workloads.cfg4_leadtime(T=3, NX=120, A=40, D=30)
+    eng, P, V, pol, _ = _solve_both(sia, oracle, w)
+    for period in range(1, w.T + 1):
+        _assert_tables(eng.values(period), eng.policy(period), V[period - 1], pol[period - 1], f"cfg4 t={period}")
+    eng.close()
+
+
+@pytest.mark.parametrize("make", [cases.f1_small, cases.f3_tenths, cases.f5_cash_leadtime, cases.f2_unclamped],
+                         ids=lambda f: f.__name__)
+def test_eval_states_off_grid(sia, oracle, make):
+    """getExpectedValue(state) for states that are not grid points (off-grid initial cash etc.)."""
+    w = make()
+    eng, P, V, pol, _ = _solve_both(sia, oracle, w)
+    rng = np.random.default_rng(7)
+    for period in (1, w.T):
+        x, cash, preq = P.state_arrays(period)
+        pick = rng.integers(0, len(x), size=37)
+        xs, cs, qs = x[pick].copy(), cash[pick].copy(), preq[pick].copy()
+        if w.desc().family in (3, 4, 5):
+            cs = cs + 0.013  # off the cash grid
+        v_next = V[period] if period < w.T else None
+        ov, oa = P.eval_states(period, v_next, xs, cs, qs)
+        gv, ga = eng.eval_states(period, xs, cs, qs)
+        _assert_tables(gv, ga, ov, oa, f"{w.name} eval t={period}")
+    eng.close()
+
+
+@pytest.mark.parametrize("make", [cases.f1_small, cases.f2_unclamped, cases.f3_testing, cases.f5_cash_leadtime],
+                         ids=lambda f: f.__name__)
+def test_reachable_set(sia, oracle, make):
+    w = make()
+    eng, P, V, pol, _ = _solve_both(sia, oracle, w)
+    reach = P.reachable()
+    for period in range(1, w.T + 1):
+        assert np.array_equal(eng.reachable(period), reach[period - 1]), f"{w.name} t={period}"
+    eng.close()
+
+
+def test_ping_pong_tables(sia, oracle):
+    w = cases.f2_clamped()
+    d = w.desc()
+    d.store_all_values = 0
+    eng = sia.SdpEngine(d, w.pmf)
+    eng.solve()
+    V, pol, _ = oracle.Problem(w.desc(), w.pmf).solve()
+    _assert_tables(eng.values(1), eng.policy(1), V[0], pol[0], "ping-pong t=1")
+    assert np.array_equal(eng.values(2), V[1])
+    with pytest.raises(sia.SdpgpuError):
+        eng.values(3)  # overwritten by V_1
+    for period in range(1, w.T + 1):
+        assert np.array_equal(eng.policy(period), pol[period - 1])
+    eng.close()
+
+
+def test_sharded_periods_single_process(sia, oracle):
+    """world_size 3 slabs driven from one process: each rank computes its slab into its own copy of
+    V_t, the test plays the all-gather by hand.  Covers slab bounds, padding and the policy slabs."""
+    import ctypes as C
+    import torch
+    w = cases.f3_tenths()
+    world = 3
+    engs = []
+    for r in range(world):
+        d = w.desc()
+        d.rank, d.world_size = r, world
+        engs.append(sia.SdpEngine(d, w.pmf, w.overhead()))
+    V, pol, _ = oracle.Problem(w.desc(), w.pmf, w.overhead()).solve()
+    bufs = []
+    for e in engs:
+        t = torch.zeros(e.values_bytes() // 8, dtype=torch.float64, device="cuda")
+        e.attach_values(t.data_ptr(), t.numel() * 8)
+        e.set_stream(torch.cuda.current_stream().cuda_stream)
+        bufs.append(t)
+    for period in range(w.T, 0, -1):
+        for e in engs:
+            e.run_period(period)
+        torch.cuda.synchronize()
+        pad, _, _ = engs[0].slab(period)
+        base = (engs[0].values_device_ptr(period) - bufs[0].data_ptr()) // 8
+        full = torch.zeros(pad, dtype=torch.float64, device="cuda")
+        for r, e in enumerate(engs):
+            _, lo, hi = e.slab(period)
+            full[lo:hi] = bufs[r][base + lo: base + hi]
+        for b in bufs:
+            b[base: base + pad] = full
+        S = engs[0].num_states(period)
+        assert np.array_equal(full[:S].cpu().numpy(), V[period - 1])
+        got = np.concatenate([e.policy(period) for e in engs])
+        assert np.array_equal(got, pol[period - 1])
+    for e in engs:
+        e.close()
+
+
+def test_mirror_api_drop_in(sia, oracle):
+    """The reference-shaped classes: construct with lambdas + functor, query like CLSPTesting.java:111-118."""
+    w = cases.f1_small()
+    f = w.functor
+    T = w.T
+    rec = sia.Recursion(sia.OptDirection.MIN, w.pmf,
+                        lambda s: f.feasibleActions(s, T),
+                        lambda s, a, r: f.stateTransition(s, a, r, T),
+                        lambda s, a, r: f.immediateValue(s, a, r, T), functor=f)
+    assert rec.validateFunctor(64) == 64
+    ini = sia.State(1, f.iniInventory)
+    m = oracle.Problem(w.desc(), w.pmf).memo()
+    assert rec.getExpectedValue(ini) == m["value"]
+    assert rec.getAction(ini) == m["action"]
+    table = rec.getOptTable()
+    assert table.shape == (m["n"], 3)
+    order = np.lexsort((m["x"], m["period"]))
+    assert np.array_equal(table[:, 0], m["period"][order].astype(float))
+    assert np.array_equal(table[:, 1], m["x"][order])
+    assert np.array_equal(table[:, 2], m["actions"][order])
+    assert table[0].tolist()[:2] == [1.0, f.iniInventory]  # FitsS.java:102-106 relies on row 0
+    acts = rec.getCacheActions()
+    assert acts[ini] == m["action"] and len(acts) == m["n"]
+
+
+def test_mirror_cash_and_leadtime(sia, oracle):
+    w = cases.f3_tenths()
+    rec = sia.CashRecursion(sia.OptDirection.MAX, w.pmf, functor=w.functor, discountFactor=1.0)
+    rec.setTreeMapCacheAction()
+    ini = sia.CashState(1, w.functor.iniInventory, w.functor.iniCash)
+    m = oracle.Problem(w.desc(), w.pmf, w.overhead()).memo()
+    assert rec.getExpectedValue(ini) == m["value"] and rec.getAction(ini) == m["action"]
+    off = sia.CashState(1, 0.0, 4.93)  # not a multiple of 0.1: answered by eval_states
+    P = oracle.Problem(w.desc(), w.pmf, w.overhead())
+    V, _, _ = P.solve()
+    ov, oa = P.eval_states(1, V[1], [0.0], [4.93], [0.0])
+    assert rec.getExpectedValue(off) == ov[0] and rec.getAction(off) == oa[0] * w.functor.stepSize
+    t = rec.getOptTable()
+    assert t.shape == (m["n"], 4)
+
+    w2 = cases.f2_unclamped()
+    lt = sia.LeadtimeRecursion(w2.pmf, functor=w2.functor)
+    m2 = oracle.Problem(w2.desc(), w2.pmf).memo()
+    ini2 = sia.LeadtimeState(1, 0.0, 0.0)
+    assert lt.getExpectedValue(ini2) == m2["value"] and lt.getAction(ini2) == m2["action"]
+    t2 = lt.getOptTable()
+    assert t2.shape == (m2["n"], 4)
+    order = np.lexsort((m2["preq"], m2["x"], m2["period"]))
+    assert np.array_equal(t2[:, 1], m2["x"][order]) and np.array_equal(t2[:, 3], m2["actions"][order])
+
+    w3 = cases.f5_cash_leadtime()
+    cl = sia.CashLeadtimeRecursion(w3.pmf, functor=w3.functor)
+    m3 = oracle.Problem(w3.desc(), w3.pmf, w3.overhead()).memo()
+    ini3 = sia.CashLeadtimeState(1, 0.0, 0.0, 0.0)
+    assert cl.getExpectedValue(ini3) == m3["value"] and cl.getAction(ini3) == m3["action"]
+    assert cl.getOptTable().shape == (m3["n"], 5)
+
+
+def test_cfg2_full_horizon_properties(sia, oracle):
+    """configs[1] at BASELINE size (1e4 x 200 x 100, 52 periods = 1.04e10 cells): too big for the
+    oracle to sweep in test time, so check (i) the two kernels against each other bit for bit,
+    (ii) 2,000 sampled states per checked period against the oracle fed the GPU's own V_{t+1},
+    (iii) the backorder structure: order-up-to levels never exceed capacity, V_t >= 0."""
+    from stochastic_inventory_amd import workloads
+    w = workloads.cfg2_clsp()
+    da, dg = w.desc(), w.desc()
+    dg.kernel = sia.KERNEL_GATHER
+    ea, eg = sia.SdpEngine(da, w.pmf), sia.SdpEngine(dg, w.pmf)
+    ea.solve()
+    eg.solve()
+    P = oracle.Problem(w.desc(), w.pmf)
+    rng = np.random.default_rng(11)
+    assert ea.stats().cells_evaluated == 10000 * 200 * 100 * 52
+    for period in (52, 51, 40, 17, 2, 1):
+        va, pa = ea.values(period), ea.policy(period)
+        assert np.array_equal(va, eg.values(period)) and np.array_equal(pa, eg.policy(period))
+        x, _, _ = P.state_arrays(period)
+        pick = np.unique(np.concatenate([rng.integers(0, len(x), size=2000), [0, 1, len(x) - 2, len(x) - 1]]))
+        v_next = ea.values(period + 1) if period < w.T else None
+        ov, oa = P.eval_states(period, v_next, x[pick])
+        _assert_tables(va[pick], pa[pick], ov, oa, f"cfg2 full t={period}")
+        assert (va >= 0).all() and pa.min() >= 0 and pa.max() <= 199
+    ea.close()
+    eg.close()

@@ -1,0 +1,83 @@
+"""N > 1 host logic on CPU: world_size-2 (and 3) `gloo` runs of the very ShardedSolver class the GPU
+bench uses, with a test double in place of the HIP engine.  The double computes its slab with the
+oracle (allowed here: tests/), so what is under test is the sharding itself -- slab bounds, padding,
+the in-place all-gather offsets, policy slabs -- not the arithmetic."""
+import os
+import sys
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+
+
+def _worker(rank, world, port, case_name, out_dir):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    import cases
+    import stochastic_inventory_amd as sia
+    from oracle import sdpref
+    from stochastic_inventory_amd.sharded import ShardedSolver, SlabBackend
+
+    w = getattr(cases, case_name)()
+    desc = w.desc()
+    desc.rank, desc.world_size = rank, world
+    geom = sia.SdpEngine(desc, w.pmf, w.overhead())  # layout/slab queries only: no GPU work on CPU
+    P = sdpref.Problem(w.desc(), w.pmf, w.overhead())
+
+    class OracleSlab(SlabBackend):
+        T = w.T
+
+        def __init__(self):
+            self.tables = {p: torch.full((geom.slab(p)[0],), float("nan"), dtype=torch.float64) for p in range(1, w.T + 1)}
+            self.policy = {}
+
+        def slab(self, period):
+            return geom.slab(period)
+
+        def table(self, period):
+            return self.tables[period]
+
+        def run_period(self, period):
+            pad, lo, hi = geom.slab(period)
+            S = geom.num_states(period)
+            v_next = self.tables[period + 1][:geom.num_states(period + 1)].numpy() if period < w.T else None
+            if v_next is not None:
+                assert not np.isnan(v_next).any(), "a slab of V_{t+1} was not gathered"
+            v = np.full(S, np.nan)
+            pol = np.zeros(S, dtype=np.int32)
+            P.period(period, v_next, lo, hi, 1, v, pol)
+            self.tables[period][lo:hi] = torch.from_numpy(v[lo:hi])
+            self.policy[period] = pol[lo:hi].copy()
+
+    be = OracleSlab()
+    solver = ShardedSolver(be)
+    solver.solve()
+    # V_1 is not exchanged by solve(); gather it here only to compare the whole table
+    solver.exchange(1)
+    np.savez(os.path.join(out_dir, f"rank{rank}.npz"),
+             **{f"v{p}": be.tables[p].numpy() for p in range(1, w.T + 1)},
+             **{f"p{p}": be.policy[p] for p in range(1, w.T + 1)})
+    geom.close()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world,case_name", [(2, "f1_small"), (2, "f3_tenths"), (3, "f2_unclamped"), (2, "f5_cash_leadtime")])
+def test_sharded_solver_gloo(tmp_path, oracle, world, case_name):
+    import cases
+    port = 29500 + (os.getpid() % 2000) + world
+    mp.spawn(_worker, args=(world, port, case_name, str(tmp_path)), nprocs=world, join=True)
+    w = getattr(cases, case_name)()
+    V, pol, _ = oracle.Problem(w.desc(), w.pmf, w.overhead()).solve()
+    ranks = [np.load(os.path.join(str(tmp_path), f"rank{r}.npz")) for r in range(world)]
+    for p in range(1, w.T + 1):
+        S = len(V[p - 1])
+        for r in range(world):
+            assert np.array_equal(ranks[r][f"v{p}"][:S], V[p - 1]), (p, r)  # every rank holds the full table
+        assert np.array_equal(np.concatenate([ranks[r][f"p{p}"] for r in range(world)]), pol[p - 1])
