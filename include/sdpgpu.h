@@ -189,7 +189,8 @@ int sdpgpu_set_pmf(sdpgpu_handle* h, int32_t t, const double* demand, const doub
 /* Optional per-period overhead cost (CashOverdraft.java:38-39 keeps an array). */
 int sdpgpu_set_overhead(sdpgpu_handle* h, int32_t t, double overhead_cost);
 
-/* Launch kernels on a caller-owned hipStream_t (NULL = the library's own stream). */
+/* Launch kernels on a caller-owned hipStream_t (NULL = the legacy default stream).  Without this
+ * call the library creates a non-blocking stream of its own. */
 int sdpgpu_set_stream(sdpgpu_handle* h, void* hip_stream);
 
 /* Record a HIP event pair around every period kernel (read back through sdpgpu_period_ms). */

@@ -64,10 +64,12 @@ struct sdpgpu_handle {
   size_t policy_elems = 0;
   hipStream_t stream = nullptr;
   bool own_stream = false;
+  bool stream_given = false;  // sdpgpu_set_stream was called (NULL then means the legacy default stream)
   bool profiling = false;
   hipEvent_t ev_solve0 = nullptr, ev_solve1 = nullptr;
   bool solve_timed = false;
-  std::vector<char> period_done;  // V_t valid
+  std::vector<char> period_done;  // V_t valid (a ping-pong table may have been overwritten since)
+  std::vector<char> policy_done;  // the policy slab of period t has been computed
   uint8_t* d_reach = nullptr;      // reachable masks, period t at reach_off[t-1]
   std::vector<size_t> reach_off;
   bool reach_done = false;
@@ -235,7 +237,7 @@ int allocate(sdpgpu_handle* h) {
   if (e != hipSuccess || ndev < 1)
     return fail(h, SDPGPU_ERR_DEVICE, "no HIP device available (%s); this library has no CPU path",
                 e == hipSuccess ? "device count 0" : hipGetErrorString(e));
-  if (!h->stream) {
+  if (!h->stream && !h->stream_given) {
     HIP_TRY(h, hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking));
     h->own_stream = true;
   }
@@ -426,6 +428,7 @@ int run_period_impl(sdpgpu_handle* h, int period) {
     p.timed = false;
   }
   h->period_done[period - 1] = 1;
+  h->policy_done[period - 1] = 1;
   if (!h->d.store_all_values && period + 2 <= h->T) h->period_done[period + 1] = 0;  // V_{t+2} was overwritten
   return SDPGPU_OK;
 }
@@ -548,6 +551,7 @@ int sdpgpu_create(const sdpgpu_desc* desc, sdpgpu_handle** out) {
     h->pmf_p.resize((size_t)h->T);
     h->pmf_set.assign((size_t)h->T, 0);
     h->period_done.assign((size_t)h->T, 0);
+    h->policy_done.assign((size_t)h->T, 0);
   } catch (...) {
     delete h;
     return fail(nullptr, SDPGPU_ERR_ARG, "out of host memory");
@@ -614,12 +618,9 @@ int sdpgpu_set_stream(sdpgpu_handle* h, void* hip_stream) {
     (void)hipStreamSynchronize(h->stream);
     (void)hipStreamDestroy(h->stream);
   }
-  h->stream = (hipStream_t)hip_stream;
+  h->stream = (hipStream_t)hip_stream;  // NULL = the legacy default stream, as in any HIP API
   h->own_stream = false;
-  if (!hip_stream && h->allocated) {
-    HIP_TRY(h, hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking));
-    h->own_stream = true;
-  }
+  h->stream_given = true;
   return SDPGPU_OK;
 }
 
@@ -787,7 +788,7 @@ int sdpgpu_policy(sdpgpu_handle* h, int32_t period, int32_t* out, int64_t lo, in
   if (!h) return SDPGPU_ERR_ARG;
   h->err.clear();
   if (period < 1 || period > h->T || !out) return fail(h, SDPGPU_ERR_ARG, "policy: bad argument");
-  if (!h->allocated || !h->period_done[period - 1]) return fail(h, SDPGPU_ERR_STATE, "period %d has not been computed", period);
+  if (!h->allocated || !h->policy_done[period - 1]) return fail(h, SDPGPU_ERR_STATE, "period %d has not been computed", period);
   const PeriodInfo& p = h->per[period - 1];
   if (lo < p.lo || n < 0 || lo + n > p.hi) return fail(h, SDPGPU_ERR_ARG, "policy: [%lld, %lld) outside this rank's slab [%lld, %lld)", (long long)lo, (long long)(lo + n), (long long)p.lo, (long long)p.hi);
   int rc = ensure_device(h);
