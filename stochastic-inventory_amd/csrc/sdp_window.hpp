@@ -1,3 +1,180 @@
-// sdp_window.hpp -- F1/F2 LDS-window period kernel (filled in after the generic path is green).
+// sdp_window.hpp -- LDS-window period kernel for the backorder family F1 (CLSP.java:251-272).
+//
+// Why a second kernel: in F1 everything a cell needs depends on ONE integer, m = i + k - j
+// (state index + action index - demand index):
+//     level      l(m) = (x_lo - d_0) + m*step                       (exact integer arithmetic)
+//     imm        = (fixed + var)(k) + M(m),   M(m) = h*max(l,0) + pi*max(-l,0)
+//     next state = clamp(l(m))  ->  V_{t+1}[clampidx(m)]
+// so a workgroup that owns 64 consecutive states and a run of actions touches only a
+// contiguous span of 62 + A_chunk + D entries of the pair table W[m] = {M(m), V_{t+1}(clamp m)}.
+// The span is staged ONCE in LDS (16 B per entry); HBM/L2 sees each V_{t+1} element once per
+// workgroup instead of once per cell.
+//
+// Thread mapping (wave64): lane = state, each lane carries R consecutive actions in registers
+// and walks the demand index j = 0..D-1 serially, in the reference's order
+// (Recursion.java:138-144): per cell
+//     imm = c0[r] + W.x;  t = p_j*imm;  acc[r] += t;  u = p_j*W.y;  acc[r] += u;      (5 fp64 ops)
+// with separate multiplies and adds (no FMA).  Cells (r, j) and (r+1, j+1) read the same W
+// entry, so the R-entry register window slides by ONE new ds_read_b128 per demand step:
+// LDS traffic is 16 B per R cells.  p_j is wave-uniform and comes through the scalar cache.
+// The five VALU ops per cell are the floor for this operation order; the kernel is bound by
+// fp64 VALU issue (4 cycles per wave64 instruction per SIMD), not by memory.
+//
+// Small grids (configs[1] has only 157 state tiles) do not fill 1024 SIMDs with whole-action
+// workgroups, so the action range is also cut into NCH chunks across workgroups; each writes a
+// partial (value, index) row and a tiny second kernel takes the lexicographic arg-opt over the
+// chunks (lowest action index wins ties, exactly the strict-compare scan of Recursion.java:146-157).
 #pragma once
 #include "sdp_device.hpp"
+
+namespace sdp {
+
+struct WinParams {
+  double lev0;   // level value of m = 0: x_lo(cur) - d_0
+  double step;
+  double h, pi, K, v;
+  int32_t idx_off;    // m -> next-grid index offset: (lev0 - x_lo(next)) / step
+  int32_t next_last;  // nx(next) - 1
+  int32_t n_actions;  // A
+  int32_t d_pad;      // demand steps, padded with p = 0 entries to a multiple of R
+  int32_t n_chunks;   // action chunks across workgroups
+  int32_t chunk_actions;  // actions per chunk (multiple of R)
+  int32_t n_tiles;        // state tiles of 64
+  int64_t partial_stride; // elements between chunk rows of the partial tables
+};
+
+// W[m] for one m: the immediate-cost part that depends on the level, and the future value.
+template <bool FUTURE>
+__device__ __forceinline__ double2 window_entry(const WinParams& W, const double* __restrict__ v_next, int m) {
+  double l = W.lev0 + (double)m * W.step;
+  double hold = W.h * jmax(l, 0.0);
+  double pen = W.pi * jmax(-l, 0.0);
+  double2 e;
+  e.x = hold + pen;  // one of the two is +-0: c0 + e.x == (c0 + hold) + pen bit for bit
+  e.y = 0.0;
+  if constexpr (FUTURE) {
+    // CLSP.java:257-258: upper clamp, then lower clamp.  In the unclamped variant every real cell
+    // is inside the next box by construction; the clamp then only keeps padded (p = 0) demand
+    // steps, padded actions and tail lanes from reading outside the table.
+    int idx = m + W.idx_off;
+    idx = idx > W.next_last ? W.next_last : idx;
+    idx = idx < 0 ? 0 : idx;
+    e.y = v_next[idx];
+  }
+  return e;
+}
+
+template <int R, bool MAXDIR, bool FUTURE>
+__global__ __launch_bounds__(256) void window_f1_kernel(WinParams W, const double* __restrict__ v_next,
+                                                        double* __restrict__ out_val, int32_t* __restrict__ out_idx,
+                                                        const double* __restrict__ pmf_p, int64_t lo, int64_t hi) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  double2* s_win = reinterpret_cast<double2*>(smem);
+  const int span = 64 + W.chunk_actions + W.d_pad;  // entries [0, span): one spare slot in front
+  double* s_val = reinterpret_cast<double*>(smem + (size_t)span * 16);
+  int* s_k = reinterpret_cast<int*>(s_val + 4 * 64);
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int chunk = blockIdx.x / W.n_tiles;
+  const int tile = blockIdx.x - chunk * W.n_tiles;
+  const int64_t i0 = lo + (int64_t)tile * 64;
+  const int kA = chunk * W.chunk_actions;
+
+  // stage the window: slot s holds m = m_lo + s, m_lo = i0 + kA - d_pad (slot 0 is the spare)
+  const int m_lo = (int)i0 + kA - W.d_pad;
+  for (int s = tid; s < span; s += 256) s_win[s] = window_entry<FUTURE>(W, v_next, m_lo + s);
+  __syncthreads();
+
+  double best = MAXDIR ? -1.7976931348623157e308 : 1.7976931348623157e308;
+  int bestk = 0;
+  const int blocks_in_chunk = W.chunk_actions / R;
+  for (int rb = wave; rb < blocks_in_chunk; rb += 4) {
+    const int k0 = kA + rb * R;
+    if (k0 >= W.n_actions) break;
+    double c0[R];
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+      double a = (double)(k0 + r) * W.step;
+      c0[r] = (a > 0 ? W.K : 0.0) + W.v * a;  // fixedCost + variableCost (wave-uniform)
+    }
+    // slot of (lane, r, j):  lane + (k0 - kA) + r - j + d_pad
+    const int base = lane + (k0 - kA) + W.d_pad;
+    double2 win[R];
+    double acc[R];
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+      win[r] = s_win[base + r];
+      acc[r] = 0.0;
+    }
+    for (int jb = 0; jb < W.d_pad; jb += R) {
+#pragma unroll
+      for (int t = 0; t < R; ++t) {
+        const double p = pmf_p[jb + t];  // uniform -> scalar load
+#pragma unroll
+        for (int r = 0; r < R; ++r) {
+          const double2 w = win[(r - t + R) % R];
+          double imm = c0[r] + w.x;
+          acc[r] += p * imm;
+          if constexpr (FUTURE) acc[r] += p * w.y;
+        }
+        // slide: the entry for (r = 0, j + 1) replaces the one (r = R-1, j) just used
+        win[(R - 1 - t) % R] = s_win[base - (jb + t + 1)];
+      }
+    }
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+      const int k = k0 + r;
+      if (k < W.n_actions && (MAXDIR ? (acc[r] > best) : (acc[r] < best))) {
+        best = acc[r];
+        bestk = k;
+      }
+    }
+  }
+
+  s_val[wave * 64 + lane] = best;
+  s_k[wave * 64 + lane] = bestk;
+  __syncthreads();
+  const int64_t idx = i0 + tid;
+  if (tid < 64 && idx < hi) {
+    double bv = s_val[tid];
+    int bk = s_k[tid];
+#pragma unroll
+    for (int w = 1; w < 4; ++w) {
+      double ov = s_val[w * 64 + tid];
+      int ok = s_k[w * 64 + tid];
+      if (better<MAXDIR>(ov, ok, bv, bk)) {
+        bv = ov;
+        bk = ok;
+      }
+    }
+    const int64_t o = (int64_t)chunk * W.partial_stride + idx;
+    out_val[o] = bv;
+    out_idx[o] = bk;
+  }
+}
+
+// arg-opt over the action chunks: rows [c * stride + idx], c = 0..n_chunks-1
+template <bool MAXDIR>
+__global__ __launch_bounds__(256) void window_combine_kernel(const double* __restrict__ part_val,
+                                                             const int32_t* __restrict__ part_idx, int n_chunks,
+                                                             int64_t stride, double* __restrict__ v_cur,
+                                                             int32_t* __restrict__ pol, int64_t lo, int64_t hi) {
+  const int64_t idx = lo + (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (idx >= hi) return;
+  double bv = part_val[idx];
+  int bk = part_idx[idx];
+  for (int c = 1; c < n_chunks; ++c) {
+    double ov = part_val[(int64_t)c * stride + idx];
+    int ok = part_idx[(int64_t)c * stride + idx];
+    if (better<MAXDIR>(ov, ok, bv, bk)) {
+      bv = ov;
+      bk = ok;
+    }
+  }
+  v_cur[idx] = bv;
+  pol[idx] = bk;
+}
+
+}  // namespace sdp

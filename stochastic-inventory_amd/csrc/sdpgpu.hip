@@ -11,7 +11,9 @@
 #include <cmath>
 #include <cstdarg>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
+#include <algorithm>
 #include <new>
 #include <string>
 #include <vector>
@@ -26,6 +28,8 @@ using sdp::Grid;
 namespace {
 
 thread_local std::string g_create_error;
+
+constexpr size_t kPmfPad = 8;  // zero-probability tail so the demand loop can run in blocks of R <= 8
 
 struct PeriodInfo {
   Grid g{};
@@ -70,6 +74,10 @@ struct sdpgpu_handle {
   bool solve_timed = false;
   std::vector<char> period_done;  // V_t valid (a ping-pong table may have been overwritten since)
   std::vector<char> policy_done;  // the policy slab of period t has been computed
+  double* d_part_val = nullptr;    // window kernel: partial arg-opt rows [chunk][slab]
+  int32_t* d_part_idx = nullptr;
+  size_t part_elems = 0;
+  int win_r = 0, win_nch = 0;      // tuning overrides (SDPGPU_WIN_R / SDPGPU_WIN_NCH), 0 = heuristic
   uint8_t* d_reach = nullptr;      // reachable masks, period t at reach_off[t-1]
   std::vector<size_t> reach_off;
   bool reach_done = false;
@@ -192,7 +200,7 @@ int layout(sdpgpu_handle* h) {
     p.hi = std::min<int64_t>(p.S, slab * (d.rank + 1));
     p.nD = (int32_t)h->pmf_d[t].size();
     p.pmf_off = pmf_off;
-    pmf_off += 2 * (size_t)p.nD;
+    pmf_off += 2 * (size_t)p.nD + kPmfPad;  // probabilities are followed by kPmfPad zeros (window kernel)
     p.v_off = v_off;
     p.pol_off = pol_off;
     pol_off += (size_t)slab;
@@ -247,9 +255,9 @@ int allocate(sdpgpu_handle* h) {
   }
   HIP_TRY(h, hipMalloc((void**)&h->d_policy, std::max<size_t>(h->policy_elems, 1) * sizeof(int32_t)));
   size_t pmf_elems = 0;
-  for (auto& p : h->per) pmf_elems += 2 * (size_t)p.nD;
+  for (auto& p : h->per) pmf_elems += 2 * (size_t)p.nD + kPmfPad;
   HIP_TRY(h, hipMalloc((void**)&h->d_pmf, std::max<size_t>(pmf_elems, 1) * sizeof(double)));
-  std::vector<double> host(pmf_elems);
+  std::vector<double> host(pmf_elems, 0.0);
   for (int t = 0; t < h->T; ++t) {
     const PeriodInfo& p = h->per[t];
     std::memcpy(&host[p.pmf_off], h->pmf_d[t].data(), (size_t)p.nD * sizeof(double));
@@ -380,7 +388,7 @@ void count_cells(sdpgpu_handle* h, int period) {
 }
 
 bool window_eligible(const sdpgpu_handle* h, int period);
-hipError_t launch_window(const sdpgpu_handle* h, const DevParams& P, int period, const double* v_next, double* v_cur,
+hipError_t launch_window(sdpgpu_handle* h, const DevParams& P, int period, const double* v_next, double* v_cur,
                          int32_t* pol, const double* pmf_d, const double* pmf_p, int64_t lo, int64_t hi, hipStream_t st);
 
 int run_period_impl(sdpgpu_handle* h, int period) {
@@ -500,10 +508,136 @@ int compute_reachable(sdpgpu_handle* h) {
   return SDPGPU_OK;
 }
 
-bool window_eligible(const sdpgpu_handle*, int) { return false; }
-hipError_t launch_window(const sdpgpu_handle*, const DevParams&, int, const double*, double*, int32_t*, const double*,
-                         const double*, int64_t, int64_t, hipStream_t) {
-  return hipErrorNotSupported;
+// ---- window kernel (F1) -----------------------------------------------------------------------
+
+struct WinPlan {
+  int R = 0, d_pad = 0, n_chunks = 1, chunk_actions = 0, n_tiles = 0;
+  size_t smem = 0;
+};
+
+// F1 with a unit-stride demand grid: d_j = d_0 + j*step.
+bool window_eligible(const sdpgpu_handle* h, int period) {
+  if (h->d.family != SDPGPU_FAMILY_BACKORDER) return false;
+  const std::vector<double>& d = h->pmf_d[period - 1];
+  for (size_t j = 1; j < d.size(); ++j)
+    if (d[j] - d[j - 1] != h->d.step) return false;
+  const PeriodInfo& p = h->per[period - 1];
+  if (p.S >= 2147483647LL - 4096) return false;
+  if ((size_t)(64 + h->n_actions_full + 8 + p.nD + 8) * 16 + 4096 > 64 * 1024 && h->n_actions_full + p.nD > 3500) return false;
+  return true;
+}
+
+WinPlan plan_window(const sdpgpu_handle* h, int period) {
+  const PeriodInfo& p = h->per[period - 1];
+  const int A = h->n_actions_full, D = p.nD;
+  WinPlan w;
+  int64_t n = p.hi - p.lo;
+  w.n_tiles = (int)((n + 63) / 64);
+  auto rup = [](int v, int r) { return (v + r - 1) / r * r; };
+  const int cand[3] = {8, 5, 4};
+  int64_t best_cost = -1;
+  for (int r : cand) {
+    if (h->win_r && r != h->win_r) continue;
+    int64_t cost = (int64_t)rup(A, r) * rup(D, r);
+    if (best_cost < 0 || cost < best_cost) {
+      best_cost = cost;
+      w.R = r;
+    }
+  }
+  if (!w.R) w.R = 8;
+  w.d_pad = rup(D, w.R);
+  const int blocks_total = rup(A, w.R) / w.R;
+  // enough waves for ~6 per SIMD (1024 SIMDs), one R-block per wave at least
+  int64_t want_chunks = (6144 + (int64_t)w.n_tiles * 4 - 1) / ((int64_t)w.n_tiles * 4);
+  int nch = (int)std::max<int64_t>(1, std::min<int64_t>(want_chunks, (blocks_total + 3) / 4));
+  if (h->win_nch) nch = std::max(1, std::min(h->win_nch, blocks_total));
+  int bpc = (blocks_total + nch - 1) / nch;
+  // LDS budget: span entries of 16 B + the arg-opt scratch
+  while ((size_t)(64 + bpc * w.R + w.d_pad) * 16 + 4 * 64 * 12 > 60 * 1024 && bpc > 1) bpc = (bpc + 1) / 2;
+  w.n_chunks = (blocks_total + bpc - 1) / bpc;
+  w.chunk_actions = bpc * w.R;
+  w.smem = (size_t)(64 + w.chunk_actions + w.d_pad) * 16 + 4 * 64 * (sizeof(double) + sizeof(int));
+  return w;
+}
+
+template <int R, bool MAXDIR>
+hipError_t launch_window_r(const sdp::WinParams& W, const WinPlan& pl, bool future, const double* v_next, double* out_val,
+                           int32_t* out_idx, const double* pmf_p, int64_t lo, int64_t hi, hipStream_t st) {
+  dim3 grid((unsigned)((int64_t)pl.n_tiles * pl.n_chunks));
+  if (future)
+    hipLaunchKernelGGL((sdp::window_f1_kernel<R, MAXDIR, true>), grid, dim3(256), pl.smem, st, W, v_next, out_val, out_idx, pmf_p, lo, hi);
+  else
+    hipLaunchKernelGGL((sdp::window_f1_kernel<R, MAXDIR, false>), grid, dim3(256), pl.smem, st, W, v_next, out_val, out_idx, pmf_p, lo, hi);
+  return hipGetLastError();
+}
+
+hipError_t launch_window(sdpgpu_handle* h, const DevParams& P, int period, const double* v_next, double* v_cur,
+                         int32_t* pol, const double* pmf_d, const double* pmf_p, int64_t lo, int64_t hi, hipStream_t st) {
+  (void)pmf_d;
+  if (hi <= lo) return hipSuccess;
+  const PeriodInfo& p = h->per[period - 1];
+  WinPlan pl = plan_window(h, period);
+  sdp::WinParams W{};
+  const double d0 = h->pmf_d[period - 1][0];
+  W.lev0 = p.g.x_lo - d0;
+  W.step = h->d.step;
+  W.h = h->d.holding_cost;
+  W.pi = h->d.penalty_cost;
+  W.K = h->d.fixed_order_cost;
+  W.v = h->d.unit_order_cost;
+  const bool future = period < h->T;
+  if (future) {
+    W.idx_off = (int32_t)((W.lev0 - h->per[period].g.x_lo) / h->d.step);
+    W.next_last = (int32_t)(h->per[period].g.nx - 1);
+  }
+  W.n_actions = h->n_actions_full;
+  W.d_pad = pl.d_pad;
+  W.n_chunks = pl.n_chunks;
+  W.chunk_actions = pl.chunk_actions;
+  W.n_tiles = pl.n_tiles;
+  double* out_val = v_cur;
+  int32_t* out_idx = pol;
+  if (pl.n_chunks > 1) {
+    int64_t slab = hi - lo;
+    size_t need = (size_t)pl.n_chunks * (size_t)slab;
+    if (need > h->part_elems) {
+      if (h->d_part_val) (void)hipFree(h->d_part_val);
+      if (h->d_part_idx) (void)hipFree(h->d_part_idx);
+      h->d_part_val = nullptr;
+      h->d_part_idx = nullptr;
+      h->part_elems = 0;
+      hipError_t e = hipMalloc((void**)&h->d_part_val, need * sizeof(double));
+      if (e != hipSuccess) return e;
+      e = hipMalloc((void**)&h->d_part_idx, need * sizeof(int32_t));
+      if (e != hipSuccess) return e;
+      h->part_elems = need;
+    }
+    W.partial_stride = slab;
+    out_val = h->d_part_val - lo;  // the kernels index rows by flat state index
+    out_idx = h->d_part_idx - lo;
+  }
+  hipError_t e = hipErrorInvalidValue;
+#define SDP_WIN(RR)                                                                                                  \
+  case RR:                                                                                                           \
+    e = P.maxdir ? launch_window_r<RR, true>(W, pl, future, v_next, out_val, out_idx, pmf_p, lo, hi, st)              \
+                 : launch_window_r<RR, false>(W, pl, future, v_next, out_val, out_idx, pmf_p, lo, hi, st);            \
+    break;
+  switch (pl.R) {
+    SDP_WIN(8)
+    SDP_WIN(5)
+    SDP_WIN(4)
+  }
+#undef SDP_WIN
+  if (e != hipSuccess) return e;
+  if (pl.n_chunks > 1) {
+    unsigned blocks = (unsigned)((hi - lo + 255) / 256);
+    if (P.maxdir)
+      hipLaunchKernelGGL((sdp::window_combine_kernel<true>), dim3(blocks), dim3(256), 0, st, out_val, out_idx, pl.n_chunks, W.partial_stride, v_cur, pol, lo, hi);
+    else
+      hipLaunchKernelGGL((sdp::window_combine_kernel<false>), dim3(blocks), dim3(256), 0, st, out_val, out_idx, pl.n_chunks, W.partial_stride, v_cur, pol, lo, hi);
+    e = hipGetLastError();
+  }
+  return e;
 }
 
 }  // namespace
@@ -552,6 +686,8 @@ int sdpgpu_create(const sdpgpu_desc* desc, sdpgpu_handle** out) {
     h->pmf_set.assign((size_t)h->T, 0);
     h->period_done.assign((size_t)h->T, 0);
     h->policy_done.assign((size_t)h->T, 0);
+    if (const char* e = std::getenv("SDPGPU_WIN_R")) h->win_r = std::atoi(e);
+    if (const char* e = std::getenv("SDPGPU_WIN_NCH")) h->win_nch = std::atoi(e);
   } catch (...) {
     delete h;
     return fail(nullptr, SDPGPU_ERR_ARG, "out of host memory");
@@ -576,6 +712,8 @@ void sdpgpu_destroy(sdpgpu_handle* h) {
   if (h->d_policy) (void)hipFree(h->d_policy);
   if (h->d_pmf) (void)hipFree(h->d_pmf);
   if (h->d_reach) (void)hipFree(h->d_reach);
+  if (h->d_part_val) (void)hipFree(h->d_part_val);
+  if (h->d_part_idx) (void)hipFree(h->d_part_idx);
   if (h->stream && h->own_stream) (void)hipStreamDestroy(h->stream);
   delete h;
 }
