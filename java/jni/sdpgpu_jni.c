@@ -1,0 +1,121 @@
+/*
+ * sdpgpu_jni.c -- JNI shim between sdp.gpu.SdpGpu and the C ABI of include/sdpgpu.h.
+ * SOURCE ONLY: jni.h does not exist in the authoring image; build recipe in SdpGpu.java.
+ * Rules: never retain a Java reference, never call back into the JVM from a HIP callback,
+ * turn every non-zero status into IllegalStateException(sdpgpu_last_error()).
+ */
+#include <jni.h>
+#include <string.h>
+
+#include "sdpgpu.h"
+
+static void throw_state(JNIEnv* env, const char* msg) {
+  jclass c = (*env)->FindClass(env, "java/lang/IllegalStateException");
+  if (c) (*env)->ThrowNew(env, c, msg);
+}
+#define H(h) ((sdpgpu_handle*)(intptr_t)(h))
+#define CHECK(env, h, rc) do { if ((rc) != 0) throw_state(env, sdpgpu_last_error(H(h))); } while (0)
+
+JNIEXPORT jlong JNICALL Java_sdp_gpu_SdpGpu_create(JNIEnv* env, jclass cls, jintArray ints, jdoubleArray dbls) {
+  sdpgpu_desc d;
+  sdpgpu_desc_init(&d);
+  jint i[12];
+  jdouble v[28];
+  (*env)->GetIntArrayRegion(env, ints, 0, 12, i);
+  (*env)->GetDoubleArrayRegion(env, dbls, 0, 28, v);
+  d.family = i[0]; d.direction = i[1]; d.periods = i[2]; d.clamp_inventory = i[3];
+  d.zero_order_last_period = i[4]; d.cash_round_int_div = i[5]; d.cash_formula = i[6]; d.kernel = i[7];
+  d.device = i[8]; d.rank = i[9]; d.world_size = i[10]; d.store_all_values = i[11];
+  d.step = v[0]; d.min_inventory = v[1]; d.max_inventory = v[2]; d.max_order_quantity = v[3];
+  d.ini_inventory = v[4]; d.ini_cash = v[5]; d.ini_preq = v[6];
+  d.fixed_order_cost = v[7]; d.unit_order_cost = v[8]; d.holding_cost = v[9]; d.penalty_cost = v[10];
+  d.price = v[11]; d.salvage_value = v[12]; d.deposit_rate = v[13]; d.overhead_cost = v[14];
+  d.overhead_rate = v[15]; d.discount_factor = v[16]; d.min_cash = v[17]; d.max_cash = v[18];
+  d.cash_round_mult = v[19]; d.cash_round_div = v[20];
+  d.r0 = v[21]; d.r2 = v[22]; d.r3 = v[23]; d.overdraft_limit = v[24]; d.interest_free_amount = v[25];
+  sdpgpu_handle* h = NULL;
+  if (sdpgpu_create(&d, &h) != 0) {
+    throw_state(env, sdpgpu_last_error(NULL));
+    return 0;
+  }
+  return (jlong)(intptr_t)h;
+}
+
+JNIEXPORT void JNICALL Java_sdp_gpu_SdpGpu_destroy(JNIEnv* env, jclass cls, jlong h) { sdpgpu_destroy(H(h)); }
+
+JNIEXPORT void JNICALL Java_sdp_gpu_SdpGpu_setPmf(JNIEnv* env, jclass cls, jlong h, jint t, jdoubleArray dem, jdoubleArray prob) {
+  jsize n = (*env)->GetArrayLength(env, dem);
+  jdouble* d = (*env)->GetPrimitiveArrayCritical(env, dem, NULL);
+  jdouble* p = (*env)->GetPrimitiveArrayCritical(env, prob, NULL);
+  int rc = sdpgpu_set_pmf(H(h), t, d, p, n); /* copies; no JNI call between Get and Release */
+  (*env)->ReleasePrimitiveArrayCritical(env, prob, p, JNI_ABORT);
+  (*env)->ReleasePrimitiveArrayCritical(env, dem, d, JNI_ABORT);
+  CHECK(env, h, rc);
+}
+
+JNIEXPORT void JNICALL Java_sdp_gpu_SdpGpu_setOverhead(JNIEnv* env, jclass cls, jlong h, jint t, jdouble oh) {
+  CHECK(env, h, sdpgpu_set_overhead(H(h), t, oh));
+}
+
+JNIEXPORT void JNICALL Java_sdp_gpu_SdpGpu_solve(JNIEnv* env, jclass cls, jlong h) { CHECK(env, h, sdpgpu_solve(H(h), 1)); }
+
+JNIEXPORT jlong JNICALL Java_sdp_gpu_SdpGpu_numStates(JNIEnv* env, jclass cls, jlong h, jint period) {
+  return sdpgpu_num_states(H(h), period);
+}
+
+JNIEXPORT jdoubleArray JNICALL Java_sdp_gpu_SdpGpu_grid(JNIEnv* env, jclass cls, jlong h, jint period) {
+  double x_lo; int64_t nx, nc, nq;
+  int rc = sdpgpu_grid(H(h), period, &x_lo, &nx, &nc, &nq);
+  CHECK(env, h, rc);
+  jdouble v[4] = {x_lo, (double)nx, (double)nc, (double)nq};
+  jdoubleArray out = (*env)->NewDoubleArray(env, 4);
+  if (out) (*env)->SetDoubleArrayRegion(env, out, 0, 4, v);
+  return out;
+}
+
+JNIEXPORT jdouble JNICALL Java_sdp_gpu_SdpGpu_cashValue(JNIEnv* env, jclass cls, jlong h, jlong ic) { return sdpgpu_cash_value(H(h), ic); }
+
+JNIEXPORT jlong JNICALL Java_sdp_gpu_SdpGpu_stateIndex(JNIEnv* env, jclass cls, jlong h, jint period, jdouble x, jdouble cash, jdouble preq) {
+  return sdpgpu_state_index(H(h), period, x, cash, preq);
+}
+
+JNIEXPORT void JNICALL Java_sdp_gpu_SdpGpu_values(JNIEnv* env, jclass cls, jlong h, jint period, jdoubleArray out) {
+  jsize n = (*env)->GetArrayLength(env, out);
+  jdouble* o = (*env)->GetPrimitiveArrayCritical(env, out, NULL);
+  int rc = sdpgpu_values(H(h), period, o, n);
+  (*env)->ReleasePrimitiveArrayCritical(env, out, o, 0);
+  CHECK(env, h, rc);
+}
+
+JNIEXPORT void JNICALL Java_sdp_gpu_SdpGpu_policy(JNIEnv* env, jclass cls, jlong h, jint period, jintArray out) {
+  jsize n = (*env)->GetArrayLength(env, out);
+  jint* o = (*env)->GetPrimitiveArrayCritical(env, out, NULL);
+  int rc = sdpgpu_policy(H(h), period, (int32_t*)o, 0, n);
+  (*env)->ReleasePrimitiveArrayCritical(env, out, o, 0);
+  CHECK(env, h, rc);
+}
+
+JNIEXPORT void JNICALL Java_sdp_gpu_SdpGpu_evalStates(JNIEnv* env, jclass cls, jlong h, jint period, jdoubleArray x, jdoubleArray cash,
+                                                      jdoubleArray preq, jdoubleArray outv, jintArray outa) {
+  jsize n = (*env)->GetArrayLength(env, x);
+  jdouble* px = (*env)->GetDoubleArrayElements(env, x, NULL);
+  jdouble* pc = cash ? (*env)->GetDoubleArrayElements(env, cash, NULL) : NULL;
+  jdouble* pq = preq ? (*env)->GetDoubleArrayElements(env, preq, NULL) : NULL;
+  jdouble* ov = (*env)->GetDoubleArrayElements(env, outv, NULL);
+  jint* oa = (*env)->GetIntArrayElements(env, outa, NULL);
+  int rc = sdpgpu_eval_states(H(h), period, n, px, pc, pq, ov, (int32_t*)oa);
+  (*env)->ReleaseIntArrayElements(env, outa, oa, 0);
+  (*env)->ReleaseDoubleArrayElements(env, outv, ov, 0);
+  if (pq) (*env)->ReleaseDoubleArrayElements(env, preq, pq, JNI_ABORT);
+  if (pc) (*env)->ReleaseDoubleArrayElements(env, cash, pc, JNI_ABORT);
+  (*env)->ReleaseDoubleArrayElements(env, x, px, JNI_ABORT);
+  CHECK(env, h, rc);
+}
+
+JNIEXPORT void JNICALL Java_sdp_gpu_SdpGpu_reachable(JNIEnv* env, jclass cls, jlong h, jint period, jbyteArray out) {
+  jsize n = (*env)->GetArrayLength(env, out);
+  jbyte* o = (*env)->GetPrimitiveArrayCritical(env, out, NULL);
+  int rc = sdpgpu_reachable(H(h), period, (uint8_t*)o, n);
+  (*env)->ReleasePrimitiveArrayCritical(env, out, o, 0);
+  CHECK(env, h, rc);
+}

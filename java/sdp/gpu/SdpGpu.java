@@ -1,0 +1,61 @@
+package sdp.gpu;
+
+/**
+ * Thin JNI binding of the C ABI in include/sdpgpu.h (one native method per entry point the Java
+ * side needs).  SOURCE ONLY in this repository: the authoring image has no JDK, so this class and
+ * java/jni/sdpgpu_jni.c are uncompiled and untested here; every parity test goes through the same
+ * C ABI from Python.  A maintainer builds it with
+ *
+ *   javac -h java/jni -d build/classes java/sdp/gpu/*.java
+ *   gcc -shared -fPIC -I$JAVA_HOME/include -I$JAVA_HOME/include/linux -Iinclude \
+ *       -o libsdpgpu_jni.so java/jni/sdpgpu_jni.c -L stochastic-inventory_amd -lsdpgpu
+ *
+ * Handles are opaque longs; arrays cross as primitive arrays (GetPrimitiveArrayCritical in the
+ * shim, never retained); errors become IllegalStateException carrying sdpgpu_last_error().
+ */
+public final class SdpGpu {
+	static {
+		System.loadLibrary("sdpgpu_jni");
+	}
+
+	private SdpGpu() {
+	}
+
+	/** Families: the closed-form lambda families of the in-scope drivers (sdpgpu_family). */
+	public static final int FAMILY_BACKORDER = 1, FAMILY_LEADTIME = 2, FAMILY_CASH = 3, FAMILY_OVERDRAFT = 4,
+			FAMILY_CASH_LEADTIME = 5;
+	public static final int MIN = 0, MAX = 1;
+
+	/**
+	 * sdpgpu_create: ints = {family, direction, periods, clampInventory, zeroOrderLastPeriod,
+	 * cashRoundIntDiv, cashFormula, kernel, device, rank, worldSize, storeAllValues}; doubles in the
+	 * order of struct sdpgpu_desc's double fields.
+	 */
+	public static native long create(int[] ints, double[] doubles);
+
+	public static native void destroy(long handle);
+
+	public static native void setPmf(long handle, int t, double[] demand, double[] prob);
+
+	public static native void setOverhead(long handle, int t, double overheadCost);
+
+	public static native void solve(long handle);
+
+	public static native long numStates(long handle, int period);
+
+	/** {x_lo, nx, nc, nq} of the period's grid. */
+	public static native double[] grid(long handle, int period);
+
+	public static native double cashValue(long handle, long ic);
+
+	public static native long stateIndex(long handle, int period, double x, double cash, double preQ);
+
+	public static native void values(long handle, int period, double[] out);
+
+	public static native void policy(long handle, int period, int[] out);
+
+	public static native void evalStates(long handle, int period, double[] x, double[] cash, double[] preQ,
+			double[] outValue, int[] outActionIndex);
+
+	public static native void reachable(long handle, int period, byte[] out);
+}

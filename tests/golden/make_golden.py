@@ -1,0 +1,37 @@
+#!/usr/bin/env python3
+"""Regenerate tests/golden/tables_*.npz.
+
+The reference cannot run here (Java, no JDK), so these tables are NOT reference outputs: they
+are the CPU oracle's value and policy tables for the small cases in tests/cases.py, frozen so
+that an accidental change to the oracle (or to a case) is caught.  The only reference-recorded
+numbers are in kat_reference.json.  Usage: python tests/golden/make_golden.py
+"""
+import os
+import sys
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(os.path.dirname(HERE))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+
+import cases  # noqa: E402
+from oracle import sdpref  # noqa: E402
+
+
+def main():
+    for make in cases.ALL:
+        w = make()
+        P = sdpref.Problem(w.desc(), w.pmf, w.overhead())
+        V, pol, cells = P.solve()
+        out = {"cells": np.int64(cells)}
+        for t in range(w.T):
+            out[f"v{t + 1}"] = V[t]
+            out[f"p{t + 1}"] = pol[t].astype(np.int16)
+        np.savez_compressed(os.path.join(HERE, f"tables_{w.name}.npz"), **out)
+        print(w.name, cells, sum(len(v) for v in V))
+
+
+if __name__ == "__main__":
+    main()
