@@ -155,6 +155,131 @@ __global__ __launch_bounds__(256) void window_f1_kernel(WinParams W, const doubl
   }
 }
 
+// ---------------------------------------------------------------------------------------------
+// F2 (Leadtime.java:50-81): state (x, preQ), level l = x + preQ - d does not depend on the action;
+// the action only selects the PLANE of V_{t+1} (next preQ = action) and the ordering cost:
+//     imm = (fixed + var)(k) + M(m),  next = V_{t+1}[k][clamp(m)],   m = ix + iq - j.
+// A workgroup owns 64 consecutive x of one preQ row and a chunk of actions; it stages M(m) and,
+// per action of the chunk, the row segment V_{t+1}[k][clamp(m)] of 64 + D entries in LDS.  A lane
+// (= state) carries R actions in registers; per demand step it reads M once and one V entry per
+// action (ds_read_b64, consecutive lanes -> conflict-free).  Same five fp64 ops per cell.
+// ---------------------------------------------------------------------------------------------
+struct RowParams {
+  double lev0;  // level of m = 0: x_lo(cur) - d_0   (preQ enters through m)
+  double step;
+  double h, pi, K, v;
+  int32_t idx_off;      // m -> next-grid inventory index offset
+  int32_t next_last;    // nx(next) - 1
+  int32_t next_nx;      // nx(next): plane stride of V_{t+1}
+  int32_t cur_nx;       // nx(cur)
+  int32_t tiles_per_row;
+  int32_t n_actions;
+  int32_t d_pad;
+  int32_t n_chunks;
+  int32_t chunk_actions;
+  int32_t n_tiles;      // tiles launched (a contiguous run of row tiles)
+  int32_t tile0;        // first tile of the run (tile = iq * tiles_per_row + ix / 64)
+  int64_t partial_stride;
+};
+
+template <int R, bool MAXDIR, bool FUTURE>
+__global__ __launch_bounds__(256) void window_f2_kernel(RowParams W, const double* __restrict__ v_next,
+                                                        double* __restrict__ out_val, int32_t* __restrict__ out_idx,
+                                                        const double* __restrict__ pmf_p, int64_t lo, int64_t hi) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int span = 64 + W.d_pad + 1;                   // slots per row segment (slot 0 spare)
+  double* s_m = reinterpret_cast<double*>(smem);       // M(m)
+  double* s_v = s_m + span;                            // [chunk_actions][span]
+  double* s_val = s_v + (size_t)(FUTURE ? W.chunk_actions : 0) * span;
+  int* s_k = reinterpret_cast<int*>(s_val + 4 * 64);
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int chunk = blockIdx.x / W.n_tiles;
+  const int tile = W.tile0 + (blockIdx.x - chunk * W.n_tiles);
+  const int iq = tile / W.tiles_per_row;
+  const int ix0 = (tile - iq * W.tiles_per_row) * 64;
+  const int kA = chunk * W.chunk_actions;
+  const int m_lo = ix0 + iq - W.d_pad;  // slot s <-> m = m_lo + s
+
+  for (int s = tid; s < span; s += 256) {
+    double l = W.lev0 + (double)(m_lo + s) * W.step;
+    s_m[s] = W.h * jmax(l, 0.0) + W.pi * jmax(-l, 0.0);
+  }
+  if constexpr (FUTURE) {
+    const int total = W.chunk_actions * span;
+    for (int e = tid; e < total; e += 256) {
+      const int row = e / span;
+      const int s = e - row * span;
+      int k = kA + row;
+      k = k < W.n_actions ? k : W.n_actions - 1;  // padded actions read a valid plane, never selected
+      int idx = m_lo + s + W.idx_off;
+      idx = idx > W.next_last ? W.next_last : idx;
+      idx = idx < 0 ? 0 : idx;
+      s_v[e] = v_next[(int64_t)k * W.next_nx + idx];
+    }
+  }
+  __syncthreads();
+
+  double best = MAXDIR ? -1.7976931348623157e308 : 1.7976931348623157e308;
+  int bestk = 0;
+  const int blocks_in_chunk = W.chunk_actions / R;
+  const int base = lane + W.d_pad;  // slot of (lane, j): base - j
+  for (int rb = wave; rb < blocks_in_chunk; rb += 4) {
+    const int k0 = kA + rb * R;
+    if (k0 >= W.n_actions) break;
+    double c0[R], acc[R];
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+      double a = (double)(k0 + r) * W.step;
+      c0[r] = (a > 0 ? W.K : 0.0) + W.v * a;
+      acc[r] = 0.0;
+    }
+    const double* rows = s_v + (size_t)(rb * R) * span + base;
+    for (int j = 0; j < W.d_pad; ++j) {
+      const double p = pmf_p[j];
+      const double mj = s_m[base - j];
+#pragma unroll
+      for (int r = 0; r < R; ++r) {
+        double imm = c0[r] + mj;
+        acc[r] += p * imm;
+        if constexpr (FUTURE) acc[r] += p * rows[r * span - j];
+      }
+    }
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+      const int k = k0 + r;
+      if (k < W.n_actions && (MAXDIR ? (acc[r] > best) : (acc[r] < best))) {
+        best = acc[r];
+        bestk = k;
+      }
+    }
+  }
+
+  s_val[wave * 64 + lane] = best;
+  s_k[wave * 64 + lane] = bestk;
+  __syncthreads();
+  const int ix = ix0 + tid;
+  const int64_t idx = (int64_t)iq * W.cur_nx + ix;
+  if (tid < 64 && ix < W.cur_nx && idx >= lo && idx < hi) {
+    double bv = s_val[tid];
+    int bk = s_k[tid];
+#pragma unroll
+    for (int w = 1; w < 4; ++w) {
+      double ov = s_val[w * 64 + tid];
+      int ok = s_k[w * 64 + tid];
+      if (better<MAXDIR>(ov, ok, bv, bk)) {
+        bv = ov;
+        bk = ok;
+      }
+    }
+    const int64_t o = (int64_t)chunk * W.partial_stride + idx;
+    out_val[o] = bv;
+    out_idx[o] = bk;
+  }
+}
+
 // arg-opt over the action chunks: rows [c * stride + idx], c = 0..n_chunks-1
 template <bool MAXDIR>
 __global__ __launch_bounds__(256) void window_combine_kernel(const double* __restrict__ part_val,

@@ -515,9 +515,9 @@ struct WinPlan {
   size_t smem = 0;
 };
 
-// F1 with a unit-stride demand grid: d_j = d_0 + j*step.
+// F1 / F2 with a unit-stride demand grid: d_j = d_0 + j*step.
 bool window_eligible(const sdpgpu_handle* h, int period) {
-  if (h->d.family != SDPGPU_FAMILY_BACKORDER) return false;
+  if (h->d.family != SDPGPU_FAMILY_BACKORDER && h->d.family != SDPGPU_FAMILY_LEADTIME) return false;
   const std::vector<double>& d = h->pmf_d[period - 1];
   for (size_t j = 1; j < d.size(); ++j)
     if (d[j] - d[j - 1] != h->d.step) return false;
@@ -571,10 +571,124 @@ hipError_t launch_window_r(const sdp::WinParams& W, const WinPlan& pl, bool futu
   return hipGetLastError();
 }
 
+hipError_t ensure_partials(sdpgpu_handle* h, size_t need) {
+  if (need <= h->part_elems) return hipSuccess;
+  if (h->d_part_val) (void)hipFree(h->d_part_val);
+  if (h->d_part_idx) (void)hipFree(h->d_part_idx);
+  h->d_part_val = nullptr;
+  h->d_part_idx = nullptr;
+  h->part_elems = 0;
+  hipError_t e = hipMalloc((void**)&h->d_part_val, need * sizeof(double));
+  if (e != hipSuccess) return e;
+  e = hipMalloc((void**)&h->d_part_idx, need * sizeof(int32_t));
+  if (e != hipSuccess) return e;
+  h->part_elems = need;
+  return hipSuccess;
+}
+
+template <bool MAXDIR>
+hipError_t launch_combine(const double* pv, const int32_t* pi, int n_chunks, int64_t stride, double* v_cur, int32_t* pol,
+                          int64_t lo, int64_t hi, hipStream_t st) {
+  unsigned blocks = (unsigned)((hi - lo + 255) / 256);
+  hipLaunchKernelGGL((sdp::window_combine_kernel<MAXDIR>), dim3(blocks), dim3(256), 0, st, pv, pi, n_chunks, stride, v_cur, pol, lo, hi);
+  return hipGetLastError();
+}
+
+// ---- row-window kernel (F2) ---------------------------------------------------------------
+template <int R, bool MAXDIR>
+hipError_t launch_row_r(const sdp::RowParams& W, size_t smem, bool future, const double* v_next, double* out_val,
+                        int32_t* out_idx, const double* pmf_p, int64_t lo, int64_t hi, hipStream_t st) {
+  dim3 grid((unsigned)((int64_t)W.n_tiles * W.n_chunks));
+  if (future)
+    hipLaunchKernelGGL((sdp::window_f2_kernel<R, MAXDIR, true>), grid, dim3(256), smem, st, W, v_next, out_val, out_idx, pmf_p, lo, hi);
+  else
+    hipLaunchKernelGGL((sdp::window_f2_kernel<R, MAXDIR, false>), grid, dim3(256), smem, st, W, v_next, out_val, out_idx, pmf_p, lo, hi);
+  return hipGetLastError();
+}
+
+hipError_t launch_row_window(sdpgpu_handle* h, const DevParams& P, int period, const double* v_next, double* v_cur,
+                             int32_t* pol, const double* pmf_p, int64_t lo, int64_t hi, hipStream_t st) {
+  const PeriodInfo& p = h->per[period - 1];
+  const int A = h->n_actions_full, D = p.nD;
+  auto rup = [](int v, int r) { return (v + r - 1) / r * r; };
+  int R = 0;
+  int64_t best_cost = -1;
+  const int cand[3] = {8, 5, 4};
+  for (int r : cand) {
+    if (h->win_r && r != h->win_r) continue;
+    int64_t cost = (int64_t)rup(A, r) * rup(D, r);
+    if (best_cost < 0 || cost < best_cost) {
+      best_cost = cost;
+      R = r;
+    }
+  }
+  if (!R) R = 8;
+  const bool future = period < h->T;
+  sdp::RowParams W{};
+  W.lev0 = p.g.x_lo - h->pmf_d[period - 1][0];
+  W.step = h->d.step;
+  W.h = h->d.holding_cost;
+  W.pi = h->d.penalty_cost;
+  W.K = h->d.fixed_order_cost;
+  W.v = h->d.unit_order_cost;
+  if (future) {
+    W.idx_off = (int32_t)((W.lev0 - h->per[period].g.x_lo) / h->d.step);
+    W.next_last = (int32_t)(h->per[period].g.nx - 1);
+    W.next_nx = (int32_t)h->per[period].g.nx;
+  }
+  W.cur_nx = (int32_t)p.g.nx;
+  W.tiles_per_row = (int32_t)((p.g.nx + 63) / 64);
+  W.n_actions = A;
+  W.d_pad = rup(D, R);
+  const int span = 64 + W.d_pad + 1;
+  const int blocks_total = rup(A, R) / R;
+  // one R-block per wave: chunks of 4 R-blocks, fewer if the LDS budget (rows of `span` doubles) says so
+  int bpc = std::min(4, blocks_total);
+  if (h->win_nch) bpc = std::max(1, (blocks_total + h->win_nch - 1) / h->win_nch);
+  auto lds = [&](int b) { return (size_t)span * 8 * (1 + (future ? b * R : 0)) + 4 * 64 * 12; };
+  while (bpc > 1 && lds(bpc) > 60 * 1024) --bpc;
+  if (lds(bpc) > 64 * 1024) return hipErrorInvalidValue;
+  W.chunk_actions = bpc * R;
+  W.n_chunks = (blocks_total + bpc - 1) / bpc;
+  // the run of row tiles that covers [lo, hi)
+  auto tile_of = [&](int64_t idx) { return (int32_t)((idx / p.g.nx) * W.tiles_per_row + (idx % p.g.nx) / 64); };
+  W.tile0 = tile_of(lo);
+  W.n_tiles = tile_of(hi - 1) - W.tile0 + 1;
+  double* out_val = v_cur;
+  int32_t* out_idx = pol;
+  if (W.n_chunks > 1) {
+    int64_t slab = hi - lo;
+    hipError_t e = ensure_partials(h, (size_t)W.n_chunks * (size_t)slab);
+    if (e != hipSuccess) return e;
+    W.partial_stride = slab;
+    out_val = h->d_part_val - lo;
+    out_idx = h->d_part_idx - lo;
+  }
+  hipError_t e = hipErrorInvalidValue;
+  size_t smem = lds(bpc);
+#define SDP_ROW(RR)                                                                                         \
+  case RR:                                                                                                  \
+    e = P.maxdir ? launch_row_r<RR, true>(W, smem, future, v_next, out_val, out_idx, pmf_p, lo, hi, st)      \
+                 : launch_row_r<RR, false>(W, smem, future, v_next, out_val, out_idx, pmf_p, lo, hi, st);    \
+    break;
+  switch (R) {
+    SDP_ROW(8)
+    SDP_ROW(5)
+    SDP_ROW(4)
+  }
+#undef SDP_ROW
+  if (e != hipSuccess) return e;
+  if (W.n_chunks > 1)
+    e = P.maxdir ? launch_combine<true>(out_val, out_idx, W.n_chunks, W.partial_stride, v_cur, pol, lo, hi, st)
+                 : launch_combine<false>(out_val, out_idx, W.n_chunks, W.partial_stride, v_cur, pol, lo, hi, st);
+  return e;
+}
+
 hipError_t launch_window(sdpgpu_handle* h, const DevParams& P, int period, const double* v_next, double* v_cur,
                          int32_t* pol, const double* pmf_d, const double* pmf_p, int64_t lo, int64_t hi, hipStream_t st) {
   (void)pmf_d;
   if (hi <= lo) return hipSuccess;
+  if (h->d.family == SDPGPU_FAMILY_LEADTIME) return launch_row_window(h, P, period, v_next, v_cur, pol, pmf_p, lo, hi, st);
   const PeriodInfo& p = h->per[period - 1];
   WinPlan pl = plan_window(h, period);
   sdp::WinParams W{};
@@ -599,19 +713,8 @@ hipError_t launch_window(sdpgpu_handle* h, const DevParams& P, int period, const
   int32_t* out_idx = pol;
   if (pl.n_chunks > 1) {
     int64_t slab = hi - lo;
-    size_t need = (size_t)pl.n_chunks * (size_t)slab;
-    if (need > h->part_elems) {
-      if (h->d_part_val) (void)hipFree(h->d_part_val);
-      if (h->d_part_idx) (void)hipFree(h->d_part_idx);
-      h->d_part_val = nullptr;
-      h->d_part_idx = nullptr;
-      h->part_elems = 0;
-      hipError_t e = hipMalloc((void**)&h->d_part_val, need * sizeof(double));
-      if (e != hipSuccess) return e;
-      e = hipMalloc((void**)&h->d_part_idx, need * sizeof(int32_t));
-      if (e != hipSuccess) return e;
-      h->part_elems = need;
-    }
+    hipError_t ea = ensure_partials(h, (size_t)pl.n_chunks * (size_t)slab);
+    if (ea != hipSuccess) return ea;
     W.partial_stride = slab;
     out_val = h->d_part_val - lo;  // the kernels index rows by flat state index
     out_idx = h->d_part_idx - lo;
@@ -629,14 +732,9 @@ hipError_t launch_window(sdpgpu_handle* h, const DevParams& P, int period, const
   }
 #undef SDP_WIN
   if (e != hipSuccess) return e;
-  if (pl.n_chunks > 1) {
-    unsigned blocks = (unsigned)((hi - lo + 255) / 256);
-    if (P.maxdir)
-      hipLaunchKernelGGL((sdp::window_combine_kernel<true>), dim3(blocks), dim3(256), 0, st, out_val, out_idx, pl.n_chunks, W.partial_stride, v_cur, pol, lo, hi);
-    else
-      hipLaunchKernelGGL((sdp::window_combine_kernel<false>), dim3(blocks), dim3(256), 0, st, out_val, out_idx, pl.n_chunks, W.partial_stride, v_cur, pol, lo, hi);
-    e = hipGetLastError();
-  }
+  if (pl.n_chunks > 1)
+    e = P.maxdir ? launch_combine<true>(out_val, out_idx, pl.n_chunks, W.partial_stride, v_cur, pol, lo, hi, st)
+                 : launch_combine<false>(out_val, out_idx, pl.n_chunks, W.partial_stride, v_cur, pol, lo, hi, st);
   return e;
 }
 

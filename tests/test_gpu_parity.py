@@ -141,13 +141,16 @@ def test_ping_pong_tables(sia, oracle):
     eng.close()
 
 
-def test_sharded_periods_single_process(sia, oracle):
-    """world_size 3 slabs driven from one process: each rank computes its slab into its own copy of
-    V_t, the test plays the all-gather by hand.  Covers slab bounds, padding and the policy slabs."""
+@pytest.mark.parametrize("make,world", [(cases.f3_tenths, 3), (cases.f2_clamped, 3), (cases.f2_unclamped, 2),
+                                        (cases.f1_small, 2), (cases.f1_clsp_main, 4)],
+                         ids=lambda v: getattr(v, "__name__", str(v)))
+def test_sharded_periods_single_process(sia, oracle, make, world):
+    """world_size N slabs driven from one process: each rank computes its slab into its own copy of
+    V_t, the test plays the all-gather by hand.  Covers slab bounds, padding and the policy slabs
+    (for F2 the slabs cut through preQ rows; for F1 through window tiles)."""
     import ctypes as C
     import torch
-    w = cases.f3_tenths()
-    world = 3
+    w = make()
     engs = []
     for r in range(world):
         d = w.desc()
