@@ -43,9 +43,36 @@ struct WinParams {
   int64_t partial_stride; // elements between chunk rows of the partial tables
 };
 
+// Deferred combine: when the previous launch (period t+1) left its arg-opt as per-chunk partial rows,
+// this launch reads V_{t+1} as the opt over those rows while staging its window, and the workgroups
+// of action chunk 0 write the final V_{t+1} / policy rows for their 64 states.  That removes the
+// separate combine launch (and its kernel boundary) from every period but the last one computed.
+struct FusedPrev {
+  const double* part_val;   // [n_chunks][stride], indexed by flat state index
+  const int32_t* part_idx;
+  double* v_out;            // final V_{t+1}
+  int32_t* pol_out;         // final policy of period t+1
+  int32_t n_chunks;
+  int64_t stride;
+#ifdef SDP_STAMPS
+  unsigned long long* stamps;
+#endif
+};
+
+template <bool MAXDIR>
+__device__ __forceinline__ double fused_value(const FusedPrev& F, int idx) {
+  double v = F.part_val[idx];
+  for (int c = 1; c < F.n_chunks; ++c) {
+    double o = F.part_val[(int64_t)c * F.stride + idx];
+    v = MAXDIR ? (o > v ? o : v) : (o < v ? o : v);
+  }
+  return v;
+}
+
 // W[m] for one m: the immediate-cost part that depends on the level, and the future value.
-template <bool FUTURE>
-__device__ __forceinline__ double2 window_entry(const WinParams& W, const double* __restrict__ v_next, int m) {
+template <bool FUTURE, bool FUSED, bool MAXDIR>
+__device__ __forceinline__ double2 window_entry(const WinParams& W, const double* __restrict__ v_next,
+                                                const FusedPrev& F, int m) {
   double l = W.lev0 + (double)m * W.step;
   double hold = W.h * jmax(l, 0.0);
   double pen = W.pi * jmax(-l, 0.0);
@@ -59,15 +86,19 @@ __device__ __forceinline__ double2 window_entry(const WinParams& W, const double
     int idx = m + W.idx_off;
     idx = idx > W.next_last ? W.next_last : idx;
     idx = idx < 0 ? 0 : idx;
-    e.y = v_next[idx];
+    if constexpr (FUSED)
+      e.y = fused_value<MAXDIR>(F, idx);
+    else
+      e.y = v_next[idx];
   }
   return e;
 }
 
-template <int R, bool MAXDIR, bool FUTURE>
+template <int R, bool MAXDIR, bool FUTURE, bool FUSED>
 __global__ __launch_bounds__(256) void window_f1_kernel(WinParams W, const double* __restrict__ v_next,
                                                         double* __restrict__ out_val, int32_t* __restrict__ out_idx,
-                                                        const double* __restrict__ pmf_p, int64_t lo, int64_t hi) {
+                                                        const double* __restrict__ pmf_p, int64_t lo, int64_t hi,
+                                                        FusedPrev F) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   double2* s_win = reinterpret_cast<double2*>(smem);
   const int span = 64 + W.chunk_actions + W.d_pad;  // entries [0, span): one spare slot in front
@@ -81,12 +112,37 @@ __global__ __launch_bounds__(256) void window_f1_kernel(WinParams W, const doubl
   const int tile = blockIdx.x - chunk * W.n_tiles;
   const int64_t i0 = lo + (int64_t)tile * 64;
   const int kA = chunk * W.chunk_actions;
+#ifdef SDP_STAMPS  // diagnostic build only (tools/stamp_window.py): per-wave timeline, never in the product
+  unsigned long long st_t0 = __builtin_amdgcn_s_memrealtime();
+  unsigned long long st_t1 = 0;
+#endif
 
   // stage the window: slot s holds m = m_lo + s, m_lo = i0 + kA - d_pad (slot 0 is the spare)
   const int m_lo = (int)i0 + kA - W.d_pad;
-  for (int s = tid; s < span; s += 256) s_win[s] = window_entry<FUTURE>(W, v_next, m_lo + s);
+  for (int s = tid; s < span; s += 256) s_win[s] = window_entry<FUTURE, FUSED, MAXDIR>(W, v_next, F, m_lo + s);
+  if constexpr (FUSED) {
+    // finalise period t+1 for this tile's states (same grid in both periods; chunk 0 only)
+    const int64_t pidx = i0 + tid;
+    if (chunk == 0 && tid < 64 && pidx < hi) {
+      double bv = F.part_val[pidx];
+      int bk = F.part_idx[pidx];
+      for (int c = 1; c < F.n_chunks; ++c) {
+        double ov = F.part_val[(int64_t)c * F.stride + pidx];
+        int ok = F.part_idx[(int64_t)c * F.stride + pidx];
+        if (better<MAXDIR>(ov, ok, bv, bk)) {
+          bv = ov;
+          bk = ok;
+        }
+      }
+      F.v_out[pidx] = bv;
+      F.pol_out[pidx] = bk;
+    }
+  }
   __syncthreads();
 
+#ifdef SDP_STAMPS
+  st_t1 = __builtin_amdgcn_s_memrealtime();
+#endif
   double best = MAXDIR ? -1.7976931348623157e308 : 1.7976931348623157e308;
   int bestk = 0;
   const int blocks_in_chunk = W.chunk_actions / R;
@@ -108,6 +164,7 @@ __global__ __launch_bounds__(256) void window_f1_kernel(WinParams W, const doubl
       win[r] = s_win[base + r];
       acc[r] = 0.0;
     }
+#pragma unroll 1
     for (int jb = 0; jb < W.d_pad; jb += R) {
 #pragma unroll
       for (int t = 0; t < R; ++t) {
@@ -133,6 +190,15 @@ __global__ __launch_bounds__(256) void window_f1_kernel(WinParams W, const doubl
     }
   }
 
+#ifdef SDP_STAMPS
+  if (F.stamps && lane == 0) {
+    unsigned long long st_t2 = __builtin_amdgcn_s_memrealtime();
+    unsigned hwid = __builtin_amdgcn_s_getreg(4 | (0 << 6) | (31 << 11));       // HW_REG_HW_ID
+    unsigned xcc = __builtin_amdgcn_s_getreg(20 | (0 << 6) | (31 << 11));       // HW_REG_XCC_ID
+    unsigned long long* o = F.stamps + ((size_t)blockIdx.x * 4 + wave) * 5;
+    o[0] = st_t0; o[1] = st_t1; o[2] = st_t2; o[3] = hwid; o[4] = xcc;
+  }
+#endif
   s_val[wave * 64 + lane] = best;
   s_k[wave * 64 + lane] = bestk;
   __syncthreads();

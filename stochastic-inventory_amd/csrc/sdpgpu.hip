@@ -74,9 +74,14 @@ struct sdpgpu_handle {
   bool solve_timed = false;
   std::vector<char> period_done;  // V_t valid (a ping-pong table may have been overwritten since)
   std::vector<char> policy_done;  // the policy slab of period t has been computed
-  double* d_part_val = nullptr;    // window kernel: partial arg-opt rows [chunk][slab]
-  int32_t* d_part_idx = nullptr;
-  size_t part_elems = 0;
+  double* d_part_val[2] = {nullptr, nullptr};  // window kernels: partial arg-opt rows [chunk][slab], by period parity
+  int32_t* d_part_idx[2] = {nullptr, nullptr};
+  size_t part_elems[2] = {0, 0};
+  // deferred combine: V_pending / policy_pending still live as partial rows (see sdp_window.hpp FusedPrev)
+  int pending_period = 0;
+  int pending_chunks = 0;
+  int64_t pending_stride = 0, pending_lo = 0, pending_hi = 0;
+  bool fuse_combine = true;
   int win_r = 0, win_nch = 0;      // tuning overrides (SDPGPU_WIN_R / SDPGPU_WIN_NCH), 0 = heuristic
   uint8_t* d_reach = nullptr;      // reachable masks, period t at reach_off[t-1]
   std::vector<size_t> reach_off;
@@ -388,6 +393,7 @@ void count_cells(sdpgpu_handle* h, int period) {
 }
 
 bool window_eligible(const sdpgpu_handle* h, int period);
+hipError_t flush_pending(sdpgpu_handle* h);
 hipError_t launch_window(sdpgpu_handle* h, const DevParams& P, int period, const double* v_next, double* v_cur,
                          int32_t* pol, const double* pmf_d, const double* pmf_p, int64_t lo, int64_t hi, hipStream_t st);
 
@@ -425,7 +431,9 @@ int run_period_impl(sdpgpu_handle* h, int period) {
     e = launch_window(h, P, period, v_next, v_cur, pol, pd, pp, p.lo, p.hi, h->stream);
     p.kernel_used = SDPGPU_KERNEL_WINDOW;
   } else {
-    e = launch_gather<false>(P, v_next, v_cur, pol, pd, pp, p.lo, p.hi, sdp::QueryStates{nullptr, nullptr, nullptr}, h->stream);
+    e = flush_pending(h);  // the gather kernel reads the final V_{t+1} row
+    if (e == hipSuccess)
+      e = launch_gather<false>(P, v_next, v_cur, pol, pd, pp, p.lo, p.hi, sdp::QueryStates{nullptr, nullptr, nullptr}, h->stream);
     p.kernel_used = SDPGPU_KERNEL_GATHER;
   }
   if (e != hipSuccess) return fail(h, SDPGPU_ERR_DEVICE, "period %d kernel launch: %s", period, hipGetErrorString(e));
@@ -561,28 +569,34 @@ WinPlan plan_window(const sdpgpu_handle* h, int period) {
 }
 
 template <int R, bool MAXDIR>
-hipError_t launch_window_r(const sdp::WinParams& W, const WinPlan& pl, bool future, const double* v_next, double* out_val,
-                           int32_t* out_idx, const double* pmf_p, int64_t lo, int64_t hi, hipStream_t st) {
+hipError_t launch_window_r(const sdp::WinParams& W, const WinPlan& pl, bool future, bool fused, const sdp::FusedPrev& F,
+                           const double* v_next, double* out_val, int32_t* out_idx, const double* pmf_p, int64_t lo,
+                           int64_t hi, hipStream_t st) {
   dim3 grid((unsigned)((int64_t)pl.n_tiles * pl.n_chunks));
-  if (future)
-    hipLaunchKernelGGL((sdp::window_f1_kernel<R, MAXDIR, true>), grid, dim3(256), pl.smem, st, W, v_next, out_val, out_idx, pmf_p, lo, hi);
+  if (future && fused)
+    hipLaunchKernelGGL((sdp::window_f1_kernel<R, MAXDIR, true, true>), grid, dim3(256), pl.smem, st, W, v_next, out_val, out_idx, pmf_p, lo, hi, F);
+  else if (future)
+    hipLaunchKernelGGL((sdp::window_f1_kernel<R, MAXDIR, true, false>), grid, dim3(256), pl.smem, st, W, v_next, out_val, out_idx, pmf_p, lo, hi, F);
   else
-    hipLaunchKernelGGL((sdp::window_f1_kernel<R, MAXDIR, false>), grid, dim3(256), pl.smem, st, W, v_next, out_val, out_idx, pmf_p, lo, hi);
+    hipLaunchKernelGGL((sdp::window_f1_kernel<R, MAXDIR, false, false>), grid, dim3(256), pl.smem, st, W, v_next, out_val, out_idx, pmf_p, lo, hi, F);
   return hipGetLastError();
 }
 
-hipError_t ensure_partials(sdpgpu_handle* h, size_t need) {
-  if (need <= h->part_elems) return hipSuccess;
-  if (h->d_part_val) (void)hipFree(h->d_part_val);
-  if (h->d_part_idx) (void)hipFree(h->d_part_idx);
-  h->d_part_val = nullptr;
-  h->d_part_idx = nullptr;
-  h->part_elems = 0;
-  hipError_t e = hipMalloc((void**)&h->d_part_val, need * sizeof(double));
+hipError_t ensure_partials(sdpgpu_handle* h, int b, size_t need) {
+  if (need <= h->part_elems[b]) return hipSuccess;
+  // (re)allocation frees a buffer earlier launches may still read: drain the stream first
+  hipError_t e = hipStreamSynchronize(h->stream);
   if (e != hipSuccess) return e;
-  e = hipMalloc((void**)&h->d_part_idx, need * sizeof(int32_t));
+  if (h->d_part_val[b]) (void)hipFree(h->d_part_val[b]);
+  if (h->d_part_idx[b]) (void)hipFree(h->d_part_idx[b]);
+  h->d_part_val[b] = nullptr;
+  h->d_part_idx[b] = nullptr;
+  h->part_elems[b] = 0;
+  e = hipMalloc((void**)&h->d_part_val[b], need * sizeof(double));
   if (e != hipSuccess) return e;
-  h->part_elems = need;
+  e = hipMalloc((void**)&h->d_part_idx[b], need * sizeof(int32_t));
+  if (e != hipSuccess) return e;
+  h->part_elems[b] = need;
   return hipSuccess;
 }
 
@@ -592,6 +606,21 @@ hipError_t launch_combine(const double* pv, const int32_t* pi, int n_chunks, int
   unsigned blocks = (unsigned)((hi - lo + 255) / 256);
   hipLaunchKernelGGL((sdp::window_combine_kernel<MAXDIR>), dim3(blocks), dim3(256), 0, st, pv, pi, n_chunks, stride, v_cur, pol, lo, hi);
   return hipGetLastError();
+}
+
+// Write the final V / policy rows of a period whose arg-opt is still held as per-chunk partial rows.
+hipError_t flush_pending(sdpgpu_handle* h) {
+  if (!h->pending_period) return hipSuccess;
+  const int period = h->pending_period;
+  const PeriodInfo& p = h->per[period - 1];
+  const int b = period & 1;
+  const int64_t lo = h->pending_lo, hi = h->pending_hi;
+  double* v_cur = h->d_values + p.v_off;
+  int32_t* pol = h->d_policy + p.pol_off - p.lo;
+  h->pending_period = 0;
+  const bool maxdir = h->d.direction == SDPGPU_MAX;
+  return maxdir ? launch_combine<true>(h->d_part_val[b] - lo, h->d_part_idx[b] - lo, h->pending_chunks, h->pending_stride, v_cur, pol, lo, hi, h->stream)
+                : launch_combine<false>(h->d_part_val[b] - lo, h->d_part_idx[b] - lo, h->pending_chunks, h->pending_stride, v_cur, pol, lo, hi, h->stream);
 }
 
 // ---- row-window kernel (F2) ---------------------------------------------------------------
@@ -608,6 +637,10 @@ hipError_t launch_row_r(const sdp::RowParams& W, size_t smem, bool future, const
 
 hipError_t launch_row_window(sdpgpu_handle* h, const DevParams& P, int period, const double* v_next, double* v_cur,
                              int32_t* pol, const double* pmf_p, int64_t lo, int64_t hi, hipStream_t st) {
+  {
+    hipError_t ef = flush_pending(h);
+    if (ef != hipSuccess) return ef;
+  }
   const PeriodInfo& p = h->per[period - 1];
   const int A = h->n_actions_full, D = p.nD;
   auto rup = [](int v, int r) { return (v + r - 1) / r * r; };
@@ -658,11 +691,12 @@ hipError_t launch_row_window(sdpgpu_handle* h, const DevParams& P, int period, c
   int32_t* out_idx = pol;
   if (W.n_chunks > 1) {
     int64_t slab = hi - lo;
-    hipError_t e = ensure_partials(h, (size_t)W.n_chunks * (size_t)slab);
+    const int b = period & 1;
+    hipError_t e = ensure_partials(h, b, (size_t)W.n_chunks * (size_t)slab);
     if (e != hipSuccess) return e;
     W.partial_stride = slab;
-    out_val = h->d_part_val - lo;
-    out_idx = h->d_part_idx - lo;
+    out_val = h->d_part_val[b] - lo;
+    out_idx = h->d_part_idx[b] - lo;
   }
   hipError_t e = hipErrorInvalidValue;
   size_t smem = lds(bpc);
@@ -709,21 +743,60 @@ hipError_t launch_window(sdpgpu_handle* h, const DevParams& P, int period, const
   W.n_chunks = pl.n_chunks;
   W.chunk_actions = pl.chunk_actions;
   W.n_tiles = pl.n_tiles;
+  // deferred combine of period+1 (see FusedPrev): possible when that period's rows are still partial,
+  // cover exactly this slab, and both periods share one grid
+  sdp::FusedPrev F{};
+  bool fused = false;
+  if (h->pending_period == period + 1 && future) {
+    const PeriodInfo& pn = h->per[period];
+    if (h->pending_lo == lo && h->pending_hi == hi && pn.S == p.S && pn.g.nx == p.g.nx) {
+      const int pb = (period + 1) & 1;
+      F.part_val = h->d_part_val[pb] - lo;
+      F.part_idx = h->d_part_idx[pb] - lo;
+      F.v_out = h->d_values + pn.v_off;
+      F.pol_out = h->d_policy + pn.pol_off - pn.lo;
+      F.n_chunks = h->pending_chunks;
+      F.stride = h->pending_stride;
+      fused = true;
+    }
+  }
+  if (!fused) {
+    hipError_t ef = flush_pending(h);
+    if (ef != hipSuccess) return ef;
+  }
+#ifdef SDP_STAMPS
+  {
+    static unsigned long long* d_stamps = nullptr;
+    if (!d_stamps) (void)hipMalloc((void**)&d_stamps, (size_t)1 << 24);
+    F.stamps = (period == 2) ? d_stamps : nullptr;  // record one mid-sweep launch
+    if (period == 1) {
+      std::vector<unsigned long long> hs((size_t)pl.n_tiles * pl.n_chunks * 4 * 5);
+      (void)hipStreamSynchronize(st);
+      (void)hipMemcpy(hs.data(), d_stamps, hs.size() * 8, hipMemcpyDeviceToHost);
+      if (FILE* f = std::fopen("gpurun_out/stamps.txt", "w")) {
+        for (size_t i = 0; i + 4 < hs.size(); i += 5)
+          std::fprintf(f, "%zu %llu %llu %llu %llu %llu\n", i / 5, hs[i], hs[i + 1], hs[i + 2], hs[i + 3], hs[i + 4]);
+        std::fclose(f);
+      }
+    }
+  }
+#endif
   double* out_val = v_cur;
   int32_t* out_idx = pol;
+  const int b = period & 1;
   if (pl.n_chunks > 1) {
     int64_t slab = hi - lo;
-    hipError_t ea = ensure_partials(h, (size_t)pl.n_chunks * (size_t)slab);
+    hipError_t ea = ensure_partials(h, b, (size_t)pl.n_chunks * (size_t)slab);
     if (ea != hipSuccess) return ea;
     W.partial_stride = slab;
-    out_val = h->d_part_val - lo;  // the kernels index rows by flat state index
-    out_idx = h->d_part_idx - lo;
+    out_val = h->d_part_val[b] - lo;  // the kernels index rows by flat state index
+    out_idx = h->d_part_idx[b] - lo;
   }
   hipError_t e = hipErrorInvalidValue;
-#define SDP_WIN(RR)                                                                                                  \
-  case RR:                                                                                                           \
-    e = P.maxdir ? launch_window_r<RR, true>(W, pl, future, v_next, out_val, out_idx, pmf_p, lo, hi, st)              \
-                 : launch_window_r<RR, false>(W, pl, future, v_next, out_val, out_idx, pmf_p, lo, hi, st);            \
+#define SDP_WIN(RR)                                                                                                   \
+  case RR:                                                                                                            \
+    e = P.maxdir ? launch_window_r<RR, true>(W, pl, future, fused, F, v_next, out_val, out_idx, pmf_p, lo, hi, st)     \
+                 : launch_window_r<RR, false>(W, pl, future, fused, F, v_next, out_val, out_idx, pmf_p, lo, hi, st);   \
     break;
   switch (pl.R) {
     SDP_WIN(8)
@@ -732,9 +805,19 @@ hipError_t launch_window(sdpgpu_handle* h, const DevParams& P, int period, const
   }
 #undef SDP_WIN
   if (e != hipSuccess) return e;
-  if (pl.n_chunks > 1)
-    e = P.maxdir ? launch_combine<true>(out_val, out_idx, pl.n_chunks, W.partial_stride, v_cur, pol, lo, hi, st)
-                 : launch_combine<false>(out_val, out_idx, pl.n_chunks, W.partial_stride, v_cur, pol, lo, hi, st);
+  if (fused) h->pending_period = 0;  // period+1 was finalised by this launch
+  if (pl.n_chunks > 1) {
+    if (h->fuse_combine && h->d.world_size == 1) {
+      h->pending_period = period;
+      h->pending_chunks = pl.n_chunks;
+      h->pending_stride = W.partial_stride;
+      h->pending_lo = lo;
+      h->pending_hi = hi;
+    } else {
+      e = P.maxdir ? launch_combine<true>(out_val, out_idx, pl.n_chunks, W.partial_stride, v_cur, pol, lo, hi, st)
+                   : launch_combine<false>(out_val, out_idx, pl.n_chunks, W.partial_stride, v_cur, pol, lo, hi, st);
+    }
+  }
   return e;
 }
 
@@ -743,6 +826,17 @@ hipError_t launch_window(sdpgpu_handle* h, const DevParams& P, int period, const
 // =================================================================================================
 // C ABI
 // =================================================================================================
+namespace {
+int flush_api(sdpgpu_handle* h) {
+  if (!h->pending_period) return SDPGPU_OK;
+  int rc = ensure_device(h);
+  if (rc) return rc;
+  hipError_t e = flush_pending(h);
+  if (e != hipSuccess) return fail(h, SDPGPU_ERR_DEVICE, "combine: %s", hipGetErrorString(e));
+  return SDPGPU_OK;
+}
+}  // namespace
+
 extern "C" {
 
 int sdpgpu_abi_version(void) { return SDPGPU_ABI_VERSION; }
@@ -786,6 +880,7 @@ int sdpgpu_create(const sdpgpu_desc* desc, sdpgpu_handle** out) {
     h->policy_done.assign((size_t)h->T, 0);
     if (const char* e = std::getenv("SDPGPU_WIN_R")) h->win_r = std::atoi(e);
     if (const char* e = std::getenv("SDPGPU_WIN_NCH")) h->win_nch = std::atoi(e);
+    if (const char* e = std::getenv("SDPGPU_FUSE_COMBINE")) h->fuse_combine = std::atoi(e) != 0;
   } catch (...) {
     delete h;
     return fail(nullptr, SDPGPU_ERR_ARG, "out of host memory");
@@ -810,8 +905,10 @@ void sdpgpu_destroy(sdpgpu_handle* h) {
   if (h->d_policy) (void)hipFree(h->d_policy);
   if (h->d_pmf) (void)hipFree(h->d_pmf);
   if (h->d_reach) (void)hipFree(h->d_reach);
-  if (h->d_part_val) (void)hipFree(h->d_part_val);
-  if (h->d_part_idx) (void)hipFree(h->d_part_idx);
+  for (int b = 0; b < 2; ++b) {
+    if (h->d_part_val[b]) (void)hipFree(h->d_part_val[b]);
+    if (h->d_part_idx[b]) (void)hipFree(h->d_part_idx[b]);
+  }
   if (h->stream && h->own_stream) (void)hipStreamDestroy(h->stream);
   delete h;
 }
@@ -953,6 +1050,7 @@ int sdpgpu_attach_values(sdpgpu_handle* h, void* device_ptr, size_t bytes) {
 void* sdpgpu_values_device_ptr(sdpgpu_handle* h, int32_t period) {
   if (!h || period < 1 || period > h->T) return nullptr;
   if (allocate(h)) return nullptr;
+  if (flush_api(h)) return nullptr;
   return h->d_values + h->per[period - 1].v_off;
 }
 
@@ -983,6 +1081,8 @@ int sdpgpu_solve(sdpgpu_handle* h, int32_t sync) {
       rc = run_period_impl(h, period);
       if (rc) return rc;
     }
+    rc = flush_api(h);
+    if (rc) return rc;
     HIP_TRY(h, hipEventRecord(h->ev_solve1, h->stream));
     h->solve_timed = true;
     for (int period = 1; period <= h->T; ++period)
@@ -1002,6 +1102,8 @@ int sdpgpu_synchronize(sdpgpu_handle* h) {
   if (!h->allocated) return SDPGPU_OK;
   int rc = ensure_device(h);
   if (rc) return rc;
+  rc = flush_api(h);
+  if (rc) return rc;
   HIP_TRY(h, hipStreamSynchronize(h->stream));
   return SDPGPU_OK;
 }
@@ -1014,6 +1116,8 @@ int sdpgpu_values(sdpgpu_handle* h, int32_t period, double* out, int64_t n) {
   const PeriodInfo& p = h->per[period - 1];
   if (n < 0 || n > p.S) return fail(h, SDPGPU_ERR_ARG, "values: n=%lld > %lld states", (long long)n, (long long)p.S);
   int rc = ensure_device(h);
+  if (rc) return rc;
+  rc = flush_api(h);
   if (rc) return rc;
   HIP_TRY(h, hipStreamSynchronize(h->stream));
   HIP_TRY(h, hipMemcpy(out, h->d_values + p.v_off, (size_t)n * sizeof(double), hipMemcpyDeviceToHost));
@@ -1028,6 +1132,8 @@ int sdpgpu_policy(sdpgpu_handle* h, int32_t period, int32_t* out, int64_t lo, in
   const PeriodInfo& p = h->per[period - 1];
   if (lo < p.lo || n < 0 || lo + n > p.hi) return fail(h, SDPGPU_ERR_ARG, "policy: [%lld, %lld) outside this rank's slab [%lld, %lld)", (long long)lo, (long long)(lo + n), (long long)p.lo, (long long)p.hi);
   int rc = ensure_device(h);
+  if (rc) return rc;
+  rc = flush_api(h);
   if (rc) return rc;
   HIP_TRY(h, hipStreamSynchronize(h->stream));
   HIP_TRY(h, hipMemcpy(out, h->d_policy + p.pol_off + (lo - p.lo), (size_t)n * sizeof(int32_t), hipMemcpyDeviceToHost));
@@ -1046,6 +1152,8 @@ int sdpgpu_eval_states(sdpgpu_handle* h, int32_t period, int64_t n, const double
   if (period < h->T && !h->period_done[period]) return fail(h, SDPGPU_ERR_STATE, "V_%d has not been computed", period + 1);
   if (n == 0) return SDPGPU_OK;
   rc = ensure_device(h);
+  if (rc) return rc;
+  rc = flush_api(h);
   if (rc) return rc;
   double* d_in = nullptr;
   double* d_val = nullptr;
