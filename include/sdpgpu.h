@@ -37,6 +37,8 @@
  *                            grid point (e.g. an off-grid period-1 initial cash,
  *                            CashConstraint.java:141) and the lazy re-entry of the
  *                            simulators (Simulation.java:62-63).
+ *   sdpgpu_simulate          the rollout loops of the simulators (Simulation.java:59-69,
+ *                            CashSimulation.java:101-112): policy look-up + imm + transition.
  *   sdpgpu_reachable         the key set of `cacheActions`, i.e. the states the
  *                            memoised recursion would have visited; getOptTable
  *                            (Recursion.java:177-186) lists exactly those.
@@ -235,6 +237,17 @@ int sdpgpu_eval_states(sdpgpu_handle* h, int32_t period, int64_t n, const double
 /* Reachable-set mask of period t (1 byte per state), forward-propagated from the ini_* state over
  * all feasible actions and all demands -- the key set the memoised recursion would build. */
 int sdpgpu_reachable(sdpgpu_handle* h, int32_t period, uint8_t* out, int64_t n);
+
+/* Roll the computed policy forward along n demand paths: the inner loops of
+ * Simulation.simulateSDPGivenSamplNum (Simulation.java:59-69) and CashSimulation (CashSimulation.java:101-112)
+ * as a batched table-lookup rollout, one path per lane.  demand[i*T + t] is the realised demand of path i in
+ * period t+1, already rounded by the caller as the reference does (Math.round, Simulation.java:64);
+ * discount[t] multiplies the immediate value of period t+1 (Math.pow(discountFactor, t) in CashSimulation,
+ * all 1.0 for the undiscounted classes).  out_sum[i] = sum_t discount[t] * imm_t; out_valid[i] = 0 when
+ * the path left the grid (possible only for unclamped families with demands outside the PMF support).
+ * The start state is (1, ini_x, ini_cash, ini_preq); world_size must be 1. */
+int sdpgpu_simulate(sdpgpu_handle* h, int64_t n_paths, const double* demand, const double* discount, double ini_x,
+                    double ini_cash, double ini_preq, double* out_sum, uint8_t* out_valid);
 
 int sdpgpu_stats_get(sdpgpu_handle* h, sdpgpu_stats* out);
 /* Kernel time of period t of the last solve (ms), needs sdpgpu_set_profiling(h, 1). */

@@ -559,6 +559,58 @@ int sdpref_eval_states(const sdpgpu_desc* d, const int32_t* pmf_off, const doubl
 }
 
 /* ------------------------------------------------------------------------------------------
+ * Forward rollout of a computed policy along demand paths: the inner loops of
+ * Simulation.simulateSDPGivenSamplNum (Simulation.java:59-69) and CashSimulation (:101-112).
+ * `policy` holds action INDICES per period (values_off as in sdpref_solve); getAction on a state the
+ * tables do not hold (an off-grid period-1 state) re-enters the recursion, Simulation.java:62.
+ * ---------------------------------------------------------------------------------------- */
+int sdpref_simulate(const sdpgpu_desc* d, const int32_t* pmf_off, const double* pmf_d, const double* pmf_p,
+                    const double* overhead, const double* values, const int32_t* policy, const int64_t* values_off,
+                    int64_t n_paths, const double* demand, const double* discount, double ini_x, double ini_cash,
+                    double ini_preq, double* out_sum, uint8_t* out_valid) {
+  sdpref_grid* grids = (sdpref_grid*)malloc(sizeof(sdpref_grid) * (size_t)d->periods);
+  int rc = sdpref_layout(d, pmf_off, pmf_d, grids);
+  if (rc) {
+    free(grids);
+    return rc;
+  }
+  ctx_t c = {d, pmf_off, pmf_d, pmf_p, overhead, d->periods};
+  int32_t T = d->periods;
+  for (int64_t i = 0; i < n_paths; i++) {
+    double sum = 0;
+    st_t state = {1, ini_x, has_cash(d->family) ? ini_cash : 0, has_preq(d->family) ? ini_preq : 0};
+    int valid = 1;
+    for (int32_t t = 0; t < T && valid; t++) {
+      int64_t idx = index_of(d, &grids[t], &state);
+      double optQ;
+      if (idx >= 0) {
+        optQ = action_value(&c, policy[values_off[t] + idx]);
+      } else if (t == 0) { /* recursion.getExpectedValue(state); recursion.getAction(state) */
+        dense_env env = {d, T > 1 ? &grids[1] : NULL, T > 1 ? values + values_off[1] : NULL, 0};
+        double val;
+        eval_state(&c, &state, dense_look, &env, &val, &optQ, NULL, NULL);
+      } else {
+        valid = 0;
+        break;
+      }
+      double randomDemand = demand[i * T + t];
+      double thisValue = imm_value(&c, &state, optQ, randomDemand);
+      sum += discount[t] * thisValue;
+      if (t + 1 < T) {
+        st_t next;
+        transition(&c, &state, optQ, randomDemand, &next);
+        if (index_of(d, &grids[t + 1], &next) < 0) valid = 0;
+        state = next;
+      }
+    }
+    out_sum[i] = sum;
+    out_valid[i] = (uint8_t)valid;
+  }
+  free(grids);
+  return 0;
+}
+
+/* ------------------------------------------------------------------------------------------
  * Forward reachable set: the key set of cacheActions after getExpectedValue(initialState).
  * ---------------------------------------------------------------------------------------- */
 int sdpref_reachable(const sdpgpu_desc* d, const int32_t* pmf_off, const double* pmf_d, const double* pmf_p,

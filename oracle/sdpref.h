@@ -66,6 +66,12 @@ int sdpref_eval_states(const sdpgpu_desc* d, const int32_t* pmf_off, const doubl
                        const double* x, const double* cash, const double* preq, double* out_value,
                        int32_t* out_action);
 
+/* Policy rollout along demand paths (Simulation.java:59-69, CashSimulation.java:101-112). */
+int sdpref_simulate(const sdpgpu_desc* d, const int32_t* pmf_off, const double* pmf_d, const double* pmf_p,
+                    const double* overhead, const double* values, const int32_t* policy, const int64_t* values_off,
+                    int64_t n_paths, const double* demand, const double* discount, double ini_x, double ini_cash,
+                    double ini_preq, double* out_sum, uint8_t* out_valid);
+
 /* Forward reachable-set mask per period (concatenated with values_off). */
 int sdpref_reachable(const sdpgpu_desc* d, const int32_t* pmf_off, const double* pmf_d, const double* pmf_p,
                      const double* overhead, uint8_t* mask, const int64_t* values_off);

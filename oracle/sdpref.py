@@ -169,6 +169,22 @@ class Problem:
             raise RuntimeError(f"sdpref_reachable failed: {rc}")
         return [mask[self.voff[t]:self.voff[t + 1]].astype(bool) for t in range(self.T)]
 
+    def simulate(self, values, policy, demand, discount, ini_x, ini_cash=0.0, ini_preq=0.0):
+        """Rollout of `policy` (list of per-period index arrays) along demand[n][T]."""
+        V = np.ascontiguousarray(np.concatenate(values), dtype=np.float64)
+        Pl = np.ascontiguousarray(np.concatenate(policy), dtype=np.int32)
+        dem = np.ascontiguousarray(demand, dtype=np.float64)
+        disc = np.ascontiguousarray(discount, dtype=np.float64)
+        n = dem.shape[0]
+        out = np.zeros(n, dtype=np.float64)
+        valid = np.zeros(n, dtype=np.uint8)
+        rc = lib().sdpref_simulate(*self._args(), _dp(V), Pl.ctypes.data_as(_IP), self.voff.ctypes.data_as(_LP),
+                                   C.c_int64(n), _dp(dem), _dp(disc), C.c_double(ini_x), C.c_double(ini_cash),
+                                   C.c_double(ini_preq), _dp(out), valid.ctypes.data_as(C.POINTER(C.c_uint8)))
+        if rc:
+            raise RuntimeError(f"sdpref_simulate failed: {rc}")
+        return out, valid.astype(bool)
+
     def state_arrays(self, period: int):
         """(x, cash, preq) value arrays of every grid state of `period`, in flat-index order."""
         g = self.grids[period - 1]

@@ -10,12 +10,15 @@ from ._abi import (FAMILY_BACKORDER, FAMILY_CASH, FAMILY_CASH_LEADTIME, FAMILY_L
 from .engine import SdpEngine
 from .functors import (BackorderFunctor, CashFunctor, CashLeadtimeFunctor, LeadtimeFunctor, OverdraftFunctor,
                        java_round)
+from .pmf import DiscreteDistribution, GetPmf, NormalDist, PoissonDist, UniformIntDist
 from .recursion import CLSP, CashLeadtimeRecursion, CashRecursion, LeadtimeRecursion, Recursion
+from .simulation import Sampling, Simulation
 from .states import CashLeadtimeState, CashState, LeadtimeState, OptDirection, State
 
 __all__ = [
     "SdpEngine", "SdpgpuDesc", "SdpgpuError", "SdpgpuStats", "desc_defaults",
     "BackorderFunctor", "LeadtimeFunctor", "CashFunctor", "OverdraftFunctor", "CashLeadtimeFunctor",
     "Recursion", "CLSP", "LeadtimeRecursion", "CashRecursion", "CashLeadtimeRecursion",
+    "GetPmf", "PoissonDist", "NormalDist", "UniformIntDist", "DiscreteDistribution", "Simulation", "Sampling",
     "State", "LeadtimeState", "CashState", "CashLeadtimeState", "OptDirection", "java_round",
 ]

@@ -137,6 +137,8 @@ EXPORTS = {
     "sdpgpu_policy": (C.c_int, [_P, C.c_int32, _IP, C.c_int64, C.c_int64]),
     "sdpgpu_eval_states": (C.c_int, [_P, C.c_int32, C.c_int64, _DP, _DP, _DP, _DP, _IP]),
     "sdpgpu_reachable": (C.c_int, [_P, C.c_int32, C.POINTER(C.c_uint8), C.c_int64]),
+    "sdpgpu_simulate": (C.c_int, [_P, C.c_int64, _DP, _DP, C.c_double, C.c_double, C.c_double, _DP,
+                                  C.POINTER(C.c_uint8)]),
     "sdpgpu_stats_get": (C.c_int, [_P, C.POINTER(SdpgpuStats)]),
     "sdpgpu_period_ms": (C.c_double, [_P, C.c_int32]),
 }

@@ -175,4 +175,53 @@ __global__ __launch_bounds__(256) void reach_kernel(DevParams P, const uint8_t* 
   }
 }
 
+// Forward rollout of the arg-opt policy along sampled demand paths (Simulation.java:59-69): one path per
+// lane; per period a policy-table gather, the family's immediate value and transition.  The running
+// sum is accumulated in period order exactly as the reference's `sum += ...` does.
+struct SimPeriod {
+  DevParams P;
+  int64_t pol_off;  // element offset of the period's policy row (indexed by flat state index)
+  int64_t n_states;
+};
+
+template <int FAM>
+__global__ __launch_bounds__(256) void simulate_kernel(const SimPeriod* __restrict__ per, int T,
+                                                       const int32_t* __restrict__ pol, const double* __restrict__ demand,
+                                                       const double* __restrict__ disc, int64_t n, int64_t idx0,
+                                                       StateT ini, int first_k, double* __restrict__ out_sum,
+                                                       uint8_t* __restrict__ out_valid) {
+  const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (i >= n) return;
+  double sum = 0.0;
+  int64_t idx = idx0;
+  StateT s = ini;
+  bool valid = true;
+  for (int t = 0; t < T && valid; ++t) {
+    const DevParams& P = per[t].P;
+    int k;
+    if (t == 0 && idx0 < 0) {
+      k = first_k;  // off-grid initial state: its action comes from sdpgpu_eval_states
+    } else {
+      decode_state<FAM>(P, idx, s);
+      k = pol[per[t].pol_off + idx];
+    }
+    ActionCtx c;
+    action_setup<FAM>(P, s, k, c);
+    const double d = demand[i * T + t];
+    int64_t ni = 0;
+    const double imm = cell<FAM>(P, s, c, d, ni);
+    sum += disc[t] * imm;
+    if (!P.is_last) {
+      if (!P.clamp_inventory) {  // unclamped boxes cover the PMF support only
+        const double level = c.base - d;
+        const double hi = P.next.x_lo + (double)(P.next.nx - 1) * P.step;
+        if (level < P.next.x_lo || level > hi) valid = false;
+      }
+      idx = ni;
+    }
+  }
+  out_sum[i] = sum;
+  out_valid[i] = valid ? 1 : 0;
+}
+
 }  // namespace sdp

@@ -164,11 +164,19 @@ __global__ __launch_bounds__(256) void window_f1_kernel(WinParams W, const doubl
       win[r] = s_win[base + r];
       acc[r] = 0.0;
     }
+    // software pipeline: the probabilities of the NEXT block of R demand steps are fetched (scalar
+    // loads) while the current block computes, so no wave ever waits on the scalar cache in the loop
+    double pc[R], pn[R];
+#pragma unroll
+    for (int t = 0; t < R; ++t) pc[t] = pmf_p[t];
 #pragma unroll 1
     for (int jb = 0; jb < W.d_pad; jb += R) {
 #pragma unroll
+      for (int t = 0; t < R; ++t) pn[t] = pmf_p[jb + R + t];  // <= d_pad + R - 1 < D + 8: zero padding
+      const double2* nxt = s_win + (base - jb - R);            // slots base-jb-1 ... base-jb-R, ascending
+#pragma unroll
       for (int t = 0; t < R; ++t) {
-        const double p = pmf_p[jb + t];  // uniform -> scalar load
+        const double p = pc[t];
 #pragma unroll
         for (int r = 0; r < R; ++r) {
           const double2 w = win[(r - t + R) % R];
@@ -177,8 +185,10 @@ __global__ __launch_bounds__(256) void window_f1_kernel(WinParams W, const doubl
           if constexpr (FUTURE) acc[r] += p * w.y;
         }
         // slide: the entry for (r = 0, j + 1) replaces the one (r = R-1, j) just used
-        win[(R - 1 - t) % R] = s_win[base - (jb + t + 1)];
+        win[(R - 1 - t) % R] = nxt[R - 1 - t];
       }
+#pragma unroll
+      for (int t = 0; t < R; ++t) pc[t] = pn[t];
     }
 #pragma unroll
     for (int r = 0; r < R; ++r) {

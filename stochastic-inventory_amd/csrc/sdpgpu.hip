@@ -29,7 +29,7 @@ namespace {
 
 thread_local std::string g_create_error;
 
-constexpr size_t kPmfPad = 8;  // zero-probability tail so the demand loop can run in blocks of R <= 8
+constexpr size_t kPmfPad = 16;  // zero-probability tail: demand loop in blocks of R <= 8, one block of prefetch
 
 struct PeriodInfo {
   Grid g{};
@@ -1192,6 +1192,82 @@ int sdpgpu_reachable(sdpgpu_handle* h, int32_t period, uint8_t* out, int64_t n) 
   const PeriodInfo& p = h->per[period - 1];
   if (n < 0 || n > p.S) return fail(h, SDPGPU_ERR_ARG, "reachable: n=%lld > %lld states", (long long)n, (long long)p.S);
   HIP_TRY(h, hipMemcpy(out, h->d_reach + h->reach_off[period - 1], (size_t)n, hipMemcpyDeviceToHost));
+  return SDPGPU_OK;
+}
+
+int sdpgpu_simulate(sdpgpu_handle* h, int64_t n_paths, const double* demand, const double* discount, double ini_x,
+                    double ini_cash, double ini_preq, double* out_sum, uint8_t* out_valid) {
+  if (!h) return SDPGPU_ERR_ARG;
+  h->err.clear();
+  if (n_paths < 0 || !demand || !discount || !out_sum || !out_valid) return fail(h, SDPGPU_ERR_ARG, "simulate: bad argument");
+  if (h->d.world_size != 1) return fail(h, SDPGPU_ERR_STATE, "simulate needs the whole policy on one GPU (world_size 1)");
+  if (!h->allocated) return fail(h, SDPGPU_ERR_STATE, "simulate: nothing has been solved");
+  for (int t = 0; t < h->T; ++t)
+    if (!h->policy_done[t]) return fail(h, SDPGPU_ERR_STATE, "simulate: period %d has not been computed", t + 1);
+  if (n_paths == 0) return SDPGPU_OK;
+  int rc = ensure_device(h);
+  if (rc) return rc;
+  rc = flush_api(h);
+  if (rc) return rc;
+  const int T = h->T;
+  if (!has_cash(h->d.family)) ini_cash = 0;
+  if (!has_preq(h->d.family)) ini_preq = 0;
+  int64_t idx0 = sdpgpu_state_index(h, 1, ini_x, ini_cash, ini_preq);
+  int32_t first_k = 0;
+  if (idx0 < 0) {
+    double v;
+    rc = sdpgpu_eval_states(h, 1, 1, &ini_x, &ini_cash, &ini_preq, &v, &first_k);
+    if (rc) return rc;
+  }
+  try {
+    std::vector<sdp::SimPeriod> per((size_t)T);
+    for (int t = 0; t < T; ++t) {
+      per[t].P = make_params(h, t + 1);
+      per[t].pol_off = (int64_t)h->per[t].pol_off - h->per[t].lo;
+      per[t].n_states = h->per[t].S;
+    }
+    const size_t nn = (size_t)n_paths;
+    sdp::SimPeriod* d_per = nullptr;
+    double *d_dem = nullptr, *d_disc = nullptr, *d_sum = nullptr;
+    uint8_t* d_valid = nullptr;
+    hipError_t e = hipMalloc((void**)&d_per, per.size() * sizeof(sdp::SimPeriod));
+    if (e == hipSuccess) e = hipMalloc((void**)&d_dem, nn * T * sizeof(double));
+    if (e == hipSuccess) e = hipMalloc((void**)&d_disc, (size_t)T * sizeof(double));
+    if (e == hipSuccess) e = hipMalloc((void**)&d_sum, nn * sizeof(double));
+    if (e == hipSuccess) e = hipMalloc((void**)&d_valid, nn);
+    if (e == hipSuccess) e = hipMemcpy(d_per, per.data(), per.size() * sizeof(sdp::SimPeriod), hipMemcpyHostToDevice);
+    if (e == hipSuccess) e = hipMemcpy(d_dem, demand, nn * T * sizeof(double), hipMemcpyHostToDevice);
+    if (e == hipSuccess) e = hipMemcpy(d_disc, discount, (size_t)T * sizeof(double), hipMemcpyHostToDevice);
+    if (e == hipSuccess) {
+      sdp::StateT ini{ini_x, ini_cash, ini_preq};
+      dim3 grid((unsigned)((n_paths + 255) / 256));
+#define SDP_SIM(F)                                                                                                   \
+  case F:                                                                                                            \
+    hipLaunchKernelGGL((sdp::simulate_kernel<F>), grid, dim3(256), 0, h->stream, d_per, T, h->d_policy, d_dem, d_disc, \
+                       n_paths, idx0, ini, (int)first_k, d_sum, d_valid);                                             \
+    break;
+      switch (h->d.family) {
+        SDP_SIM(sdp::FAM_BACKORDER)
+        SDP_SIM(sdp::FAM_LEADTIME)
+        SDP_SIM(sdp::FAM_CASH)
+        SDP_SIM(sdp::FAM_OVERDRAFT)
+        SDP_SIM(sdp::FAM_CASH_LEADTIME)
+      }
+#undef SDP_SIM
+      e = hipGetLastError();
+    }
+    if (e == hipSuccess) e = hipStreamSynchronize(h->stream);
+    if (e == hipSuccess) e = hipMemcpy(out_sum, d_sum, nn * sizeof(double), hipMemcpyDeviceToHost);
+    if (e == hipSuccess) e = hipMemcpy(out_valid, d_valid, nn, hipMemcpyDeviceToHost);
+    (void)hipFree(d_per);
+    (void)hipFree(d_dem);
+    (void)hipFree(d_disc);
+    (void)hipFree(d_sum);
+    (void)hipFree(d_valid);
+    if (e != hipSuccess) return fail(h, SDPGPU_ERR_DEVICE, "simulate: %s", hipGetErrorString(e));
+  } catch (...) {
+    return fail(h, SDPGPU_ERR_ARG, "simulate: out of host memory");
+  }
   return SDPGPU_OK;
 }
 

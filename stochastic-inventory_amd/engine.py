@@ -163,6 +163,21 @@ class SdpEngine:
         self._check(self._lib.sdpgpu_reachable(self._h, period, out.ctypes.data_as(C.POINTER(C.c_uint8)), n))
         return out.astype(bool)
 
+    def simulate(self, demand, discount, ini_x: float, ini_cash: float = 0.0, ini_preq: float = 0.0):
+        """Roll the policy along demand paths: demand[n][T] (rounded), discount[T] -> (sums[n], valid[n])."""
+        dem = np.ascontiguousarray(demand, dtype=np.float64)
+        if dem.ndim != 2 or dem.shape[1] != self.T:
+            raise ValueError(f"demand must be [n_paths][{self.T}]")
+        disc = np.ascontiguousarray(discount, dtype=np.float64)
+        if disc.shape != (self.T,):
+            raise ValueError("discount must have one entry per period")
+        n = dem.shape[0]
+        out = np.empty(n, dtype=np.float64)
+        valid = np.empty(n, dtype=np.uint8)
+        self._check(self._lib.sdpgpu_simulate(self._h, n, _dp(dem), _dp(disc), float(ini_x), float(ini_cash),
+                                              float(ini_preq), _dp(out), valid.ctypes.data_as(C.POINTER(C.c_uint8))))
+        return out, valid.astype(bool)
+
     def stats(self) -> SdpgpuStats:
         st = SdpgpuStats()
         self._check(self._lib.sdpgpu_stats_get(self._h, C.byref(st)))

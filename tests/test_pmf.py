@@ -1,0 +1,54 @@
+"""GetPmf restatement.  SSJ is absent, so PMF parity is unpinned; these tests pin
+the STRUCTURE GetPmf.java:82-134 prescribes (support, truncation, normalisation, quirks)."""
+import math
+
+import numpy as np
+
+from stochastic_inventory_amd import pmf as P
+from stochastic_inventory_amd.workloads import truncated_poisson_tile
+
+
+def test_poisson_support_and_normalisation():
+    T = 3
+    tiles = P.GetPmf([P.PoissonDist(10.0)] * T, 0.9999, 1).getpmf()
+    assert len(tiles) == T
+    t = tiles[0]
+    assert t[0, 0] == 0.0 and t[-1, 0] == 24.0 and len(t) == 25  # LB forced to 0, UB = (int) inverseF(0.9999)
+    assert abs(t[:, 1].sum() - 1.0) < 1e-13
+    ref = truncated_poisson_tile(10.0, 25)
+    assert np.allclose(t[:, 1], ref[:, 1], rtol=1e-12, atol=0)
+    assert np.array_equal(t[:, 0], ref[:, 0])
+
+
+def test_normal_discretisation():
+    d = P.NormalDist(20.0, 5.0)
+    t = P.GetPmf([d, d], 0.9999, 1).getpmf()[0]
+    lb, ub = int(d.inverseF(0.0001)), int(d.inverseF(0.9999))
+    assert t[0, 0] == lb and t[-1, 0] == ub and len(t) == ub - lb + 1
+    assert abs(t[:, 1].sum() - 1.0) < 1e-12
+    j = len(t) // 2
+    want = (d.cdf(t[j, 0] + 0.5) - d.cdf(t[j, 0] - 0.5)) / (d.cdf(ub + 0.5) - d.cdf(lb - 0.5))
+    assert t[j, 1] == want
+
+
+def test_uniform_int_uses_first_distribution_for_every_period():
+    tiles = P.GetPmf([P.UniformIntDist(2, 5), P.UniformIntDist(0, 9)], 0.99, 1).getpmf()
+    assert all(np.array_equal(t[:, 0], [2, 3, 4, 5]) and np.allclose(t[:, 1], 0.25) for t in tiles)
+
+
+def test_clsp_inline_pmf_normalises_by_2q_minus_1():
+    dd = P.DiscreteDistribution([0, 1, 2, 3], [0.1, 0.2, 0.3, 0.4])
+    t = P.clsp_pmf([dd], 0.999, 1)[0]
+    assert t[0, 0] == dd.inverseF(0.001) and np.isclose(t[1, 1], 0.2 / (2 * 0.999 - 1))
+    tp = P.clsp_pmf([P.PoissonDist(9.0)], 0.99999, 1)[0]
+    assert abs(tp[:, 1].sum() - 1.0) < 1e-12  # Poisson goes through the cdf-difference branch
+
+
+def test_pmf_feeds_the_engine_descriptor():
+    import stochastic_inventory_amd as sia
+    tiles = P.GetPmf([P.PoissonDist(m) for m in (9, 23, 53, 29)], 0.9999, 1).getpmf()
+    f = sia.BackorderFunctor(fixedOrderingCost=500, holdingCost=2, penaltyCost=10, minInventory=-300,
+                             maxInventory=300, maxOrderQuantity=60)
+    eng = sia.SdpEngine(f.to_desc(4), tiles)
+    assert eng.num_states(1) == 601
+    eng.close()
