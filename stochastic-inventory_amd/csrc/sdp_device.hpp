@@ -143,21 +143,24 @@ __device__ __forceinline__ int cash_index(const DevParams& P, double next_cash) 
   next_cash = next_cash > P.max_cash ? P.max_cash : next_cash;
   next_cash = next_cash < P.min_cash ? P.min_cash : next_cash;
   double r = jround_d(next_cash * P.round_mult);
-  if (P.cash_round_int_div) r = trunc(r / P.round_div);  // `/ 10`: long division truncates
+  // `/ 10`: long division truncates.  (r / 1.0 == r: the common integer-cash quantiser skips the divide.)
+  if (P.cash_round_int_div && P.round_div != 1.0) r = trunc(r / P.round_div);
   return (int)r - (int)P.next.k_lo;
 }
 
 // One cell: immediate value and (when the period has a future) flat index of the next state.
-template <int FAM>
+// LASTMODE: 1 = period T (no transition, salvage applies), 0 = a period with a future, -1 = read P.is_last.
+template <int FAM, int LASTMODE = -1>
 __device__ __forceinline__ double cell(const DevParams& P, const StateT& s, const ActionCtx& c, double d,
                                        int64_t& next_idx) {
+  const bool is_last = LASTMODE < 0 ? (P.is_last != 0) : (LASTMODE != 0);
   if constexpr (FAM == FAM_BACKORDER || FAM == FAM_LEADTIME) {
     // CLSP.java:263-272 / Leadtime.java:71-81
     double level = c.base - d;
     double hold = P.h * jmax(level, 0.0);
     double pen = P.pi * jmax(-level, 0.0);
     double imm = c.fv + hold + pen;
-    if (!P.is_last) {
+    if (!is_last) {
       double nx = level;  // CLSP.java:255-258 / Leadtime.java:62-63
       if (P.clamp_inventory) {
         nx = nx > P.max_inventory ? P.max_inventory : nx;
@@ -176,11 +179,11 @@ __device__ __forceinline__ double cell(const DevParams& P, const StateT& s, cons
       inc = P.one_minus_overhead_rate * revenue + c.deposit - hold - P.overhead - s.cash;
     else
       inc = revenue - c.fixed - c.var - hold - P.overhead;
-    double sal = P.is_last ? P.salvage * jmax(level, 0.0) : 0.0;
+    double sal = is_last ? P.salvage * jmax(level, 0.0) : 0.0;
     inc += sal;
     double end_cash = s.cash + inc;
     if (end_cash < 0) inc += P.pi * end_cash;
-    if (!P.is_last) {
+    if (!is_last) {
       // CashConstraint.java:124-131
       double ninv = jmax(0.0, level);
       double ncash = s.cash + inc;
@@ -195,9 +198,9 @@ __device__ __forceinline__ double cell(const DevParams& P, const StateT& s, cons
     double level = c.base - d;
     double after = c.before - c.interest + revenue;
     double inc = after - s.cash;
-    double sal = P.is_last ? P.salvage * jmax(level, 0.0) : 0.0;
+    double sal = is_last ? P.salvage * jmax(level, 0.0) : 0.0;
     inc += sal;
-    if (!P.is_last) {
+    if (!is_last) {
       double ninv = jmax(0.0, level);
       double ncash = s.cash + inc;
       ninv = ninv > P.max_inventory ? P.max_inventory : ninv;

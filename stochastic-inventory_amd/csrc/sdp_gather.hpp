@@ -81,14 +81,14 @@ __global__ __launch_bounds__(256) void gather_period_kernel(DevParams P, const d
       for (int j = 0; j < nD; ++j) {
         double2 dp = s_pmf[j];
         int64_t ni;
-        double imm = cell<FAM>(P, s, c, dp.x, ni);
+        double imm = cell<FAM, 1>(P, s, c, dp.x, ni);
         acc += dp.y * imm;
       }
     } else {
       for (int j = 0; j < nD; ++j) {
         double2 dp = s_pmf[j];
         int64_t ni = 0;
-        double imm = cell<FAM>(P, s, c, dp.x, ni);
+        double imm = cell<FAM, 0>(P, s, c, dp.x, ni);
         acc += dp.y * imm;
         acc += (dp.y * P.gamma) * v_next[ni];  // CashRecursion.java:120: p * gamma * V
       }

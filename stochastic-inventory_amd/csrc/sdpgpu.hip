@@ -21,6 +21,7 @@
 #include "sdp_device.hpp"
 #include "sdp_gather.hpp"
 #include "sdp_window.hpp"
+#include "sdp_cash.hpp"
 
 using sdp::DevParams;
 using sdp::Grid;
@@ -82,6 +83,7 @@ struct sdpgpu_handle {
   int pending_chunks = 0;
   int64_t pending_stride = 0, pending_lo = 0, pending_hi = 0;
   bool fuse_combine = true;
+  bool use_cash_shift = true;
   int win_r = 0, win_nch = 0;      // tuning overrides (SDPGPU_WIN_R / SDPGPU_WIN_NCH), 0 = heuristic
   uint8_t* d_reach = nullptr;      // reachable masks, period t at reach_off[t-1]
   std::vector<size_t> reach_off;
@@ -393,7 +395,10 @@ void count_cells(sdpgpu_handle* h, int period) {
 }
 
 bool window_eligible(const sdpgpu_handle* h, int period);
+bool cash_shift_eligible(const sdpgpu_handle* h, int period);
 hipError_t flush_pending(sdpgpu_handle* h);
+hipError_t launch_cash_shift(sdpgpu_handle* h, const DevParams& P, int period, const double* v_next, double* v_cur,
+                             int32_t* pol, const double* pmf_d, const double* pmf_p, int64_t lo, int64_t hi, hipStream_t st);
 hipError_t launch_window(sdpgpu_handle* h, const DevParams& P, int period, const double* v_next, double* v_cur,
                          int32_t* pol, const double* pmf_d, const double* pmf_p, int64_t lo, int64_t hi, hipStream_t st);
 
@@ -430,6 +435,10 @@ int run_period_impl(sdpgpu_handle* h, int period) {
   if (use_window) {
     e = launch_window(h, P, period, v_next, v_cur, pol, pd, pp, p.lo, p.hi, h->stream);
     p.kernel_used = SDPGPU_KERNEL_WINDOW;
+  } else if (h->d.kernel != SDPGPU_KERNEL_GATHER && h->use_cash_shift && cash_shift_eligible(h, period)) {
+    e = flush_pending(h);
+    if (e == hipSuccess) e = launch_cash_shift(h, P, period, v_next, v_cur, pol, pd, pp, p.lo, p.hi, h->stream);
+    p.kernel_used = SDPGPU_KERNEL_WINDOW;  // reported as a specialised (non-gather) kernel
   } else {
     e = flush_pending(h);  // the gather kernel reads the final V_{t+1} row
     if (e == hipSuccess)
@@ -514,6 +523,85 @@ int compute_reachable(sdpgpu_handle* h) {
   if (e != hipSuccess) return fail(h, SDPGPU_ERR_DEVICE, "reachable: %s", hipGetErrorString(e));
   h->reach_done = true;
   return SDPGPU_OK;
+}
+
+// ---- uniform-shift kernel (F3 on dyadic grids) ---------------------------------------------------
+bool dyadic(double x, double scale, double max_abs) { return std::fabs(x) <= max_abs && x * scale == std::floor(x * scale); }
+
+// All arithmetic of the F3 lambdas is exact (see sdp_cash.hpp) iff the rates and the penalty are zero, the
+// cash quantum is a power of two and every parameter is a multiple of 2^-10 of bounded size.
+bool cash_shift_eligible(const sdpgpu_handle* h, int period) {
+  const sdpgpu_desc& d = h->d;
+  if (d.family != SDPGPU_FAMILY_CASH || !d.clamp_inventory) return false;
+  if (d.deposit_rate != 0 || d.overhead_rate != 0 || d.penalty_cost != 0) return false;
+  double q;
+  if (d.cash_round_int_div) {
+    if (d.cash_round_mult != 1.0 || d.cash_round_div != 1.0) return false;
+    q = 1.0;
+  } else {
+    q = d.cash_round_div;  // == mult (validated at create)
+  }
+  if (!is_pow2_int(q) || q > 1024) return false;
+  const PeriodInfo& p = h->per[period - 1];
+  const double S = 1024.0, M = 4096.0;
+  if (!dyadic(d.price, S, M) || !dyadic(d.fixed_order_cost, S, M) || !dyadic(d.unit_order_cost, S, M) ||
+      !dyadic(d.holding_cost, S, M) || !dyadic(d.salvage_value, S, M) || !dyadic(p.overhead, S, 1048576.0))
+    return false;
+  if (!(d.unit_order_cost != 0)) return false;
+  if (!dyadic(d.min_cash, q, 1e9) || !dyadic(d.max_cash, q, 1e9)) return false;
+  if (!dyadic(d.discount_factor, 1.0, 1.0) && d.discount_factor != 1.0) {
+    // gamma only multiplies p_j (inexact anyway, same product as the general kernel): any value is fine
+  }
+  double ymax = std::fabs(d.max_inventory) + std::fabs(d.min_inventory) + d.max_order_quantity * d.step;
+  double dmax = 0;
+  for (double v : h->pmf_d[period - 1]) dmax = std::max(dmax, std::fabs(v));
+  if (ymax > 1048576.0 || dmax > 1048576.0) return false;
+  double incmax = (std::fabs(d.price) + std::fabs(d.holding_cost) + std::fabs(d.salvage_value)) * (ymax + dmax) +
+                  std::fabs(d.fixed_order_cost) + std::fabs(d.unit_order_cost) * d.max_order_quantity * d.step + std::fabs(p.overhead);
+  if (incmax * q > 1.0e9) return false;
+  if (p.S >= 2147483647LL || p.nD > 2000) return false;
+  return true;
+}
+
+hipError_t launch_cash_shift(sdpgpu_handle* h, const DevParams& P, int period, const double* v_next, double* v_cur,
+                             int32_t* pol, const double* pmf_d, const double* pmf_p, int64_t lo, int64_t hi, hipStream_t st) {
+  if (hi <= lo) return hipSuccess;
+  const sdpgpu_desc& d = h->d;
+  const PeriodInfo& p = h->per[period - 1];
+  sdp::CashShiftParams C{};
+  C.price = d.price;
+  C.K = d.fixed_order_cost;
+  C.v = d.unit_order_cost;
+  C.h = d.holding_cost;
+  C.overhead = p.overhead;
+  C.salvage = d.salvage_value;
+  C.gamma = P.gamma;
+  C.step = d.step;
+  C.x_lo = p.g.x_lo;
+  C.min_inventory = d.min_inventory;
+  C.max_inventory = d.max_inventory;
+  C.next_x_lo = period < h->T ? h->per[period].g.x_lo : p.g.x_lo;
+  C.q = d.cash_round_int_div ? 1.0 : d.cash_round_div;
+  C.k_lo = p.g.k_lo;
+  C.nx = (int32_t)p.g.nx;
+  C.nc = (int32_t)p.g.nc;
+  C.n_demand = p.nD;
+  C.max_order_quantity = d.max_order_quantity;
+  C.is_last = period == h->T;
+  C.tiles_per_row = (int32_t)((p.g.nc + 63) / 64);
+  const int64_t row_lo = lo / p.g.nc, row_hi = (hi - 1) / p.g.nc;
+  C.row0 = (int32_t)row_lo;
+  dim3 grid((unsigned)((row_hi - row_lo + 1) * C.tiles_per_row));
+  size_t smem = (size_t)p.nD * 16 * 5 + 4 * 64 * (sizeof(double) + sizeof(int));
+  const bool last = period == h->T;
+#define SDP_CS(MX, LS) hipLaunchKernelGGL((sdp::cash_shift_kernel<MX, LS>), grid, dim3(256), smem, st, C, v_next, v_cur, pol, pmf_d, pmf_p, lo, hi)
+  if (P.maxdir) {
+    if (last) SDP_CS(true, true); else SDP_CS(true, false);
+  } else {
+    if (last) SDP_CS(false, true); else SDP_CS(false, false);
+  }
+#undef SDP_CS
+  return hipGetLastError();
 }
 
 // ---- window kernel (F1) -----------------------------------------------------------------------
@@ -881,6 +969,7 @@ int sdpgpu_create(const sdpgpu_desc* desc, sdpgpu_handle** out) {
     if (const char* e = std::getenv("SDPGPU_WIN_R")) h->win_r = std::atoi(e);
     if (const char* e = std::getenv("SDPGPU_WIN_NCH")) h->win_nch = std::atoi(e);
     if (const char* e = std::getenv("SDPGPU_FUSE_COMBINE")) h->fuse_combine = std::atoi(e) != 0;
+    if (const char* e = std::getenv("SDPGPU_CASH_SHIFT")) h->use_cash_shift = std::atoi(e) != 0;
   } catch (...) {
     delete h;
     return fail(nullptr, SDPGPU_ERR_ARG, "out of host memory");

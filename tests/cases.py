@@ -79,6 +79,17 @@ def f3_testing(T=4):
     return Workload("f3_testing", f, OptDirection.MAX, _pmf([4, 6, 3, 5][:T], 9))
 
 
+def f3_dyadic(T=3):
+    """Formula 0 on a half-unit cash grid (Math.round(c*2)/2.0) with quarter/half-valued costs: every
+    operation of the lambda is exact, which is what the uniform-shift kernel requires; gamma != 1."""
+    f = CashFunctor(price=3.5, fixOrderCost=2.25, variCost=0.75, holdingCost=0.25, overheadCost=1.5,
+                    salvageValue=0.375, penaltyCost=0, discountFactor=0.9375, maxOrderQuantity=11,
+                    minInventoryState=0, maxInventoryState=14, minCashState=-4, maxCashState=60,
+                    cashRoundMult=2.0, cashRoundDiv=2.0, cashRoundIntDiv=False, cashFormula=0, iniInventory=1,
+                    iniCash=9.5, overheadCosts=[1.5, 0.5, 2.0][:T])
+    return Workload("f3_dyadic", f, OptDirection.MAX, _pmf([3, 5, 4][:T], 9))
+
+
 def f3_min_gamma(T=3):
     f = CashFunctor(price=4, fixOrderCost=2, variCost=1, holdingCost=0.5, overheadCost=1, salvageValue=0.25,
                     penaltyCost=1.5, discountFactor=0.95, maxOrderQuantity=6, minInventoryState=0,
@@ -107,6 +118,6 @@ def f5_cash_leadtime(T=3):
     return Workload("f5_cash_leadtime", f, OptDirection.MAX, _pmf([3, 3, 3][:T], 6))
 
 
-ALL = [f1_small, f1_max, f1_gapped, f2_unclamped, f2_clamped, f3_tenths, f3_testing, f3_min_gamma, f4_overdraft,
-       f5_cash_leadtime]
+ALL = [f1_small, f1_max, f1_gapped, f2_unclamped, f2_clamped, f3_tenths, f3_testing, f3_dyadic, f3_min_gamma,
+       f4_overdraft, f5_cash_leadtime]
 TINY = [f1_small, f1_max, f1_gapped, f2_unclamped, f3_testing, f3_min_gamma, f4_overdraft]

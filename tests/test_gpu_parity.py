@@ -267,3 +267,15 @@ def test_cfg2_full_horizon_properties(sia, oracle):
         assert (va >= 0).all() and pa.min() >= 0 and pa.max() <= 199
     ea.close()
     eg.close()
+
+
+def test_kernel_selection(sia):
+    """The specialised kernels are the ones that run where they apply (kernel_used: 1 gather, 2 specialised)."""
+    expect = {cases.f1_small: 2, cases.f1_gapped: 1, cases.f2_clamped: 2, cases.f2_unclamped: 2, cases.f3_tenths: 1,
+              cases.f3_testing: 2, cases.f3_dyadic: 2, cases.f3_min_gamma: 1, cases.f4_overdraft: 1,
+              cases.f5_cash_leadtime: 1}
+    for make, kind in expect.items():
+        w = make()
+        with sia.SdpEngine(w.desc(), w.pmf, w.overhead()) as eng:
+            eng.solve()
+            assert eng.stats().kernel_used == kind, w.name
