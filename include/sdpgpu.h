@@ -223,7 +223,21 @@ void* sdpgpu_values_device_ptr(sdpgpu_handle* h, int32_t period);
 /* Use caller-owned device memory for the value tables: `bytes` >= sdpgpu_values_bytes(h). */
 size_t sdpgpu_values_bytes(const sdpgpu_handle* h);
 int sdpgpu_attach_values(sdpgpu_handle* h, void* device_ptr, size_t bytes);
-/* Block until everything queued on the handle's stream has finished. */
+/* The row a sharded caller all-gathers after sdpgpu_run_period(period) and before the next period:
+ * padded_row 8-byte elements (sdpgpu_slab).  Usually the fp64 V_period row; on small grids, where a
+ * tile is shared by several tasks, the row of order-preserving uint64 keys the kernels reduce into and
+ * the next period reads directly (the fp64 row is then written by sdpgpu_finalize).  The key arena can be
+ * caller memory, like the value arena: sdpgpu_keys_bytes() is 0 when the handle never uses keys. */
+void* sdpgpu_exchange_ptr(sdpgpu_handle* h, int32_t period);
+size_t sdpgpu_keys_bytes(const sdpgpu_handle* h);
+int sdpgpu_attach_keys(sdpgpu_handle* h, void* device_ptr, size_t bytes);
+
+/* Enqueue (do not wait for) whatever deferred read-out work is outstanding, so that in stream order every
+ * V_t and policy row of the periods run so far is complete.  On small grids the window kernel leaves
+ * the arg-opt of a period as per-chunk rows and resolves all periods in one launch; every reader
+ * below does this implicitly, a caller that reads the device tables itself calls it explicitly. */
+int sdpgpu_finalize(sdpgpu_handle* h);
+/* sdpgpu_finalize, then block until everything queued on the handle's stream has finished. */
 int sdpgpu_synchronize(sdpgpu_handle* h);
 
 /* ---- results ----------------------------------------------------------------------------- */

@@ -132,6 +132,10 @@ EXPORTS = {
     "sdpgpu_values_device_ptr": (_P, [_P, C.c_int32]),
     "sdpgpu_values_bytes": (C.c_size_t, [_P]),
     "sdpgpu_attach_values": (C.c_int, [_P, _P, C.c_size_t]),
+    "sdpgpu_exchange_ptr": (_P, [_P, C.c_int32]),
+    "sdpgpu_keys_bytes": (C.c_size_t, [_P]),
+    "sdpgpu_attach_keys": (C.c_int, [_P, _P, C.c_size_t]),
+    "sdpgpu_finalize": (C.c_int, [_P]),
     "sdpgpu_synchronize": (C.c_int, [_P]),
     "sdpgpu_values": (C.c_int, [_P, C.c_int32, _DP, C.c_int64]),
     "sdpgpu_policy": (C.c_int, [_P, C.c_int32, _IP, C.c_int64, C.c_int64]),

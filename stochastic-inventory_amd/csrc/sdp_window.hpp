@@ -20,10 +20,8 @@
 // The five VALU ops per cell are the floor for this operation order; the kernel is bound by
 // fp64 VALU issue (4 cycles per wave64 instruction per SIMD), not by memory.
 //
-// Small grids (configs[1] has only 157 state tiles) do not fill 1024 SIMDs with whole-action
-// workgroups, so the action range is also cut into NCH chunks across workgroups; each writes a
-// partial (value, index) row and a tiny second kernel takes the lexicographic arg-opt over the
-// chunks (lowest action index wins ties, exactly the strict-compare scan of Recursion.java:146-157).
+// Small grids (configs[1] has only 157 state tiles) do not fill 1024 SIMDs with whole-action tasks,
+// so the action range of a tile is cut into chunks handled by different waves (see window_f1_kernel).
 #pragma once
 #include "sdp_device.hpp"
 
@@ -36,43 +34,31 @@ struct WinParams {
   int32_t idx_off;    // m -> next-grid index offset: (lev0 - x_lo(next)) / step
   int32_t next_last;  // nx(next) - 1
   int32_t n_actions;  // A
-  int32_t d_pad;      // demand steps, padded with p = 0 entries to a multiple of R
-  int32_t n_chunks;   // action chunks across workgroups
-  int32_t chunk_actions;  // actions per chunk (multiple of R)
+  int32_t d_pad;      // demand steps rounded up to a multiple of R (sizes the LDS window)
+  int32_t d_main;     // demand steps handled by full blocks of R: floor(D / R) * R
+  int32_t n_demand;   // D
+  int32_t n_chunks;   // tasks per state tile: the action range is cut into n_chunks runs of R-blocks
+  int32_t chunk_blocks;   // R-blocks per task
   int32_t n_tiles;        // state tiles of 64
+  int32_t n_tasks;        // n_tiles * n_chunks (one task per wave)
   int64_t partial_stride; // elements between chunk rows of the partial tables
 };
 
-// Deferred combine: when the previous launch (period t+1) left its arg-opt as per-chunk partial rows,
-// this launch reads V_{t+1} as the opt over those rows while staging its window, and the workgroups
-// of action chunk 0 write the final V_{t+1} / policy rows for their 64 states.  That removes the
-// separate combine launch (and its kernel boundary) from every period but the last one computed.
-struct FusedPrev {
-  const double* part_val;   // [n_chunks][stride], indexed by flat state index
-  const int32_t* part_idx;
-  double* v_out;            // final V_{t+1}
-  int32_t* pol_out;         // final policy of period t+1
-  int32_t n_chunks;
-  int64_t stride;
-#ifdef SDP_STAMPS
-  unsigned long long* stamps;
-#endif
-};
-
-template <bool MAXDIR>
-__device__ __forceinline__ double fused_value(const FusedPrev& F, int idx) {
-  double v = F.part_val[idx];
-  for (int c = 1; c < F.n_chunks; ++c) {
-    double o = F.part_val[(int64_t)c * F.stride + idx];
-    v = MAXDIR ? (o > v ? o : v) : (o < v ? o : v);
-  }
-  return v;
+// Order-preserving map double -> uint64 (and back): lets a 64-bit atomic min/max reduce fp64 values
+// exactly.  Used for V_t when several tasks share a state tile.
+__device__ __forceinline__ unsigned long long f64_key(double v) {
+  unsigned long long u = (unsigned long long)__double_as_longlong(v);
+  return (u >> 63) ? ~u : (u | 0x8000000000000000ull);
+}
+__device__ __forceinline__ double f64_unkey(unsigned long long k) {
+  unsigned long long u = (k >> 63) ? (k & 0x7fffffffffffffffull) : ~k;
+  return __longlong_as_double((long long)u);
 }
 
 // W[m] for one m: the immediate-cost part that depends on the level, and the future value.
-template <bool FUTURE, bool FUSED, bool MAXDIR>
+template <bool FUTURE, bool KEYED_IN>
 __device__ __forceinline__ double2 window_entry(const WinParams& W, const double* __restrict__ v_next,
-                                                const FusedPrev& F, int m) {
+                                                const unsigned long long* __restrict__ k_next, int m) {
   double l = W.lev0 + (double)m * W.step;
   double hold = W.h * jmax(l, 0.0);
   double pen = W.pi * jmax(-l, 0.0);
@@ -86,67 +72,63 @@ __device__ __forceinline__ double2 window_entry(const WinParams& W, const double
     int idx = m + W.idx_off;
     idx = idx > W.next_last ? W.next_last : idx;
     idx = idx < 0 ? 0 : idx;
-    if constexpr (FUSED)
-      e.y = fused_value<MAXDIR>(F, idx);
+    if constexpr (KEYED_IN)
+      e.y = f64_unkey(k_next[idx]);
     else
       e.y = v_next[idx];
   }
   return e;
 }
 
-template <int R, bool MAXDIR, bool FUTURE, bool FUSED>
+// One TASK per wave: (state tile of 64, run of R-blocks of the action axis).  Tasks are numbered
+// chunk-major (task = chunk * n_tiles + tile) and packed four to a workgroup regardless of tile, so
+// every workgroup carries four equal tasks -- one per SIMD -- and a launch of n_tasks/4 workgroups
+// loads the 1024 SIMDs evenly (the measured timeline of one SIMD is strictly task after task).  Each
+// wave stages its OWN window in its own LDS region: there is no workgroup barrier in this kernel.
+//
+// When a tile is shared by several tasks (n_chunks > 1, small grids) a task publishes its best value
+// with a 64-bit atomic min/max on the order-preserving key of V_t (exact), and stores its
+// (value, action) pair in its chunk row; the arg-opt ACTION is resolved later, off the critical
+// path, by finalize_kernel: the lowest chunk whose value equals V_t holds the lowest optimal action
+// index (chunks are ascending action ranges), which is the reference's tie rule.
+template <int R, bool MAXDIR, bool FUTURE, bool KEYED_IN>
 __global__ __launch_bounds__(256) void window_f1_kernel(WinParams W, const double* __restrict__ v_next,
+                                                        const unsigned long long* __restrict__ k_next,
                                                         double* __restrict__ out_val, int32_t* __restrict__ out_idx,
-                                                        const double* __restrict__ pmf_p, int64_t lo, int64_t hi,
-                                                        FusedPrev F) {
+                                                        unsigned long long* __restrict__ k_cur,
+                                                        const double* __restrict__ pmf_p, int64_t lo, int64_t hi
+#ifdef SDP_STAMPS
+                                                        , unsigned long long* stamps
+#endif
+) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
-  double2* s_win = reinterpret_cast<double2*>(smem);
-  const int span = 64 + W.chunk_actions + W.d_pad;  // entries [0, span): one spare slot in front
-  double* s_val = reinterpret_cast<double*>(smem + (size_t)span * 16);
-  int* s_k = reinterpret_cast<int*>(s_val + 4 * 64);
-
   const int tid = threadIdx.x;
   const int lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int chunk = blockIdx.x / W.n_tiles;
-  const int tile = blockIdx.x - chunk * W.n_tiles;
+  const int task = blockIdx.x * 4 + wave;
+  if (task >= W.n_tasks) return;  // no barriers below: a wave may leave on its own
+  const int chunk = task / W.n_tiles;
+  const int tile = task - chunk * W.n_tiles;
+  const int chunk_actions = W.chunk_blocks * R;
+  const int span = 64 + chunk_actions + W.d_pad;  // entries [0, span): slot 0 is a spare
+  double2* s_win = reinterpret_cast<double2*>(smem) + (size_t)wave * span;
   const int64_t i0 = lo + (int64_t)tile * 64;
-  const int kA = chunk * W.chunk_actions;
+  const int kA = chunk * chunk_actions;
 #ifdef SDP_STAMPS  // diagnostic build only (tools/stamp_window.py): per-wave timeline, never in the product
   unsigned long long st_t0 = __builtin_amdgcn_s_memrealtime();
-  unsigned long long st_t1 = 0;
 #endif
 
-  // stage the window: slot s holds m = m_lo + s, m_lo = i0 + kA - d_pad (slot 0 is the spare)
+  // stage this wave's window: slot s holds m = m_lo + s, m_lo = i0 + kA - d_pad
   const int m_lo = (int)i0 + kA - W.d_pad;
-  for (int s = tid; s < span; s += 256) s_win[s] = window_entry<FUTURE, FUSED, MAXDIR>(W, v_next, F, m_lo + s);
-  if constexpr (FUSED) {
-    // finalise period t+1 for this tile's states (same grid in both periods; chunk 0 only)
-    const int64_t pidx = i0 + tid;
-    if (chunk == 0 && tid < 64 && pidx < hi) {
-      double bv = F.part_val[pidx];
-      int bk = F.part_idx[pidx];
-      for (int c = 1; c < F.n_chunks; ++c) {
-        double ov = F.part_val[(int64_t)c * F.stride + pidx];
-        int ok = F.part_idx[(int64_t)c * F.stride + pidx];
-        if (better<MAXDIR>(ov, ok, bv, bk)) {
-          bv = ov;
-          bk = ok;
-        }
-      }
-      F.v_out[pidx] = bv;
-      F.pol_out[pidx] = bk;
-    }
-  }
-  __syncthreads();
-
+  for (int s = lane; s < span; s += 64) s_win[s] = window_entry<FUTURE, KEYED_IN>(W, v_next, k_next, m_lo + s);
+  __builtin_amdgcn_wave_barrier();
 #ifdef SDP_STAMPS
-  st_t1 = __builtin_amdgcn_s_memrealtime();
+  unsigned long long st_t1 = __builtin_amdgcn_s_memrealtime();
 #endif
+
   double best = MAXDIR ? -1.7976931348623157e308 : 1.7976931348623157e308;
   int bestk = 0;
-  const int blocks_in_chunk = W.chunk_actions / R;
-  for (int rb = wave; rb < blocks_in_chunk; rb += 4) {
+  for (int rb = 0; rb < W.chunk_blocks; ++rb) {
     const int k0 = kA + rb * R;
     if (k0 >= W.n_actions) break;
     double c0[R];
@@ -164,19 +146,12 @@ __global__ __launch_bounds__(256) void window_f1_kernel(WinParams W, const doubl
       win[r] = s_win[base + r];
       acc[r] = 0.0;
     }
-    // software pipeline: the probabilities of the NEXT block of R demand steps are fetched (scalar
-    // loads) while the current block computes, so no wave ever waits on the scalar cache in the loop
-    double pc[R], pn[R];
-#pragma unroll
-    for (int t = 0; t < R; ++t) pc[t] = pmf_p[t];
 #pragma unroll 1
-    for (int jb = 0; jb < W.d_pad; jb += R) {
-#pragma unroll
-      for (int t = 0; t < R; ++t) pn[t] = pmf_p[jb + R + t];  // <= d_pad + R - 1 < D + 8: zero padding
-      const double2* nxt = s_win + (base - jb - R);            // slots base-jb-1 ... base-jb-R, ascending
+    for (int jb = 0; jb < W.d_main; jb += R) {
+      const double2* nxt = s_win + (base - jb - R);  // slots base-jb-R ... base-jb-1
 #pragma unroll
       for (int t = 0; t < R; ++t) {
-        const double p = pc[t];
+        const double p = pmf_p[jb + t];  // wave-uniform -> scalar load
 #pragma unroll
         for (int r = 0; r < R; ++r) {
           const double2 w = win[(r - t + R) % R];
@@ -187,8 +162,27 @@ __global__ __launch_bounds__(256) void window_f1_kernel(WinParams W, const doubl
         // slide: the entry for (r = 0, j + 1) replaces the one (r = R-1, j) just used
         win[(R - 1 - t) % R] = nxt[R - 1 - t];
       }
+    }
+    // the last D mod R demand steps: the same unrolled body under wave-uniform guards (the register
+    // window is back in its canonical rotation after every full block)
+    if (W.d_main < W.n_demand) {
+      const int jb = W.d_main;
+      const int rem = W.n_demand - W.d_main;
+      const double2* nxt = s_win + (base - jb - R);
 #pragma unroll
-      for (int t = 0; t < R; ++t) pc[t] = pn[t];
+      for (int t = 0; t < R - 1; ++t) {
+        if (t < rem) {
+          const double p = pmf_p[jb + t];
+#pragma unroll
+          for (int r = 0; r < R; ++r) {
+            const double2 w = win[(r - t + R) % R];
+            double imm = c0[r] + w.x;
+            acc[r] += p * imm;
+            if constexpr (FUTURE) acc[r] += p * w.y;
+          }
+          win[(R - 1 - t) % R] = nxt[R - 1 - t];
+        }
+      }
     }
 #pragma unroll
     for (int r = 0; r < R; ++r) {
@@ -200,35 +194,73 @@ __global__ __launch_bounds__(256) void window_f1_kernel(WinParams W, const doubl
     }
   }
 
+  const int64_t idx = i0 + lane;
+  if (idx < hi) {
+    const int64_t o = (int64_t)chunk * W.partial_stride + idx;
+    out_val[o] = best;
+    out_idx[o] = bestk;
+    if (W.n_chunks > 1) {
+      if (MAXDIR)
+        atomicMax(k_cur + idx, f64_key(best));
+      else
+        atomicMin(k_cur + idx, f64_key(best));
+    }
+  }
 #ifdef SDP_STAMPS
-  if (F.stamps && lane == 0) {
+  if (stamps && lane == 0) {
     unsigned long long st_t2 = __builtin_amdgcn_s_memrealtime();
-    unsigned hwid = __builtin_amdgcn_s_getreg(4 | (0 << 6) | (31 << 11));       // HW_REG_HW_ID
-    unsigned xcc = __builtin_amdgcn_s_getreg(20 | (0 << 6) | (31 << 11));       // HW_REG_XCC_ID
-    unsigned long long* o = F.stamps + ((size_t)blockIdx.x * 4 + wave) * 5;
+    unsigned hwid = __builtin_amdgcn_s_getreg(4 | (0 << 6) | (31 << 11));  // HW_REG_HW_ID
+    unsigned xcc = __builtin_amdgcn_s_getreg(20 | (0 << 6) | (31 << 11));  // HW_REG_XCC_ID
+    unsigned long long* o = stamps + (size_t)task * 5;
     o[0] = st_t0; o[1] = st_t1; o[2] = st_t2; o[3] = hwid; o[4] = xcc;
   }
 #endif
-  s_val[wave * 64 + lane] = best;
-  s_k[wave * 64 + lane] = bestk;
-  __syncthreads();
-  const int64_t idx = i0 + tid;
-  if (tid < 64 && idx < hi) {
-    double bv = s_val[tid];
-    int bk = s_k[tid];
-#pragma unroll
-    for (int w = 1; w < 4; ++w) {
-      double ov = s_val[w * 64 + tid];
-      int ok = s_k[w * 64 + tid];
-      if (better<MAXDIR>(ov, ok, bv, bk)) {
-        bv = ov;
-        bk = ok;
-      }
-    }
-    const int64_t o = (int64_t)chunk * W.partial_stride + idx;
-    out_val[o] = bv;
-    out_idx[o] = bk;
+}
+
+// Fill the key rows with the reduction identity (+-Double.MAX_VALUE, the `val` initialiser of
+// Recursion.java:132-133).
+__global__ __launch_bounds__(256) void key_fill_kernel(unsigned long long* __restrict__ keys, int64_t n, int maxdir) {
+  const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (i < n) keys[i] = f64_key(maxdir ? -1.7976931348623157e308 : 1.7976931348623157e308);
+}
+
+// Deferred read-out for chunked periods: V_t = unkey(K_t); policy = action of the lowest chunk whose
+// best value equals V_t.  One launch covers every pending period (jobs sorted by first state).
+struct FinalizeJob {
+  const unsigned long long* keys;  // indexed by flat state index
+  const double* part_val;          // [n_chunks][stride], indexed by flat state index
+  const int32_t* part_idx;
+  double* v_out;
+  int32_t* pol_out;
+  int64_t stride;
+  int64_t lo, hi;    // states whose policy this job resolves (this rank's slab)
+  int64_t vlo, vhi;  // states whose value it decodes (the whole row when sharded)
+  int64_t first;     // prefix sum of (vhi - vlo) over earlier jobs
+  int32_t n_chunks;
+  int32_t pad;
+};
+
+__global__ __launch_bounds__(256) void finalize_kernel(const FinalizeJob* __restrict__ jobs, int n_jobs, int64_t total) {
+  const int64_t g = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (g >= total) return;
+  int a = 0, b = n_jobs - 1;
+  while (a < b) {  // last job with first <= g
+    int mid = (a + b + 1) >> 1;
+    if (jobs[mid].first <= g) a = mid; else b = mid - 1;
   }
+  const FinalizeJob& J = jobs[a];
+  const int64_t idx = J.vlo + (g - J.first);
+  const double v = f64_unkey(J.keys[idx]);
+  J.v_out[idx] = v;
+  if (idx < J.lo || idx >= J.hi) return;
+  int k = 0;
+  for (int c = 0; c < J.n_chunks; ++c) {
+    if (J.part_val[(int64_t)c * J.stride + idx] == v) {
+      k = J.part_idx[(int64_t)c * J.stride + idx];
+      break;
+    }
+  }
+  J.pol_out[idx] = k;
 }
 
 // ---------------------------------------------------------------------------------------------

@@ -78,12 +78,23 @@ struct sdpgpu_handle {
   double* d_part_val[2] = {nullptr, nullptr};  // window kernels: partial arg-opt rows [chunk][slab], by period parity
   int32_t* d_part_idx[2] = {nullptr, nullptr};
   size_t part_elems[2] = {0, 0};
-  // deferred combine: V_pending / policy_pending still live as partial rows (see sdp_window.hpp FusedPrev)
-  int pending_period = 0;
-  int pending_chunks = 0;
-  int64_t pending_stride = 0, pending_lo = 0, pending_hi = 0;
+  // F1 window kernel with several tasks per tile (small grids): V_t is reduced into order-preserving
+  // keys by atomics and the (value, action) rows of the chunks are kept until flush_pending() turns
+  // them into the final V_t / policy rows in ONE launch (see sdp_window.hpp finalize_kernel).
+  unsigned long long* d_keys = nullptr;  // [T][key_stride]
+  bool keys_external = false;            // caller memory (sdpgpu_attach_keys), e.g. a tensor RCCL can address
+  size_t key_stride = 0;
+  std::vector<char> key_row_clean;       // row t holds the reduction identity (+-Double.MAX_VALUE)
+  double* d_chunk_val = nullptr;         // arena of chunk rows, period t at chunk_off[t-1]
+  int32_t* d_chunk_idx = nullptr;
+  size_t chunk_elems = 0;
+  std::vector<size_t> chunk_off;
+  std::vector<int> pending_chunks;       // >0: period's final rows not written yet (value = n_chunks)
+  int n_pending = 0;
+  sdp::FinalizeJob* d_jobs = nullptr;
   bool fuse_combine = true;
   bool use_cash_shift = true;
+  int win_lds_floor = 0;  // bytes of LDS a window workgroup claims at least (limits workgroups per CU)
   int win_r = 0, win_nch = 0;      // tuning overrides (SDPGPU_WIN_R / SDPGPU_WIN_NCH), 0 = heuristic
   uint8_t* d_reach = nullptr;      // reachable masks, period t at reach_off[t-1]
   std::vector<size_t> reach_off;
@@ -607,7 +618,7 @@ hipError_t launch_cash_shift(sdpgpu_handle* h, const DevParams& P, int period, c
 // ---- window kernel (F1) -----------------------------------------------------------------------
 
 struct WinPlan {
-  int R = 0, d_pad = 0, n_chunks = 1, chunk_actions = 0, n_tiles = 0;
+  int R = 0, d_pad = 0, n_chunks = 1, chunk_blocks = 0, n_tiles = 0, n_tasks = 0;
   size_t smem = 0;
 };
 
@@ -619,55 +630,60 @@ bool window_eligible(const sdpgpu_handle* h, int period) {
     if (d[j] - d[j - 1] != h->d.step) return false;
   const PeriodInfo& p = h->per[period - 1];
   if (p.S >= 2147483647LL - 4096) return false;
-  if ((size_t)(64 + h->n_actions_full + 8 + p.nD + 8) * 16 + 4096 > 64 * 1024 && h->n_actions_full + p.nD > 3500) return false;
+  if (h->n_actions_full + p.nD > 3500) return false;
   return true;
 }
 
-WinPlan plan_window(const sdpgpu_handle* h, int period) {
+// One task = one wave = (tile of 64 states, run of R-blocks).  The measured timeline of a SIMD is task
+// after task, so a launch costs  rounds x task time  with rounds = ceil(tasks / 1024 SIMDs): pick the
+// register block R and the number of chunks per tile that minimise it (fewest chunks on ties: fewer
+// chunk rows, less staging).
+WinPlan plan_window(const sdpgpu_handle* h, int period, int64_t lo, int64_t hi) {
   const PeriodInfo& p = h->per[period - 1];
   const int A = h->n_actions_full, D = p.nD;
-  WinPlan w;
-  int64_t n = p.hi - p.lo;
-  w.n_tiles = (int)((n + 63) / 64);
+  WinPlan best;
+  double best_cost = -1;
+  const int64_t n_tiles = (hi - lo + 63) / 64;
   auto rup = [](int v, int r) { return (v + r - 1) / r * r; };
   const int cand[3] = {8, 5, 4};
-  int64_t best_cost = -1;
+  const bool may_chunk = h->fuse_combine && h->d.store_all_values;
   for (int r : cand) {
     if (h->win_r && r != h->win_r) continue;
-    int64_t cost = (int64_t)rup(A, r) * rup(D, r);
-    if (best_cost < 0 || cost < best_cost) {
-      best_cost = cost;
-      w.R = r;
+    const int d_pad = rup(D, r);
+    const int blocks_total = rup(A, r) / r;
+    // cost of one R-block on one SIMD, in fp64-instruction units: 5 ops per cell plus a per-step overhead
+    // (LDS read, scalar load, waits) that a wider register block amortises better
+    const double block_cost = (double)D * (5.0 * r + 3.0) + 60.0;
+    // register budget -> waves a SIMD can hold (76 / 86 / 65 VGPRs for R = 8 / 5 / 4)
+    const int occupancy = r == 8 ? 6 : (r == 5 ? 5 : 7);
+    for (int nch = 1; nch <= blocks_total; ++nch) {
+      if (h->win_nch && nch != std::min(h->win_nch, blocks_total)) continue;
+      const int bpc = (blocks_total + nch - 1) / nch;
+      if ((blocks_total + bpc - 1) / bpc != nch) continue;  // same plan as a smaller nch
+      if (nch > 1 && !may_chunk) continue;  // chunk rows need the deferred key/finalize scheme
+      const size_t smem = (size_t)4 * (64 + bpc * r + d_pad) * 16;
+      if (smem > 64 * 1024) continue;
+      const int64_t tasks = n_tiles * nch;
+      const int64_t rounds = (tasks + 1023) / 1024;  // tasks the busiest SIMD runs, one after the other
+      // fp64 issue rate one SIMD sustains with w resident waves (tools/valu_probe): 0.76 / 0.86 / 0.94 / 0.97
+      const int64_t w = std::min<int64_t>(rounds, occupancy);
+      const double eff = w >= 8 ? 0.97 : (w >= 4 ? 0.94 : (w >= 3 ? 0.90 : (w >= 2 ? 0.86 : 0.76)));
+      const double staging = 400.0 + 4.0 * (64 + bpc * r + d_pad);
+      const double cost = (double)rounds * (bpc * block_cost + staging) / eff;
+      if (best_cost < 0 || cost < best_cost * 0.999) {
+        best_cost = cost;
+        best.R = r;
+        best.d_pad = d_pad;
+        best.n_chunks = nch;
+        best.chunk_blocks = bpc;
+        best.n_tiles = (int)n_tiles;
+        best.n_tasks = (int)tasks;
+        best.smem = smem;
+      }
     }
   }
-  if (!w.R) w.R = 8;
-  w.d_pad = rup(D, w.R);
-  const int blocks_total = rup(A, w.R) / w.R;
-  // enough waves for ~6 per SIMD (1024 SIMDs), one R-block per wave at least
-  int64_t want_chunks = (6144 + (int64_t)w.n_tiles * 4 - 1) / ((int64_t)w.n_tiles * 4);
-  int nch = (int)std::max<int64_t>(1, std::min<int64_t>(want_chunks, (blocks_total + 3) / 4));
-  if (h->win_nch) nch = std::max(1, std::min(h->win_nch, blocks_total));
-  int bpc = (blocks_total + nch - 1) / nch;
-  // LDS budget: span entries of 16 B + the arg-opt scratch
-  while ((size_t)(64 + bpc * w.R + w.d_pad) * 16 + 4 * 64 * 12 > 60 * 1024 && bpc > 1) bpc = (bpc + 1) / 2;
-  w.n_chunks = (blocks_total + bpc - 1) / bpc;
-  w.chunk_actions = bpc * w.R;
-  w.smem = (size_t)(64 + w.chunk_actions + w.d_pad) * 16 + 4 * 64 * (sizeof(double) + sizeof(int));
-  return w;
-}
-
-template <int R, bool MAXDIR>
-hipError_t launch_window_r(const sdp::WinParams& W, const WinPlan& pl, bool future, bool fused, const sdp::FusedPrev& F,
-                           const double* v_next, double* out_val, int32_t* out_idx, const double* pmf_p, int64_t lo,
-                           int64_t hi, hipStream_t st) {
-  dim3 grid((unsigned)((int64_t)pl.n_tiles * pl.n_chunks));
-  if (future && fused)
-    hipLaunchKernelGGL((sdp::window_f1_kernel<R, MAXDIR, true, true>), grid, dim3(256), pl.smem, st, W, v_next, out_val, out_idx, pmf_p, lo, hi, F);
-  else if (future)
-    hipLaunchKernelGGL((sdp::window_f1_kernel<R, MAXDIR, true, false>), grid, dim3(256), pl.smem, st, W, v_next, out_val, out_idx, pmf_p, lo, hi, F);
-  else
-    hipLaunchKernelGGL((sdp::window_f1_kernel<R, MAXDIR, false, false>), grid, dim3(256), pl.smem, st, W, v_next, out_val, out_idx, pmf_p, lo, hi, F);
-  return hipGetLastError();
+  if (best.R && h->win_lds_floor > 0) best.smem = std::max<size_t>(best.smem, (size_t)h->win_lds_floor);
+  return best;
 }
 
 hipError_t ensure_partials(sdpgpu_handle* h, int b, size_t need) {
@@ -696,19 +712,45 @@ hipError_t launch_combine(const double* pv, const int32_t* pi, int n_chunks, int
   return hipGetLastError();
 }
 
-// Write the final V / policy rows of a period whose arg-opt is still held as per-chunk partial rows.
+// Turn every pending period's keys + chunk rows into its final V_t / policy rows: one launch.
 hipError_t flush_pending(sdpgpu_handle* h) {
-  if (!h->pending_period) return hipSuccess;
-  const int period = h->pending_period;
-  const PeriodInfo& p = h->per[period - 1];
-  const int b = period & 1;
-  const int64_t lo = h->pending_lo, hi = h->pending_hi;
-  double* v_cur = h->d_values + p.v_off;
-  int32_t* pol = h->d_policy + p.pol_off - p.lo;
-  h->pending_period = 0;
-  const bool maxdir = h->d.direction == SDPGPU_MAX;
-  return maxdir ? launch_combine<true>(h->d_part_val[b] - lo, h->d_part_idx[b] - lo, h->pending_chunks, h->pending_stride, v_cur, pol, lo, hi, h->stream)
-                : launch_combine<false>(h->d_part_val[b] - lo, h->d_part_idx[b] - lo, h->pending_chunks, h->pending_stride, v_cur, pol, lo, hi, h->stream);
+  if (h->n_pending == 0) return hipSuccess;
+  std::vector<sdp::FinalizeJob> jobs;
+  int64_t total = 0;
+  for (int t = 0; t < h->T; ++t) {
+    if (h->pending_chunks[t] <= 0) continue;
+    const PeriodInfo& p = h->per[t];
+    sdp::FinalizeJob J{};
+    J.keys = h->d_keys + (size_t)t * h->key_stride;
+    J.part_val = h->d_chunk_val + h->chunk_off[t] - p.lo;
+    J.part_idx = h->d_chunk_idx + h->chunk_off[t] - p.lo;
+    J.v_out = h->d_values + p.v_off;
+    J.pol_out = h->d_policy + p.pol_off - p.lo;
+    J.stride = p.hi - p.lo;
+    J.lo = p.lo;
+    J.hi = p.hi;
+    // V_t is decoded over the whole row (after the all-gather every rank holds all keys), the policy
+    // only for this rank's slab
+    J.vlo = h->d.world_size > 1 ? 0 : p.lo;
+    J.vhi = h->d.world_size > 1 ? p.S : p.hi;
+    J.first = total;
+    J.n_chunks = h->pending_chunks[t];
+    total += J.vhi - J.vlo;
+    jobs.push_back(J);
+    h->pending_chunks[t] = 0;
+  }
+  h->n_pending = 0;
+  if (jobs.empty() || total == 0) return hipSuccess;
+  if (!h->d_jobs) {
+    hipError_t e = hipMalloc((void**)&h->d_jobs, (size_t)h->T * sizeof(sdp::FinalizeJob));
+    if (e != hipSuccess) return e;
+  }
+  // pageable source: HIP stages the bytes before hipMemcpyAsync returns, so `jobs` may go out of scope
+  hipError_t e = hipMemcpyAsync(h->d_jobs, jobs.data(), jobs.size() * sizeof(sdp::FinalizeJob), hipMemcpyHostToDevice, h->stream);
+  if (e != hipSuccess) return e;
+  hipLaunchKernelGGL(sdp::finalize_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, h->stream, h->d_jobs,
+                     (int)jobs.size(), total);
+  return hipGetLastError();
 }
 
 // ---- row-window kernel (F2) ---------------------------------------------------------------
@@ -811,8 +853,56 @@ hipError_t launch_window(sdpgpu_handle* h, const DevParams& P, int period, const
   (void)pmf_d;
   if (hi <= lo) return hipSuccess;
   if (h->d.family == SDPGPU_FAMILY_LEADTIME) return launch_row_window(h, P, period, v_next, v_cur, pol, pmf_p, lo, hi, st);
-  const PeriodInfo& p = h->per[period - 1];
-  WinPlan pl = plan_window(h, period);
+  PeriodInfo& p = h->per[period - 1];
+  WinPlan pl = plan_window(h, period, lo, hi);
+  if (!pl.R) return hipErrorInvalidValue;
+  const bool future = period < h->T;
+  const bool chunked = pl.n_chunks > 1;
+  // a period is never re-run on top of its own pending rows, and a new sweep (period T) first
+  // finalizes what the previous one left: the key rows are about to be reset
+  if (h->n_pending > 0 && (h->pending_chunks[period - 1] > 0 || period == h->T)) {
+    hipError_t e = flush_pending(h);
+    if (e != hipSuccess) return e;
+  }
+  // where V_{t+1} comes from: its key row while that period is still pending, else the final fp64 row
+  const bool keyed_in = future && h->pending_chunks[period] > 0;
+  if (chunked) {
+    if (!h->d_chunk_val) {  // one-time arenas: a key row per period, the chunk rows of every chunked period
+      size_t stride = 0;
+      for (const PeriodInfo& q : h->per) stride = std::max<size_t>(stride, (size_t)q.S_pad);
+      hipError_t e = hipSuccess;
+      if (!h->d_keys) e = hipMalloc((void**)&h->d_keys, (size_t)h->T * stride * sizeof(unsigned long long));
+      if (e != hipSuccess) return e;
+      h->key_stride = stride;
+      h->key_row_clean.assign((size_t)h->T, 0);
+      h->chunk_off.assign((size_t)h->T, 0);
+      size_t total = 0;
+      for (int t = 0; t < h->T; ++t) {
+        const PeriodInfo& q = h->per[t];
+        h->chunk_off[t] = total;
+        if (window_eligible(h, t + 1))
+          total += (size_t)plan_window(h, t + 1, q.lo, q.hi).n_chunks * (size_t)(q.hi - q.lo);
+      }
+      e = hipMalloc((void**)&h->d_chunk_val, std::max<size_t>(total, 1) * sizeof(double));
+      if (e == hipSuccess) e = hipMalloc((void**)&h->d_chunk_idx, std::max<size_t>(total, 1) * sizeof(int32_t));
+      if (e != hipSuccess) return e;
+      h->chunk_elems = total;
+    }
+    if (!h->key_row_clean[period - 1]) {
+      // reset key rows to the reduction identity: all of them when nothing is pending (the usual case:
+      // period T of a new sweep), else only this period's row (periods re-run out of order)
+      const bool all = h->n_pending == 0;
+      const int64_t n = (all ? (int64_t)h->T : 1) * (int64_t)h->key_stride;
+      unsigned long long* base = all ? h->d_keys : h->d_keys + (size_t)(period - 1) * h->key_stride;
+      hipLaunchKernelGGL(sdp::key_fill_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, base, n, (int)P.maxdir);
+      hipError_t e = hipGetLastError();
+      if (e != hipSuccess) return e;
+      if (all)
+        std::fill(h->key_row_clean.begin(), h->key_row_clean.end(), 1);
+      else
+        h->key_row_clean[period - 1] = 1;
+    }
+  }
   sdp::WinParams W{};
   const double d0 = h->pmf_d[period - 1][0];
   W.lev0 = p.g.x_lo - d0;
@@ -821,90 +911,86 @@ hipError_t launch_window(sdpgpu_handle* h, const DevParams& P, int period, const
   W.pi = h->d.penalty_cost;
   W.K = h->d.fixed_order_cost;
   W.v = h->d.unit_order_cost;
-  const bool future = period < h->T;
   if (future) {
     W.idx_off = (int32_t)((W.lev0 - h->per[period].g.x_lo) / h->d.step);
     W.next_last = (int32_t)(h->per[period].g.nx - 1);
   }
   W.n_actions = h->n_actions_full;
   W.d_pad = pl.d_pad;
+  W.d_main = p.nD / pl.R * pl.R;
+  W.n_demand = p.nD;
   W.n_chunks = pl.n_chunks;
-  W.chunk_actions = pl.chunk_actions;
+  W.chunk_blocks = pl.chunk_blocks;
   W.n_tiles = pl.n_tiles;
-  // deferred combine of period+1 (see FusedPrev): possible when that period's rows are still partial,
-  // cover exactly this slab, and both periods share one grid
-  sdp::FusedPrev F{};
-  bool fused = false;
-  if (h->pending_period == period + 1 && future) {
-    const PeriodInfo& pn = h->per[period];
-    if (h->pending_lo == lo && h->pending_hi == hi && pn.S == p.S && pn.g.nx == p.g.nx) {
-      const int pb = (period + 1) & 1;
-      F.part_val = h->d_part_val[pb] - lo;
-      F.part_idx = h->d_part_idx[pb] - lo;
-      F.v_out = h->d_values + pn.v_off;
-      F.pol_out = h->d_policy + pn.pol_off - pn.lo;
-      F.n_chunks = h->pending_chunks;
-      F.stride = h->pending_stride;
-      fused = true;
-    }
+  W.n_tasks = pl.n_tasks;
+  double* out_val = v_cur;
+  int32_t* out_idx = pol;
+  unsigned long long* k_cur = nullptr;
+  const unsigned long long* k_next = keyed_in ? h->d_keys + (size_t)period * h->key_stride : nullptr;
+  if (chunked) {
+    W.partial_stride = hi - lo;
+    out_val = h->d_chunk_val + h->chunk_off[period - 1] - lo;  // the kernel indexes rows by flat state index
+    out_idx = h->d_chunk_idx + h->chunk_off[period - 1] - lo;
+    k_cur = h->d_keys + (size_t)(period - 1) * h->key_stride;
   }
-  if (!fused) {
-    hipError_t ef = flush_pending(h);
-    if (ef != hipSuccess) return ef;
-  }
+  const dim3 grid((unsigned)((pl.n_tasks + 3) / 4));
 #ifdef SDP_STAMPS
-  {
-    static unsigned long long* d_stamps = nullptr;
-    if (!d_stamps) (void)hipMalloc((void**)&d_stamps, (size_t)1 << 24);
-    F.stamps = (period == 2) ? d_stamps : nullptr;  // record one mid-sweep launch
-    if (period == 1) {
-      std::vector<unsigned long long> hs((size_t)pl.n_tiles * pl.n_chunks * 4 * 5);
-      (void)hipStreamSynchronize(st);
-      (void)hipMemcpy(hs.data(), d_stamps, hs.size() * 8, hipMemcpyDeviceToHost);
-      if (FILE* f = std::fopen("gpurun_out/stamps.txt", "w")) {
-        for (size_t i = 0; i + 4 < hs.size(); i += 5)
-          std::fprintf(f, "%zu %llu %llu %llu %llu %llu\n", i / 5, hs[i], hs[i + 1], hs[i + 2], hs[i + 3], hs[i + 4]);
-        std::fclose(f);
-      }
+  static unsigned long long* d_stamps = nullptr;
+  if (!d_stamps) (void)hipMalloc((void**)&d_stamps, (size_t)1 << 24);
+  unsigned long long* stamps = (period == 2) ? d_stamps : nullptr;  // record one mid-sweep launch
+#define SDP_STAMP_ARG , stamps
+#else
+#define SDP_STAMP_ARG
+#endif
+#define SDP_WIN_GO(RR, MX, FU, KI)                                                                                      \
+  hipLaunchKernelGGL((sdp::window_f1_kernel<RR, MX, FU, KI>), grid, dim3(256), pl.smem, st, W, v_next, k_next, out_val, \
+                     out_idx, k_cur, pmf_p, lo, hi SDP_STAMP_ARG)
+#define SDP_WIN_R(RR)                                       \
+  case RR:                                                  \
+    if (P.maxdir) {                                         \
+      if (!future)                                          \
+        SDP_WIN_GO(RR, true, false, false);                 \
+      else if (keyed_in)                                    \
+        SDP_WIN_GO(RR, true, true, true);                   \
+      else                                                  \
+        SDP_WIN_GO(RR, true, true, false);                  \
+    } else {                                                \
+      if (!future)                                          \
+        SDP_WIN_GO(RR, false, false, false);                \
+      else if (keyed_in)                                    \
+        SDP_WIN_GO(RR, false, true, true);                  \
+      else                                                  \
+        SDP_WIN_GO(RR, false, true, false);                 \
+    }                                                       \
+    break;
+  switch (pl.R) {
+    SDP_WIN_R(8)
+    SDP_WIN_R(5)
+    SDP_WIN_R(4)
+    default:
+      return hipErrorInvalidValue;
+  }
+#undef SDP_WIN_R
+#undef SDP_WIN_GO
+#undef SDP_STAMP_ARG
+  hipError_t e = hipGetLastError();
+  if (e != hipSuccess) return e;
+#ifdef SDP_STAMPS
+  if (period == 1) {
+    std::vector<unsigned long long> hs((size_t)pl.n_tasks * 5);
+    (void)hipStreamSynchronize(st);
+    (void)hipMemcpy(hs.data(), d_stamps, hs.size() * 8, hipMemcpyDeviceToHost);
+    if (FILE* f = std::fopen("gpurun_out/stamps.txt", "w")) {
+      for (size_t i = 0; i + 4 < hs.size(); i += 5)
+        std::fprintf(f, "%zu %llu %llu %llu %llu %llu\n", i / 5, hs[i], hs[i + 1], hs[i + 2], hs[i + 3], hs[i + 4]);
+      std::fclose(f);
     }
   }
 #endif
-  double* out_val = v_cur;
-  int32_t* out_idx = pol;
-  const int b = period & 1;
-  if (pl.n_chunks > 1) {
-    int64_t slab = hi - lo;
-    hipError_t ea = ensure_partials(h, b, (size_t)pl.n_chunks * (size_t)slab);
-    if (ea != hipSuccess) return ea;
-    W.partial_stride = slab;
-    out_val = h->d_part_val[b] - lo;  // the kernels index rows by flat state index
-    out_idx = h->d_part_idx[b] - lo;
-  }
-  hipError_t e = hipErrorInvalidValue;
-#define SDP_WIN(RR)                                                                                                   \
-  case RR:                                                                                                            \
-    e = P.maxdir ? launch_window_r<RR, true>(W, pl, future, fused, F, v_next, out_val, out_idx, pmf_p, lo, hi, st)     \
-                 : launch_window_r<RR, false>(W, pl, future, fused, F, v_next, out_val, out_idx, pmf_p, lo, hi, st);   \
-    break;
-  switch (pl.R) {
-    SDP_WIN(8)
-    SDP_WIN(5)
-    SDP_WIN(4)
-  }
-#undef SDP_WIN
-  if (e != hipSuccess) return e;
-  if (fused) h->pending_period = 0;  // period+1 was finalised by this launch
-  if (pl.n_chunks > 1) {
-    if (h->fuse_combine && h->d.world_size == 1) {
-      h->pending_period = period;
-      h->pending_chunks = pl.n_chunks;
-      h->pending_stride = W.partial_stride;
-      h->pending_lo = lo;
-      h->pending_hi = hi;
-    } else {
-      e = P.maxdir ? launch_combine<true>(out_val, out_idx, pl.n_chunks, W.partial_stride, v_cur, pol, lo, hi, st)
-                   : launch_combine<false>(out_val, out_idx, pl.n_chunks, W.partial_stride, v_cur, pol, lo, hi, st);
-    }
+  if (chunked) {
+    h->pending_chunks[period - 1] = pl.n_chunks;
+    h->n_pending++;
+    h->key_row_clean[period - 1] = 0;  // holds data now; re-filled when the next sweep starts
   }
   return e;
 }
@@ -915,8 +1001,19 @@ hipError_t launch_window(sdpgpu_handle* h, const DevParams& P, int period, const
 // C ABI
 // =================================================================================================
 namespace {
+// does any period run the F1 window kernel with several tasks per tile (=> key rows are used)?
+bool keys_needed(sdpgpu_handle* h) {
+  if (h->d.family != SDPGPU_FAMILY_BACKORDER || h->d.kernel == SDPGPU_KERNEL_GATHER) return false;
+  if (layout(h)) return false;
+  for (int t = 1; t <= h->T; ++t) {
+    const PeriodInfo& q = h->per[t - 1];
+    if (window_eligible(h, t) && q.hi > q.lo && plan_window(h, t, q.lo, q.hi).n_chunks > 1) return true;
+  }
+  return false;
+}
+
 int flush_api(sdpgpu_handle* h) {
-  if (!h->pending_period) return SDPGPU_OK;
+  if (h->n_pending == 0) return SDPGPU_OK;
   int rc = ensure_device(h);
   if (rc) return rc;
   hipError_t e = flush_pending(h);
@@ -966,10 +1063,12 @@ int sdpgpu_create(const sdpgpu_desc* desc, sdpgpu_handle** out) {
     h->pmf_set.assign((size_t)h->T, 0);
     h->period_done.assign((size_t)h->T, 0);
     h->policy_done.assign((size_t)h->T, 0);
+    h->pending_chunks.assign((size_t)h->T + 1, 0);
     if (const char* e = std::getenv("SDPGPU_WIN_R")) h->win_r = std::atoi(e);
     if (const char* e = std::getenv("SDPGPU_WIN_NCH")) h->win_nch = std::atoi(e);
     if (const char* e = std::getenv("SDPGPU_FUSE_COMBINE")) h->fuse_combine = std::atoi(e) != 0;
     if (const char* e = std::getenv("SDPGPU_CASH_SHIFT")) h->use_cash_shift = std::atoi(e) != 0;
+    if (const char* e = std::getenv("SDPGPU_WIN_LDS")) h->win_lds_floor = std::atoi(e);
   } catch (...) {
     delete h;
     return fail(nullptr, SDPGPU_ERR_ARG, "out of host memory");
@@ -998,6 +1097,10 @@ void sdpgpu_destroy(sdpgpu_handle* h) {
     if (h->d_part_val[b]) (void)hipFree(h->d_part_val[b]);
     if (h->d_part_idx[b]) (void)hipFree(h->d_part_idx[b]);
   }
+  if (h->d_keys && !h->keys_external) (void)hipFree(h->d_keys);
+  if (h->d_chunk_val) (void)hipFree(h->d_chunk_val);
+  if (h->d_chunk_idx) (void)hipFree(h->d_chunk_idx);
+  if (h->d_jobs) (void)hipFree(h->d_jobs);
   if (h->stream && h->own_stream) (void)hipStreamDestroy(h->stream);
   delete h;
 }
@@ -1183,6 +1286,39 @@ int sdpgpu_solve(sdpgpu_handle* h, int32_t sync) {
   } catch (...) {
     return fail(h, SDPGPU_ERR_ARG, "unknown exception");
   }
+}
+
+size_t sdpgpu_keys_bytes(const sdpgpu_handle* hc) {
+  sdpgpu_handle* h = const_cast<sdpgpu_handle*>(hc);
+  if (!h || !keys_needed(h)) return 0;
+  size_t stride = 0;
+  for (const PeriodInfo& q : h->per) stride = std::max<size_t>(stride, (size_t)q.S_pad);
+  return (size_t)h->T * stride * sizeof(unsigned long long);
+}
+
+int sdpgpu_attach_keys(sdpgpu_handle* h, void* device_ptr, size_t bytes) {
+  if (!h) return SDPGPU_ERR_ARG;
+  h->err.clear();
+  if (h->d_keys) return fail(h, SDPGPU_ERR_STATE, "attach_keys must precede the first run");
+  size_t need = sdpgpu_keys_bytes(h);
+  if (!device_ptr || bytes < need) return fail(h, SDPGPU_ERR_ARG, "attach_keys: need %zu bytes", need);
+  h->d_keys = (unsigned long long*)device_ptr;
+  h->keys_external = true;
+  return SDPGPU_OK;
+}
+
+void* sdpgpu_exchange_ptr(sdpgpu_handle* h, int32_t period) {
+  if (!h || period < 1 || period > h->T) return nullptr;
+  if (allocate(h)) return nullptr;
+  if (h->pending_chunks[period - 1] > 0) return h->d_keys + (size_t)(period - 1) * h->key_stride;
+  return h->d_values + h->per[period - 1].v_off;
+}
+
+int sdpgpu_finalize(sdpgpu_handle* h) {
+  if (!h) return SDPGPU_ERR_ARG;
+  h->err.clear();
+  if (!h->allocated) return SDPGPU_OK;
+  return flush_api(h);
 }
 
 int sdpgpu_synchronize(sdpgpu_handle* h) {

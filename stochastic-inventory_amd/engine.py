@@ -115,6 +115,22 @@ class SdpEngine:
     def run_period(self, period: int):
         self._check(self._lib.sdpgpu_run_period(self._h, period))
 
+    def keys_bytes(self) -> int:
+        return int(self._lib.sdpgpu_keys_bytes(self._h))
+
+    def attach_keys(self, device_ptr: int, nbytes: int):
+        self._check(self._lib.sdpgpu_attach_keys(self._h, C.c_void_p(device_ptr), nbytes))
+
+    def exchange_ptr(self, period: int) -> int:
+        p = self._lib.sdpgpu_exchange_ptr(self._h, period)
+        if not p:
+            raise SdpgpuError(3, self._lib.sdpgpu_last_error(self._h).decode() or "no exchange table")
+        return int(p)
+
+    def finalize(self):
+        """Enqueue the deferred read-out of every period run so far (no host wait)."""
+        self._check(self._lib.sdpgpu_finalize(self._h))
+
     def synchronize(self):
         self._check(self._lib.sdpgpu_synchronize(self._h))
 

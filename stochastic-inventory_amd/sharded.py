@@ -32,11 +32,16 @@ class SlabBackend:
     def slab(self, period: int):  # -> (padded, lo, hi)
         raise NotImplementedError
 
-    def table(self, period: int) -> torch.Tensor:  # the full padded V_period row (this rank's copy)
+    def table(self, period: int) -> torch.Tensor:
+        """The full padded row (this rank's copy) that must be all-gathered after run_period(period):
+        8-byte elements -- the fp64 V_period row, or the engine's uint64 key row on small grids."""
         raise NotImplementedError
 
     def run_period(self, period: int) -> None:  # compute this rank's slab of V_period into table(period)
         raise NotImplementedError
+
+    def finalize(self) -> None:  # enqueue any deferred read-out work (policy rows), no host wait
+        pass
 
 
 class GpuSlabBackend(SlabBackend):
@@ -50,6 +55,11 @@ class GpuSlabBackend(SlabBackend):
         nbytes = self.engine.values_bytes()
         self.arena = torch.zeros(nbytes // 8, dtype=torch.float64, device=self.device)
         self.engine.attach_values(self.arena.data_ptr(), nbytes)
+        kbytes = self.engine.keys_bytes()
+        self.key_arena = None
+        if kbytes:
+            self.key_arena = torch.zeros(kbytes // 8, dtype=torch.int64, device=self.device)
+            self.engine.attach_keys(self.key_arena.data_ptr(), kbytes)
         self.engine.set_stream(torch.cuda.current_stream(self.device).cuda_stream)
         self._views = {}
 
@@ -57,14 +67,25 @@ class GpuSlabBackend(SlabBackend):
         return self.engine.slab(period)
 
     def table(self, period: int) -> torch.Tensor:
+        """Valid once run_period(period) has been issued (which row is exchanged is decided then; the
+        choice is the same in every sweep, so the view is cached)."""
         if period not in self._views:
             pad, _, _ = self.engine.slab(period)
-            base = (self.engine.values_device_ptr(period) - self.arena.data_ptr()) // 8
-            self._views[period] = self.arena[base: base + pad]
+            ptr = self.engine.exchange_ptr(period)
+            for arena in (self.arena, self.key_arena):
+                if arena is not None and arena.data_ptr() <= ptr < arena.data_ptr() + arena.numel() * 8:
+                    base = (ptr - arena.data_ptr()) // 8
+                    self._views[period] = arena[base: base + pad]
+                    break
+            else:
+                raise RuntimeError("exchange row is not inside an arena this backend owns")
         return self._views[period]
 
     def run_period(self, period: int) -> None:
         self.engine.run_period(period)
+
+    def finalize(self) -> None:
+        self.engine.finalize()
 
     def close(self):
         self.engine.close()
@@ -96,6 +117,7 @@ class ShardedSolver:
             self.backend.run_period(period)
             if period > first_period:  # V_1 is never read by another period
                 self.exchange(period)
+        self.backend.finalize()  # the sweep is done when every policy row exists
 
     def gather_policy(self, period: int, local: torch.Tensor) -> Optional[List[torch.Tensor]]:
         """Collect the per-rank policy slabs on rank 0 (host-side read-out, not on the hot path)."""

@@ -157,26 +157,43 @@ def test_sharded_periods_single_process(sia, oracle, make, world):
         d.rank, d.world_size = r, world
         engs.append(sia.SdpEngine(d, w.pmf, w.overhead()))
     V, pol, _ = oracle.Problem(w.desc(), w.pmf, w.overhead()).solve()
-    bufs = []
+    bufs, kbufs = [], []
     for e in engs:
         t = torch.zeros(e.values_bytes() // 8, dtype=torch.float64, device="cuda")
         e.attach_values(t.data_ptr(), t.numel() * 8)
+        k = torch.zeros(max(e.keys_bytes() // 8, 1), dtype=torch.int64, device="cuda")
+        if e.keys_bytes():
+            e.attach_keys(k.data_ptr(), k.numel() * 8)
         e.set_stream(torch.cuda.current_stream().cuda_stream)
         bufs.append(t)
+        kbufs.append(k)
+
+    def row_of(r, period):  # the 8-byte-element row rank r exchanges after run_period(period)
+        ptr = engs[r].exchange_ptr(period)
+        pad, _, _ = engs[r].slab(period)
+        for arena in (bufs[r], kbufs[r]):
+            if arena.data_ptr() <= ptr < arena.data_ptr() + arena.numel() * 8:
+                base = (ptr - arena.data_ptr()) // 8
+                return arena[base: base + pad].view(torch.int64)
+        raise AssertionError("exchange row outside the attached arenas")
+
     for period in range(w.T, 0, -1):
         for e in engs:
             e.run_period(period)
         torch.cuda.synchronize()
-        pad, _, _ = engs[0].slab(period)
-        base = (engs[0].values_device_ptr(period) - bufs[0].data_ptr()) // 8
-        full = torch.zeros(pad, dtype=torch.float64, device="cuda")
+        rows = [row_of(r, period) for r in range(world)]
+        full = torch.zeros_like(rows[0])
         for r, e in enumerate(engs):
             _, lo, hi = e.slab(period)
-            full[lo:hi] = bufs[r][base + lo: base + hi]
-        for b in bufs:
-            b[base: base + pad] = full
-        S = engs[0].num_states(period)
-        assert np.array_equal(full[:S].cpu().numpy(), V[period - 1])
+            full[lo:hi] = rows[r][lo:hi]
+        for r in range(world):
+            rows[r].copy_(full)  # the all-gather, by hand
+    for e in engs:
+        e.finalize()
+    torch.cuda.synchronize()
+    for period in range(1, w.T + 1):
+        for e in engs:
+            assert np.array_equal(e.values(period), V[period - 1])  # every rank holds the whole table
         got = np.concatenate([e.policy(period) for e in engs])
         assert np.array_equal(got, pol[period - 1])
     for e in engs:
