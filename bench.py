@@ -37,6 +37,8 @@ def parse_args():
     ap.add_argument("--periods", type=int, default=0, help="override the horizon")
     ap.add_argument("--kernel", type=int, default=0, help="0 auto, 1 gather, 2 window")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--backend", default="nccl", help="nccl (RCCL, default) | gloo (debug: N ranks on one GPU, host-staged)")
+    ap.add_argument("--check", action="store_true", help="compare the sharded result with a single-rank sweep (rank 0)")
     ap.add_argument("--cpu-seconds", type=float, default=15.0, help="target CPU time of the oracle sample")
     return ap.parse_args()
 
@@ -114,11 +116,16 @@ def main():
         raise SystemExit(f"WORLD_SIZE={world} but --gpus {args.gpus}")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the engine has no CPU path")
+    if args.backend == "gloo":
+        local_rank = local_rank % torch.cuda.device_count()  # rehearsal: several ranks share a GPU
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=dev)
+        if args.backend == "gloo":
+            dist.init_process_group("gloo")
+        else:
+            dist.init_process_group("nccl", device_id=dev)
 
     import stochastic_inventory_amd as sia
     from stochastic_inventory_amd.sharded import GpuSlabBackend, ShardedSolver
@@ -128,7 +135,7 @@ def main():
     desc.rank, desc.world_size = rank, world
     desc.kernel = args.kernel
     backend = GpuSlabBackend(desc, w.pmf, w.overhead(), device=dev)
-    solver = ShardedSolver(backend)
+    solver = ShardedSolver(backend, stage_through_host=(args.backend == "gloo"))
     eng = backend.engine
     T = w.T
 
@@ -172,6 +179,28 @@ def main():
     inner = [m for m in per_kernel[:-1]] or per_kernel
     kernel_ms_avg = sum(per_kernel) / len(per_kernel)
 
+    check = None
+    if args.check:
+        import numpy as np
+        v1 = eng.values(1)  # every rank holds the whole V_1 after finalize? V_1 is not exchanged: gather it
+        pol_local = eng.policy(1)
+        if world > 1:
+            solver.exchange(1)
+            torch.cuda.synchronize(dev)
+            eng.finalize()
+            v1 = eng.values(1)
+            gathered = [None] * world
+            dist.all_gather_object(gathered, pol_local)
+            pol_all = np.concatenate(gathered)
+        else:
+            pol_all = pol_local
+        if rank == 0:
+            d1 = w.desc()
+            d1.device = dev.index
+            with sia.SdpEngine(d1, w.pmf, w.overhead()) as ref:
+                ref.solve()
+                check = bool(np.array_equal(ref.values(1), v1) and np.array_equal(ref.policy(1), pol_all)
+                             and np.array_equal(ref.values(2 if T > 1 else 1), eng.values(2 if T > 1 else 1)))
     if rank == 0:
         traffic = None
         prof = os.path.join(ROOT, "profiles", "pmc_traffic.json")
@@ -219,6 +248,8 @@ def main():
                         "so HBM traffic is far below this figure and the true limiter is fp64 VALU issue",
             },
         }
+        if check is not None:
+            out["check_vs_single_rank"] = check
         if not args.no_cpu_baseline:
             import copy
             from stochastic_inventory_amd import workloads

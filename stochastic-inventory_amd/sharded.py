@@ -94,9 +94,12 @@ class GpuSlabBackend(SlabBackend):
 class ShardedSolver:
     """Backward sweep t = T..1 with one all-gather of V_t between periods."""
 
-    def __init__(self, backend: SlabBackend, group=None):
+    def __init__(self, backend: SlabBackend, group=None, stage_through_host: bool = False):
         self.backend = backend
         self.group = group
+        # debug only: a `gloo` group cannot address device memory, so the shard is bounced through the
+        # host (used to rehearse N ranks on ONE GPU; the production path is RCCL on device memory)
+        self.stage_through_host = stage_through_host
         self.world = dist.get_world_size(group) if dist.is_initialized() else 1
         self.rank = dist.get_rank(group) if dist.is_initialized() else 0
         self.gathered_bytes = 0
@@ -108,8 +111,13 @@ class ShardedSolver:
         full = self.backend.table(period)
         n = pad // self.world
         shard = full[self.rank * n: (self.rank + 1) * n]
-        # in place: this rank's shard already sits at its offset inside `full`
-        dist.all_gather_into_tensor(full, shard, group=self.group)
+        if self.stage_through_host and full.is_cuda:
+            host_full = torch.empty(full.shape, dtype=full.dtype)
+            dist.all_gather_into_tensor(host_full, shard.cpu(), group=self.group)
+            full.copy_(host_full)
+        else:
+            # in place: this rank's shard already sits at its offset inside `full`
+            dist.all_gather_into_tensor(full, shard, group=self.group)
         self.gathered_bytes += pad * 8
 
     def solve(self, first_period: int = 1) -> None:

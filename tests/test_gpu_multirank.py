@@ -1,0 +1,27 @@
+"""Two real processes, each driving its own slab through the HIP engine on the SAME GPU, exchange
+their key / value rows every period (gloo, host-staged: RCCL cannot put two ranks on one device).
+bench.py --check compares the sharded tables with a single-rank sweep bit for bit."""
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.mark.parametrize("extra", [["--periods", "6"], ["--workload", "cfg5", "--states", "100000", "--periods", "3"]],
+                         ids=["cfg2_small_slabs_key_rows", "f1_large_slabs"])
+def test_two_ranks_match_single_rank(extra):
+    port = 29600 + os.getpid() % 300
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr",
+           "127.0.0.1", "--master-port", str(port), os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2",
+           "--warmup", "1", "--backend", "gloo", "--check", "--no-cpu-baseline", *extra]
+    out = subprocess.run(cmd, capture_output=True, text=True, timeout=240, cwd=ROOT)
+    assert out.returncode == 0, out.stderr[-2000:]
+    line = [l for l in out.stdout.splitlines() if l.startswith("{")][-1]
+    rec = json.loads(line)
+    assert rec["n_gpus"] == 2 and rec["check_vs_single_rank"] is True
+    assert rec["scaling"] == "weak" and rec["value"] > 0
