@@ -38,6 +38,8 @@ def parse_args():
     ap.add_argument("--kernel", type=int, default=0, help="0 auto, 1 gather, 2 window")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--backend", default="nccl", help="nccl (RCCL, default) | gloo (debug: N ranks on one GPU, host-staged)")
+    ap.add_argument("--split", action="store_true", help="rehearsal: force the interior/boundary split of every period")
+    ap.add_argument("--no-overlap", action="store_true", help="blocking all-gather between periods (no compute overlap)")
     ap.add_argument("--check", action="store_true", help="compare the sharded result with a single-rank sweep (rank 0)")
     ap.add_argument("--cpu-seconds", type=float, default=15.0, help="target CPU time of the oracle sample")
     return ap.parse_args()
@@ -136,6 +138,8 @@ def main():
     desc.kernel = args.kernel
     backend = GpuSlabBackend(desc, w.pmf, w.overhead(), device=dev)
     solver = ShardedSolver(backend, stage_through_host=(args.backend == "gloo"))
+    solver.force_split = args.split
+    overlap = not args.no_overlap
     eng = backend.engine
     T = w.T
 
@@ -145,13 +149,13 @@ def main():
         torch.cuda.synchronize(dev)
 
     for _ in range(args.warmup):
-        solver.solve()
+        solver.solve(overlap=overlap)
     barrier()
     ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]
     t0 = time.perf_counter()
     for k in range(args.steps):
         ev[k][0].record()
-        solver.solve()
+        solver.solve(overlap=overlap)
         ev[k][1].record()
     barrier()
     elapsed = time.perf_counter() - t0
@@ -172,7 +176,7 @@ def main():
 
     # per-kernel event times in a separate, un-timed pass (cross-check for the rocprofv3 summary)
     eng.set_profiling(True)
-    solver.solve()
+    solver.solve(overlap=overlap)
     torch.cuda.synchronize(dev)
     per_kernel = [eng.period_ms(p) for p in range(1, T + 1)]
     eng.set_profiling(False)

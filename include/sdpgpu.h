@@ -218,6 +218,14 @@ int sdpgpu_solve(sdpgpu_handle* h, int32_t sync);
 /* One period for this rank's slab, reading the FULL V_{period+1} table.  With world_size > 1
  * the caller all-gathers V_period (device pointer below) across ranks before the next call. */
 int sdpgpu_run_period(sdpgpu_handle* h, int32_t period);
+/* The same in two halves, so that a sharded caller can overlap the all-gather of V_{period+1} with
+ * compute: INTERIOR = the states all of whose cells read only THIS rank's slab of V_{period+1} (it may
+ * run while the exchange is in flight; empty for families without a bounded footprint), BOUNDARY = the
+ * rest (after the exchange).  INTERIOR followed by BOUNDARY equals sdpgpu_run_period. */
+#define SDPGPU_PART_ALL 0
+#define SDPGPU_PART_INTERIOR 1
+#define SDPGPU_PART_BOUNDARY 2
+int sdpgpu_run_period_part(sdpgpu_handle* h, int32_t period, int32_t part);
 /* Device address of the V_period table (padded row, fp64) -- for the in-place all-gather. */
 void* sdpgpu_values_device_ptr(sdpgpu_handle* h, int32_t period);
 /* Use caller-owned device memory for the value tables: `bytes` >= sdpgpu_values_bytes(h). */

@@ -27,6 +27,10 @@ KERNEL_AUTO = 0
 KERNEL_GATHER = 1
 KERNEL_WINDOW = 2
 
+PART_ALL = 0
+PART_INTERIOR = 1
+PART_BOUNDARY = 2
+
 
 class SdpgpuDesc(C.Structure):
     """struct sdpgpu_desc (include/sdpgpu.h), field for field."""
@@ -129,6 +133,7 @@ EXPORTS = {
     "sdpgpu_state_index": (C.c_int64, [_P, C.c_int32, C.c_double, C.c_double, C.c_double]),
     "sdpgpu_solve": (C.c_int, [_P, C.c_int32]),
     "sdpgpu_run_period": (C.c_int, [_P, C.c_int32]),
+    "sdpgpu_run_period_part": (C.c_int, [_P, C.c_int32, C.c_int32]),
     "sdpgpu_values_device_ptr": (_P, [_P, C.c_int32]),
     "sdpgpu_values_bytes": (C.c_size_t, [_P]),
     "sdpgpu_attach_values": (C.c_int, [_P, _P, C.c_size_t]),

@@ -8,7 +8,7 @@
 //   d-sum is never split across lanes, that would change the rounding of Q(s,a).
 //   arg-opt over actions: in-lane strict compare (ascending), then a wave-shuffle
 //   (value, index) reduction across the action slots of a state, then across the four waves
-//   through LDS.  The demand PMF tile {d_j, p_j*gamma... } is staged once per workgroup in LDS.
+//   through LDS.  The demand PMF tile {d_j, p_j} is staged once per workgroup in LDS.
 //
 // Roofline: every cell reads one fp64 of V_{t+1} (8 B algorithmic); the table (80 KB .. 800 MB)
 // lives in L2 / Infinity Cache, so the kernel is bound by fp64 VALU issue and L2 gather rate,
@@ -45,7 +45,7 @@ __global__ __launch_bounds__(256) void gather_period_kernel(DevParams P, const d
   constexpr int AS = 256 / SX;          // action slots per workgroup
   constexpr int AS_WAVE = (SX >= 64) ? 1 : 64 / SX;  // action slots inside one wave
   extern __shared__ __attribute__((aligned(16))) char smem[];
-  double2* s_pmf = reinterpret_cast<double2*>(smem);  // {demand, p*gamma... p} pairs: x = d, y = p
+  double2* s_pmf = reinterpret_cast<double2*>(smem);  // {d_j, p_j} pairs: x = demand, y = probability
   double* s_val = reinterpret_cast<double*>(smem + (size_t)P.n_demand * 16);
   int* s_k = reinterpret_cast<int*>(s_val + 4 * 64);
 
@@ -112,7 +112,6 @@ __global__ __launch_bounds__(256) void gather_period_kernel(DevParams P, const d
     }
   }
   // across waves through LDS
-  constexpr int NW_SHARE = (SX >= 64) ? 4 : 4;  // all four waves hold slots of the same states
   const int wave = tid >> 6;
   const int lane = tid & 63;
   if constexpr (SX >= 64) {
@@ -129,7 +128,7 @@ __global__ __launch_bounds__(256) void gather_period_kernel(DevParams P, const d
     double bv = s_val[tid];
     int bk = s_k[tid];
 #pragma unroll
-    for (int w = 1; w < NW_SHARE; ++w) {
+    for (int w = 1; w < 4; ++w) {  // all four waves hold action slots of the same states
       double ov = s_val[w * 64 + tid];
       int ok = s_k[w * 64 + tid];
       if (better<MAXDIR>(ov, ok, bv, bk)) {

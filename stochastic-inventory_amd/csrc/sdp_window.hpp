@@ -39,8 +39,11 @@ struct WinParams {
   int32_t n_demand;   // D
   int32_t n_chunks;   // tasks per state tile: the action range is cut into n_chunks runs of R-blocks
   int32_t chunk_blocks;   // R-blocks per task
-  int32_t n_tiles;        // state tiles of 64
+  int32_t n_tiles;        // state tiles of 64 covered by THIS launch
   int32_t n_tasks;        // n_tiles * n_chunks (one task per wave)
+  int32_t tile_first;     // launch tile u maps to slab tile tile_first + u (+ tile_gap when u >= tile_gap_at):
+  int32_t tile_gap_at;    // lets one launch cover the interior run of tiles, or the two boundary runs
+  int32_t tile_gap;
   int64_t partial_stride; // elements between chunk rows of the partial tables
 };
 
@@ -108,7 +111,8 @@ __global__ __launch_bounds__(256) void window_f1_kernel(WinParams W, const doubl
   const int task = blockIdx.x * 4 + wave;
   if (task >= W.n_tasks) return;  // no barriers below: a wave may leave on its own
   const int chunk = task / W.n_tiles;
-  const int tile = task - chunk * W.n_tiles;
+  int tile = task - chunk * W.n_tiles;
+  tile = W.tile_first + tile + (tile >= W.tile_gap_at ? W.tile_gap : 0);
   const int chunk_actions = W.chunk_blocks * R;
   const int span = 64 + chunk_actions + W.d_pad;  // entries [0, span): slot 0 is a spare
   double2* s_win = reinterpret_cast<double2*>(smem) + (size_t)wave * span;

@@ -60,7 +60,6 @@ struct sdpgpu_handle {
   std::vector<char> pmf_set;
   bool laid_out = false;
   bool allocated = false;
-  bool pmf_uploaded = false;
   double* d_pmf = nullptr;
   double* d_values = nullptr;
   size_t values_elems = 0;
@@ -87,14 +86,12 @@ struct sdpgpu_handle {
   std::vector<char> key_row_clean;       // row t holds the reduction identity (+-Double.MAX_VALUE)
   double* d_chunk_val = nullptr;         // arena of chunk rows, period t at chunk_off[t-1]
   int32_t* d_chunk_idx = nullptr;
-  size_t chunk_elems = 0;
   std::vector<size_t> chunk_off;
   std::vector<int> pending_chunks;       // >0: period's final rows not written yet (value = n_chunks)
   int n_pending = 0;
   sdp::FinalizeJob* d_jobs = nullptr;
   bool fuse_combine = true;
   bool use_cash_shift = true;
-  int win_lds_floor = 0;  // bytes of LDS a window workgroup claims at least (limits workgroups per CU)
   int win_r = 0, win_nch = 0;      // tuning overrides (SDPGPU_WIN_R / SDPGPU_WIN_NCH), 0 = heuristic
   uint8_t* d_reach = nullptr;      // reachable masks, period t at reach_off[t-1]
   std::vector<size_t> reach_off;
@@ -411,9 +408,13 @@ hipError_t flush_pending(sdpgpu_handle* h);
 hipError_t launch_cash_shift(sdpgpu_handle* h, const DevParams& P, int period, const double* v_next, double* v_cur,
                              int32_t* pol, const double* pmf_d, const double* pmf_p, int64_t lo, int64_t hi, hipStream_t st);
 hipError_t launch_window(sdpgpu_handle* h, const DevParams& P, int period, const double* v_next, double* v_cur,
-                         int32_t* pol, const double* pmf_d, const double* pmf_p, int64_t lo, int64_t hi, hipStream_t st);
+                         int32_t* pol, const double* pmf_d, const double* pmf_p, int64_t lo, int64_t hi, hipStream_t st,
+                         int part);
+bool window_interior_tiles(const sdpgpu_handle* h, int period, int64_t lo, int64_t hi, int* first, int* count);
 
-int run_period_impl(sdpgpu_handle* h, int period) {
+// part: SDPGPU_PART_ALL, or the two halves a sharded caller overlaps with the all-gather of V_{t+1}:
+// INTERIOR = the states whose cells read only THIS rank's slab of V_{t+1}, BOUNDARY = the rest.
+int run_period_impl(sdpgpu_handle* h, int period, int part = SDPGPU_PART_ALL) {
   int rc = allocate(h);
   if (rc) return rc;
   if (period < 1 || period > h->T) return fail(h, SDPGPU_ERR_ARG, "period %d out of 1..%d", period, h->T);
@@ -442,9 +443,17 @@ int run_period_impl(sdpgpu_handle* h, int period) {
   } else if (h->d.kernel == SDPGPU_KERNEL_AUTO) {
     use_window = window_eligible(h, period);
   }
+  if (part != SDPGPU_PART_ALL) {
+    // only the F1 window kernel has a bounded dependency footprint; everything else is "all boundary"
+    const bool splittable = use_window && window_interior_tiles(h, period, p.lo, p.hi, nullptr, nullptr);
+    if (!splittable) {
+      if (part == SDPGPU_PART_INTERIOR) return SDPGPU_OK;  // nothing can start before the exchange
+      part = SDPGPU_PART_ALL;
+    }
+  }
   hipError_t e;
   if (use_window) {
-    e = launch_window(h, P, period, v_next, v_cur, pol, pd, pp, p.lo, p.hi, h->stream);
+    e = launch_window(h, P, period, v_next, v_cur, pol, pd, pp, p.lo, p.hi, h->stream, part);
     p.kernel_used = SDPGPU_KERNEL_WINDOW;
   } else if (h->d.kernel != SDPGPU_KERNEL_GATHER && h->use_cash_shift && cash_shift_eligible(h, period)) {
     e = flush_pending(h);
@@ -463,6 +472,7 @@ int run_period_impl(sdpgpu_handle* h, int period) {
   } else {
     p.timed = false;
   }
+  if (part == SDPGPU_PART_INTERIOR) return SDPGPU_OK;  // the period is complete only after its boundary part
   h->period_done[period - 1] = 1;
   h->policy_done[period - 1] = 1;
   if (!h->d.store_all_values && period + 2 <= h->T) h->period_done[period + 1] = 0;  // V_{t+2} was overwritten
@@ -682,7 +692,6 @@ WinPlan plan_window(const sdpgpu_handle* h, int period, int64_t lo, int64_t hi) 
       }
     }
   }
-  if (best.R && h->win_lds_floor > 0) best.smem = std::max<size_t>(best.smem, (size_t)h->win_lds_floor);
   return best;
 }
 
@@ -848,8 +857,39 @@ hipError_t launch_row_window(sdpgpu_handle* h, const DevParams& P, int period, c
   return e;
 }
 
+// The interior run of slab tiles of a period: tiles whose whole V_{t+1} footprint
+// [i0 + idx_off - (D-1), i0 + 63 + idx_off + A - 1] (before the clamp to the grid) lies inside this rank's
+// slab of the next period's row, or is clamped at a grid edge this rank owns.
+bool window_interior_tiles(const sdpgpu_handle* h, int period, int64_t lo, int64_t hi, int* first, int* count) {
+  if (h->d.family != SDPGPU_FAMILY_BACKORDER || period >= h->T || h->d.world_size == 1) return false;
+  const PeriodInfo& p = h->per[period - 1];
+  const PeriodInfo& pn = h->per[period];
+  const int64_t n_tiles = (hi - lo + 63) / 64;
+  const double lev0 = p.g.x_lo - h->pmf_d[period - 1][0];
+  const int64_t idx_off = (int64_t)((lev0 - pn.g.x_lo) / h->d.step);
+  const int64_t A = h->n_actions_full, D = p.nD;
+  int64_t f = -1, c = 0;
+  for (int64_t u = 0; u < n_tiles; ++u) {
+    const int64_t i0 = lo + u * 64;
+    int64_t a = i0 + idx_off - (D - 1), b = i0 + 63 + idx_off + A - 1;
+    a = std::max<int64_t>(0, std::min<int64_t>(a, pn.g.nx - 1));  // the kernel clamps reads to the grid
+    b = std::max<int64_t>(0, std::min<int64_t>(b, pn.g.nx - 1));
+    const bool inside = a >= pn.lo && b < pn.hi;
+    if (inside) {
+      if (f < 0) f = u;
+      if (u != f + c) return false;  // not one contiguous run: do not split
+      ++c;
+    }
+  }
+  if (c <= 0) return false;
+  if (first) *first = (int)f;
+  if (count) *count = (int)c;
+  return true;
+}
+
 hipError_t launch_window(sdpgpu_handle* h, const DevParams& P, int period, const double* v_next, double* v_cur,
-                         int32_t* pol, const double* pmf_d, const double* pmf_p, int64_t lo, int64_t hi, hipStream_t st) {
+                         int32_t* pol, const double* pmf_d, const double* pmf_p, int64_t lo, int64_t hi, hipStream_t st,
+                         int part) {
   (void)pmf_d;
   if (hi <= lo) return hipSuccess;
   if (h->d.family == SDPGPU_FAMILY_LEADTIME) return launch_row_window(h, P, period, v_next, v_cur, pol, pmf_p, lo, hi, st);
@@ -860,7 +900,9 @@ hipError_t launch_window(sdpgpu_handle* h, const DevParams& P, int period, const
   const bool chunked = pl.n_chunks > 1;
   // a period is never re-run on top of its own pending rows, and a new sweep (period T) first
   // finalizes what the previous one left: the key rows are about to be reset
-  if (h->n_pending > 0 && (h->pending_chunks[period - 1] > 0 || period == h->T)) {
+  // (the BOUNDARY half of a split period continues what its INTERIOR half started: no reset there)
+  const bool continuing = part == SDPGPU_PART_BOUNDARY;
+  if (!continuing && h->n_pending > 0 && (h->pending_chunks[period - 1] > 0 || period == h->T)) {
     hipError_t e = flush_pending(h);
     if (e != hipSuccess) return e;
   }
@@ -886,9 +928,8 @@ hipError_t launch_window(sdpgpu_handle* h, const DevParams& P, int period, const
       e = hipMalloc((void**)&h->d_chunk_val, std::max<size_t>(total, 1) * sizeof(double));
       if (e == hipSuccess) e = hipMalloc((void**)&h->d_chunk_idx, std::max<size_t>(total, 1) * sizeof(int32_t));
       if (e != hipSuccess) return e;
-      h->chunk_elems = total;
     }
-    if (!h->key_row_clean[period - 1]) {
+    if (!continuing && !h->key_row_clean[period - 1]) {
       // reset key rows to the reduction identity: all of them when nothing is pending (the usual case:
       // period T of a new sweep), else only this period's row (periods re-run out of order)
       const bool all = h->n_pending == 0;
@@ -923,6 +964,24 @@ hipError_t launch_window(sdpgpu_handle* h, const DevParams& P, int period, const
   W.chunk_blocks = pl.chunk_blocks;
   W.n_tiles = pl.n_tiles;
   W.n_tasks = pl.n_tasks;
+  W.tile_first = 0;
+  W.tile_gap_at = pl.n_tiles;  // no gap
+  W.tile_gap = 0;
+  if (part != SDPGPU_PART_ALL) {
+    int first = 0, count = 0;
+    if (!window_interior_tiles(h, period, lo, hi, &first, &count)) return hipErrorInvalidValue;
+    if (part == SDPGPU_PART_INTERIOR) {
+      W.tile_first = first;
+      W.n_tiles = count;
+    } else {  // the tiles below and above the interior run, in one launch
+      W.n_tiles = pl.n_tiles - count;
+      W.tile_gap_at = first;
+      W.tile_gap = count;
+    }
+    W.n_tasks = W.n_tiles * pl.n_chunks;
+    W.tile_gap_at = std::min(W.tile_gap_at, W.n_tiles);
+    if (W.n_tiles == 0) return hipSuccess;
+  }
   double* out_val = v_cur;
   int32_t* out_idx = pol;
   unsigned long long* k_cur = nullptr;
@@ -933,7 +992,7 @@ hipError_t launch_window(sdpgpu_handle* h, const DevParams& P, int period, const
     out_idx = h->d_chunk_idx + h->chunk_off[period - 1] - lo;
     k_cur = h->d_keys + (size_t)(period - 1) * h->key_stride;
   }
-  const dim3 grid((unsigned)((pl.n_tasks + 3) / 4));
+  const dim3 grid((unsigned)((W.n_tasks + 3) / 4));
 #ifdef SDP_STAMPS
   static unsigned long long* d_stamps = nullptr;
   if (!d_stamps) (void)hipMalloc((void**)&d_stamps, (size_t)1 << 24);
@@ -987,7 +1046,7 @@ hipError_t launch_window(sdpgpu_handle* h, const DevParams& P, int period, const
     }
   }
 #endif
-  if (chunked) {
+  if (chunked && h->pending_chunks[period - 1] == 0) {
     h->pending_chunks[period - 1] = pl.n_chunks;
     h->n_pending++;
     h->key_row_clean[period - 1] = 0;  // holds data now; re-filled when the next sweep starts
@@ -1068,7 +1127,6 @@ int sdpgpu_create(const sdpgpu_desc* desc, sdpgpu_handle** out) {
     if (const char* e = std::getenv("SDPGPU_WIN_NCH")) h->win_nch = std::atoi(e);
     if (const char* e = std::getenv("SDPGPU_FUSE_COMBINE")) h->fuse_combine = std::atoi(e) != 0;
     if (const char* e = std::getenv("SDPGPU_CASH_SHIFT")) h->use_cash_shift = std::atoi(e) != 0;
-    if (const char* e = std::getenv("SDPGPU_WIN_LDS")) h->win_lds_floor = std::atoi(e);
   } catch (...) {
     delete h;
     return fail(nullptr, SDPGPU_ERR_ARG, "out of host memory");
@@ -1252,6 +1310,21 @@ int sdpgpu_run_period(sdpgpu_handle* h, int32_t period) {
   try {
     int rc = run_period_impl(h, period);
     if (rc == SDPGPU_OK) count_cells(h, period);
+    return rc;
+  } catch (const std::exception& e) {
+    return fail(h, SDPGPU_ERR_ARG, "exception: %s", e.what());
+  } catch (...) {
+    return fail(h, SDPGPU_ERR_ARG, "unknown exception");
+  }
+}
+
+int sdpgpu_run_period_part(sdpgpu_handle* h, int32_t period, int32_t part) {
+  if (!h) return SDPGPU_ERR_ARG;
+  h->err.clear();
+  if (part < SDPGPU_PART_ALL || part > SDPGPU_PART_BOUNDARY) return fail(h, SDPGPU_ERR_ARG, "run_period_part: part %d", part);
+  try {
+    int rc = run_period_impl(h, period, part);
+    if (rc == SDPGPU_OK && part != SDPGPU_PART_INTERIOR) count_cells(h, period);
     return rc;
   } catch (const std::exception& e) {
     return fail(h, SDPGPU_ERR_ARG, "exception: %s", e.what());

@@ -131,6 +131,9 @@ class SdpEngine:
         """Enqueue the deferred read-out of every period run so far (no host wait)."""
         self._check(self._lib.sdpgpu_finalize(self._h))
 
+    def run_period_part(self, period: int, part: int):
+        self._check(self._lib.sdpgpu_run_period_part(self._h, period, part))
+
     def synchronize(self):
         self._check(self._lib.sdpgpu_synchronize(self._h))
 

@@ -43,6 +43,12 @@ class SlabBackend:
     def finalize(self) -> None:  # enqueue any deferred read-out work (policy rows), no host wait
         pass
 
+    def run_period_part(self, period: int, part: int) -> None:
+        """part 1 = the states that need only this rank's slab of V_{period+1}, part 2 = the rest.
+        Backends without a bounded dependency footprint do everything in part 2."""
+        if part == 2:
+            self.run_period(period)
+
 
 class GpuSlabBackend(SlabBackend):
     """SdpEngine on one GPU with its value arena held in a torch tensor (so RCCL can address it)."""
@@ -87,6 +93,9 @@ class GpuSlabBackend(SlabBackend):
     def finalize(self) -> None:
         self.engine.finalize()
 
+    def run_period_part(self, period: int, part: int) -> None:
+        self.engine.run_period_part(period, part)
+
     def close(self):
         self.engine.close()
 
@@ -100,31 +109,51 @@ class ShardedSolver:
         # debug only: a `gloo` group cannot address device memory, so the shard is bounced through the
         # host (used to rehearse N ranks on ONE GPU; the production path is RCCL on device memory)
         self.stage_through_host = stage_through_host
+        self.force_split = False  # rehearsal/testing: take the interior + boundary path after a blocking exchange too
         self.world = dist.get_world_size(group) if dist.is_initialized() else 1
         self.rank = dist.get_rank(group) if dist.is_initialized() else 0
         self.gathered_bytes = 0
 
-    def exchange(self, period: int) -> None:
+    def exchange(self, period: int, async_op: bool = False):
+        """All-gather the row of `period`.  With async_op the collective runs on the communicator's own
+        stream (ordered after everything already queued on the compute stream) and the returned work's
+        wait() makes the compute stream wait for it -- the host never blocks."""
         if self.world == 1:
-            return
+            return None
         pad, lo, hi = self.backend.slab(period)
         full = self.backend.table(period)
         n = pad // self.world
         shard = full[self.rank * n: (self.rank + 1) * n]
+        self.gathered_bytes += pad * 8
         if self.stage_through_host and full.is_cuda:
             host_full = torch.empty(full.shape, dtype=full.dtype)
             dist.all_gather_into_tensor(host_full, shard.cpu(), group=self.group)
             full.copy_(host_full)
-        else:
-            # in place: this rank's shard already sits at its offset inside `full`
-            dist.all_gather_into_tensor(full, shard, group=self.group)
-        self.gathered_bytes += pad * 8
+            return None
+        # in place: this rank's shard already sits at its offset inside `full`
+        return dist.all_gather_into_tensor(full, shard, group=self.group, async_op=async_op)
 
-    def solve(self, first_period: int = 1) -> None:
+    def solve(self, first_period: int = 1, overlap: bool = True) -> None:
+        """t = T..first_period.  With `overlap` (and more than one rank) the all-gather of V_{t+1} runs
+        beside the INTERIOR half of period t -- the states whose cells read only this rank's slab of
+        V_{t+1} -- and only the BOUNDARY half waits for it; interior + boundary = the whole period, so
+        the result is the same as the sequential schedule."""
+        in_flight = None  # work handle of the exchange of period+1
         for period in range(self.backend.T, first_period - 1, -1):
-            self.backend.run_period(period)
+            if in_flight is not None:
+                self.backend.run_period_part(period, 1)
+                if in_flight is not True:
+                    in_flight.wait()
+                in_flight = None
+                self.backend.run_period_part(period, 2)
+            else:
+                self.backend.run_period(period)
             if period > first_period:  # V_1 is never read by another period
-                self.exchange(period)
+                in_flight = self.exchange(period, async_op=overlap)
+                if in_flight is None and self.force_split and self.world > 1:
+                    in_flight = True
+        if in_flight is not None and in_flight is not True:
+            in_flight.wait()
         self.backend.finalize()  # the sweep is done when every policy row exists
 
     def gather_policy(self, period: int, local: torch.Tensor) -> Optional[List[torch.Tensor]]:

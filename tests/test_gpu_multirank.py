@@ -12,8 +12,11 @@ pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-@pytest.mark.parametrize("extra", [["--periods", "6"], ["--workload", "cfg5", "--states", "100000", "--periods", "3"]],
-                         ids=["cfg2_small_slabs_key_rows", "f1_large_slabs"])
+@pytest.mark.parametrize("extra", [["--periods", "6"], ["--workload", "cfg5", "--states", "100000", "--periods", "3"],
+                                   ["--periods", "6", "--split"],
+                                   ["--workload", "cfg5", "--states", "100000", "--periods", "3", "--split"]],
+                         ids=["cfg2_small_slabs_key_rows", "f1_large_slabs", "cfg2_interior_boundary_split",
+                              "f1_large_interior_boundary_split"])
 def test_two_ranks_match_single_rank(extra):
     port = 29600 + os.getpid() % 300
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr",

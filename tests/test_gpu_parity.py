@@ -178,8 +178,12 @@ def test_sharded_periods_single_process(sia, oracle, make, world):
         raise AssertionError("exchange row outside the attached arenas")
 
     for period in range(w.T, 0, -1):
-        for e in engs:
-            e.run_period(period)
+        for r, e in enumerate(engs):
+            if period < w.T and (r + period) % 2 == 0:  # mix whole-period and interior+boundary launches
+                e.run_period_part(period, sia._abi.PART_INTERIOR)
+                e.run_period_part(period, sia._abi.PART_BOUNDARY)
+            else:
+                e.run_period(period)
         torch.cuda.synchronize()
         rows = [row_of(r, period) for r in range(world)]
         full = torch.zeros_like(rows[0])
