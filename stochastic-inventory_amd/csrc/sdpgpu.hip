@@ -653,7 +653,12 @@ WinPlan plan_window(const sdpgpu_handle* h, int period, int64_t lo, int64_t hi) 
   const int A = h->n_actions_full, D = p.nD;
   WinPlan best;
   double best_cost = -1;
-  const int64_t n_tiles = (hi - lo + 63) / 64;
+  // The plan (register block, chunks per tile) is chosen from the NOMINAL slab S_pad / world_size, which is
+  // the same on every rank: ranks must agree on whether a period's row is exchanged as keys or as fp64
+  // values, whatever their own (possibly clipped or empty) slab looks like.
+  const int64_t nominal = p.S_pad / std::max(1, h->d.world_size);
+  const int64_t n_tiles = std::max<int64_t>(1, (nominal + 63) / 64);
+  const int64_t own_tiles = (hi - lo + 63) / 64;
   auto rup = [](int v, int r) { return (v + r - 1) / r * r; };
   const int cand[3] = {8, 5, 4};
   const bool may_chunk = h->fuse_combine && h->d.store_all_values;
@@ -686,8 +691,8 @@ WinPlan plan_window(const sdpgpu_handle* h, int period, int64_t lo, int64_t hi) 
         best.d_pad = d_pad;
         best.n_chunks = nch;
         best.chunk_blocks = bpc;
-        best.n_tiles = (int)n_tiles;
-        best.n_tasks = (int)tasks;
+        best.n_tiles = (int)own_tiles;
+        best.n_tasks = (int)(own_tiles * nch);
         best.smem = smem;
       }
     }
@@ -891,8 +896,11 @@ hipError_t launch_window(sdpgpu_handle* h, const DevParams& P, int period, const
                          int32_t* pol, const double* pmf_d, const double* pmf_p, int64_t lo, int64_t hi, hipStream_t st,
                          int part) {
   (void)pmf_d;
-  if (hi <= lo) return hipSuccess;
-  if (h->d.family == SDPGPU_FAMILY_LEADTIME) return launch_row_window(h, P, period, v_next, v_cur, pol, pmf_p, lo, hi, st);
+  if (h->d.family == SDPGPU_FAMILY_LEADTIME) {
+    if (hi <= lo) return hipSuccess;
+    return launch_row_window(h, P, period, v_next, v_cur, pol, pmf_p, lo, hi, st);
+  }
+  // (an empty slab still goes through the bookkeeping below: every rank must treat the row alike)
   PeriodInfo& p = h->per[period - 1];
   WinPlan pl = plan_window(h, period, lo, hi);
   if (!pl.R) return hipErrorInvalidValue;
@@ -923,7 +931,7 @@ hipError_t launch_window(sdpgpu_handle* h, const DevParams& P, int period, const
         const PeriodInfo& q = h->per[t];
         h->chunk_off[t] = total;
         if (window_eligible(h, t + 1))
-          total += (size_t)plan_window(h, t + 1, q.lo, q.hi).n_chunks * (size_t)(q.hi - q.lo);
+          total += (size_t)plan_window(h, t + 1, q.lo, q.hi).n_chunks * (size_t)std::max<int64_t>(q.hi - q.lo, 0);
       }
       e = hipMalloc((void**)&h->d_chunk_val, std::max<size_t>(total, 1) * sizeof(double));
       if (e == hipSuccess) e = hipMalloc((void**)&h->d_chunk_idx, std::max<size_t>(total, 1) * sizeof(int32_t));
@@ -992,7 +1000,7 @@ hipError_t launch_window(sdpgpu_handle* h, const DevParams& P, int period, const
     out_idx = h->d_chunk_idx + h->chunk_off[period - 1] - lo;
     k_cur = h->d_keys + (size_t)(period - 1) * h->key_stride;
   }
-  const dim3 grid((unsigned)((W.n_tasks + 3) / 4));
+  const dim3 grid((unsigned)std::max(1, (W.n_tasks + 3) / 4));
 #ifdef SDP_STAMPS
   static unsigned long long* d_stamps = nullptr;
   if (!d_stamps) (void)hipMalloc((void**)&d_stamps, (size_t)1 << 24);
@@ -1001,6 +1009,7 @@ hipError_t launch_window(sdpgpu_handle* h, const DevParams& P, int period, const
 #else
 #define SDP_STAMP_ARG
 #endif
+  if (W.n_tasks > 0) {
 #define SDP_WIN_GO(RR, MX, FU, KI)                                                                                      \
   hipLaunchKernelGGL((sdp::window_f1_kernel<RR, MX, FU, KI>), grid, dim3(256), pl.smem, st, W, v_next, k_next, out_val, \
                      out_idx, k_cur, pmf_p, lo, hi SDP_STAMP_ARG)
@@ -1032,6 +1041,7 @@ hipError_t launch_window(sdpgpu_handle* h, const DevParams& P, int period, const
 #undef SDP_WIN_R
 #undef SDP_WIN_GO
 #undef SDP_STAMP_ARG
+  }
   hipError_t e = hipGetLastError();
   if (e != hipSuccess) return e;
 #ifdef SDP_STAMPS
@@ -1066,7 +1076,7 @@ bool keys_needed(sdpgpu_handle* h) {
   if (layout(h)) return false;
   for (int t = 1; t <= h->T; ++t) {
     const PeriodInfo& q = h->per[t - 1];
-    if (window_eligible(h, t) && q.hi > q.lo && plan_window(h, t, q.lo, q.hi).n_chunks > 1) return true;
+    if (window_eligible(h, t) && plan_window(h, t, q.lo, q.hi).n_chunks > 1) return true;
   }
   return false;
 }

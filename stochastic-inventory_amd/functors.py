@@ -64,6 +64,7 @@ class BackorderFunctor(_Base):
     maxOrderQuantity: float = 0.0
     stepSize: float = 1.0
     iniInventory: float = 0.0
+    clampInventory: bool = True  # every in-scope F1 driver clamps (CLSP.java:257-258)
 
     state_type = State
 
@@ -73,7 +74,7 @@ class BackorderFunctor(_Base):
         d.step = self.stepSize
         d.min_inventory, d.max_inventory = self.minInventory, self.maxInventory
         d.max_order_quantity = self.maxOrderQuantity
-        d.clamp_inventory = 1
+        d.clamp_inventory = 1 if self.clampInventory else 0
         d.fixed_order_cost, d.unit_order_cost = self.fixedOrderingCost, self.variOrderingCost
         d.holding_cost, d.penalty_cost = self.holdingCost, self.penaltyCost
         d.ini_inventory = self.iniInventory
@@ -99,8 +100,9 @@ class BackorderFunctor(_Base):
 
     def stateTransition(self, s, action, randomDemand, T=None):
         nextInventory = s.getIniInventory() + action - randomDemand
-        nextInventory = self.maxInventory if nextInventory > self.maxInventory else nextInventory
-        nextInventory = self.minInventory if nextInventory < self.minInventory else nextInventory
+        if self.clampInventory:
+            nextInventory = self.maxInventory if nextInventory > self.maxInventory else nextInventory
+            nextInventory = self.minInventory if nextInventory < self.minInventory else nextInventory
         return State(s.getPeriod() + 1, nextInventory)
 
 

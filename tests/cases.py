@@ -41,6 +41,28 @@ def f1_max(T=3):
     return Workload("f1_max", f, OptDirection.MAX, _pmf([2, 3, 2][:T], 6))
 
 
+def f1_unclamped(T=3):
+    """Backorder family without the inventory clamp: per-period boxes grown from the initial state."""
+    f = BackorderFunctor(fixedOrderingCost=4, variOrderingCost=1, holdingCost=1, penaltyCost=6, maxOrderQuantity=9,
+                         iniInventory=2, clampInventory=False)
+    w = Workload("f1_unclamped", f, OptDirection.MIN, _pmf([3, 4, 3][:T], 8, d0=1))
+    return w
+
+
+def f1_edge_single(T=1):
+    """Degenerate sizes: one period, one action, one demand point, three states."""
+    f = BackorderFunctor(fixedOrderingCost=1, variOrderingCost=1, holdingCost=1, penaltyCost=2, minInventory=-1,
+                         maxInventory=1, maxOrderQuantity=0, iniInventory=0)
+    return Workload("f1_edge_single", f, OptDirection.MIN, discrete_pmf(T, [1], [1.0]))
+
+
+def f1_wide(T=2):
+    """Action and demand ranges too wide for the window kernel's LDS span: falls back to the gather kernel."""
+    f = BackorderFunctor(fixedOrderingCost=50, variOrderingCost=1, holdingCost=1, penaltyCost=9, minInventory=-40,
+                         maxInventory=60, maxOrderQuantity=2400, iniInventory=0)
+    return Workload("f1_wide", f, OptDirection.MIN, _pmf([600, 580][:T], 1200))
+
+
 def f1_gapped(T=3):
     """Non-unit-stride demand support (DiscreteDistribution style): forces the gather kernel."""
     f = BackorderFunctor(fixedOrderingCost=10, variOrderingCost=1, holdingCost=1, penaltyCost=5, minInventory=-20,
@@ -118,6 +140,6 @@ def f5_cash_leadtime(T=3):
     return Workload("f5_cash_leadtime", f, OptDirection.MAX, _pmf([3, 3, 3][:T], 6))
 
 
-ALL = [f1_small, f1_max, f1_gapped, f2_unclamped, f2_clamped, f3_tenths, f3_testing, f3_dyadic, f3_min_gamma,
+ALL = [f1_small, f1_max, f1_gapped, f1_unclamped, f1_edge_single, f2_unclamped, f2_clamped, f3_tenths, f3_testing, f3_dyadic, f3_min_gamma,
        f4_overdraft, f5_cash_leadtime]
-TINY = [f1_small, f1_max, f1_gapped, f2_unclamped, f3_testing, f3_min_gamma, f4_overdraft]
+TINY = [f1_small, f1_max, f1_gapped, f1_unclamped, f2_unclamped, f3_testing, f3_min_gamma, f4_overdraft]

@@ -125,13 +125,24 @@ def test_reachable_set(sia, oracle, make):
     eng.close()
 
 
-def test_ping_pong_tables(sia, oracle):
-    w = cases.f2_clamped()
+def test_wide_ranges_fall_back_to_the_gather_kernel(sia, oracle):
+    """2401 actions x 1200 demand points exceed the window kernel's LDS span."""
+    w = cases.f1_wide()
+    eng, P, V, pol, _ = _solve_both(sia, oracle, w)
+    assert eng.stats().kernel_used == 1
+    for period in range(1, w.T + 1):
+        _assert_tables(eng.values(period), eng.policy(period), V[period - 1], pol[period - 1], f"wide t={period}")
+    eng.close()
+
+
+@pytest.mark.parametrize("make", [cases.f2_clamped, cases.f1_clsp_main, cases.f3_testing], ids=lambda f: f.__name__)
+def test_ping_pong_tables(sia, oracle, make):
+    w = make()
     d = w.desc()
     d.store_all_values = 0
-    eng = sia.SdpEngine(d, w.pmf)
+    eng = sia.SdpEngine(d, w.pmf, w.overhead())
     eng.solve()
-    V, pol, _ = oracle.Problem(w.desc(), w.pmf).solve()
+    V, pol, _ = oracle.Problem(w.desc(), w.pmf, w.overhead()).solve()
     _assert_tables(eng.values(1), eng.policy(1), V[0], pol[0], "ping-pong t=1")
     assert np.array_equal(eng.values(2), V[1])
     with pytest.raises(sia.SdpgpuError):
@@ -142,7 +153,8 @@ def test_ping_pong_tables(sia, oracle):
 
 
 @pytest.mark.parametrize("make,world", [(cases.f3_tenths, 3), (cases.f2_clamped, 3), (cases.f2_unclamped, 2),
-                                        (cases.f1_small, 2), (cases.f1_clsp_main, 4)],
+                                        (cases.f1_small, 2), (cases.f1_clsp_main, 4), (cases.f1_unclamped, 2),
+                                        (cases.f3_testing, 3), (cases.f3_dyadic, 2), (cases.f5_cash_leadtime, 2)],
                          ids=lambda v: getattr(v, "__name__", str(v)))
 def test_sharded_periods_single_process(sia, oracle, make, world):
     """world_size N slabs driven from one process: each rank computes its slab into its own copy of
@@ -292,7 +304,7 @@ def test_cfg2_full_horizon_properties(sia, oracle):
 
 def test_kernel_selection(sia):
     """The specialised kernels are the ones that run where they apply (kernel_used: 1 gather, 2 specialised)."""
-    expect = {cases.f1_small: 2, cases.f1_gapped: 1, cases.f2_clamped: 2, cases.f2_unclamped: 2, cases.f3_tenths: 1,
+    expect = {cases.f1_small: 2, cases.f1_gapped: 1, cases.f1_unclamped: 2, cases.f1_edge_single: 2, cases.f2_clamped: 2, cases.f2_unclamped: 2, cases.f3_tenths: 1,
               cases.f3_testing: 2, cases.f3_dyadic: 2, cases.f3_min_gamma: 1, cases.f4_overdraft: 1,
               cases.f5_cash_leadtime: 1}
     for make, kind in expect.items():
