@@ -35,7 +35,7 @@ def parse_args():
     ap.add_argument("--workload", default="cfg2", help="cfg2 (default) | cfg1 | cfg3 | cfg4 | cfg5")
     ap.add_argument("--states", type=int, default=0, help="override the per-GPU state count (cfg2/cfg5)")
     ap.add_argument("--periods", type=int, default=0, help="override the horizon")
-    ap.add_argument("--kernel", type=int, default=0, help="0 auto, 1 gather, 2 window")
+    ap.add_argument("--kernel", type=int, default=0, help="0 auto, 1 gather, 2 window, 3 separable (opt-in, F1)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--backend", default="nccl", help="nccl (RCCL, default) | gloo (debug: N ranks on one GPU, host-staged)")
     ap.add_argument("--split", action="store_true", help="rehearsal: force the interior/boundary split of every period")
@@ -235,7 +235,7 @@ def main():
                 "demands": len(w.pmf[0]), "periods": T,
                 "cells_per_step": cells_step_all,
                 "parallelism": f"state-sharded x{world}, all-gather V_t per period" if world > 1 else "single GPU",
-                "kernel": {0: "auto", 1: "gather", 2: "window"}[int(st.kernel_used)],
+                "kernel": {0: "auto", 1: "gather", 2: "window", 3: "separable (opt-in, not the graded path)"}[int(st.kernel_used)],
             },
             "roofline": {
                 "bound": "hbm",

@@ -26,6 +26,7 @@ MAX = 1
 KERNEL_AUTO = 0
 KERNEL_GATHER = 1
 KERNEL_WINDOW = 2
+KERNEL_SEPARABLE = 3  # opt-in, F1 only: reassociated sum, values to 1e-9, arg-opt may differ on near-ties
 
 PART_ALL = 0
 PART_INTERIOR = 1

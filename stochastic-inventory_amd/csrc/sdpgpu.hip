@@ -436,6 +436,57 @@ int run_period_impl(sdpgpu_handle* h, int period, int part = SDPGPU_PART_ALL) {
     }
     HIP_TRY(h, hipEventRecord(p.ev0, h->stream));
   }
+  if (h->d.kernel == SDPGPU_KERNEL_SEPARABLE) {
+    if (h->d.family != SDPGPU_FAMILY_BACKORDER) return fail(h, SDPGPU_ERR_UNSUPPORTED, "the separable mode exists for the backorder family only");
+    if (h->n_actions_full > 6000) return fail(h, SDPGPU_ERR_UNSUPPORTED, "separable mode: action range exceeds the LDS tile");
+    if (part == SDPGPU_PART_INTERIOR) return SDPGPU_OK;
+    hipError_t es = flush_pending(h);
+    if (es == hipSuccess) {
+      sdp::SepParams S{};
+      S.x_lo = p.g.x_lo;
+      S.step = h->d.step;
+      S.h = h->d.holding_cost;
+      S.pi = h->d.penalty_cost;
+      S.K = h->d.fixed_order_cost;
+      S.v = h->d.unit_order_cost;
+      S.inv_step = 1.0 / h->d.step;
+      S.min_inventory = h->d.min_inventory;
+      S.max_inventory = h->d.max_inventory;
+      S.clamp_inventory = h->d.clamp_inventory;
+      S.n_actions = h->n_actions_full;
+      S.n_demand = p.nD;
+      S.d_min = h->pmf_d[period - 1].front();  // demands are strictly ascending (checked at set_pmf)
+      S.d_range = (int32_t)((h->pmf_d[period - 1].back() - S.d_min) / h->d.step);
+      const bool future = period < h->T;
+      if (future) {
+        S.next_x_lo = h->per[period].g.x_lo;
+        S.next_last = (int32_t)(h->per[period].g.nx - 1);
+      }
+      const int64_t n = p.hi - p.lo;
+      if (n > 0) {
+        dim3 grid((unsigned)((n + 63) / 64));
+        size_t smem = (size_t)(64 + S.n_actions + S.d_range) * 16 + (size_t)(64 + S.n_actions) * 8 +
+                      4 * 64 * (sizeof(double) + sizeof(int));
+        if (smem > 64 * 1024) return fail(h, SDPGPU_ERR_UNSUPPORTED, "separable mode: action + demand range exceeds the LDS tile");
+        const bool mx = P.maxdir != 0;
+        if (mx && future) hipLaunchKernelGGL((sdp::separable_f1_kernel<true, true>), grid, dim3(256), smem, h->stream, S, v_next, v_cur, pol, pd, pp, p.lo, p.hi);
+        else if (mx) hipLaunchKernelGGL((sdp::separable_f1_kernel<true, false>), grid, dim3(256), smem, h->stream, S, v_next, v_cur, pol, pd, pp, p.lo, p.hi);
+        else if (future) hipLaunchKernelGGL((sdp::separable_f1_kernel<false, true>), grid, dim3(256), smem, h->stream, S, v_next, v_cur, pol, pd, pp, p.lo, p.hi);
+        else hipLaunchKernelGGL((sdp::separable_f1_kernel<false, false>), grid, dim3(256), smem, h->stream, S, v_next, v_cur, pol, pd, pp, p.lo, p.hi);
+        es = hipGetLastError();
+      }
+    }
+    if (es != hipSuccess) return fail(h, SDPGPU_ERR_DEVICE, "period %d separable kernel: %s", period, hipGetErrorString(es));
+    p.kernel_used = SDPGPU_KERNEL_SEPARABLE;
+    if (h->profiling) {
+      HIP_TRY(h, hipEventRecord(p.ev1, h->stream));
+      p.timed = true;
+    }
+    h->period_done[period - 1] = 1;
+    h->policy_done[period - 1] = 1;
+    if (!h->d.store_all_values && period + 2 <= h->T) h->period_done[period + 1] = 0;
+    return SDPGPU_OK;
+  }
   bool use_window = false;
   if (h->d.kernel == SDPGPU_KERNEL_WINDOW) {
     if (!window_eligible(h, period)) return fail(h, SDPGPU_ERR_UNSUPPORTED, "window kernel needs the backorder / lead-time family with a unit-stride demand grid");
