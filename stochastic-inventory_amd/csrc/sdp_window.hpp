@@ -44,6 +44,7 @@ struct WinParams {
   int32_t tile_first;     // launch tile u maps to slab tile tile_first + u (+ tile_gap when u >= tile_gap_at):
   int32_t tile_gap_at;    // lets one launch cover the interior run of tiles, or the two boundary runs
   int32_t tile_gap;
+  int32_t prio_fair;      // s_setprio by progress: resident waves of a SIMD advance together
   int64_t partial_stride; // elements between chunk rows of the partial tables
 };
 
@@ -152,6 +153,18 @@ __global__ __launch_bounds__(256) void window_f1_kernel(WinParams W, const doubl
     }
 #pragma unroll 1
     for (int jb = 0; jb < W.d_main; jb += R) {
+      if (W.prio_fair) {
+        // The SIMD issues by priority, then age: left alone, the oldest resident wave runs ahead and the
+        // last task of a SIMD ends up alone (one wave sustains 76 % of the fp64 issue rate, four 94 %).
+        // Priority by progress -- the further behind, the higher -- keeps the resident waves level, so
+        // they finish together (+4 % on configs[1]; nothing to gain on grids with many rounds).
+        const unsigned done = (unsigned)(rb * W.d_main + jb);
+        const unsigned pr = 3u - (4u * done) / (unsigned)(W.chunk_blocks * W.d_main + 1);
+        if (pr == 0) __builtin_amdgcn_s_setprio(0);
+        else if (pr == 1) __builtin_amdgcn_s_setprio(1);
+        else if (pr == 2) __builtin_amdgcn_s_setprio(2);
+        else __builtin_amdgcn_s_setprio(3);
+      }
       const double2* nxt = s_win + (base - jb - R);  // slots base-jb-R ... base-jb-1
 #pragma unroll
       for (int t = 0; t < R; ++t) {

@@ -92,6 +92,7 @@ struct sdpgpu_handle {
   sdp::FinalizeJob* d_jobs = nullptr;
   bool fuse_combine = true;
   bool use_cash_shift = true;
+  int win_prio_fair = 1;  // window kernel: s_setprio by progress (SDPGPU_WIN_PRIO=0 turns it off)
   int win_r = 0, win_nch = 0;      // tuning overrides (SDPGPU_WIN_R / SDPGPU_WIN_NCH), 0 = heuristic
   uint8_t* d_reach = nullptr;      // reachable masks, period t at reach_off[t-1]
   std::vector<size_t> reach_off;
@@ -1024,6 +1025,7 @@ hipError_t launch_window(sdpgpu_handle* h, const DevParams& P, int period, const
   W.n_tiles = pl.n_tiles;
   W.n_tasks = pl.n_tasks;
   W.tile_first = 0;
+  W.prio_fair = h->win_prio_fair;
   W.tile_gap_at = pl.n_tiles;  // no gap
   W.tile_gap = 0;
   if (part != SDPGPU_PART_ALL) {
@@ -1188,6 +1190,7 @@ int sdpgpu_create(const sdpgpu_desc* desc, sdpgpu_handle** out) {
     if (const char* e = std::getenv("SDPGPU_WIN_NCH")) h->win_nch = std::atoi(e);
     if (const char* e = std::getenv("SDPGPU_FUSE_COMBINE")) h->fuse_combine = std::atoi(e) != 0;
     if (const char* e = std::getenv("SDPGPU_CASH_SHIFT")) h->use_cash_shift = std::atoi(e) != 0;
+    if (const char* e = std::getenv("SDPGPU_WIN_PRIO")) h->win_prio_fair = std::atoi(e) != 0;
   } catch (...) {
     delete h;
     return fail(nullptr, SDPGPU_ERR_ARG, "out of host memory");
