@@ -275,6 +275,34 @@ int sdpgpu_simulate(sdpgpu_handle* h, int64_t n_paths, const double* demand, con
                     double ini_cash, double ini_preq, double* out_sum, uint8_t* out_valid);
 
 int sdpgpu_stats_get(sdpgpu_handle* h, sdpgpu_stats* out);
+
+/* ---- reachable-set engine for the two-product lead-time family -------------------------------------
+ * Replaces `new CashRecursionMultiLead(...).getExpectedValue(iniState)` / getAction
+ * (src/sdp/cash/multiItem/CashRecursionMultiLead.java:31-95) for the lambdas of
+ * src/cash/overdraft/MultiProductLeadtime.java:150-223 with DiscreteDistribution demands
+ * (GetPmfMulti.java:157-172).  The state (I1, I2, preQ1, preQ2, cash) carries an un-rounded cash balance,
+ * so there is no grid: the engine enumerates the reachable set level by level on the GPU, as the
+ * reference's memoised recursion does on the host.  This is the family whose outputs the reference records
+ * (MultiProductLeadtime.java:30-50). */
+typedef struct sdpgpu_multilead {
+  int32_t T;       /* horizon (TLength) */
+  int32_t q_bound; /* actions (i, j), i, j in [0, Qbound) */
+  double price[2], vari_cost[2], sal_value[2];
+  double ini_cash, ini_i1, ini_i2;
+  double r0, r1, r2, limit, interest_free;
+  double min_inventory, max_inventory, min_cash, max_cash;
+  double discount;
+  double overhead[16]; /* overheadCost[t] */
+  int32_t n1, n2;      /* demand points per product */
+  double v1[16], p1[16], v2[16], p2[16];
+} sdpgpu_multilead;
+
+/* final_value = iniCash + V_1(iniState) (MultiProductLeadtime.java:234), (q1, q2) = getAction(iniState);
+ * states_per_period (T entries, may be NULL) = size of the reachable set per period, cells = (state, action,
+ * demand) evaluations, gpu_ms = device time of expansion + recursion. */
+int sdpgpu_multilead_solve(const sdpgpu_multilead* k, double* final_value, int32_t* q1, int32_t* q2,
+                           int64_t* states_per_period, int64_t* cells, double* gpu_ms);
+const char* sdpgpu_multilead_last_error(void);
 /* Kernel time of period t of the last solve (ms), needs sdpgpu_set_profiling(h, 1). */
 double sdpgpu_period_ms(sdpgpu_handle* h, int32_t period);
 

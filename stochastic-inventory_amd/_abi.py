@@ -112,6 +112,23 @@ def desc_defaults() -> SdpgpuDesc:
     return d
 
 
+class SdpgpuMultilead(C.Structure):
+    """struct sdpgpu_multilead (include/sdpgpu.h)."""
+
+    _fields_ = [
+        ("T", C.c_int32), ("q_bound", C.c_int32),
+        ("price", C.c_double * 2), ("vari_cost", C.c_double * 2), ("sal_value", C.c_double * 2),
+        ("ini_cash", C.c_double), ("ini_i1", C.c_double), ("ini_i2", C.c_double),
+        ("r0", C.c_double), ("r1", C.c_double), ("r2", C.c_double), ("limit", C.c_double),
+        ("interest_free", C.c_double),
+        ("min_inventory", C.c_double), ("max_inventory", C.c_double), ("min_cash", C.c_double),
+        ("max_cash", C.c_double), ("discount", C.c_double),
+        ("overhead", C.c_double * 16),
+        ("n1", C.c_int32), ("n2", C.c_int32),
+        ("v1", C.c_double * 16), ("p1", C.c_double * 16), ("v2", C.c_double * 16), ("p2", C.c_double * 16),
+    ]
+
+
 # every symbol include/sdpgpu.h declares: name -> (restype, argtypes)
 _P = C.c_void_p
 _DP = C.POINTER(C.c_double)
@@ -151,6 +168,8 @@ EXPORTS = {
                                   C.POINTER(C.c_uint8)]),
     "sdpgpu_stats_get": (C.c_int, [_P, C.POINTER(SdpgpuStats)]),
     "sdpgpu_period_ms": (C.c_double, [_P, C.c_int32]),
+    "sdpgpu_multilead_solve": (C.c_int, [C.POINTER(SdpgpuMultilead), _DP, _IP, _IP, _LP, _LP, _DP]),
+    "sdpgpu_multilead_last_error": (C.c_char_p, []),
 }
 
 _lib = None

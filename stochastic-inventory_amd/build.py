@@ -29,7 +29,7 @@ HIPCC_FLAGS = [
 
 
 def sources():
-    return [os.path.join(CSRC, "sdpgpu.hip")]
+    return [os.path.join(CSRC, "sdpgpu.hip"), os.path.join(CSRC, "sdpgpu_sparse.hip")]
 
 
 def deps():

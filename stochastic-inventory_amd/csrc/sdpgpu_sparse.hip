@@ -1,0 +1,450 @@
+// sdpgpu_sparse.hip -- reachable-set ("sparse") SDP engine for state spaces that are not grids.
+//
+// The dense engine (sdpgpu.hip) needs a gridded state space.  The reference's two-product classes have
+// none: `CashRecursionMultiLead` (src/sdp/cash/multiItem/CashRecursionMultiLead.java:54-90) driven by the
+// lambdas of `MultiProductLeadtime.main` (src/cash/overdraft/MultiProductLeadtime.java:150-223) carries
+// an UN-ROUNDED cash balance in its 5-tuple state (I1, I2, preQ1, preQ2, cash), so only the states
+// actually reachable from the initial one exist -- which is exactly what the reference's memoised
+// recursion enumerates.  This file does the same on the GPU, level by level:
+//
+//   forward  t = 1..T-1 : expand every state of S_t over all (action, demand) pairs, sort the candidates
+//                          by a 64-bit hash of the tuple (rocPRIM radix sort through hipCUB), keep one
+//                          representative per distinct tuple -> S_{t+1}; every candidate remembers the id of
+//                          its representative, so the backward pass needs no searching.
+//   backward t = T..1   : one workgroup per state: Q(s, a) for the q_bound^2 actions (lanes = actions,
+//                          demand loop serial and in the reference's order), then the reference's
+//                          tolerance scan `if (Q > val + 0.1)` in action order.
+//
+// A hash collision can only make two equal tuples land in two representatives (both are then evaluated,
+// to the same value); it cannot merge different tuples, because representatives are cut by comparing
+// the full tuples.  This family is the one the reference records outputs for (KAT-1/KAT-2,
+// MultiProductLeadtime.java:30-50): tests/test_gpu_multilead.py reproduces them on the GPU.
+#include "../../include/sdpgpu.h"
+
+#include <hip/hip_runtime.h>
+#include <hipcub/hipcub.hpp>
+
+#include <algorithm>
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <vector>
+
+namespace {
+
+thread_local std::string g_ml_error;
+
+struct MLParams {
+  double price[2], vari[2], sal[2];
+  double r0, r1, r2, limit, interest_free;
+  double min_inventory, max_inventory, min_cash, max_cash, discount;
+  double overhead;  // of the period being processed
+  int32_t qb;       // actions (i, j), i, j in [0, qb)
+  int32_t nd;       // demand pairs, index = i1 * n2 + i2 (GetPmfMulti.java:157-172)
+  int32_t is_last;  // period == T: salvage applies, no transition
+};
+
+struct Tuple {
+  double i1, i2, q1, q2, cash;
+};
+
+__device__ __forceinline__ double jmax(double a, double b) { return fmax(a, b); }
+__device__ __forceinline__ double jmin(double a, double b) { return fmin(a, b); }
+
+// Piecewise overdraft interest, MultiProductLeadtime.java:186-194.
+__device__ __forceinline__ double ml_interest(const MLParams& P, double before) {
+  double interest;
+  if (before >= 0)
+    interest = -P.r0 * before;
+  else if (before >= -P.interest_free)
+    interest = 0;
+  else if (before >= -P.limit)
+    interest = P.r1 * (-before - P.interest_free);
+  else
+    interest = P.r2 * (-before - P.limit) + P.r1 * (P.limit - P.interest_free);
+  return interest;
+}
+
+// Demand-dependent pieces of one state, shared by all actions (MultiProductLeadtime.java:170-183).
+struct DemandTerms {
+  double revenue, sal_value, next_i1, next_i2;
+};
+
+__device__ __forceinline__ DemandTerms demand_terms(const MLParams& P, const Tuple& s, double d1, double d2) {
+  DemandTerms t;
+  const double end1 = jmax(0.0, s.i1 + s.q1 - d1);
+  const double end2 = jmax(0.0, s.i2 + s.q2 - d2);
+  const double revenue1 = P.price[0] * jmin(d1, s.i1 + s.q1);
+  const double revenue2 = P.price[1] * jmin(s.i2 + s.q2, d2);
+  t.revenue = revenue1 + revenue2;
+  t.sal_value = P.is_last ? (P.sal[0] * end1 + P.sal[1] * end2) : 0.0;
+  // the transition's own end inventories (:210-221): upper clamp on product 1 only, lower clamp on
+  // product 2 only, then (int) casts
+  double n1 = s.i1 + s.q1 - d1;
+  n1 = jmax(0.0, n1);
+  double n2 = s.i2 + s.q2 - d2;
+  n2 = jmax(0.0, n2);
+  n1 = n1 > P.max_inventory ? P.max_inventory : n1;
+  n2 = n2 < P.min_inventory ? P.min_inventory : n2;
+  t.next_i1 = (double)(int)n1;
+  t.next_i2 = (double)(int)n2;
+  return t;
+}
+
+// cashIncrement of (state, action, demand): MultiProductLeadtime.java:177-198 with the action-only part
+// (`bi` = cashBalanceBefore - interest) hoisted by the caller.
+__device__ __forceinline__ double cash_increment(const Tuple& s, double bi, const DemandTerms& t) {
+  const double after = bi + t.revenue + t.sal_value;
+  return after - s.cash;
+}
+
+__device__ __forceinline__ double next_cash(const MLParams& P, const Tuple& s, double inc) {
+  double c = s.cash + inc;
+  c = c > P.max_cash ? P.max_cash : c;
+  c = c < P.min_cash ? P.min_cash : c;
+  return c;
+}
+
+__device__ __forceinline__ unsigned long long mix64(unsigned long long h, double v) {
+  v += 0.0;  // -0.0 -> +0.0 (the reference's equals() compares with ==)
+  unsigned long long u = (unsigned long long)__double_as_longlong(v);
+  h ^= u + 0x9e3779b97f4a7c15ull + (h << 6) + (h >> 2);
+  h *= 0xff51afd7ed558ccdull;
+  h ^= h >> 33;
+  return h;
+}
+
+__device__ __forceinline__ unsigned long long tuple_hash(const Tuple& t) {
+  unsigned long long h = 0x243f6a8885a308d3ull;
+  h = mix64(h, t.i1);
+  h = mix64(h, t.i2);
+  h = mix64(h, t.q1);
+  h = mix64(h, t.q2);
+  h = mix64(h, t.cash);
+  return h;
+}
+
+__device__ __forceinline__ bool tuple_eq(const Tuple& a, const Tuple& b) {
+  return a.i1 == b.i1 && a.i2 == b.i2 && a.q1 == b.q1 && a.q2 == b.q2 && a.cash == b.cash;
+}
+
+// The successor of (state, action a, demand j).
+__device__ __forceinline__ Tuple successor(const MLParams& P, const Tuple& s, int a, const double2* dem, int j) {
+  const int a1 = a / P.qb, a2 = a - a1 * P.qb;
+  const double oc = P.vari[0] * (double)a1 + P.vari[1] * (double)a2;
+  const double before = s.cash - oc - P.overhead;
+  const double bi = before - ml_interest(P, before);
+  const DemandTerms t = demand_terms(P, s, dem[j].x, dem[j].y);
+  Tuple n;
+  n.i1 = t.next_i1;
+  n.i2 = t.next_i2;
+  n.q1 = (double)a1;
+  n.q2 = (double)a2;
+  n.cash = next_cash(P, s, cash_increment(s, bi, t));
+  return n;
+}
+
+// ---- forward: candidates of one period ------------------------------------------------------------
+// candidate index c = (s * NA + a) * ND + j
+__global__ __launch_bounds__(256) void expand_kernel(MLParams P, const Tuple* __restrict__ states, int64_t n_states,
+                                                     const double2* __restrict__ dem, unsigned long long* __restrict__ hash,
+                                                     unsigned int* __restrict__ order) {
+  const int NA = P.qb * P.qb;
+  const int64_t g = (int64_t)blockIdx.x * 256 + threadIdx.x;  // (s, a)
+  if (g >= n_states * NA) return;
+  const int64_t s = g / NA;
+  const int a = (int)(g - s * NA);
+  const Tuple st = states[s];
+  for (int j = 0; j < P.nd; ++j) {
+    const Tuple n = successor(P, st, a, dem, j);
+    const int64_t c = g * P.nd + j;
+    hash[c] = tuple_hash(n);
+    order[c] = (unsigned int)c;
+  }
+}
+
+// heads of runs of equal tuples in hash-sorted order
+__global__ __launch_bounds__(256) void mark_heads_kernel(MLParams P, const Tuple* __restrict__ states,
+                                                         const double2* __restrict__ dem,
+                                                         const unsigned int* __restrict__ sorted, int64_t n,
+                                                         int* __restrict__ head) {
+  const int NA = P.qb * P.qb;
+  const int64_t k = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (k >= n) return;
+  auto tuple_of = [&](unsigned int c) {
+    const int64_t g = c / P.nd;
+    const int j = (int)(c - g * P.nd);
+    const int64_t s = g / NA;
+    return successor(P, states[s], (int)(g - s * NA), dem, j);
+  };
+  if (k == 0) {
+    head[0] = 1;
+    return;
+  }
+  head[k] = tuple_eq(tuple_of(sorted[k]), tuple_of(sorted[k - 1])) ? 0 : 1;
+}
+
+// rank[k] = inclusive scan of head; representative id = rank - 1
+__global__ __launch_bounds__(256) void scatter_kernel(MLParams P, const Tuple* __restrict__ states,
+                                                      const double2* __restrict__ dem,
+                                                      const unsigned int* __restrict__ sorted,
+                                                      const int* __restrict__ head, const int* __restrict__ rank,
+                                                      int64_t n, Tuple* __restrict__ next_states,
+                                                      int* __restrict__ uid) {
+  const int NA = P.qb * P.qb;
+  const int64_t k = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (k >= n) return;
+  const unsigned int c = sorted[k];
+  const int id = rank[k] - 1;
+  uid[c] = id;
+  if (head[k]) {
+    const int64_t g = c / P.nd;
+    const int j = (int)(c - g * P.nd);
+    const int64_t s = g / NA;
+    next_states[id] = successor(P, states[s], (int)(g - s * NA), dem, j);
+  }
+}
+
+// ---- backward: one workgroup per state ------------------------------------------------------------
+__global__ __launch_bounds__(256) void backward_kernel(MLParams P, const Tuple* __restrict__ states, int64_t s_first,
+                                                       int64_t n_states,
+                                                       const double2* __restrict__ dem, const double* __restrict__ prob,
+                                                       const double* __restrict__ v_next, const int* __restrict__ uid,
+                                                       double* __restrict__ v_out, int* __restrict__ act_out) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int NA = P.qb * P.qb;
+  double* s_q = reinterpret_cast<double*>(smem);                       // Q(s, a)
+  DemandTerms* s_t = reinterpret_cast<DemandTerms*>(s_q + NA);         // per demand pair
+  double* s_p = reinterpret_cast<double*>(s_t + P.nd);
+  const int64_t s = s_first + blockIdx.x;
+  if (s >= n_states) return;
+  const Tuple st = states[s];
+  const int tid = threadIdx.x;
+  for (int j = tid; j < P.nd; j += 256) {
+    s_t[j] = demand_terms(P, st, dem[j].x, dem[j].y);
+    s_p[j] = prob[j];
+  }
+  __syncthreads();
+  for (int a = tid; a < NA; a += 256) {
+    const int a1 = a / P.qb, a2 = a - a1 * P.qb;
+    const double oc = P.vari[0] * (double)a1 + P.vari[1] * (double)a2;
+    const double before = st.cash - oc - P.overhead;
+    const double bi = before - ml_interest(P, before);
+    double acc = 0.0;  // thisActionsValue, CashRecursionMultiLead.java:72-80
+    for (int j = 0; j < P.nd; ++j) {
+      const double p = s_p[j];
+      acc += p * cash_increment(st, bi, s_t[j]);
+      if (!P.is_last) acc += p * P.discount * v_next[uid[((int64_t)s * NA + a) * P.nd + j]];
+    }
+    s_q[a] = acc;
+  }
+  __syncthreads();
+  // `if (actionValues[i] > val + 0.1)` in action order (CashRecursionMultiLead.java:82): a serial
+  // scan, done 64 candidates at a time by the first wave (each pass jumps to the next improvement)
+  if (tid < 64) {
+    double val = -1.7976931348623157e308;
+    int best = 0;  // new Actions(0, 0)
+    for (int base = 0; base < NA; base += 64) {
+      const int a = base + tid;
+      const double q = a < NA ? s_q[a] : -1.7976931348623157e308;
+      int from = 0;
+      while (true) {
+        const unsigned long long m = __ballot(a < NA && tid >= from && q > val + 0.1);
+        if (!m) break;
+        const int first = __ffsll((long long)m) - 1;
+        val = __shfl(q, first, 64);
+        best = base + first;
+        from = first + 1;
+      }
+    }
+    if (tid == 0) {
+      v_out[s] = val;
+      act_out[s] = best;
+    }
+  }
+}
+
+#define ML_TRY(expr)                                                                     \
+  do {                                                                                   \
+    hipError_t e_ = (expr);                                                              \
+    if (e_ != hipSuccess) {                                                              \
+      g_ml_error = std::string(#expr) + ": " + hipGetErrorString(e_);                    \
+      goto fail;                                                                         \
+    }                                                                                    \
+  } while (0)
+
+}  // namespace
+
+extern "C" {
+
+const char* sdpgpu_multilead_last_error(void) { return g_ml_error.c_str(); }
+
+int sdpgpu_multilead_solve(const sdpgpu_multilead* k, double* final_value, int32_t* q1, int32_t* q2,
+                           int64_t* states_per_period, int64_t* cells, double* gpu_ms) {
+  g_ml_error.clear();
+  if (!k || k->T < 1 || k->T > 16 || k->n1 < 1 || k->n1 > 16 || k->n2 < 1 || k->n2 > 16 || k->q_bound < 1 ||
+      k->q_bound > 256) {
+    g_ml_error = "multilead: bad descriptor";
+    return SDPGPU_ERR_ARG;
+  }
+  int ndev = 0;
+  if (hipGetDeviceCount(&ndev) != hipSuccess || ndev < 1) {
+    g_ml_error = "no HIP device available; this library has no CPU path";
+    return SDPGPU_ERR_DEVICE;
+  }
+  const int T = k->T, nd = k->n1 * k->n2, NA = k->q_bound * k->q_bound;
+  std::vector<double2> h_dem((size_t)nd);
+  std::vector<double> h_prob((size_t)nd);
+  for (int i = 0; i < k->n1; ++i)
+    for (int j = 0; j < k->n2; ++j) {
+      // `new Demands((int) dAndP[j][0], (int) dAndP[j][1])`, CashRecursionMultiLead.java:74
+      h_dem[(size_t)i * k->n2 + j] = make_double2((double)(int)k->v1[i], (double)(int)k->v2[j]);
+      h_prob[(size_t)i * k->n2 + j] = k->p1[i] * k->p2[j];
+    }
+  MLParams P{};
+  for (int i = 0; i < 2; ++i) {
+    P.price[i] = k->price[i];
+    P.vari[i] = k->vari_cost[i];
+    P.sal[i] = k->sal_value[i];
+  }
+  P.r0 = k->r0; P.r1 = k->r1; P.r2 = k->r2; P.limit = k->limit; P.interest_free = k->interest_free;
+  P.min_inventory = k->min_inventory; P.max_inventory = k->max_inventory;
+  P.min_cash = k->min_cash; P.max_cash = k->max_cash; P.discount = k->discount;
+  P.qb = k->q_bound; P.nd = nd;
+
+  std::vector<Tuple*> d_states((size_t)T, nullptr);
+  std::vector<int*> d_uid((size_t)T, nullptr);
+  std::vector<int64_t> n_states((size_t)T, 0);
+  double2* d_dem = nullptr;
+  double* d_prob = nullptr;
+  unsigned long long *d_hash = nullptr, *d_hash2 = nullptr;
+  unsigned int *d_order = nullptr, *d_order2 = nullptr;
+  int *d_head = nullptr, *d_rank = nullptr;
+  void* d_tmp = nullptr;
+  double *d_vcur = nullptr, *d_vnext = nullptr;
+  int* d_act = nullptr;
+  hipEvent_t ev0 = nullptr, ev1 = nullptr;
+  int64_t total_cells = 0;
+  int rc = SDPGPU_ERR_DEVICE;
+  {
+    ML_TRY(hipEventCreate(&ev0));
+    ML_TRY(hipEventCreate(&ev1));
+    ML_TRY(hipMalloc((void**)&d_dem, (size_t)nd * sizeof(double2)));
+    ML_TRY(hipMalloc((void**)&d_prob, (size_t)nd * sizeof(double)));
+    ML_TRY(hipMemcpy(d_dem, h_dem.data(), (size_t)nd * sizeof(double2), hipMemcpyHostToDevice));
+    ML_TRY(hipMemcpy(d_prob, h_prob.data(), (size_t)nd * sizeof(double), hipMemcpyHostToDevice));
+    Tuple ini{k->ini_i1, k->ini_i2, 0.0, 0.0, k->ini_cash};  // MultiProductLeadtime.java:232
+    ML_TRY(hipMalloc((void**)&d_states[0], sizeof(Tuple)));
+    ML_TRY(hipMemcpy(d_states[0], &ini, sizeof(Tuple), hipMemcpyHostToDevice));
+    n_states[0] = 1;
+    ML_TRY(hipEventRecord(ev0, 0));
+    // ---- forward ----
+    for (int t = 0; t + 1 < T; ++t) {
+      const int64_t nc = n_states[t] * NA * nd;
+      if (nc >= 2000000000LL) {
+        g_ml_error = "multilead: the reachable set outgrows 32-bit candidate indices (the reference's own comment calls such instances unsolvable)";
+        rc = SDPGPU_ERR_UNSUPPORTED;
+        goto fail;
+      }
+      P.overhead = k->overhead[t];
+      P.is_last = 0;
+      ML_TRY(hipMalloc((void**)&d_hash, (size_t)nc * 8));
+      ML_TRY(hipMalloc((void**)&d_hash2, (size_t)nc * 8));
+      ML_TRY(hipMalloc((void**)&d_order, (size_t)nc * 4));
+      ML_TRY(hipMalloc((void**)&d_order2, (size_t)nc * 4));
+      ML_TRY(hipMalloc((void**)&d_head, (size_t)nc * 4));
+      ML_TRY(hipMalloc((void**)&d_rank, (size_t)nc * 4));
+      ML_TRY(hipMalloc((void**)&d_uid[t], (size_t)nc * 4));
+      const unsigned gsa = (unsigned)((n_states[t] * NA + 255) / 256);
+      hipLaunchKernelGGL(expand_kernel, dim3(gsa), dim3(256), 0, 0, P, d_states[t], n_states[t], d_dem, d_hash, d_order);
+      ML_TRY(hipGetLastError());
+      size_t tmp_bytes = 0;
+      ML_TRY(hipcub::DeviceRadixSort::SortPairs(nullptr, tmp_bytes, d_hash, d_hash2, d_order, d_order2, (int)nc));
+      ML_TRY(hipMalloc(&d_tmp, tmp_bytes));
+      ML_TRY(hipcub::DeviceRadixSort::SortPairs(d_tmp, tmp_bytes, d_hash, d_hash2, d_order, d_order2, (int)nc));
+      ML_TRY(hipFree(d_tmp));
+      d_tmp = nullptr;
+      const unsigned gc = (unsigned)((nc + 255) / 256);
+      hipLaunchKernelGGL(mark_heads_kernel, dim3(gc), dim3(256), 0, 0, P, d_states[t], d_dem, d_order2, nc, d_head);
+      ML_TRY(hipGetLastError());
+      ML_TRY(hipcub::DeviceScan::InclusiveSum(nullptr, tmp_bytes, d_head, d_rank, (int)nc));
+      ML_TRY(hipMalloc(&d_tmp, tmp_bytes));
+      ML_TRY(hipcub::DeviceScan::InclusiveSum(d_tmp, tmp_bytes, d_head, d_rank, (int)nc));
+      ML_TRY(hipFree(d_tmp));
+      d_tmp = nullptr;
+      int n_next = 0;
+      ML_TRY(hipMemcpy(&n_next, d_rank + (nc - 1), 4, hipMemcpyDeviceToHost));
+      n_states[t + 1] = n_next;
+      ML_TRY(hipMalloc((void**)&d_states[t + 1], (size_t)n_next * sizeof(Tuple)));
+      hipLaunchKernelGGL(scatter_kernel, dim3(gc), dim3(256), 0, 0, P, d_states[t], d_dem, d_order2, d_head, d_rank, nc,
+                         d_states[t + 1], d_uid[t]);
+      ML_TRY(hipGetLastError());
+      ML_TRY(hipDeviceSynchronize());
+      (void)hipFree(d_hash); (void)hipFree(d_hash2); (void)hipFree(d_order); (void)hipFree(d_order2);
+      (void)hipFree(d_head); (void)hipFree(d_rank);
+      d_hash = d_hash2 = nullptr;
+      d_order = d_order2 = nullptr;
+      d_head = d_rank = nullptr;
+    }
+    // ---- backward ----
+    for (int t = T - 1; t >= 0; --t) {
+      P.overhead = k->overhead[t];
+      P.is_last = (t == T - 1);
+      ML_TRY(hipMalloc((void**)&d_vcur, (size_t)n_states[t] * 8));
+      if (d_act) (void)hipFree(d_act);
+      d_act = nullptr;
+      ML_TRY(hipMalloc((void**)&d_act, (size_t)n_states[t] * 4));
+      const size_t smem = (size_t)NA * 8 + (size_t)nd * (sizeof(DemandTerms) + 8);
+      // a dispatch carries at most 2^32 work-items: batches of 4M workgroups (2^30 lanes)
+      for (int64_t first = 0; first < n_states[t]; first += (int64_t)1 << 22) {
+        const int64_t nb = std::min<int64_t>((int64_t)1 << 22, n_states[t] - first);
+        hipLaunchKernelGGL(backward_kernel, dim3((unsigned)nb), dim3(256), smem, 0, P, d_states[t], first, n_states[t],
+                           d_dem, d_prob, d_vnext, d_uid[t], d_vcur, d_act);
+        ML_TRY(hipGetLastError());
+      }
+      total_cells += n_states[t] * (int64_t)NA * nd;
+      if (d_vnext) (void)hipFree(d_vnext);
+      d_vnext = d_vcur;
+      d_vcur = nullptr;
+    }
+    ML_TRY(hipEventRecord(ev1, 0));
+    ML_TRY(hipEventSynchronize(ev1));
+    double v = 0;
+    int act = 0;
+    ML_TRY(hipMemcpy(&v, d_vnext, 8, hipMemcpyDeviceToHost));
+    ML_TRY(hipMemcpy(&act, d_act, 4, hipMemcpyDeviceToHost));
+    if (final_value) *final_value = k->ini_cash + v;  // MultiProductLeadtime.java:234
+    if (q1) *q1 = act / k->q_bound;
+    if (q2) *q2 = act % k->q_bound;
+    if (states_per_period)
+      for (int t = 0; t < T; ++t) states_per_period[t] = n_states[t];
+    if (cells) *cells = total_cells;
+    if (gpu_ms) {
+      float ms = 0;
+      (void)hipEventElapsedTime(&ms, ev0, ev1);
+      *gpu_ms = ms;
+    }
+    rc = SDPGPU_OK;
+  }
+fail:
+  for (Tuple* p : d_states) if (p) (void)hipFree(p);
+  for (int* p : d_uid) if (p) (void)hipFree(p);
+  if (d_dem) (void)hipFree(d_dem);
+  if (d_prob) (void)hipFree(d_prob);
+  if (d_hash) (void)hipFree(d_hash);
+  if (d_hash2) (void)hipFree(d_hash2);
+  if (d_order) (void)hipFree(d_order);
+  if (d_order2) (void)hipFree(d_order2);
+  if (d_head) (void)hipFree(d_head);
+  if (d_rank) (void)hipFree(d_rank);
+  if (d_tmp) (void)hipFree(d_tmp);
+  if (d_vcur) (void)hipFree(d_vcur);
+  if (d_vnext) (void)hipFree(d_vnext);
+  if (d_act) (void)hipFree(d_act);
+  if (ev0) (void)hipEventDestroy(ev0);
+  if (ev1) (void)hipEventDestroy(ev1);
+  return rc;
+}
+
+}  // extern "C"
