@@ -10,7 +10,9 @@
  *     lead-time transition): PINNED by KAT-1, the reference's own recorded output
  *     "final optimal cash is -17.800000000000008, Q1 = 40, Q2 = 20"
  *     (src/cash/overdraft/MultiProductLeadtime.java:41-43), reproduced bit for bit by
- *     sdpref_kat_multilead() in tests/test_oracle_kat.py.
+ *     sdpref_kat_multilead() in tests/test_oracle_kat.py.  (The GPU product's reachable-set engine
+ *     reproduces that value and three more recorded ones directly, tests/test_gpu_multilead.py; the
+ *     three-period ones are ~1e11..1e12 cells, hours for this single-threaded recursion.)
  *   - single-item classes (Recursion, CLSP.f, LeadtimeRecursion, CashRecursion,
  *     CashLeadtimeRecursion): PARITY UNPINNED by the reference -- it stores no outputs for
  *     them and cannot be run here (no JDK).  They are pinned only against this line-by-line
