@@ -10,6 +10,7 @@ from ._abi import (FAMILY_BACKORDER, FAMILY_CASH, FAMILY_CASH_LEADTIME, FAMILY_L
 from .engine import SdpEngine
 from .functors import (BackorderFunctor, CashFunctor, CashLeadtimeFunctor, LeadtimeFunctor, OverdraftFunctor,
                        java_round)
+from .multiitem import MultiLeadResult, multilead_solve
 from .pmf import DiscreteDistribution, GetPmf, NormalDist, PoissonDist, UniformIntDist
 from .recursion import CLSP, CashLeadtimeRecursion, CashRecursion, LeadtimeRecursion, Recursion
 from .simulation import Sampling, Simulation
@@ -19,6 +20,7 @@ __all__ = [
     "SdpEngine", "SdpgpuDesc", "SdpgpuError", "SdpgpuStats", "desc_defaults",
     "BackorderFunctor", "LeadtimeFunctor", "CashFunctor", "OverdraftFunctor", "CashLeadtimeFunctor",
     "Recursion", "CLSP", "LeadtimeRecursion", "CashRecursion", "CashLeadtimeRecursion",
+    "multilead_solve", "MultiLeadResult",
     "GetPmf", "PoissonDist", "NormalDist", "UniformIntDist", "DiscreteDistribution", "Simulation", "Sampling",
     "State", "LeadtimeState", "CashState", "CashLeadtimeState", "OptDirection", "java_round",
 ]
