@@ -56,6 +56,10 @@ def make_workload(args, world):
     if args.workload == "cfg5":
         per_gpu = args.states or 1000000
         return workloads.cfg5_scaled(S=per_gpu * world, **kw)
+    if args.workload == "cfg4":  # weak scaling along the inventory axis of every preQ row
+        return workloads.cfg4_leadtime(NX=(args.states or 1000) * world, **kw)
+    if args.workload == "cfg3":  # weak scaling along the inventory axis (cash rows stay whole)
+        return workloads.cfg3_cash(NX=(args.states or 200) * world, **kw)
     if world > 1:
         raise SystemExit(f"workload {args.workload} has no sharded bench definition")
     return workloads.by_name(args.workload, **kw)

@@ -78,12 +78,15 @@ def cfg3_cash(T: int = 6, NX: int = 200, NC: int = 5000, A: int = 300, D: int = 
                     "src/cash CashConstraint via CashRecursion, cash quantum 1")
 
 
-def cfg4_leadtime(T: int = 4, NX: int = 250, A: int = 200, D: int = 100) -> Workload:
-    """configs[3] (lead time 1 shape of Leadtime.java, clamped synthetic grid)."""
+def cfg4_leadtime(T: int = 50, NX: int = 1000, A: int = 200, D: int = 100) -> Workload:
+    """configs[3]: the lead-time pipeline state of src/leadtime -- (period, inventory, preQ), the three
+    fields of the reference's LeadtimeState (LeadtimeState.java:10-20) -- at about 1e7 state cells
+    (50 periods x 1000 inventory points x 200 pipeline quantities), 200 actions, 100 demands; lead time 1
+    exactly as Leadtime.java, on a clamped synthetic grid."""
     f = LeadtimeFunctor(fixedOrderingCost=0, variOrderingCost=1, holdingCost=2, penaltyCost=10,
                         maxOrderQuantity=A - 1, clampInventory=True, minInventory=-50,
                         maxInventory=NX - 51, iniInventory=0, iniPreQ=0)
-    return Workload(f"cfg4_leadtime_{NX}x{A}q x{A}x{D}x{T}", f, OptDirection.MIN, seasonal_pmf(T, D),
+    return Workload(f"cfg4_leadtime_{NX}x{A}q_{A}x{D}x{T}", f, OptDirection.MIN, seasonal_pmf(T, D),
                     "src/leadtime via LeadtimeRecursion")
 
 
