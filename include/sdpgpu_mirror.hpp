@@ -1,0 +1,476 @@
+// sdpgpu_mirror.hpp -- C++17 host-side mirror of the reference's recursion classes over the C ABI of
+// sdpgpu.h (header-only; link with -lsdpgpu).
+//
+// The reference is Java and the build image has no JDK, so this is the compiled-language host side:
+// the same class names, constructor argument order, method names and argument meaning as
+//
+//     sdp.inventory.State / LeadtimeState          src/sdp/inventory/State.java:12-76, LeadtimeState.java:10-52
+//     sdp.cash.CashState / CashLeadtimeState       src/sdp/cash/CashState.java:12-48, CashLeadtimeState.java:11-46
+//     sdp.inventory.Recursion                      src/sdp/inventory/Recursion.java:33-188
+//     sdp.inventory.LeadtimeRecursion              src/sdp/inventory/LeadtimeRecursion.java:19-104
+//     sdp.cash.CashRecursion                       src/sdp/cash/CashRecursion.java:23-218
+//     sdp.cash.CashLeadtimeRecursion               src/sdp/cash/CashLeadtimeRecursion.java:19-107
+//     StateTransitionFunction / ImmediateValueFunction   StateTransition.java:20-22, ImmediateValue.java:23-25
+//
+// plus ONE extra constructor argument: the functor descriptor naming the closed-form family the three
+// lambdas belong to (a GPU cannot call host closures per cell).  The lambdas are kept and handed back
+// by getStateTransitionFunction / getImmediateValueFunction exactly as the simulators expect
+// (Simulation.java:39-40).  getExpectedValue(state) runs the whole backward sweep on the GPU on first
+// use.  Errors of the C ABI become std::runtime_error carrying sdpgpu_last_error().
+#pragma once
+
+#include <array>
+#include <cmath>
+#include <functional>
+#include <map>
+#include <stdexcept>
+#include <string>
+#include <vector>
+
+#include "sdpgpu.h"
+
+namespace sdp {
+
+enum class OptDirection { MIN, MAX };  // Recursion.java:44-47, CashRecursion.java:34-37
+
+/** double[][][] pmf: pmf[t][j] = {demand, probability} (Recursion.java:38). */
+using Pmf = std::vector<std::vector<std::array<double, 2>>>;
+
+template <class S, class A, class R, class S2>
+using StateTransitionFunction = std::function<S2(const S&, A, R)>;
+template <class S, class A, class R, class V>
+using ImmediateValueFunction = std::function<V(const S&, A, R)>;
+
+namespace inventory {
+
+class State {
+ public:
+  State(int period, double initialInventory) : period(period), initialInventory(initialInventory) {}
+  int getPeriod() const { return period; }
+  double getIniInventory() const { return initialInventory; }
+  bool operator==(const State& o) const { return period == o.period && initialInventory == o.initialInventory; }
+
+ protected:
+  int period;
+  double initialInventory;
+};
+
+class LeadtimeState : public State {
+ public:
+  LeadtimeState(int period, double initialInventory, double preQ) : State(period, initialInventory), preQ(preQ) {}
+  double getPreQ() const { return preQ; }
+  bool operator==(const LeadtimeState& o) const { return State::operator==(o) && preQ == o.preQ; }
+
+ private:
+  double preQ;
+};
+
+}  // namespace inventory
+
+namespace cash {
+
+class CashState : public inventory::State {
+ public:
+  CashState(int period, double initialInventory, double iniCash) : State(period, initialInventory), iniCash(iniCash) {}
+  double getIniCash() const { return iniCash; }
+  bool operator==(const CashState& o) const { return State::operator==(o) && iniCash == o.iniCash; }
+  double iniCash;
+};
+
+class CashLeadtimeState : public CashState {
+ public:
+  CashLeadtimeState(int period, double initialInventory, double iniCash, double preQ)
+      : CashState(period, initialInventory, iniCash), preQ(preQ) {}
+  double getPreQ() const { return preQ; }
+
+ private:
+  double preQ;
+};
+
+}  // namespace cash
+
+namespace gpu {
+
+// ---- functor descriptors: field names are the reference's local variable names -----------------------
+struct BackorderFunctor {  // CLSP.java:251-272, CLSPTesting.java:78-106
+  double fixedOrderingCost = 0, variOrderingCost = 0, holdingCost = 0, penaltyCost = 0;
+  double minInventory = 0, maxInventory = 0, maxOrderQuantity = 0, stepSize = 1, iniInventory = 0;
+  void fill(sdpgpu_desc& d) const {
+    d.family = SDPGPU_FAMILY_BACKORDER;
+    d.step = stepSize;
+    d.min_inventory = minInventory;
+    d.max_inventory = maxInventory;
+    d.max_order_quantity = maxOrderQuantity;
+    d.fixed_order_cost = fixedOrderingCost;
+    d.unit_order_cost = variOrderingCost;
+    d.holding_cost = holdingCost;
+    d.penalty_cost = penaltyCost;
+    d.ini_inventory = iniInventory;
+  }
+};
+
+struct LeadtimeFunctor {  // Leadtime.java:50-81
+  double fixedOrderingCost = 0, variOrderingCost = 0, holdingCost = 0, penaltyCost = 0;
+  double maxOrderQuantity = 0, stepSize = 1, iniInventory = 0, iniPreQ = 0;
+  bool clampInventory = false;  // Leadtime.java:65-66 has the clamp commented out
+  double minInventory = 0, maxInventory = 0;
+  void fill(sdpgpu_desc& d) const {
+    d.family = SDPGPU_FAMILY_LEADTIME;
+    d.step = stepSize;
+    d.clamp_inventory = clampInventory ? 1 : 0;
+    d.min_inventory = minInventory;
+    d.max_inventory = maxInventory;
+    d.max_order_quantity = maxOrderQuantity;
+    d.fixed_order_cost = fixedOrderingCost;
+    d.unit_order_cost = variOrderingCost;
+    d.holding_cost = holdingCost;
+    d.penalty_cost = penaltyCost;
+    d.ini_inventory = iniInventory;
+    d.ini_preq = iniPreQ;
+  }
+};
+
+struct CashFunctor {  // CashConstraint.java:95-133 (cashFormula 0), CashConstraintTesting.java:110-148 (1)
+  double price = 0, fixOrderCost = 0, variCost = 1, holdingCost = 0, depositeRate = 0, overheadCost = 0;
+  double overheadRate = 0, salvageValue = 0, penaltyCost = 0, maxOrderQuantity = 0, stepSize = 1;
+  double minInventoryState = 0, maxInventoryState = 0, minCashState = 0, maxCashState = 0;
+  double cashRoundMult = 10, cashRoundDiv = 10;  // Math.round(nextCash * 10) / 10.0
+  bool cashRoundIntDiv = false;                  // `/ 10` (long division), CashOverdraft.java:116
+  int cashFormula = 0;
+  double iniInventory = 0, iniCash = 0;
+  // overdraft schedule (CashOverdraft.java:86-95); family switches to OVERDRAFT when `overdraft` is set
+  bool overdraft = false;
+  double r0 = 0, r2 = 0, r3 = 0, limit = 0, interestFreeAmount = 0;
+  std::vector<double> overheadCosts;  // per period, optional
+  void fill(sdpgpu_desc& d) const {
+    d.family = overdraft ? SDPGPU_FAMILY_OVERDRAFT : SDPGPU_FAMILY_CASH;
+    d.step = stepSize;
+    d.min_inventory = minInventoryState;
+    d.max_inventory = maxInventoryState;
+    d.max_order_quantity = maxOrderQuantity;
+    d.fixed_order_cost = fixOrderCost;
+    d.unit_order_cost = variCost;
+    d.holding_cost = holdingCost;
+    d.penalty_cost = penaltyCost;
+    d.price = price;
+    d.salvage_value = salvageValue;
+    d.deposit_rate = depositeRate;
+    d.overhead_cost = overheadCost;
+    d.overhead_rate = overheadRate;
+    d.min_cash = minCashState;
+    d.max_cash = maxCashState;
+    d.cash_round_mult = cashRoundMult;
+    d.cash_round_div = cashRoundDiv;
+    d.cash_round_int_div = cashRoundIntDiv ? 1 : 0;
+    d.cash_formula = cashFormula;
+    d.ini_inventory = iniInventory;
+    d.ini_cash = iniCash;
+    d.r0 = r0;
+    d.r2 = r2;
+    d.r3 = r3;
+    d.overdraft_limit = limit;
+    d.interest_free_amount = interestFreeAmount;
+  }
+};
+
+struct CashLeadtimeFunctor : CashFunctor {  // SingleProductLeadtime.java:72-119
+  double iniPreQ = 0;
+  bool zeroOrderLastPeriod = true;
+  CashLeadtimeFunctor() {
+    cashRoundMult = 100;
+    cashRoundDiv = 100;
+  }
+  void fill(sdpgpu_desc& d) const {
+    CashFunctor::fill(d);
+    d.family = SDPGPU_FAMILY_CASH_LEADTIME;
+    d.ini_preq = iniPreQ;
+    d.zero_order_last_period = zeroOrderLastPeriod ? 1 : 0;
+  }
+};
+
+// ---- RAII wrapper of one sdpgpu_handle ---------------------------------------------------------------
+class Engine {
+ public:
+  Engine(sdpgpu_desc desc, const Pmf& pmf, const std::vector<double>& overhead = {}) : T_((int)pmf.size()) {
+    desc.periods = T_;
+    if (sdpgpu_create(&desc, &h_) != 0) throw std::runtime_error(sdpgpu_last_error(nullptr));
+    try {
+      for (int t = 0; t < T_; ++t) {
+        std::vector<double> d, p;
+        for (const auto& dp : pmf[t]) {
+          d.push_back(dp[0]);
+          p.push_back(dp[1]);
+        }
+        check(sdpgpu_set_pmf(h_, t, d.data(), p.data(), (int32_t)d.size()));
+      }
+      for (size_t t = 0; t < overhead.size(); ++t) check(sdpgpu_set_overhead(h_, (int32_t)t, overhead[t]));
+    } catch (...) {
+      sdpgpu_destroy(h_);
+      throw;
+    }
+  }
+  ~Engine() { sdpgpu_destroy(h_); }
+  Engine(const Engine&) = delete;
+  Engine& operator=(const Engine&) = delete;
+
+  int periods() const { return T_; }
+  sdpgpu_handle* handle() { return h_; }
+  void check(int rc) const {
+    if (rc != 0) throw std::runtime_error(sdpgpu_last_error(h_));
+  }
+  void solve() {
+    if (!solved_) {
+      check(sdpgpu_solve(h_, 1));
+      solved_ = true;
+    }
+  }
+  /** (value, action index) of a state: from the dense tables, or evaluated on the device if off-grid. */
+  std::pair<double, int> lookup(int period, double x, double cash, double preq) {
+    solve();
+    if (period < 1 || period > T_) throw std::out_of_range("period");
+    const int64_t idx = sdpgpu_state_index(h_, period, x, cash, preq);
+    if (idx >= 0) {
+      table(period);
+      return {values_[period - 1][(size_t)idx], policy_[period - 1][(size_t)idx]};
+    }
+    double v;
+    int32_t a;
+    check(sdpgpu_eval_states(h_, period, 1, &x, &cash, &preq, &v, &a));
+    return {v, a};
+  }
+  void table(int period) {
+    if (values_.empty()) {
+      values_.resize((size_t)T_);
+      policy_.resize((size_t)T_);
+    }
+    if (!values_[period - 1].empty()) return;
+    const int64_t n = sdpgpu_num_states(h_, period);
+    values_[period - 1].resize((size_t)n);
+    policy_[period - 1].resize((size_t)n);
+    check(sdpgpu_values(h_, period, values_[period - 1].data(), n));
+    check(sdpgpu_policy(h_, period, policy_[period - 1].data(), 0, n));
+  }
+  const std::vector<int32_t>& policy(int period) {
+    solve();
+    table(period);
+    return policy_[period - 1];
+  }
+  std::vector<uint8_t> reachable(int period) {
+    solve();
+    std::vector<uint8_t> m((size_t)sdpgpu_num_states(h_, period));
+    check(sdpgpu_reachable(h_, period, m.data(), (int64_t)m.size()));
+    return m;
+  }
+
+ private:
+  sdpgpu_handle* h_ = nullptr;
+  int T_;
+  bool solved_ = false;
+  std::vector<std::vector<double>> values_;
+  std::vector<std::vector<int32_t>> policy_;
+};
+
+inline sdpgpu_desc make_desc(OptDirection dir) {
+  sdpgpu_desc d;
+  sdpgpu_desc_init(&d);
+  d.direction = dir == OptDirection::MIN ? SDPGPU_MIN : SDPGPU_MAX;
+  return d;
+}
+
+// ---- sdp.inventory.Recursion -------------------------------------------------------------------------
+class Recursion {
+ public:
+  using State = inventory::State;
+  using Trans = StateTransitionFunction<State, double, double, State>;
+  using Imm = ImmediateValueFunction<State, double, double, double>;
+  using Actions = std::function<std::vector<double>(const State&)>;
+
+  Recursion(OptDirection optDirection, const Pmf& pmf, Actions getFeasibleAction, Trans stateTransition,
+            Imm immediateValue, const BackorderFunctor& functor)
+      : getFeasibleActions(std::move(getFeasibleAction)), stateTransition(std::move(stateTransition)),
+        immediateValue(std::move(immediateValue)), step_(functor.stepSize), engine_(desc_of(optDirection, functor), pmf) {}
+
+  Trans getStateTransitionFunction() const { return stateTransition; }
+  Imm getImmediateValueFunction() const { return immediateValue; }
+  void setTreeMapCacheAction() {}  // the dense tables are already in comparator order (Recursion.java:80-86)
+
+  double getExpectedValue(const State& s) { return engine_.lookup(s.getPeriod(), s.getIniInventory(), 0, 0).first; }
+  double getAction(const State& s) { return engine_.lookup(s.getPeriod(), s.getIniInventory(), 0, 0).second * step_; }
+
+  /** rows {period, inventory, Q} of the reachable states in (period, inventory) order (Recursion.java:177-186). */
+  std::vector<std::array<double, 3>> getOptTable() {
+    std::vector<std::array<double, 3>> rows;
+    for (int period = 1; period <= engine_.periods(); ++period) {
+      const auto mask = engine_.reachable(period);
+      const auto& pol = engine_.policy(period);
+      double x_lo;
+      int64_t nx, nc, nq;
+      engine_.check(sdpgpu_grid(engine_.handle(), period, &x_lo, &nx, &nc, &nq));
+      for (size_t i = 0; i < mask.size(); ++i)
+        if (mask[i]) rows.push_back({(double)period, x_lo + (double)i * step_, pol[i] * step_});
+    }
+    return rows;
+  }
+  Engine& engine() { return engine_; }
+
+  Actions getFeasibleActions;
+  Trans stateTransition;
+  Imm immediateValue;
+
+ private:
+  static sdpgpu_desc desc_of(OptDirection dir, const BackorderFunctor& f) {
+    sdpgpu_desc d = make_desc(dir);
+    f.fill(d);
+    return d;
+  }
+  double step_;
+  Engine engine_;
+};
+
+// ---- sdp.inventory.LeadtimeRecursion (MIN only, LeadtimeRecursion.java:52,66) ------------------------
+class LeadtimeRecursion {
+ public:
+  using State = inventory::LeadtimeState;
+  using Trans = StateTransitionFunction<State, double, double, State>;
+  using Imm = ImmediateValueFunction<State, double, double, double>;
+  using Actions = std::function<std::vector<double>(const State&)>;
+
+  LeadtimeRecursion(const Pmf& pmf, Actions getFeasibleAction, Trans stateTransition, Imm immediateValue,
+                    const LeadtimeFunctor& functor)
+      : getFeasibleActions(std::move(getFeasibleAction)), stateTransition(std::move(stateTransition)),
+        immediateValue(std::move(immediateValue)), step_(functor.stepSize), engine_(desc_of(functor), pmf) {}
+
+  double getExpectedValue(const State& s) {
+    return engine_.lookup(s.getPeriod(), s.getIniInventory(), 0, s.getPreQ()).first;
+  }
+  double getAction(const State& s) {
+    return engine_.lookup(s.getPeriod(), s.getIniInventory(), 0, s.getPreQ()).second * step_;
+  }
+  /** rows {period, inventory, preQ, Q} ordered by (period, inventory, preQ) (LeadtimeRecursion.java:37-40,93-102). */
+  std::vector<std::array<double, 4>> getOptTable() {
+    std::vector<std::array<double, 4>> rows;
+    for (int period = 1; period <= engine_.periods(); ++period) {
+      const auto mask = engine_.reachable(period);
+      const auto& pol = engine_.policy(period);
+      double x_lo;
+      int64_t nx, nc, nq;
+      engine_.check(sdpgpu_grid(engine_.handle(), period, &x_lo, &nx, &nc, &nq));
+      for (int64_t ix = 0; ix < nx; ++ix)
+        for (int64_t iq = 0; iq < nq; ++iq) {
+          const size_t i = (size_t)(iq * nx + ix);
+          if (mask[i]) rows.push_back({(double)period, x_lo + (double)ix * step_, (double)iq * step_, pol[i] * step_});
+        }
+    }
+    return rows;
+  }
+  Engine& engine() { return engine_; }
+
+  Actions getFeasibleActions;
+  Trans stateTransition;
+  Imm immediateValue;
+
+ private:
+  static sdpgpu_desc desc_of(const LeadtimeFunctor& f) {
+    sdpgpu_desc d = make_desc(OptDirection::MIN);
+    f.fill(d);
+    return d;
+  }
+  double step_;
+  Engine engine_;
+};
+
+// ---- sdp.cash.CashRecursion ----------------------------------------------------------------------------
+class CashRecursion {
+ public:
+  using State = cash::CashState;
+  using Trans = StateTransitionFunction<State, double, double, State>;
+  using Imm = ImmediateValueFunction<State, double, double, double>;
+  using Actions = std::function<std::vector<double>(const State&)>;
+
+  CashRecursion(OptDirection optDirection, const Pmf& pmf, Actions getFeasibleAction, Trans stateTransition,
+                Imm immediateValue, double discountFactor, const CashFunctor& functor)
+      : getFeasibleActions(std::move(getFeasibleAction)), stateTransition(std::move(stateTransition)),
+        immediateValue(std::move(immediateValue)), step_(functor.stepSize),
+        engine_(desc_of(optDirection, discountFactor, functor), pmf, functor.overheadCosts) {}
+
+  Trans getStateTransitionFunction() const { return stateTransition; }
+  Imm getImmediateValueFunction() const { return immediateValue; }
+  void setTreeMapCacheAction() {}
+
+  double getExpectedValue(const State& s) {
+    return engine_.lookup(s.getPeriod(), s.getIniInventory(), s.getIniCash(), 0).first;
+  }
+  double getAction(const State& s) {
+    return engine_.lookup(s.getPeriod(), s.getIniInventory(), s.getIniCash(), 0).second * step_;
+  }
+  /** rows {period, inventory, cash, Q} (CashRecursion.java:209-218), ordered by (period, inventory, cash). */
+  std::vector<std::array<double, 4>> getOptTable() {
+    std::vector<std::array<double, 4>> rows;
+    for (int period = 1; period <= engine_.periods(); ++period) {
+      const auto mask = engine_.reachable(period);
+      const auto& pol = engine_.policy(period);
+      double x_lo;
+      int64_t nx, nc, nq;
+      engine_.check(sdpgpu_grid(engine_.handle(), period, &x_lo, &nx, &nc, &nq));
+      for (size_t i = 0; i < mask.size(); ++i)
+        if (mask[i])
+          rows.push_back({(double)period, x_lo + (double)(i / (size_t)nc) * step_,
+                          sdpgpu_cash_value(engine_.handle(), (int64_t)(i % (size_t)nc)), pol[i] * step_});
+    }
+    return rows;
+  }
+  Engine& engine() { return engine_; }
+
+  Actions getFeasibleActions;
+  Trans stateTransition;
+  Imm immediateValue;
+
+ private:
+  static sdpgpu_desc desc_of(OptDirection dir, double discountFactor, const CashFunctor& f) {
+    sdpgpu_desc d = make_desc(dir);
+    f.fill(d);
+    d.discount_factor = discountFactor;
+    return d;
+  }
+  double step_;
+  Engine engine_;
+};
+
+// ---- sdp.cash.CashLeadtimeRecursion (MAX only, CashLeadtimeRecursion.java:53,70) -----------------------
+class CashLeadtimeRecursion {
+ public:
+  using State = cash::CashLeadtimeState;
+  using Trans = StateTransitionFunction<State, double, double, State>;
+  using Imm = ImmediateValueFunction<State, double, double, double>;
+  using Actions = std::function<std::vector<double>(const State&)>;
+
+  CashLeadtimeRecursion(const Pmf& pmf, Actions getFeasibleAction, Trans stateTransition, Imm immediateValue,
+                        const CashLeadtimeFunctor& functor)
+      : getFeasibleActions(std::move(getFeasibleAction)), stateTransition(std::move(stateTransition)),
+        immediateValue(std::move(immediateValue)), step_(functor.stepSize),
+        engine_(desc_of(functor), pmf, functor.overheadCosts) {}
+
+  double getExpectedValue(const State& s) {
+    return engine_.lookup(s.getPeriod(), s.getIniInventory(), s.getIniCash(), s.getPreQ()).first;
+  }
+  double getAction(const State& s) {
+    return engine_.lookup(s.getPeriod(), s.getIniInventory(), s.getIniCash(), s.getPreQ()).second * step_;
+  }
+  Engine& engine() { return engine_; }
+
+  Actions getFeasibleActions;
+  Trans stateTransition;
+  Imm immediateValue;
+
+ private:
+  static sdpgpu_desc desc_of(const CashLeadtimeFunctor& f) {
+    sdpgpu_desc d = make_desc(OptDirection::MAX);
+    f.fill(d);
+    return d;
+  }
+  double step_;
+  Engine engine_;
+};
+
+}  // namespace gpu
+}  // namespace sdp

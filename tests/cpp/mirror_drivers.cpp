@@ -1,0 +1,221 @@
+// mirror_drivers.cpp -- the reference's driver mains, transcribed to C++ over include/sdpgpu_mirror.hpp:
+// same local variable names, same lambdas, one constructor swapped (Recursion -> sdp::gpu::Recursion + a
+// functor descriptor).  tests/test_gpu_cpp_mirror.py compiles this with g++, runs it on the GPU and
+// compares what it prints with the CPU oracle.
+//
+//   clsp       capacitated.CLSPTesting.main   (src/capacitated/CLSPTesting.java:52-119, one parameter set)
+//   leadtime   leadtime.Leadtime.main         (src/leadtime/Leadtime.java:25-99)
+//   cash       cash.singleItem.CashConstraint.main (src/cash/singleItem/CashConstraint.java:44-146), smaller grid
+#include <cmath>
+#include <cstdio>
+#include <cstdlib>
+#include <fstream>
+#include <iostream>
+#include <string>
+
+#include "sdpgpu_mirror.hpp"
+
+using namespace sdp;
+
+static Pmf read_pmf(const char* path) {
+  std::ifstream f(path);
+  int T;
+  f >> T;
+  Pmf pmf((size_t)T);
+  for (int t = 0; t < T; ++t) {
+    int n;
+    f >> n;
+    pmf[t].resize((size_t)n);
+    for (auto& dp : pmf[t]) f >> dp[0] >> dp[1];
+  }
+  return pmf;
+}
+
+static long java_round(double x) {  // Math.round
+  double fl = std::floor(x);
+  return (long)((x - fl >= 0.5) ? fl + 1 : fl);
+}
+
+static int clsp(const Pmf& pmf) {
+  using inventory::State;
+  double fixedOrderingCost = 200, variOrderingCost = 1, penaltyCost = 10, holdingCost = 1;
+  int maxOrderQuantity = 500;
+  double minInventory = -500, maxInventory = 500, stepSize = 1;
+
+  auto getFeasibleAction = [=](const State&) {
+    std::vector<double> feasibleActions((size_t)(maxOrderQuantity / stepSize) + 1);
+    int index = 0;
+    for (double i = 0; i <= maxOrderQuantity; i = i + stepSize) feasibleActions[(size_t)index++] = i;
+    return feasibleActions;
+  };
+  auto stateTransition = [=](const State& state, double action, double randomDemand) {
+    double nextInventory = state.getIniInventory() + action - randomDemand;
+    nextInventory = nextInventory > maxInventory ? maxInventory : nextInventory;
+    nextInventory = nextInventory < minInventory ? minInventory : nextInventory;
+    return State(state.getPeriod() + 1, nextInventory);
+  };
+  auto immediateValue = [=](const State& state, double action, double randomDemand) {
+    double fixedCost = action > 0 ? fixedOrderingCost : 0;
+    double variableCost = variOrderingCost * action;
+    double inventoryLevel = state.getIniInventory() + action - randomDemand;
+    double holdingCosts = holdingCost * std::fmax(inventoryLevel, 0);
+    double penaltyCosts = penaltyCost * std::fmax(-inventoryLevel, 0);
+    return fixedCost + variableCost + holdingCosts + penaltyCosts;
+  };
+
+  gpu::BackorderFunctor functor;
+  functor.fixedOrderingCost = fixedOrderingCost;
+  functor.variOrderingCost = variOrderingCost;
+  functor.holdingCost = holdingCost;
+  functor.penaltyCost = penaltyCost;
+  functor.minInventory = minInventory;
+  functor.maxInventory = maxInventory;
+  functor.maxOrderQuantity = maxOrderQuantity;
+  gpu::Recursion recursion(OptDirection::MIN, pmf, getFeasibleAction, stateTransition, immediateValue, functor);
+  int period = 1;
+  double iniInventory = 0;
+  State initialState(period, iniInventory);
+  double finalValue = recursion.getExpectedValue(initialState);
+  std::printf("final optimal expected value is: %.17g\n", finalValue);
+  std::printf("optimal order quantity in the first priod is : %.17g\n", recursion.getAction(initialState));
+  auto optTable = recursion.getOptTable();
+  std::printf("optTable rows %zu first %.17g %.17g %.17g\n", optTable.size(), optTable[0][0], optTable[0][1], optTable[0][2]);
+  // Simulation.simulateSDPGivenSamplNum's inner loop (Simulation.java:59-69) on one fixed demand path,
+  // through the lambdas the recursion hands back
+  auto trans = recursion.getStateTransitionFunction();
+  auto imm = recursion.getImmediateValueFunction();
+  double sum = 0;
+  State state = initialState;
+  for (size_t t = 0; t < pmf.size(); ++t) {
+    double optQ = recursion.getAction(state);
+    double randomDemand = (double)java_round(pmf[t][pmf[t].size() / 2][0] + 0.4);
+    sum += imm(state, optQ, randomDemand);
+    state = trans(state, optQ, randomDemand);
+  }
+  std::printf("simulated path value %.17g\n", sum);
+  return 0;
+}
+
+static int leadtime(const Pmf& pmf) {
+  using inventory::LeadtimeState;
+  double fixedOrderingCost = 0, variOrderingCost = 1, holdingCost = 2, penaltyCost = 10, stepSize = 1;
+  int maxOrderQuantity = 100;
+
+  auto getFeasibleAction = [=](const LeadtimeState&) {
+    std::vector<double> feasibleActions((size_t)(maxOrderQuantity / stepSize) + 1);
+    int index = 0;
+    for (double i = 0; i <= maxOrderQuantity; i = i + stepSize) feasibleActions[(size_t)index++] = i;
+    return feasibleActions;
+  };
+  auto stateTransition = [=](const LeadtimeState& s, double action, double randomDemand) {
+    double nextInventory = s.getIniInventory() + s.getPreQ() - randomDemand;
+    return LeadtimeState(s.getPeriod() + 1, nextInventory, action);
+  };
+  auto immediateValue = [=](const LeadtimeState& s, double action, double randomDemand) {
+    double fixedCost = action > 0 ? fixedOrderingCost : 0;
+    double variableCost = variOrderingCost * action;
+    double inventoryLevel = s.getIniInventory() + s.getPreQ() - randomDemand;
+    double holdingCosts = holdingCost * std::fmax(inventoryLevel, 0);
+    double penaltyCosts = penaltyCost * std::fmax(-inventoryLevel, 0);
+    return fixedCost + variableCost + holdingCosts + penaltyCosts;
+  };
+  gpu::LeadtimeFunctor functor;
+  functor.fixedOrderingCost = fixedOrderingCost;
+  functor.variOrderingCost = variOrderingCost;
+  functor.holdingCost = holdingCost;
+  functor.penaltyCost = penaltyCost;
+  functor.maxOrderQuantity = maxOrderQuantity;
+  gpu::LeadtimeRecursion recursion(pmf, getFeasibleAction, stateTransition, immediateValue, functor);
+  LeadtimeState initialState(1, 0, 0);
+  double opt = recursion.getExpectedValue(initialState);
+  std::printf("final optimal expected value is: %.17g\n", opt);
+  std::printf("optimal order quantity in the first priod is : %.17g\n", recursion.getAction(initialState));
+  auto optTable = recursion.getOptTable();
+  std::printf("optTable rows %zu\n", optTable.size());
+  return 0;
+}
+
+static int cash_constraint(const Pmf& pmf) {
+  using cash::CashState;
+  const int T = (int)pmf.size();
+  double iniInventory = 0, iniCash = 100, fixOrderCost = 0, variCost = 1, price = 10, depositeRate = 0;
+  double salvageValue = 0.5 * variCost, holdingCost = 0, overheadCost = 0, overheadRate = 0, maxOrderQuantity = 100;
+  int stepSize = 1;
+  double minInventoryState = 0, maxInventoryState = 120, minCashState = 0, maxCashState = 600, penaltyCost = 0;
+  double discountFactor = 1;
+
+  auto getFeasibleAction = [=](const CashState& s) {
+    double maxQ = (int)std::fmin(maxOrderQuantity, std::fmax(0, (s.getIniCash() - overheadCost - fixOrderCost) / variCost));
+    std::vector<double> a((size_t)((int)maxQ + 1));
+    for (size_t i = 0; i < a.size(); ++i) a[i] = (double)i * stepSize;
+    return a;
+  };
+  auto immediateValue = [=](const CashState& state, double action, double randomDemand) {
+    double revenue = price * std::fmin(state.getIniInventory() + action, randomDemand);
+    double fixedCost = action > 0 ? fixOrderCost : 0;
+    double variableCost = variCost * action;
+    double deposite = (state.getIniCash() - fixedCost - variableCost) * (1 + depositeRate);
+    double inventoryLevel = state.getIniInventory() + action - randomDemand;
+    double holdCosts = holdingCost * std::fmax(inventoryLevel, 0);
+    double cashIncrement = (1 - overheadRate) * revenue + deposite - holdCosts - overheadCost - state.getIniCash();
+    double salValue = state.getPeriod() == T ? salvageValue * std::fmax(inventoryLevel, 0) : 0;
+    cashIncrement += salValue;
+    double endCash = state.getIniCash() + cashIncrement;
+    if (endCash < 0) cashIncrement += penaltyCost * endCash;
+    return cashIncrement;
+  };
+  auto stateTransition = [=](const CashState& state, double action, double randomDemand) {
+    double nextInventory = std::fmax(0, state.getIniInventory() + action - randomDemand);
+    double nextCash = state.getIniCash() + immediateValue(state, action, randomDemand);
+    nextCash = nextCash > maxCashState ? maxCashState : nextCash;
+    nextCash = nextCash < minCashState ? minCashState : nextCash;
+    nextInventory = nextInventory > maxInventoryState ? maxInventoryState : nextInventory;
+    nextInventory = nextInventory < minInventoryState ? minInventoryState : nextInventory;
+    nextCash = java_round(nextCash * 10) / 10.0;
+    return CashState(state.getPeriod() + 1, nextInventory, nextCash);
+  };
+  gpu::CashFunctor functor;
+  functor.price = price;
+  functor.fixOrderCost = fixOrderCost;
+  functor.variCost = variCost;
+  functor.holdingCost = holdingCost;
+  functor.depositeRate = depositeRate;
+  functor.overheadCost = overheadCost;
+  functor.overheadRate = overheadRate;
+  functor.salvageValue = salvageValue;
+  functor.penaltyCost = penaltyCost;
+  functor.maxOrderQuantity = maxOrderQuantity;
+  functor.minInventoryState = minInventoryState;
+  functor.maxInventoryState = maxInventoryState;
+  functor.minCashState = minCashState;
+  functor.maxCashState = maxCashState;
+  functor.iniInventory = iniInventory;
+  functor.iniCash = iniCash;
+  gpu::CashRecursion recursion(OptDirection::MAX, pmf, getFeasibleAction, stateTransition, immediateValue, discountFactor,
+                               functor);
+  CashState initialState(1, iniInventory, iniCash);
+  recursion.setTreeMapCacheAction();
+  double finalValue = recursion.getExpectedValue(initialState);
+  std::printf("final optimal cash increment is %.17g\n", finalValue);
+  std::printf("optimal order quantity in the first priod is : %.17g\n", recursion.getAction(initialState));
+  // one step through the lambdas from the optimal action, then read the table at the successor
+  double q = recursion.getAction(initialState);
+  CashState next = stateTransition(initialState, q, pmf[0][pmf[0].size() / 2][0]);
+  std::printf("successor value %.17g\n", recursion.getExpectedValue(next));
+  return 0;
+}
+
+int main(int argc, char** argv) {
+  if (argc < 3) return 1;
+  try {
+    const Pmf pmf = read_pmf(argv[2]);
+    const std::string which = argv[1];
+    if (which == "clsp") return clsp(pmf);
+    if (which == "leadtime") return leadtime(pmf);
+    if (which == "cash") return cash_constraint(pmf);
+  } catch (const std::exception& e) {
+    std::fprintf(stderr, "error: %s\n", e.what());
+    return 2;
+  }
+  return 1;
+}

@@ -1,0 +1,93 @@
+"""The compiled-language host mirror (include/sdpgpu_mirror.hpp): the reference's driver mains transcribed
+to C++ (tests/cpp/mirror_drivers.cpp) run on the GPU and print what the CPU oracle computes."""
+import os
+import subprocess
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.fixture(scope="module")
+def exe(tmp_path_factory):
+    out = tmp_path_factory.mktemp("cpp") / "mirror_drivers"
+    libdir = os.path.join(ROOT, "stochastic-inventory_amd")
+    subprocess.run(["g++", "-std=c++17", "-O1", "-Wall", "-I", os.path.join(ROOT, "include"), "-o", str(out),
+                    os.path.join(ROOT, "tests", "cpp", "mirror_drivers.cpp"), "-L", libdir, "-lsdpgpu",
+                    f"-Wl,-rpath,{libdir}"], check=True)
+    return str(out)
+
+
+def _write_pmf(path, pmf):
+    with open(path, "w") as f:
+        f.write(f"{len(pmf)}\n")
+        for tile in pmf:
+            f.write(f"{len(tile)}\n")
+            for d, p in tile:
+                f.write(f"{float(d)!r} {float(p)!r}\n")
+
+
+def _run(exe, which, pmf, tmp_path):
+    path = tmp_path / f"{which}.pmf"
+    _write_pmf(path, pmf)
+    out = subprocess.run([exe, which, str(path)], check=True, capture_output=True, text=True).stdout
+    return out.strip().splitlines()
+
+
+def _last_number(line):
+    return float(line.rsplit(" ", 1)[1])
+
+
+def test_clsp_testing_main(exe, tmp_path, sia, oracle):
+    """CLSPTesting.main's first parameter set (K = 200, v = 1, pi = 10, h = 1; :46-56) on Poisson demands."""
+    tiles = sia.GetPmf([sia.PoissonDist(m) for m in (10, 10, 10, 10, 10, 10, 10, 10)], 0.9999, 1).getpmf()
+    lines = _run(exe, "clsp", tiles, tmp_path)
+    f = sia.BackorderFunctor(fixedOrderingCost=200, variOrderingCost=1, holdingCost=1, penaltyCost=10,
+                             minInventory=-500, maxInventory=500, maxOrderQuantity=500, iniInventory=0)
+    m = oracle.Problem(f.to_desc(8), tiles).memo()
+    assert _last_number(lines[0]) == m["value"]
+    assert _last_number(lines[1]) == m["action"]
+    parts = lines[2].split()
+    assert int(parts[2]) == m["n"] and [float(v) for v in parts[4:7]] == [1.0, 0.0, m["action"]]
+    # the simulated path: replay it with the oracle's tables
+    lookup = {(int(p), float(x)): float(a) for p, x, a in zip(m["period"], m["x"], m["actions"])}
+    x, total = 0.0, 0.0
+    for t, tile in enumerate(tiles):
+        q = lookup[(t + 1, x)]
+        d = float(sia.java_round(float(tile[len(tile) // 2][0]) + 0.4))
+        level = x + q - d
+        total += (200 if q > 0 else 0) + 1 * q + 1 * max(level, 0.0) + 10 * max(-level, 0.0)
+        x = min(500.0, max(-500.0, level))
+    assert _last_number(lines[3]) == total
+
+
+def test_leadtime_main(exe, tmp_path, sia, oracle):
+    """Leadtime.main as it stands: meanDemand {10, 10, 10}, no inventory clamp, maxOrderQuantity 100."""
+    tiles = sia.GetPmf([sia.PoissonDist(10.0)] * 3, 0.9999, 1).getpmf()
+    lines = _run(exe, "leadtime", tiles, tmp_path)
+    f = sia.LeadtimeFunctor(fixedOrderingCost=0, variOrderingCost=1, holdingCost=2, penaltyCost=10, maxOrderQuantity=100,
+                            clampInventory=False, iniInventory=0, iniPreQ=0)
+    m = oracle.Problem(f.to_desc(3), tiles).memo()
+    assert _last_number(lines[0]) == m["value"]
+    assert _last_number(lines[1]) == m["action"]
+    assert int(lines[2].split()[-1]) == m["n"]
+
+
+def test_cash_constraint_main(exe, tmp_path, sia, oracle):
+    """CashConstraint.main's lambdas (cash in tenths, formula 0) on a smaller state box."""
+    tiles = sia.GetPmf([sia.PoissonDist(10.0)] * 4, 0.9999, 1).getpmf()
+    lines = _run(exe, "cash", tiles, tmp_path)
+    f = sia.CashFunctor(price=10, fixOrderCost=0, variCost=1, holdingCost=0, salvageValue=0.5, maxOrderQuantity=100,
+                        minInventoryState=0, maxInventoryState=120, minCashState=0, maxCashState=600, iniInventory=0,
+                        iniCash=100)
+    P = oracle.Problem(f.to_desc(4, sia.OptDirection.MAX), tiles)
+    V, pol, _ = P.solve(nthreads=8)
+    i0 = (0 * 6001) + 1000  # x = 0, cash = 100.0 -> key 1000
+    assert _last_number(lines[0]) == V[0][i0]
+    assert _last_number(lines[1]) == pol[0][i0]
+    q, d = float(pol[0][i0]), float(tiles[0][len(tiles[0]) // 2][0])
+    s1 = f.stateTransition(sia.CashState(1, 0.0, 100.0), q, d, 4)
+    idx = int(s1.getIniInventory()) * 6001 + int(round(s1.getIniCash() * 10))
+    assert _last_number(lines[2]) == V[1][idx]
