@@ -37,6 +37,7 @@ def parse_args():
     ap.add_argument("--periods", type=int, default=0, help="override the horizon")
     ap.add_argument("--kernel", type=int, default=0, help="0 auto, 1 gather, 2 window, 3 separable (opt-in, F1)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-target-grid", action="store_true", help="skip the informational 1e6 x 500 x 200 probe")
     ap.add_argument("--backend", default="nccl", help="nccl (RCCL, default) | gloo (debug: N ranks on one GPU, host-staged)")
     ap.add_argument("--split", action="store_true", help="rehearsal: force the interior/boundary split of every period")
     ap.add_argument("--no-overlap", action="store_true", help="blocking all-gather between periods (no compute overlap)")
@@ -106,6 +107,31 @@ def cpu_baseline(w, target_seconds: float):
         "sample": f"{k} periods (with future term) of {w.name} = {total_cells:.3g} cells in {total_t:.1f} s on {cores} threads",
         "single_thread_cells_per_s": c1 / t1,
     }
+
+
+def target_grid_probe(sia, dev):
+    """Secondary, informational: the grid BASELINE.json's target sentence names (1e6 states x 500 actions x
+    200 demands) for 3 periods on this one GPU, same kernels, same accounting.  Not the bench metric."""
+    import torch
+    from stochastic_inventory_amd import workloads
+    w = workloads.cfg5_scaled(S=1000000, T=3)
+    d = w.desc()
+    d.device = dev.index
+    with sia.SdpEngine(d, w.pmf) as eng:
+        eng.set_stream(torch.cuda.current_stream(dev).cuda_stream)
+        eng.solve(sync=True)  # warm-up
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        steps = 3
+        e0.record()
+        for _ in range(steps):
+            eng.solve(sync=False)
+        e1.record()
+        torch.cuda.synchronize(dev)
+        ms = e0.elapsed_time(e1) / steps
+        cells = int(eng.stats().cells_evaluated)
+    gbps = algorithmic_bytes(cells, 3 * 1000000) / (ms * 1e-3) / 1e9
+    return {"workload": w.name, "value": cells / (ms * 1e-3), "unit": "cells/s", "ms_per_step": ms,
+            "algorithmic_GBps": gbps, "frac_of_hbm_peak": gbps / HBM_PEAK_GBPS}
 
 
 def main():
@@ -259,10 +285,10 @@ def main():
         if check is not None:
             out["check_vs_single_rank"] = check
         if not args.no_cpu_baseline:
-            import copy
-            from stochastic_inventory_amd import workloads
             wb = make_workload(args, 1)
             out["cpu_baseline"] = cpu_baseline(wb, args.cpu_seconds)
+        if world == 1 and args.workload == "cfg2" and not args.no_target_grid:
+            out["north_star_grid"] = target_grid_probe(sia, dev)
         print(json.dumps(out), flush=True)
     if world > 1:
         dist.barrier()
