@@ -282,6 +282,15 @@ def main():
                         "so HBM traffic is far below this figure and the true limiter is fp64 VALU issue",
             },
         }
+        if int(st.kernel_used) == 2 and args.workload in ("cfg2", "cfg5"):
+            # the bound that actually limits the window kernel: fp64 add/mul issue (no FMA by contract).
+            # 5 ops per cell with a future term, 3 in the last period; peak = 16 lanes/clk/SIMD x 1024 SIMDs
+            # x 2.4 GHz (tools/valu_probe.hip measures 3.8e13 of it at the clock the chip holds).
+            ops_per_sweep = cells_step_rank * (5.0 * (T - 1) + 3.0) / T
+            lane_ops = ops_per_sweep * args.steps / (dev_ms * 1e-3)
+            out["valu_roofline"] = {"bound": "fp64 add/mul issue", "achieved": lane_ops / 1e12, "peak": 39.3,
+                                    "unit": "T lane-op/s", "frac": lane_ops / 39.3e12,
+                                    "ops_per_cell": [5, 3], "note": "secondary: the north star prices this path against HBM"}
         if check is not None:
             out["check_vs_single_rank"] = check
         if not args.no_cpu_baseline:
