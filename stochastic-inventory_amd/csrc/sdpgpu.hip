@@ -333,12 +333,17 @@ DevParams make_params(const sdpgpu_handle* h, int period) {
 
 // ---- launch helpers --------------------------------------------------------------------------
 
+// A dispatch carries at most 2^32 - 1 work-items (AQL grid_size is 32 bits); beyond that the launch is
+// silently truncated.  Every launcher below sends 256-thread workgroups and refuses a grid over the limit.
+inline bool grid_ok(int64_t blocks) { return blocks > 0 && blocks * 256 < 4294967296LL; }
+
 template <int FAM, bool MAXDIR, int SX, bool QUERY>
 hipError_t launch_gather_sx(const DevParams& P, const double* v_next, double* v_cur, int32_t* pol, const double* pmf_d,
                             const double* pmf_p, int64_t lo, int64_t hi, sdp::QueryStates q, hipStream_t st) {
   int64_t n = hi - lo;
   if (n <= 0) return hipSuccess;
   int64_t blocks = (n + SX - 1) / SX;
+  if (!grid_ok(blocks)) return hipErrorInvalidValue;
   size_t smem = (size_t)P.n_demand * 16 + 4 * 64 * (sizeof(double) + sizeof(int));
   hipLaunchKernelGGL((sdp::gather_period_kernel<FAM, MAXDIR, SX, QUERY>), dim3((unsigned)blocks), dim3(256), smem, st, P,
                      v_next, v_cur, pol, pmf_d, pmf_p, lo, hi, q);
@@ -664,6 +669,7 @@ hipError_t launch_cash_shift(sdpgpu_handle* h, const DevParams& P, int period, c
   C.tiles_per_row = (int32_t)((p.g.nc + 63) / 64);
   const int64_t row_lo = lo / p.g.nc, row_hi = (hi - 1) / p.g.nc;
   C.row0 = (int32_t)row_lo;
+  if (!grid_ok((row_hi - row_lo + 1) * (int64_t)C.tiles_per_row)) return hipErrorInvalidValue;
   dim3 grid((unsigned)((row_hi - row_lo + 1) * C.tiles_per_row));
   size_t smem = (size_t)p.nD * 16 * 5 + 4 * 64 * (sizeof(double) + sizeof(int));
   const bool last = period == h->T;
@@ -823,6 +829,7 @@ hipError_t flush_pending(sdpgpu_handle* h) {
 template <int R, bool MAXDIR>
 hipError_t launch_row_r(const sdp::RowParams& W, size_t smem, bool future, const double* v_next, double* out_val,
                         int32_t* out_idx, const double* pmf_p, int64_t lo, int64_t hi, hipStream_t st) {
+  if (!grid_ok((int64_t)W.n_tiles * W.n_chunks)) return hipErrorInvalidValue;
   dim3 grid((unsigned)((int64_t)W.n_tiles * W.n_chunks));
   if (future)
     hipLaunchKernelGGL((sdp::window_f2_kernel<R, MAXDIR, true>), grid, dim3(256), smem, st, W, v_next, out_val, out_idx, pmf_p, lo, hi);
@@ -1053,6 +1060,7 @@ hipError_t launch_window(sdpgpu_handle* h, const DevParams& P, int period, const
     out_idx = h->d_chunk_idx + h->chunk_off[period - 1] - lo;
     k_cur = h->d_keys + (size_t)(period - 1) * h->key_stride;
   }
+  if (W.n_tasks > 0 && !grid_ok((W.n_tasks + 3) / 4)) return hipErrorInvalidValue;
   const dim3 grid((unsigned)std::max(1, (W.n_tasks + 3) / 4));
 #ifdef SDP_STAMPS
   static unsigned long long* d_stamps = nullptr;

@@ -1,0 +1,18 @@
+"""configs[4] at full width on one GPU (1e8 states x 500 actions x 200 demands, 2 periods = 2e13 cells):
+the oracle cannot sweep that, so 3000 sampled states per period are compared with the oracle fed the GPU's
+own V_{t+1} -- bit for bit -- plus the clamp edges of the grid."""
+import os
+import subprocess
+import sys
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_1e8_state_grid_sampled_parity():
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "big_grid_check.py"), "100000000"],
+                         capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-2000:]
+    assert out.stdout.count("bit-identical") == 2
