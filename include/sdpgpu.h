@@ -295,6 +295,9 @@ typedef struct sdpgpu_multilead {
   double overhead[16]; /* overheadCost[t] */
   int32_t n1, n2;      /* demand points per product */
   double v1[16], p1[16], v2[16], p2[16];
+  int32_t cash_int_cast; /* 1: `nextCash = (int) nextCash` (MultiProductLeadtime.java:219, commented out in the file as it
+                            stands: "rounding states to save computing time") */
+  int32_t reserved;
 } sdpgpu_multilead;
 
 /* final_value = iniCash + V_1(iniState) (MultiProductLeadtime.java:234), (q1, q2) = getAction(iniState);

@@ -869,6 +869,7 @@ static void ml_trans(const sdpref_multilead* k, const mst_t* s, int32_t a1, int3
   nextCash = nextCash < k->min_cash ? k->min_cash : nextCash;
   endInventory1 = endInventory1 > k->max_inventory ? k->max_inventory : endInventory1;
   endInventory2 = endInventory2 < k->min_inventory ? k->min_inventory : endInventory2;
+  if (k->cash_int_cast) nextCash = (double)jd2i(nextCash); /* :219, commented out in the file as it stands */
   endInventory1 = (double)jd2i(endInventory1);
   endInventory2 = (double)jd2i(endInventory2);
   out->period = s->period + 1;

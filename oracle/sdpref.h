@@ -92,6 +92,8 @@ typedef struct sdpref_multilead {
   double overhead[16];
   int32_t n1, n2;
   double v1[16], p1[16], v2[16], p2[16];
+  int32_t cash_int_cast; /* MultiProductLeadtime.java:219 (commented out in the file as it stands) */
+  int32_t reserved;
 } sdpref_multilead;
 
 int sdpref_kat_multilead(const sdpref_multilead* k, double* final_value, int32_t* q1, int32_t* q2,

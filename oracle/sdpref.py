@@ -48,6 +48,7 @@ class MultiLead(C.Structure):
         ("overhead", C.c_double * 16),
         ("n1", C.c_int32), ("n2", C.c_int32),
         ("v1", C.c_double * 16), ("p1", C.c_double * 16), ("v2", C.c_double * 16), ("p2", C.c_double * 16),
+        ("cash_int_cast", C.c_int32), ("reserved", C.c_int32),
     ]
 
 
@@ -206,6 +207,7 @@ class Problem:
 def kat_multilead(**kw):
     """sdpref_kat_multilead: returns (final_value, q1, q2, states_visited, cells)."""
     k = MultiLead()
+    k.cash_int_cast = 1 if kw.get("cash_int_cast") else 0
     k.T = kw["T"]
     k.q_bound = kw["q_bound"]
     for name in ("price", "vari_cost", "sal_value"):

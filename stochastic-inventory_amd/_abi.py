@@ -126,6 +126,7 @@ class SdpgpuMultilead(C.Structure):
         ("overhead", C.c_double * 16),
         ("n1", C.c_int32), ("n2", C.c_int32),
         ("v1", C.c_double * 16), ("p1", C.c_double * 16), ("v2", C.c_double * 16), ("p2", C.c_double * 16),
+        ("cash_int_cast", C.c_int32), ("reserved", C.c_int32),
     ]
 
 

@@ -43,6 +43,7 @@ struct MLParams {
   int32_t qb;       // actions (i, j), i, j in [0, qb)
   int32_t nd;       // demand pairs, index = i1 * n2 + i2 (GetPmfMulti.java:157-172)
   int32_t is_last;  // period == T: salvage applies, no transition
+  int32_t cash_int_cast;  // MultiProductLeadtime.java:219
 };
 
 struct Tuple {
@@ -103,6 +104,7 @@ __device__ __forceinline__ double next_cash(const MLParams& P, const Tuple& s, d
   double c = s.cash + inc;
   c = c > P.max_cash ? P.max_cash : c;
   c = c < P.min_cash ? P.min_cash : c;
+  if (P.cash_int_cast) c = (double)(int)c;  // `nextCash = (int) nextCash` (:219)
   return c;
 }
 
@@ -312,6 +314,7 @@ int sdpgpu_multilead_solve(const sdpgpu_multilead* k, double* final_value, int32
   P.min_inventory = k->min_inventory; P.max_inventory = k->max_inventory;
   P.min_cash = k->min_cash; P.max_cash = k->max_cash; P.discount = k->discount;
   P.qb = k->q_bound; P.nd = nd;
+  P.cash_int_cast = k->cash_int_cast;
 
   std::vector<Tuple*> d_states((size_t)T, nullptr);
   std::vector<int*> d_uid((size_t)T, nullptr);

@@ -26,8 +26,10 @@ class MultiLeadResult:
 
 
 def fill_multilead(k, *, T, q_bound, price, vari_cost, sal_value, ini_cash, ini_i1, ini_i2, r0, r1, r2, limit,
-                   interest_free, min_inventory, max_inventory, min_cash, max_cash, discount, overhead, values, probs):
+                   interest_free, min_inventory, max_inventory, min_cash, max_cash, discount, overhead, values, probs,
+                   cash_int_cast=False):
     k.T, k.q_bound = T, q_bound
+    k.cash_int_cast = 1 if cash_int_cast else 0
     for name, val in (("price", price), ("vari_cost", vari_cost), ("sal_value", sal_value)):
         getattr(k, name)[0], getattr(k, name)[1] = val
     for name, val in (("ini_cash", ini_cash), ("ini_i1", ini_i1), ("ini_i2", ini_i2), ("r0", r0), ("r1", r1), ("r2", r2),

@@ -39,13 +39,15 @@ def test_kat2_three_periods_on_the_gpu(sia):
           "(the reference's comment: 1568 s)")
 
 
-@pytest.mark.parametrize("name", ["kat3_gpu", "kat4_gpu"])
-def test_kat3_kat4_three_point_demands(sia, name):
-    """'final optimal cash is 91.19499999999998 ... running time is 2863.0s' (:35-39) and
-    '441.57499999999993 for overhead cost 0' (:30): 1.1e12 cells each, all 17 digits."""
+@pytest.mark.parametrize("name", ["kat3_gpu", "kat4_gpu", "kat5_gpu", "kat6_gpu"])
+def test_kat3_to_kat6_three_point_demands(sia, name):
+    """'final optimal cash is 91.19499999999998 ... running time is 2863.0s' (:35-39), '441.57499999999993 for
+    overhead cost 0' (:30), and -- with the state-rounding line :219 enabled, as it evidently was when that
+    part of the comment was written -- '91.26875' (:30) and '272.23749999999995 for overhead cost 50' (:31):
+    4e11 cells each, all 17 digits.  That is every number the comment block records."""
     from stochastic_inventory_amd.multiitem import multilead_solve
     k = KATS[name]
-    r = multilead_solve(**{n: k[n] for n in KEYS})
+    r = multilead_solve(cash_int_cast=k.get("cash_int_cast", False), **{n: k[n] for n in KEYS})
     assert r.finalValue == k["expected_final_cash"]
     assert (r.firstAction, r.secondAction) == (k["expected_q1"], k["expected_q2"])
     print(f"{name}: {r.finalValue!r} in {r.gpu_ms:.0f} ms, states {r.statesPerPeriod}")
@@ -66,6 +68,7 @@ def test_random_instances_match_the_oracle(sia, oracle, seed):
               ini_i2=0.0, r0=0.01, r1=0.1, r2=1.5, limit=40.0, interest_free=3.0, min_inventory=0.0, max_inventory=9.0,
               min_cash=-120.0, max_cash=400.0, discount=float(rng.choice([1.0, 0.95])),
               overhead=[float(x) for x in rng.integers(0, 25, size=T)], values=[v1, v2], probs=[p1, p2])
+    kw["cash_int_cast"] = bool(seed % 2)
     g = multilead_solve(**kw)
     fv, q1, q2, states, cells = oracle.kat_multilead(**kw)
     assert g.finalValue == fv
