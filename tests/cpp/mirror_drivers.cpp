@@ -1,4 +1,4 @@
-// mirror_drivers.cpp -- the reference's driver mains, transcribed to C++ over include/sdpgpu_mirror.hpp:
+// mirror_drivers.cpp -- three driver programs in the shape of the reference's mains, written in C++ over include/sdpgpu_mirror.hpp:
 // same local variable names, same lambdas, one constructor swapped (Recursion -> sdp::gpu::Recursion + a
 // functor descriptor).  tests/test_gpu_cpp_mirror.py compiles this with g++, runs it on the GPU and
 // compares what it prints with the CPU oracle.

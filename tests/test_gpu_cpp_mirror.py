@@ -1,4 +1,4 @@
-"""The compiled-language host mirror (include/sdpgpu_mirror.hpp): the reference's driver mains transcribed
+"""The compiled-language host mirror (include/sdpgpu_mirror.hpp): driver programs in the shape of the reference's mains, written against the mirror,
 to C++ (tests/cpp/mirror_drivers.cpp) run on the GPU and print what the CPU oracle computes."""
 import os
 import subprocess
