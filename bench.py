@@ -32,7 +32,7 @@ def parse_args():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--workload", default="cfg2", help="cfg2 (default) | cfg1 | cfg3 | cfg4 | cfg5")
+    ap.add_argument("--workload", default="cfg2", help="cfg2 (default) | cfg1 | cfg3 | cfg4 | cfg4p | cfg5")
     ap.add_argument("--states", type=int, default=0, help="override the per-GPU state count (cfg2/cfg5)")
     ap.add_argument("--periods", type=int, default=0, help="override the horizon")
     ap.add_argument("--kernel", type=int, default=0, help="0 auto, 1 gather, 2 window, 3 separable (opt-in, F1)")
@@ -59,6 +59,8 @@ def make_workload(args, world):
         return workloads.cfg5_scaled(S=per_gpu * world, **kw)
     if args.workload == "cfg4":  # weak scaling along the inventory axis of every preQ row
         return workloads.cfg4_leadtime(NX=(args.states or 1000) * world, **kw)
+    if args.workload == "cfg4p":  # the 3-D pipeline state (x, q1, q2): weak scaling along x
+        return workloads.cfg4_pipeline(NX=(args.states or 250) * world, **kw)
     if args.workload == "cfg3":  # weak scaling along the inventory axis (cash rows stay whole)
         return workloads.cfg3_cash(NX=(args.states or 200) * world, **kw)
     if world > 1:

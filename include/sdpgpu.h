@@ -63,7 +63,7 @@
 extern "C" {
 #endif
 
-#define SDPGPU_ABI_VERSION 1
+#define SDPGPU_ABI_VERSION 2
 
 /* status codes */
 #define SDPGPU_OK 0
@@ -77,7 +77,9 @@ typedef enum sdpgpu_family {
   /* state (x). CLSP.java:251-272, CLSPTesting.java:78-106, CLSPforDraw.java:86-103,
    * LevelFitsS.java:85-102.  Backorder, two-ternary clamp, imm on unclamped level. */
   SDPGPU_FAMILY_BACKORDER = 1,
-  /* state (x, preQ). Leadtime.java:50-81.  Lead time 1, order arrives next period. */
+  /* state (x, preQ). Leadtime.java:50-81.  Lead time 1, order arrives next period.  With
+   * desc.lead_time = 2 (a generalisation the reference does not have; BASELINE configs[3]) the state is
+   * (x, q1, q2): q1 arrives this period, q2 the next; x' = x + q1 - d, q1' = q2, q2' = action. */
   SDPGPU_FAMILY_LEADTIME = 2,
   /* state (x, cash). CashConstraint.java:95-133 (cash_formula 0) and
    * CashConstraintTesting.java:110-148 (cash_formula 1).  Lost sales, cash-limited orders. */
@@ -158,7 +160,10 @@ typedef struct sdpgpu_desc {
   int32_t rank;        /* state-axis slab owned by this handle: rank of world_size */
   int32_t world_size;  /* 1 = whole grid */
   int32_t store_all_values; /* 1: keep V_t for every t (values query); 0: two ping-pong tables */
-  int32_t reserved0;
+  int32_t lead_time;   /* LEADTIME family only: 0 or 1 = the reference's lead time 1 (Leadtime.java); 2 = two-stage
+                          pipeline, state (x, q1, q2), needs clamp_inventory = 1 */
+  double ini_preq2;    /* lead_time 2: q2 of the period-1 state (ini_preq is q1) */
+  double reserved1;
 } sdpgpu_desc;
 
 typedef struct sdpgpu_stats {
@@ -207,12 +212,17 @@ int64_t sdpgpu_num_states(const sdpgpu_handle* h, int32_t period);
 /* Padded row length of the V_t table (multiple of world_size) and this rank's slab [lo, hi). */
 int sdpgpu_slab(const sdpgpu_handle* h, int32_t period, int64_t* padded, int64_t* lo, int64_t* hi);
 /* Grid of period t: x = x_lo + i*step (i < nx); cash index ic < nc; preQ index iq < nq.
- * Flat index = (iq * nx + ix) * nc + ic. */
+ * Flat index = (iq * nx + ix) * nc + ic.  With lead_time 2 the pipeline axis is the pair
+ * iq = iq2 * nq1 + iq1 and sdpgpu_grid reports nq = nq1 * nq2; sdpgpu_grid2 reports both. */
 int sdpgpu_grid(const sdpgpu_handle* h, int32_t period, double* x_lo, int64_t* nx, int64_t* nc, int64_t* nq);
+int sdpgpu_grid2(const sdpgpu_handle* h, int32_t period, double* x_lo, int64_t* nx, int64_t* nc, int64_t* nq1,
+                 int64_t* nq2);
 /* Cash value of cash index ic (k / div, exactly the double the reference's rounding yields). */
 double sdpgpu_cash_value(const sdpgpu_handle* h, int64_t ic);
 /* Dense index of a state tuple in period t, or -1 if it is not a grid point. */
 int64_t sdpgpu_state_index(const sdpgpu_handle* h, int32_t period, double x, double cash, double preq);
+/* The same with the second pipeline quantity (lead_time 2; preq2 must be 0 otherwise). */
+int64_t sdpgpu_state_index2(const sdpgpu_handle* h, int32_t period, double x, double cash, double preq, double preq2);
 
 /* ---- solving ----------------------------------------------------------------------------- */
 /* Whole backward sweep t = T..1 on this handle (world_size must be 1).  Asynchronous on the
@@ -259,6 +269,9 @@ int sdpgpu_policy(sdpgpu_handle* h, int32_t period, int32_t* out, int64_t lo, in
 /* Evaluate arbitrary states of period t against V_{t+1}: out_value/out_action_index get n entries. */
 int sdpgpu_eval_states(sdpgpu_handle* h, int32_t period, int64_t n, const double* x, const double* cash,
                        const double* preq, double* out_value, int32_t* out_action_index);
+/* The same with the second pipeline quantity per state (lead_time 2; preq2 may be NULL = zeros). */
+int sdpgpu_eval_states2(sdpgpu_handle* h, int32_t period, int64_t n, const double* x, const double* cash,
+                        const double* preq, const double* preq2, double* out_value, int32_t* out_action_index);
 /* Reachable-set mask of period t (1 byte per state), forward-propagated from the ini_* state over
  * all feasible actions and all demands -- the key set the memoised recursion would build. */
 int sdpgpu_reachable(sdpgpu_handle* h, int32_t period, uint8_t* out, int64_t n);
@@ -270,7 +283,7 @@ int sdpgpu_reachable(sdpgpu_handle* h, int32_t period, uint8_t* out, int64_t n);
  * discount[t] multiplies the immediate value of period t+1 (Math.pow(discountFactor, t) in CashSimulation,
  * all 1.0 for the undiscounted classes).  out_sum[i] = sum_t discount[t] * imm_t; out_valid[i] = 0 when
  * the path left the grid (possible only for unclamped families with demands outside the PMF support).
- * The start state is (1, ini_x, ini_cash, ini_preq); world_size must be 1. */
+ * The start state is (1, ini_x, ini_cash, ini_preq[, desc.ini_preq2 with lead_time 2]); world_size must be 1. */
 int sdpgpu_simulate(sdpgpu_handle* h, int64_t n_paths, const double* demand, const double* discount, double ini_x,
                     double ini_cash, double ini_preq, double* out_sum, uint8_t* out_valid);
 

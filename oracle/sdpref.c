@@ -67,6 +67,8 @@ int32_t sdpref_java_d2i(double x) {
 typedef struct st {
   int32_t period;
   double x, cash, preq;
+  double preq2; /* lead_time 2 only (a generalisation the reference does not have): the order arriving
+                   next period; preq is the one arriving this period */
 } st_t;
 
 typedef struct ctx {
@@ -226,6 +228,7 @@ static void transition(const ctx_t* c, const st_t* s, double action, double rand
   out->period = s->period + 1;
   out->cash = 0;
   out->preq = 0;
+  out->preq2 = 0;
   switch (d->family) {
     case SDPGPU_FAMILY_BACKORDER: { /* CLSP.java:255-260 == CLSPTesting.java:89-94 */
       double nextInventory = s->x + action - randomDemand;
@@ -243,7 +246,12 @@ static void transition(const ctx_t* c, const st_t* s, double action, double rand
         nextInventory = nextInventory < d->min_inventory ? d->min_inventory : nextInventory;
       }
       out->x = nextInventory;
-      out->preq = action;
+      if (d->lead_time == 2) { /* synthetic two-stage pipeline (BASELINE configs[3]): the queue shifts by one */
+        out->preq = s->preq2;
+        out->preq2 = action;
+      } else {
+        out->preq = action;
+      }
       return;
     }
     case SDPGPU_FAMILY_CASH:       /* CashConstraint.java:122-133 */
@@ -362,6 +370,11 @@ int sdpref_layout(const sdpgpu_desc* d, const int32_t* pmf_off, const double* pm
     nc = k_hi - k_lo + 1;
   }
   if (has_preq(d->family)) nq = full_action_count(d);
+  int64_t nq1 = nq;
+  if (d->lead_time == 2) {
+    if (d->family != SDPGPU_FAMILY_LEADTIME || !d->clamp_inventory) return 4;
+    nq = nq1 * nq1;
+  }
   double lo = d->min_inventory, hi = d->max_inventory;
   if (!d->clamp_inventory) {
     if (d->family != SDPGPU_FAMILY_BACKORDER && d->family != SDPGPU_FAMILY_LEADTIME) return 4;
@@ -372,6 +385,7 @@ int sdpref_layout(const sdpgpu_desc* d, const int32_t* pmf_off, const double* pm
     g[t].nx = (int64_t)((hi - lo) / d->step) + 1;
     g[t].nc = nc;
     g[t].nq = nq;
+    g[t].nq1 = nq1;
     g[t].k_lo = k_lo;
     if (!d->clamp_inventory) { /* box of period t+2 grown over all actions and demands */
       double dmin = pmf_d[pmf_off[t]], dmax = dmin;
@@ -401,7 +415,13 @@ static int64_t index_of(const sdpgpu_desc* d, const sdpref_grid* g, const st_t* 
   if (has_preq(d->family)) {
     double qq = s->preq / d->step;
     iq = (int64_t)qq;
-    if ((double)iq != qq || iq < 0 || iq >= g->nq) return -1;
+    if ((double)iq != qq || iq < 0 || iq >= g->nq1) return -1;
+  }
+  if (d->lead_time == 2) {
+    double qq = s->preq2 / d->step;
+    int64_t iq2 = (int64_t)qq;
+    if ((double)iq2 != qq || iq2 < 0 || iq2 >= g->nq / g->nq1) return -1;
+    iq += iq2 * g->nq1;
   }
   return (iq * g->nx + ix) * g->nc + ic;
 }
@@ -413,7 +433,8 @@ static void state_of(const sdpgpu_desc* d, const sdpref_grid* g, int32_t period,
   s->period = period;
   s->x = g->x_lo + (double)ix * d->step;
   s->cash = has_cash(d->family) ? cash_of_key(d, g->k_lo + ic) : 0;
-  s->preq = has_preq(d->family) ? (double)iq * d->step : 0;
+  s->preq = has_preq(d->family) ? (double)(iq % g->nq1) * d->step : 0;
+  s->preq2 = (double)(iq / g->nq1) * d->step;
 }
 
 typedef struct dense_env {
@@ -536,8 +557,8 @@ int sdpref_solve(const sdpgpu_desc* d, const int32_t* pmf_off, const double* pmf
 
 int sdpref_eval_states(const sdpgpu_desc* d, const int32_t* pmf_off, const double* pmf_d, const double* pmf_p,
                        const double* overhead, int32_t period, const double* v_next, int64_t n,
-                       const double* x, const double* cash, const double* preq, double* out_value,
-                       int32_t* out_action) {
+                       const double* x, const double* cash, const double* preq, const double* preq2,
+                       double* out_value, int32_t* out_action) {
   if (period < 1 || period > d->periods) return 1;
   sdpref_grid* grids = (sdpref_grid*)malloc(sizeof(sdpref_grid) * (size_t)d->periods);
   int rc = sdpref_layout(d, pmf_off, pmf_d, grids);
@@ -545,7 +566,7 @@ int sdpref_eval_states(const sdpgpu_desc* d, const int32_t* pmf_off, const doubl
     ctx_t c = {d, pmf_off, pmf_d, pmf_p, overhead, d->periods};
     dense_env env = {d, period < d->periods ? &grids[period] : NULL, v_next, 0};
     for (int64_t i = 0; i < n; i++) {
-      st_t s = {period, x[i], cash ? cash[i] : 0, preq ? preq[i] : 0};
+      st_t s = {period, x[i], cash ? cash[i] : 0, preq ? preq[i] : 0, (preq2 && d->lead_time == 2) ? preq2[i] : 0};
       double val;
       int32_t bestk;
       eval_state(&c, &s, dense_look, &env, &val, NULL, &bestk, NULL);
@@ -578,7 +599,8 @@ int sdpref_simulate(const sdpgpu_desc* d, const int32_t* pmf_off, const double* 
   int32_t T = d->periods;
   for (int64_t i = 0; i < n_paths; i++) {
     double sum = 0;
-    st_t state = {1, ini_x, has_cash(d->family) ? ini_cash : 0, has_preq(d->family) ? ini_preq : 0};
+    st_t state = {1, ini_x, has_cash(d->family) ? ini_cash : 0, has_preq(d->family) ? ini_preq : 0,
+                  d->lead_time == 2 ? d->ini_preq2 : 0};
     int valid = 1;
     for (int32_t t = 0; t < T && valid; t++) {
       int64_t idx = index_of(d, &grids[t], &state);
@@ -627,7 +649,8 @@ int sdpref_reachable(const sdpgpu_desc* d, const int32_t* pmf_off, const double*
     const sdpref_grid* g = &grids[t];
     memset(mask + values_off[t], 0, (size_t)(g->nx * g->nc * g->nq));
   }
-  st_t ini = {1, d->ini_inventory, has_cash(d->family) ? d->ini_cash : 0, has_preq(d->family) ? d->ini_preq : 0};
+  st_t ini = {1, d->ini_inventory, has_cash(d->family) ? d->ini_cash : 0, has_preq(d->family) ? d->ini_preq : 0,
+              d->lead_time == 2 ? d->ini_preq2 : 0};
   int64_t i0 = index_of(d, &grids[0], &ini);
   for (int32_t period = 1; period <= T; period++) {
     const sdpref_grid* g = &grids[period - 1];
@@ -682,13 +705,14 @@ typedef struct memo {
 
 static uint64_t hash_st(const st_t* s) {
   uint64_t h = 1469598103934665603ull;
-  uint64_t w[4];
-  double x = s->x + 0.0, ca = s->cash + 0.0, pq = s->preq + 0.0; /* -0.0 -> +0.0 */
+  uint64_t w[5];
+  double x = s->x + 0.0, ca = s->cash + 0.0, pq = s->preq + 0.0, pq2 = s->preq2 + 0.0; /* -0.0 -> +0.0 */
   w[0] = (uint64_t)s->period;
   memcpy(&w[1], &x, 8);
   memcpy(&w[2], &ca, 8);
   memcpy(&w[3], &pq, 8);
-  for (int i = 0; i < 4; i++) {
+  memcpy(&w[4], &pq2, 8);
+  for (int i = 0; i < 5; i++) {
     h ^= w[i];
     h *= 1099511628211ull;
     h ^= h >> 29;
@@ -696,7 +720,7 @@ static uint64_t hash_st(const st_t* s) {
   return h;
 }
 static int eq_st(const st_t* a, const st_t* b) {
-  return a->period == b->period && a->x == b->x && a->cash == b->cash && a->preq == b->preq;
+  return a->period == b->period && a->x == b->x && a->cash == b->cash && a->preq == b->preq && a->preq2 == b->preq2;
 }
 
 static mentry* memo_find(memo_t* m, const st_t* s) {
@@ -736,7 +760,7 @@ static double memo_value(void* env, const st_t* s) {
 
 int sdpref_memo(const sdpgpu_desc* d, const int32_t* pmf_off, const double* pmf_d, const double* pmf_p,
                 const double* overhead, double* root_value, double* root_action, int64_t cap,
-                int32_t* out_period, double* out_x, double* out_cash, double* out_preq,
+                int32_t* out_period, double* out_x, double* out_cash, double* out_preq, double* out_preq2,
                 double* out_value, double* out_action, int64_t* n_out) {
   ctx_t c = {d, pmf_off, pmf_d, pmf_p, overhead, d->periods};
   memo_t m;
@@ -745,7 +769,8 @@ int sdpref_memo(const sdpgpu_desc* d, const int32_t* pmf_off, const double* pmf_
   m.n = 0;
   m.cells = 0;
   m.tab = (mentry*)calloc((size_t)m.cap, sizeof(mentry));
-  st_t ini = {1, d->ini_inventory, has_cash(d->family) ? d->ini_cash : 0, has_preq(d->family) ? d->ini_preq : 0};
+  st_t ini = {1, d->ini_inventory, has_cash(d->family) ? d->ini_cash : 0, has_preq(d->family) ? d->ini_preq : 0,
+              d->lead_time == 2 ? d->ini_preq2 : 0};
   double v = memo_value(&m, &ini);
   if (root_value) *root_value = v;
   if (root_action) *root_action = memo_find(&m, &ini)->action;
@@ -762,6 +787,7 @@ int sdpref_memo(const sdpgpu_desc* d, const int32_t* pmf_off, const double* pmf_
           out_x[k] = m.tab[i].key.x;
           out_cash[k] = m.tab[i].key.cash;
           out_preq[k] = m.tab[i].key.preq;
+          if (out_preq2) out_preq2[k] = m.tab[i].key.preq2;
           out_value[k] = m.tab[i].value;
           out_action[k] = m.tab[i].action;
           k++;

@@ -35,6 +35,7 @@ typedef struct sdpref_grid {
   double x_lo;
   int64_t nx, nc, nq;
   int64_t k_lo; /* cash key of cash index 0 */
+  int64_t nq1;  /* inner pipeline axis (== nq unless lead_time 2, where iq = iq2 * nq1 + iq1) */
 } sdpref_grid;
 
 /* pmf is passed flat: pmf_off[t]..pmf_off[t+1] index demand/prob of period t+1, t = 0..T-1.
@@ -59,14 +60,14 @@ int sdpref_period(const sdpgpu_desc* d, const int32_t* pmf_off, const double* pm
  * passes capacity `cap`; returns the number visited through *n_out, error if cap too small). */
 int sdpref_memo(const sdpgpu_desc* d, const int32_t* pmf_off, const double* pmf_d, const double* pmf_p,
                 const double* overhead, double* root_value, double* root_action, int64_t cap,
-                int32_t* out_period, double* out_x, double* out_cash, double* out_preq,
+                int32_t* out_period, double* out_x, double* out_cash, double* out_preq, double* out_preq2,
                 double* out_value, double* out_action, int64_t* n_out);
 
 /* Evaluate arbitrary states of `period` against a dense v_next table. */
 int sdpref_eval_states(const sdpgpu_desc* d, const int32_t* pmf_off, const double* pmf_d, const double* pmf_p,
                        const double* overhead, int32_t period, const double* v_next, int64_t n,
-                       const double* x, const double* cash, const double* preq, double* out_value,
-                       int32_t* out_action);
+                       const double* x, const double* cash, const double* preq, const double* preq2,
+                       double* out_value, int32_t* out_action);
 
 /* Policy rollout along demand paths (Simulation.java:59-69, CashSimulation.java:101-112). */
 int sdpref_simulate(const sdpgpu_desc* d, const int32_t* pmf_off, const double* pmf_d, const double* pmf_p,

@@ -33,7 +33,8 @@ def build(force: bool = False) -> str:
 
 
 class Grid(C.Structure):
-    _fields_ = [("x_lo", C.c_double), ("nx", C.c_int64), ("nc", C.c_int64), ("nq", C.c_int64), ("k_lo", C.c_int64)]
+    _fields_ = [("x_lo", C.c_double), ("nx", C.c_int64), ("nc", C.c_int64), ("nq", C.c_int64), ("k_lo", C.c_int64),
+                ("nq1", C.c_int64)]
 
 
 class MultiLead(C.Structure):
@@ -138,25 +139,27 @@ class Problem:
         """Literal memoised recursion from the ini_* state: dict with root value/action + visited states."""
         rv, ra, n = C.c_double(), C.c_double(), C.c_int64()
         per = np.zeros(cap, dtype=np.int32)
-        arrs = [np.zeros(cap, dtype=np.float64) for _ in range(5)]
+        arrs = [np.zeros(cap, dtype=np.float64) for _ in range(6)]
         rc = lib().sdpref_memo(*self._args(), C.byref(rv), C.byref(ra), C.c_int64(cap), per.ctypes.data_as(_IP),
                                *[_dp(a) for a in arrs], C.byref(n))
         if rc:
             raise RuntimeError(f"sdpref_memo failed: {rc} (visited {n.value})")
         k = n.value
         return {"value": rv.value, "action": ra.value, "n": k, "period": per[:k], "x": arrs[0][:k],
-                "cash": arrs[1][:k], "preq": arrs[2][:k], "values": arrs[3][:k], "actions": arrs[4][:k]}
+                "cash": arrs[1][:k], "preq": arrs[2][:k], "preq2": arrs[3][:k], "values": arrs[4][:k],
+                "actions": arrs[5][:k]}
 
-    def eval_states(self, period: int, v_next, x, cash=None, preq=None):
+    def eval_states(self, period: int, v_next, x, cash=None, preq=None, preq2=None):
         x = np.ascontiguousarray(x, dtype=np.float64)
         n = len(x)
         ca = None if cash is None else np.ascontiguousarray(cash, dtype=np.float64)
         pq = None if preq is None else np.ascontiguousarray(preq, dtype=np.float64)
+        pq2 = None if preq2 is None else np.ascontiguousarray(preq2, dtype=np.float64)
         vn = None if v_next is None else np.ascontiguousarray(v_next, dtype=np.float64)
         val = np.zeros(n, dtype=np.float64)
         act = np.zeros(n, dtype=np.int32)
         rc = lib().sdpref_eval_states(*self._args(), period, _dp(vn), C.c_int64(n), _dp(x), _dp(ca), _dp(pq),
-                                      _dp(val), act.ctypes.data_as(_IP))
+                                      _dp(pq2), _dp(val), act.ctypes.data_as(_IP))
         if rc:
             raise RuntimeError(f"sdpref_eval_states failed: {rc}")
         return val, act
@@ -200,8 +203,14 @@ class Problem:
             cash = k if d.cash_round_int_div else k / d.cash_round_div
         else:
             cash = np.zeros(len(idx))
-        preq = iq * d.step if d.family in (2, 5) else np.zeros(len(idx))
+        preq = (iq % g.nq1) * d.step if d.family in (2, 5) else np.zeros(len(idx))
         return x.astype(np.float64), cash.astype(np.float64), preq.astype(np.float64)
+
+    def preq2_array(self, period: int):
+        """q2 (the order arriving next period; lead_time 2 only) of every grid state, flat-index order."""
+        g = self.grids[period - 1]
+        idx = np.arange(g.nx * g.nc * g.nq)
+        return ((idx // (g.nc * g.nx)) // g.nq1 * self.desc.step).astype(np.float64)
 
 
 def kat_multilead(**kw):

@@ -12,7 +12,7 @@ import os
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libsdpgpu.so")
 
-SDPGPU_ABI_VERSION = 1
+SDPGPU_ABI_VERSION = 2
 
 FAMILY_BACKORDER = 1
 FAMILY_LEADTIME = 2
@@ -76,7 +76,9 @@ class SdpgpuDesc(C.Structure):
         ("rank", C.c_int32),
         ("world_size", C.c_int32),
         ("store_all_values", C.c_int32),
-        ("reserved0", C.c_int32),
+        ("lead_time", C.c_int32),
+        ("ini_preq2", C.c_double),
+        ("reserved1", C.c_double),
     ]
 
 
@@ -148,8 +150,10 @@ EXPORTS = {
     "sdpgpu_num_states": (C.c_int64, [_P, C.c_int32]),
     "sdpgpu_slab": (C.c_int, [_P, C.c_int32, _LP, _LP, _LP]),
     "sdpgpu_grid": (C.c_int, [_P, C.c_int32, _DP, _LP, _LP, _LP]),
+    "sdpgpu_grid2": (C.c_int, [_P, C.c_int32, _DP, _LP, _LP, _LP, _LP]),
     "sdpgpu_cash_value": (C.c_double, [_P, C.c_int64]),
     "sdpgpu_state_index": (C.c_int64, [_P, C.c_int32, C.c_double, C.c_double, C.c_double]),
+    "sdpgpu_state_index2": (C.c_int64, [_P, C.c_int32, C.c_double, C.c_double, C.c_double, C.c_double]),
     "sdpgpu_solve": (C.c_int, [_P, C.c_int32]),
     "sdpgpu_run_period": (C.c_int, [_P, C.c_int32]),
     "sdpgpu_run_period_part": (C.c_int, [_P, C.c_int32, C.c_int32]),
@@ -164,6 +168,7 @@ EXPORTS = {
     "sdpgpu_values": (C.c_int, [_P, C.c_int32, _DP, C.c_int64]),
     "sdpgpu_policy": (C.c_int, [_P, C.c_int32, _IP, C.c_int64, C.c_int64]),
     "sdpgpu_eval_states": (C.c_int, [_P, C.c_int32, C.c_int64, _DP, _DP, _DP, _DP, _IP]),
+    "sdpgpu_eval_states2": (C.c_int, [_P, C.c_int32, C.c_int64, _DP, _DP, _DP, _DP, _DP, _IP]),
     "sdpgpu_reachable": (C.c_int, [_P, C.c_int32, C.POINTER(C.c_uint8), C.c_int64]),
     "sdpgpu_simulate": (C.c_int, [_P, C.c_int64, _DP, _DP, C.c_double, C.c_double, C.c_double, _DP,
                                   C.POINTER(C.c_uint8)]),

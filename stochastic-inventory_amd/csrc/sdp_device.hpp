@@ -21,8 +21,9 @@ struct Grid {
   double x_lo;   // inventory value of ix = 0
   int64_t nx;    // inventory points
   int64_t nc;    // cash points (1 when the family has no cash axis)
-  int64_t nq;    // pipeline (preQ) points (1 when no lead time)
+  int64_t nq;    // pipeline (preQ) points (1 when no lead time); lead time 2: nq1 * nq2, iq = iq2 * nq1 + iq1
   int64_t k_lo;  // cash key of ic = 0
+  int64_t nq1;   // points of the inner pipeline axis (== nq unless lead time 2)
 };
 
 // Everything a period kernel needs, passed by value in the kernarg segment.
@@ -35,6 +36,8 @@ struct DevParams {
   int32_t cash_formula;
   int32_t cash_round_int_div;
   int32_t n_actions_full;  // (int)(maxOrderQuantity/step)+1, already 1 when zero_order_last_period hits
+  int32_t lead2;           // LEADTIME family with a two-stage pipeline (x, q1, q2)
+  int32_t pad0;
   double step, inv_step;
   double min_inventory, max_inventory;
   double max_order_quantity;
@@ -59,6 +62,7 @@ __device__ __forceinline__ double jround_d(double x) {
 
 struct StateT {
   double x, cash, preq;
+  double preq2 = 0;  // lead time 2: the order arriving next period
 };
 
 // getFeasibleActions.apply(state).length -- see n_actions() in oracle/sdpref.c for the citations.
@@ -116,7 +120,10 @@ __device__ __forceinline__ void action_setup(const DevParams& P, const StateT& s
     c.base = s.x + c.a;
   } else if constexpr (FAM == FAM_LEADTIME) {
     c.base = s.x + s.preq;
-    c.next_q_off = (int64_t)k * P.next.nx * P.next.nc;
+    if (P.lead2)  // next state (x', q1' = q2, q2' = action): plane iq' = k * nq1 + iq2
+      c.next_q_off = ((int64_t)k * P.next.nq1 + (int64_t)(s.preq2 * P.inv_step)) * P.next.nx;
+    else
+      c.next_q_off = (int64_t)k * P.next.nx * P.next.nc;
   } else if constexpr (FAM == FAM_CASH) {
     c.base = s.x + c.a;
     c.deposit = (s.cash - c.fixed - c.var) * P.one_plus_deposit;
@@ -221,8 +228,10 @@ __device__ __forceinline__ void decode_state(const DevParams& P, int64_t idx, St
   } else if constexpr (FAM == FAM_LEADTIME) {
     int64_t iq = idx / P.cur.nx;
     int64_t ix = idx - iq * P.cur.nx;
+    int64_t iq2 = iq / P.cur.nq1;  // 0 with lead time 1 (nq1 == nq)
     s.x = P.cur.x_lo + (double)ix * P.step;
-    s.preq = (double)iq * P.step;
+    s.preq = (double)(iq - iq2 * P.cur.nq1) * P.step;
+    s.preq2 = (double)iq2 * P.step;
   } else {
     int64_t ic = idx % P.cur.nc;
     int64_t r = idx / P.cur.nc;

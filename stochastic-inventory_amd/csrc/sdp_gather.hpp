@@ -34,6 +34,7 @@ struct QueryStates {
   const double* x;
   const double* cash;
   const double* preq;
+  const double* preq2;
 };
 
 template <int FAM, bool MAXDIR, int SX, bool QUERY>
@@ -65,6 +66,7 @@ __global__ __launch_bounds__(256) void gather_period_kernel(DevParams P, const d
     s.x = live ? q.x[idx] : 0.0;
     s.cash = (live && q.cash) ? q.cash[idx] : 0.0;
     s.preq = (live && q.preq) ? q.preq[idx] : 0.0;
+    s.preq2 = (live && q.preq2) ? q.preq2[idx] : 0.0;
   } else {
     decode_state<FAM>(P, live ? idx : lo, s);
   }
@@ -158,6 +160,7 @@ __global__ __launch_bounds__(256) void reach_kernel(DevParams P, const uint8_t* 
     s.x = q.x[idx];
     s.cash = q.cash ? q.cash[idx] : 0.0;
     s.preq = q.preq ? q.preq[idx] : 0.0;
+    s.preq2 = q.preq2 ? q.preq2[idx] : 0.0;
   } else {
     if (!mask_cur[idx]) return;
     decode_state<FAM>(P, idx, s);

@@ -304,6 +304,9 @@ struct RowParams {
   int32_t chunk_actions;
   int32_t n_tiles;      // tiles launched (a contiguous run of row tiles)
   int32_t tile0;        // first tile of the run (tile = iq * tiles_per_row + ix / 64)
+  int32_t nq1;          // inner pipeline axis: iq = iq2 * nq1 + iq1 (lead time 1: nq1 = nq, iq2 = 0)
+  int64_t plane_stride; // V_{t+1} elements between the planes of consecutive actions: nx(next), or nq1 * nx(next)
+                        // with lead time 2, where the plane of action k is row (k * nq1 + iq2)
   int64_t partial_stride;
 };
 
@@ -326,7 +329,10 @@ __global__ __launch_bounds__(256) void window_f2_kernel(RowParams W, const doubl
   const int iq = tile / W.tiles_per_row;
   const int ix0 = (tile - iq * W.tiles_per_row) * 64;
   const int kA = chunk * W.chunk_actions;
-  const int m_lo = ix0 + iq - W.d_pad;  // slot s <-> m = m_lo + s
+  const int iq2 = iq / W.nq1;
+  const int iq1 = iq - iq2 * W.nq1;     // the quantity arriving this period
+  const int m_lo = ix0 + iq1 - W.d_pad;  // slot s <-> m = m_lo + s
+  const int64_t row_off = (int64_t)iq2 * W.next_nx;
 
   for (int s = tid; s < span; s += 256) {
     double l = W.lev0 + (double)(m_lo + s) * W.step;
@@ -342,7 +348,7 @@ __global__ __launch_bounds__(256) void window_f2_kernel(RowParams W, const doubl
       int idx = m_lo + s + W.idx_off;
       idx = idx > W.next_last ? W.next_last : idx;
       idx = idx < 0 ? 0 : idx;
-      s_v[e] = v_next[(int64_t)k * W.next_nx + idx];
+      s_v[e] = v_next[(int64_t)k * W.plane_stride + row_off + idx];
     }
   }
   __syncthreads();

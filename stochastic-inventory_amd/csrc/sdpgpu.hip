@@ -172,6 +172,11 @@ int validate(const sdpgpu_desc& d) {
     if (d.cash_round_int_div && d.cash_round_div != std::floor(d.cash_round_div)) return fail(nullptr, SDPGPU_ERR_ARG, "integer cash divisor must be integral");
     if (std::fabs(d.min_cash * d.cash_round_mult) > 2.0e9 || std::fabs(d.max_cash * d.cash_round_mult) > 2.0e9) return fail(nullptr, SDPGPU_ERR_UNSUPPORTED, "cash keys exceed 32 bits");
   }
+  if (d.lead_time < 0 || d.lead_time > 2) return fail(nullptr, SDPGPU_ERR_ARG, "lead_time %d (0/1 = the reference's lead time 1, 2 = two-stage pipeline)", d.lead_time);
+  if (d.lead_time == 2) {
+    if (d.family != SDPGPU_FAMILY_LEADTIME) return fail(nullptr, SDPGPU_ERR_UNSUPPORTED, "lead_time 2 exists for the LEADTIME family only");
+    if (!d.clamp_inventory) return fail(nullptr, SDPGPU_ERR_UNSUPPORTED, "lead_time 2 needs clamp_inventory = 1");
+  }
   if ((d.family == SDPGPU_FAMILY_LEADTIME) && d.direction != SDPGPU_MIN) return fail(nullptr, SDPGPU_ERR_ARG, "LeadtimeRecursion is MIN only (LeadtimeRecursion.java:52,66)");
   if ((d.family == SDPGPU_FAMILY_CASH_LEADTIME) && d.direction != SDPGPU_MAX) return fail(nullptr, SDPGPU_ERR_ARG, "CashLeadtimeRecursion is MAX only (CashLeadtimeRecursion.java:53,70)");
   return SDPGPU_OK;
@@ -196,6 +201,8 @@ int layout(sdpgpu_handle* h) {
   }
   h->n_actions_full = full_action_count(d);
   if (has_preq(d.family)) nq = java_d2i(d.max_order_quantity / d.step) + 1;
+  const int64_t nq1 = nq;
+  if (d.lead_time == 2) nq = nq1 * nq1;  // (q1, q2): iq = iq2 * nq1 + iq1
   double lo = d.min_inventory, hi = d.max_inventory;
   if (!d.clamp_inventory) lo = hi = d.ini_inventory;
   size_t v_off = 0, pol_off = 0, pmf_off = 0;
@@ -206,6 +213,7 @@ int layout(sdpgpu_handle* h) {
     p.g.nx = (int64_t)((hi - lo) / d.step) + 1;
     p.g.nc = nc;
     p.g.nq = nq;
+    p.g.nq1 = nq1;
     p.g.k_lo = k_lo;
     if (p.g.nx >= 2147483647LL || nc >= 2147483647LL) return fail(h, SDPGPU_ERR_UNSUPPORTED, "axis longer than 2^31");
     p.S = p.g.nx * p.g.nc * p.g.nq;
@@ -298,6 +306,7 @@ DevParams make_params(const sdpgpu_handle* h, int period) {
   P.cash_formula = d.cash_formula;
   P.cash_round_int_div = d.cash_round_int_div;
   P.n_actions_full = h->n_actions_full;
+  P.lead2 = d.lead_time == 2;
   if (d.family == SDPGPU_FAMILY_CASH_LEADTIME && d.zero_order_last_period && period == h->T) P.n_actions_full = 1;
   P.step = d.step;
   P.inv_step = 1.0 / d.step;  // exact: step is a power of two
@@ -519,7 +528,7 @@ int run_period_impl(sdpgpu_handle* h, int period, int part = SDPGPU_PART_ALL) {
   } else {
     e = flush_pending(h);  // the gather kernel reads the final V_{t+1} row
     if (e == hipSuccess)
-      e = launch_gather<false>(P, v_next, v_cur, pol, pd, pp, p.lo, p.hi, sdp::QueryStates{nullptr, nullptr, nullptr}, h->stream);
+      e = launch_gather<false>(P, v_next, v_cur, pol, pd, pp, p.lo, p.hi, sdp::QueryStates{nullptr, nullptr, nullptr, nullptr}, h->stream);
     p.kernel_used = SDPGPU_KERNEL_GATHER;
   }
   if (e != hipSuccess) return fail(h, SDPGPU_ERR_DEVICE, "period %d kernel launch: %s", period, hipGetErrorString(e));
@@ -576,8 +585,9 @@ int compute_reachable(sdpgpu_handle* h) {
   if (!h->d_reach) HIP_TRY(h, hipMalloc((void**)&h->d_reach, std::max<size_t>(total, 1)));
   HIP_TRY(h, hipMemsetAsync(h->d_reach, 0, std::max<size_t>(total, 1), h->stream));
   const sdpgpu_desc& d = h->d;
-  double ini[3] = {d.ini_inventory, has_cash(d.family) ? d.ini_cash : 0.0, has_preq(d.family) ? d.ini_preq : 0.0};
-  int64_t i0 = sdpgpu_state_index(h, 1, ini[0], ini[1], ini[2]);
+  double ini[4] = {d.ini_inventory, has_cash(d.family) ? d.ini_cash : 0.0, has_preq(d.family) ? d.ini_preq : 0.0,
+                   d.lead_time == 2 ? d.ini_preq2 : 0.0};
+  int64_t i0 = sdpgpu_state_index2(h, 1, ini[0], ini[1], ini[2], ini[3]);
   if (i0 >= 0) {
     uint8_t one = 1;
     HIP_TRY(h, hipMemcpyAsync(h->d_reach + i0, &one, 1, hipMemcpyHostToDevice, h->stream));
@@ -592,9 +602,9 @@ int compute_reachable(sdpgpu_handle* h) {
     const double* pd = h->d_pmf + p.pmf_off;
     uint8_t* mnext = h->d_reach + h->reach_off[period];
     if (period == 1)
-      e = launch_reach(P, nullptr, mnext, pd, 1, sdp::QueryStates{d_ini, d_ini + 1, d_ini + 2}, true, h->stream);
+      e = launch_reach(P, nullptr, mnext, pd, 1, sdp::QueryStates{d_ini, d_ini + 1, d_ini + 2, d_ini + 3}, true, h->stream);
     else
-      e = launch_reach(P, h->d_reach + h->reach_off[period - 1], mnext, pd, p.S, sdp::QueryStates{nullptr, nullptr, nullptr}, false, h->stream);
+      e = launch_reach(P, h->d_reach + h->reach_off[period - 1], mnext, pd, p.S, sdp::QueryStates{nullptr, nullptr, nullptr, nullptr}, false, h->stream);
   }
   if (e == hipSuccess) e = hipStreamSynchronize(h->stream);
   (void)hipFree(d_ini);
@@ -873,6 +883,8 @@ hipError_t launch_row_window(sdpgpu_handle* h, const DevParams& P, int period, c
     W.next_nx = (int32_t)h->per[period].g.nx;
   }
   W.cur_nx = (int32_t)p.g.nx;
+  W.nq1 = (int32_t)p.g.nq1;
+  W.plane_stride = P.lead2 ? (int64_t)W.nq1 * W.next_nx : (int64_t)W.next_nx;
   W.tiles_per_row = (int32_t)((p.g.nx + 63) / 64);
   W.n_actions = A;
   W.d_pad = rup(D, R);
@@ -1305,7 +1317,8 @@ int sdpgpu_slab(const sdpgpu_handle* hc, int32_t period, int64_t* padded, int64_
   return SDPGPU_OK;
 }
 
-int sdpgpu_grid(const sdpgpu_handle* hc, int32_t period, double* x_lo, int64_t* nx, int64_t* nc, int64_t* nq) {
+int sdpgpu_grid2(const sdpgpu_handle* hc, int32_t period, double* x_lo, int64_t* nx, int64_t* nc, int64_t* nq1,
+                 int64_t* nq2) {
   sdpgpu_handle* h = const_cast<sdpgpu_handle*>(hc);
   if (!h) return SDPGPU_ERR_ARG;
   if (period < 1 || period > h->T) return fail(h, SDPGPU_ERR_ARG, "period %d", period);
@@ -1315,8 +1328,16 @@ int sdpgpu_grid(const sdpgpu_handle* hc, int32_t period, double* x_lo, int64_t* 
   if (x_lo) *x_lo = g.x_lo;
   if (nx) *nx = g.nx;
   if (nc) *nc = g.nc;
-  if (nq) *nq = g.nq;
+  if (nq1) *nq1 = g.nq1;
+  if (nq2) *nq2 = g.nq / g.nq1;
   return SDPGPU_OK;
+}
+
+int sdpgpu_grid(const sdpgpu_handle* hc, int32_t period, double* x_lo, int64_t* nx, int64_t* nc, int64_t* nq) {
+  int64_t q1 = 1, q2 = 1;
+  int rc = sdpgpu_grid2(hc, period, x_lo, nx, nc, &q1, &q2);
+  if (rc == SDPGPU_OK && nq) *nq = q1 * q2;
+  return rc;
 }
 
 double sdpgpu_cash_value(const sdpgpu_handle* hc, int64_t ic) {
@@ -1327,6 +1348,10 @@ double sdpgpu_cash_value(const sdpgpu_handle* hc, int64_t ic) {
 }
 
 int64_t sdpgpu_state_index(const sdpgpu_handle* hc, int32_t period, double x, double cash, double preq) {
+  return sdpgpu_state_index2(hc, period, x, cash, preq, 0.0);
+}
+
+int64_t sdpgpu_state_index2(const sdpgpu_handle* hc, int32_t period, double x, double cash, double preq, double preq2) {
   sdpgpu_handle* h = const_cast<sdpgpu_handle*>(hc);
   if (!h || period < 1 || period > h->T || layout(h)) return -1;
   const sdpgpu_desc& d = h->d;
@@ -1345,7 +1370,15 @@ int64_t sdpgpu_state_index(const sdpgpu_handle* hc, int32_t period, double x, do
   if (has_preq(d.family)) {
     double qq = preq / d.step;
     iq = (int64_t)qq;
-    if ((double)iq != qq || iq < 0 || iq >= g.nq) return -1;
+    if ((double)iq != qq || iq < 0 || iq >= g.nq1) return -1;
+  }
+  if (d.lead_time == 2) {
+    double qq = preq2 / d.step;
+    int64_t iq2 = (int64_t)qq;
+    if ((double)iq2 != qq || iq2 < 0 || iq2 >= g.nq / g.nq1) return -1;
+    iq += iq2 * g.nq1;
+  } else if (preq2 != 0.0) {
+    return -1;
   }
   return (iq * g.nx + ix) * g.nc + ic;
 }
@@ -1512,6 +1545,11 @@ int sdpgpu_policy(sdpgpu_handle* h, int32_t period, int32_t* out, int64_t lo, in
 
 int sdpgpu_eval_states(sdpgpu_handle* h, int32_t period, int64_t n, const double* x, const double* cash,
                        const double* preq, double* out_value, int32_t* out_action_index) {
+  return sdpgpu_eval_states2(h, period, n, x, cash, preq, nullptr, out_value, out_action_index);
+}
+
+int sdpgpu_eval_states2(sdpgpu_handle* h, int32_t period, int64_t n, const double* x, const double* cash,
+                        const double* preq, const double* preq2, double* out_value, int32_t* out_action_index) {
   if (!h) return SDPGPU_ERR_ARG;
   h->err.clear();
   if (period < 1 || period > h->T || n < 0 || !x || !out_value || !out_action_index) return fail(h, SDPGPU_ERR_ARG, "eval_states: bad argument");
@@ -1529,18 +1567,20 @@ int sdpgpu_eval_states(sdpgpu_handle* h, int32_t period, int64_t n, const double
   double* d_val = nullptr;
   int32_t* d_act = nullptr;
   size_t nn = (size_t)n;
-  HIP_TRY(h, hipMalloc((void**)&d_in, 3 * nn * sizeof(double)));
+  if (h->d.lead_time != 2) preq2 = nullptr;
+  HIP_TRY(h, hipMalloc((void**)&d_in, 4 * nn * sizeof(double)));
   hipError_t e = hipMalloc((void**)&d_val, nn * sizeof(double));
   if (e == hipSuccess) e = hipMalloc((void**)&d_act, nn * sizeof(int32_t));
   if (e == hipSuccess) e = hipMemcpy(d_in, x, nn * sizeof(double), hipMemcpyHostToDevice);
   if (e == hipSuccess && cash) e = hipMemcpy(d_in + nn, cash, nn * sizeof(double), hipMemcpyHostToDevice);
   if (e == hipSuccess && preq) e = hipMemcpy(d_in + 2 * nn, preq, nn * sizeof(double), hipMemcpyHostToDevice);
+  if (e == hipSuccess && preq2) e = hipMemcpy(d_in + 3 * nn, preq2, nn * sizeof(double), hipMemcpyHostToDevice);
   if (e == hipSuccess) {
     DevParams P = make_params(h, period);
     const PeriodInfo& p = h->per[period - 1];
     const double* v_next = period < h->T ? h->d_values + h->per[period].v_off : nullptr;
     const double* pd = h->d_pmf + p.pmf_off;
-    sdp::QueryStates q{d_in, cash ? d_in + nn : nullptr, preq ? d_in + 2 * nn : nullptr};
+    sdp::QueryStates q{d_in, cash ? d_in + nn : nullptr, preq ? d_in + 2 * nn : nullptr, preq2 ? d_in + 3 * nn : nullptr};
     e = launch_gather<true>(P, v_next, d_val, d_act, pd, pd + p.nD, 0, n, q, h->stream);
   }
   if (e == hipSuccess) e = hipStreamSynchronize(h->stream);
@@ -1582,11 +1622,12 @@ int sdpgpu_simulate(sdpgpu_handle* h, int64_t n_paths, const double* demand, con
   const int T = h->T;
   if (!has_cash(h->d.family)) ini_cash = 0;
   if (!has_preq(h->d.family)) ini_preq = 0;
-  int64_t idx0 = sdpgpu_state_index(h, 1, ini_x, ini_cash, ini_preq);
+  double ini_preq2 = h->d.lead_time == 2 ? h->d.ini_preq2 : 0.0;
+  int64_t idx0 = sdpgpu_state_index2(h, 1, ini_x, ini_cash, ini_preq, ini_preq2);
   int32_t first_k = 0;
   if (idx0 < 0) {
     double v;
-    rc = sdpgpu_eval_states(h, 1, 1, &ini_x, &ini_cash, &ini_preq, &v, &first_k);
+    rc = sdpgpu_eval_states2(h, 1, 1, &ini_x, &ini_cash, &ini_preq, &ini_preq2, &v, &first_k);
     if (rc) return rc;
   }
   try {
@@ -1609,7 +1650,7 @@ int sdpgpu_simulate(sdpgpu_handle* h, int64_t n_paths, const double* demand, con
     if (e == hipSuccess) e = hipMemcpy(d_dem, demand, nn * T * sizeof(double), hipMemcpyHostToDevice);
     if (e == hipSuccess) e = hipMemcpy(d_disc, discount, (size_t)T * sizeof(double), hipMemcpyHostToDevice);
     if (e == hipSuccess) {
-      sdp::StateT ini{ini_x, ini_cash, ini_preq};
+      sdp::StateT ini{ini_x, ini_cash, ini_preq, ini_preq2};
       dim3 grid((unsigned)((n_paths + 255) / 256));
 #define SDP_SIM(F)                                                                                                   \
   case F:                                                                                                            \

@@ -96,11 +96,19 @@ class SdpEngine:
         self._check(self._lib.sdpgpu_grid(self._h, period, C.byref(x_lo), C.byref(nx), C.byref(nc), C.byref(nq)))
         return x_lo.value, nx.value, nc.value, nq.value
 
+    def grid2(self, period: int):
+        """(x_lo, nx, nc, nq1, nq2): the pipeline axis split in two (lead_time 2), nq2 = 1 otherwise."""
+        x_lo = C.c_double()
+        nx, nc, q1, q2 = C.c_int64(), C.c_int64(), C.c_int64(), C.c_int64()
+        self._check(self._lib.sdpgpu_grid2(self._h, period, C.byref(x_lo), C.byref(nx), C.byref(nc), C.byref(q1),
+                                           C.byref(q2)))
+        return x_lo.value, nx.value, nc.value, q1.value, q2.value
+
     def cash_value(self, ic: int) -> float:
         return float(self._lib.sdpgpu_cash_value(self._h, ic))
 
-    def state_index(self, period: int, x: float, cash: float = 0.0, preq: float = 0.0) -> int:
-        return int(self._lib.sdpgpu_state_index(self._h, period, float(x), float(cash), float(preq)))
+    def state_index(self, period: int, x: float, cash: float = 0.0, preq: float = 0.0, preq2: float = 0.0) -> int:
+        return int(self._lib.sdpgpu_state_index2(self._h, period, float(x), float(cash), float(preq), float(preq2)))
 
     # -- execution --------------------------------------------------------------------------
     def set_stream(self, hip_stream: int):
@@ -163,17 +171,19 @@ class SdpEngine:
         self._check(self._lib.sdpgpu_policy(self._h, period, _ip(out), lo, hi - lo))
         return out
 
-    def eval_states(self, period: int, x, cash=None, preq=None):
+    def eval_states(self, period: int, x, cash=None, preq=None, preq2=None):
         x = np.ascontiguousarray(x, dtype=np.float64)
         n = len(x)
         cash_a = None if cash is None else np.ascontiguousarray(cash, dtype=np.float64)
         preq_a = None if preq is None else np.ascontiguousarray(preq, dtype=np.float64)
+        preq2_a = None if preq2 is None else np.ascontiguousarray(preq2, dtype=np.float64)
         val = np.empty(n, dtype=np.float64)
         act = np.empty(n, dtype=np.int32)
         self._check(
-            self._lib.sdpgpu_eval_states(
+            self._lib.sdpgpu_eval_states2(
                 self._h, period, n, _dp(x), None if cash_a is None else _dp(cash_a),
-                None if preq_a is None else _dp(preq_a), _dp(val), _ip(act)))
+                None if preq_a is None else _dp(preq_a), None if preq2_a is None else _dp(preq2_a), _dp(val),
+                _ip(act)))
         return val, act
 
     def reachable(self, period: int) -> np.ndarray:

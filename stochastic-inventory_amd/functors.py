@@ -108,7 +108,12 @@ class BackorderFunctor(_Base):
 
 @dataclass
 class LeadtimeFunctor(_Base):
-    """F2: Leadtime.java:50-81 (lead time 1; the inventory clamp is commented out there)."""
+    """F2: Leadtime.java:50-81 (lead time 1; the inventory clamp is commented out there).
+
+    leadTime = 2 is the synthetic two-stage pipeline of BASELINE configs[3] (the reference has lead time 1 only):
+    state (x, q1, q2), x' = x + q1 - d, q1' = q2, q2' = action; same cost terms.  It exists at the engine level
+    (SdpEngine / the C ABI); the reference-shaped LeadtimeRecursion mirror keeps the reference's two-field state.
+    """
 
     fixedOrderingCost: float = 0.0
     variOrderingCost: float = 0.0
@@ -121,6 +126,8 @@ class LeadtimeFunctor(_Base):
     maxInventory: float = 0.0
     iniInventory: float = 0.0
     iniPreQ: float = 0.0
+    leadTime: int = 1
+    iniPreQ2: float = 0.0
 
     state_type = LeadtimeState
 
@@ -134,6 +141,8 @@ class LeadtimeFunctor(_Base):
         d.fixed_order_cost, d.unit_order_cost = self.fixedOrderingCost, self.variOrderingCost
         d.holding_cost, d.penalty_cost = self.holdingCost, self.penaltyCost
         d.ini_inventory, d.ini_preq = self.iniInventory, self.iniPreQ
+        d.lead_time = int(self.leadTime)
+        d.ini_preq2 = self.iniPreQ2 if self.leadTime == 2 else 0.0
         return self._common(d, T, direction)
 
     def make_state(self, period, x, cash=0.0, preq=0.0):

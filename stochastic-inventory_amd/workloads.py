@@ -90,6 +90,18 @@ def cfg4_leadtime(T: int = 50, NX: int = 1000, A: int = 200, D: int = 100) -> Wo
                     "src/leadtime via LeadtimeRecursion")
 
 
+def cfg4_pipeline(T: int = 4, NX: int = 250, A: int = 200, D: int = 100) -> Workload:
+    """configs[3] as SURVEY.md section 8(d) lays it out: F2 generalised to lead time 2, 3-D state (x, q1, q2) with
+    x in [-50, 199] and q1, q2 in [0, 199] = 1e7 states per period, 200 actions, 100 demands (2e11 cells per
+    period), inventory clamped.  The reference has lead time 1 only (LeadtimeState.java:10-20): cfg4_leadtime is
+    its exact shape, this one the synthetic generalisation."""
+    f = LeadtimeFunctor(fixedOrderingCost=0, variOrderingCost=1, holdingCost=2, penaltyCost=10,
+                        maxOrderQuantity=A - 1, clampInventory=True, minInventory=-50,
+                        maxInventory=NX - 51, iniInventory=0, iniPreQ=0, leadTime=2, iniPreQ2=0)
+    return Workload(f"cfg4_pipeline_{NX}x{A}q1x{A}q2_{A}x{D}x{T}", f, OptDirection.MIN, seasonal_pmf(T, D),
+                    "src/leadtime generalised to a two-stage pipeline")
+
+
 def cfg5_scaled(S: int, T: int = 3, A: int = 500, D: int = 200) -> Workload:
     """configs[4] / the north-star target grid: F1 scaled to S states, 500 actions, 200 demands."""
     f = BackorderFunctor(fixedOrderingCost=500, variOrderingCost=1, holdingCost=2, penaltyCost=10,
@@ -98,7 +110,7 @@ def cfg5_scaled(S: int, T: int = 3, A: int = 500, D: int = 200) -> Workload:
 
 
 def by_name(name: str, **kw) -> Workload:
-    table = {"cfg1": cfg1_sS, "cfg2": cfg2_clsp, "cfg3": cfg3_cash, "cfg4": cfg4_leadtime}
+    table = {"cfg1": cfg1_sS, "cfg2": cfg2_clsp, "cfg3": cfg3_cash, "cfg4": cfg4_leadtime, "cfg4p": cfg4_pipeline}
     if name in table:
         return table[name](**kw)
     if name == "cfg5":

@@ -83,6 +83,15 @@ def f2_clamped(T=4):
     return Workload("f2_clamped", f, OptDirection.MIN, _pmf([4, 6, 3, 5][:T], 10))
 
 
+def f2_pipeline(T=4):
+    """Lead time 2 (BASELINE configs[3]'s 3-D pipeline state; the reference has lead time 1 only):
+    state (x, q1, q2), 36 x 7 x 7 states."""
+    f = LeadtimeFunctor(fixedOrderingCost=3, variOrderingCost=1, holdingCost=2, penaltyCost=10, maxOrderQuantity=6,
+                        clampInventory=True, minInventory=-10, maxInventory=25, iniInventory=2, iniPreQ=3,
+                        leadTime=2, iniPreQ2=1)
+    return Workload("f2_pipeline", f, OptDirection.MIN, _pmf([4, 6, 3, 5][:T], 10))
+
+
 def f3_tenths(T=3):
     """CashConstraint.java shape: cash rounded to tenths (Math.round(c*10)/10.0), fractional prices."""
     f = CashFunctor(price=2.3, fixOrderCost=1.2, variCost=0.7, holdingCost=0.1, depositeRate=0.01, overheadCost=0.5,
@@ -140,6 +149,6 @@ def f5_cash_leadtime(T=3):
     return Workload("f5_cash_leadtime", f, OptDirection.MAX, _pmf([3, 3, 3][:T], 6))
 
 
-ALL = [f1_small, f1_max, f1_gapped, f1_unclamped, f1_edge_single, f2_unclamped, f2_clamped, f3_tenths, f3_testing, f3_dyadic, f3_min_gamma,
+ALL = [f1_small, f1_max, f1_gapped, f1_unclamped, f1_edge_single, f2_unclamped, f2_clamped, f2_pipeline, f3_tenths, f3_testing, f3_dyadic, f3_min_gamma,
        f4_overdraft, f5_cash_leadtime]
 TINY = [f1_small, f1_max, f1_gapped, f1_unclamped, f2_unclamped, f3_testing, f3_min_gamma, f4_overdraft]

@@ -22,7 +22,7 @@ def lib(sia):
 def test_every_declared_symbol_is_exported(sia, lib):
     header = open(os.path.join(ROOT, "include", "sdpgpu.h")).read()
     header = re.sub(r"/\*.*?\*/", "", header, flags=re.S)
-    declared = set(re.findall(r"\b(sdpgpu_[a-z_]+)\s*\(", header))
+    declared = set(re.findall(r"\b(sdpgpu_[a-z0-9_]+)\s*\(", header))
     assert declared == set(sia._abi.EXPORTS), declared ^ set(sia._abi.EXPORTS)
     for name in declared:
         assert hasattr(lib, name)
@@ -46,7 +46,7 @@ def test_struct_layout_matches_the_header(sia, lib):
     assert int(out[0]) == C.sizeof(sia.SdpgpuDesc)
     assert [int(v) for v in out[1:-1]] == [getattr(sia.SdpgpuDesc, f).offset for f in fields]
     assert int(out[-1]) == C.sizeof(sia.SdpgpuStats)
-    assert d.abi_version == 1 and d.discount_factor == 1.0 and d.cash_round_div == 10.0 and d.world_size == 1
+    assert d.abi_version == 2 and d.discount_factor == 1.0 and d.cash_round_div == 10.0 and d.world_size == 1
 
 
 def test_create_rejects_bad_descriptors(sia, lib):
@@ -76,8 +76,10 @@ def test_layout_agrees_with_the_oracle(sia, oracle, make):
         assert eng.grid(period) == (g.x_lo, g.nx, g.nc, g.nq)
         assert eng.num_states(period) == P.S[period - 1]
         x, cash, preq = P.state_arrays(period)
+        preq2 = P.preq2_array(period)
+        assert eng.grid2(period) == (g.x_lo, g.nx, g.nc, g.nq1, g.nq // g.nq1)
         for idx in (0, len(x) // 3, len(x) - 1):
-            assert eng.state_index(period, x[idx], cash[idx], preq[idx]) == idx
+            assert eng.state_index(period, x[idx], cash[idx], preq[idx], preq2[idx]) == idx
             if g.nc > 1:
                 assert eng.cash_value(idx % g.nc) == cash[idx]
     assert eng.state_index(1, 0.5, 0.0, 0.0) == -1

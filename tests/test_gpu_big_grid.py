@@ -16,3 +16,11 @@ def test_1e8_state_grid_sampled_parity():
                          capture_output=True, text=True, timeout=600)
     assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-2000:]
     assert out.stdout.count("bit-identical") == 2
+
+
+def test_1e7_state_pipeline_grid_sampled_parity():
+    """configs[3] at full size: (x, q1, q2) = 250 x 200 x 200 states x 200 actions x 100 demands, 3 periods."""
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "pipeline_grid_check.py"), "3"],
+                         capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-2000:]
+    assert out.stdout.count("bit-identical") == 3

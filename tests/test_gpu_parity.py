@@ -94,6 +94,46 @@ def test_cfg4_shape_reduced(sia, oracle):
     eng.close()
 
 
+@pytest.mark.parametrize("kernel", [0, 1], ids=["auto", "gather"])
+def test_cfg4_pipeline_shape_reduced(sia, oracle, kernel):
+    """configs[3] as a two-stage pipeline (x, q1, q2) at 90 x 24 x 24 states (the full shape is 250 x 200 x 200)."""
+    from stochastic_inventory_amd import workloads
+    w = workloads.cfg4_pipeline(T=3, NX=90, A=24, D=30)
+    eng, P, V, pol, cells = _solve_both(sia, oracle, w, kernel)
+    assert eng.stats().cells_evaluated == cells == 3 * 90 * 24 * 24 * 24 * 30
+    assert eng.stats().kernel_used == (2 if kernel == 0 else 1)
+    for period in range(1, w.T + 1):
+        _assert_tables(eng.values(period), eng.policy(period), V[period - 1], pol[period - 1], f"cfg4p t={period}")
+    eng.close()
+
+
+def test_pipeline_eval_reachable_simulate(sia, oracle):
+    """Lead time 2: off-grid queries, the reachable set from (x, q1, q2) = (2, 3, 1) and the policy rollout."""
+    w = cases.f2_pipeline()
+    eng, P, V, pol, _ = _solve_both(sia, oracle, w)
+    rng = np.random.default_rng(11)
+    for period in (1, 2, w.T):
+        x, _, q1 = P.state_arrays(period)
+        q2 = P.preq2_array(period)
+        pick = rng.integers(0, len(x), size=53)
+        v_next = V[period] if period < w.T else None
+        ov, oa = P.eval_states(period, v_next, x[pick], None, q1[pick], q2[pick])
+        gv, ga = eng.eval_states(period, x[pick], None, q1[pick], q2[pick])
+        _assert_tables(gv, ga, ov, oa, f"pipeline eval t={period}")
+        assert np.array_equal(gv, V[period - 1][pick])
+    reach = P.reachable()
+    for period in range(1, w.T + 1):
+        assert np.array_equal(eng.reachable(period), reach[period - 1]), f"pipeline reach t={period}"
+    assert reach[1].sum() > 1 and reach[0].sum() == 1
+    dem = rng.integers(0, 10, size=(200, w.T)).astype(np.float64)
+    disc = np.ones(w.T)
+    f = w.functor
+    osum, ovalid = P.simulate(V, pol, dem, disc, f.iniInventory, 0.0, f.iniPreQ)
+    gsum, gvalid = eng.simulate(dem, disc, f.iniInventory, 0.0, f.iniPreQ)
+    assert np.array_equal(gsum, osum) and np.array_equal(gvalid, ovalid) and ovalid.all()
+    eng.close()
+
+
 @pytest.mark.parametrize("make", [cases.f1_small, cases.f3_tenths, cases.f5_cash_leadtime, cases.f2_unclamped],
                          ids=lambda f: f.__name__)
 def test_eval_states_off_grid(sia, oracle, make):
@@ -154,7 +194,8 @@ def test_ping_pong_tables(sia, oracle, make):
 
 @pytest.mark.parametrize("make,world", [(cases.f3_tenths, 3), (cases.f2_clamped, 3), (cases.f2_unclamped, 2),
                                         (cases.f1_small, 2), (cases.f1_clsp_main, 4), (cases.f1_unclamped, 2),
-                                        (cases.f3_testing, 3), (cases.f3_dyadic, 2), (cases.f5_cash_leadtime, 2)],
+                                        (cases.f3_testing, 3), (cases.f3_dyadic, 2), (cases.f5_cash_leadtime, 2),
+                                        (cases.f2_pipeline, 3)],
                          ids=lambda v: getattr(v, "__name__", str(v)))
 def test_sharded_periods_single_process(sia, oracle, make, world):
     """world_size N slabs driven from one process: each rank computes its slab into its own copy of

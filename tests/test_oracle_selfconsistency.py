@@ -25,7 +25,7 @@ def test_dense_equals_memoised_on_reachable_set(oracle, make):
     step = f.stepSize
     for i in range(m["n"]):
         period = int(m["period"][i])
-        idx = _index(P, period, m["x"][i], m["cash"][i], m["preq"][i])
+        idx = _index(P, period, m["x"][i], m["cash"][i], m["preq"][i], m["preq2"][i])
         if idx < 0:
             assert period == 1
             continue
@@ -38,10 +38,10 @@ def _ini_on_grid(P, w):
     x, c, q = w.functor.tuple_of(w.functor.make_state(1, getattr(w.functor, "iniInventory", 0.0),
                                                       getattr(w.functor, "iniCash", 0.0),
                                                       getattr(w.functor, "iniPreQ", 0.0)))
-    return _index(P, 1, x, c, q) >= 0
+    return _index(P, 1, x, c, q, getattr(w.functor, "iniPreQ2", 0.0)) >= 0
 
 
-def _index(P, period, x, cash, preq):
+def _index(P, period, x, cash, preq, preq2=0.0):
     g = P.grids[period - 1]
     d = P.desc
     ix = (x - g.x_lo) / d.step
@@ -58,8 +58,13 @@ def _index(P, period, x, cash, preq):
             return -1
     if d.family in (2, 5):
         iq = preq / d.step
-        if iq != int(iq) or not (0 <= iq < g.nq):
+        if iq != int(iq) or not (0 <= iq < g.nq1):
             return -1
+    if d.lead_time == 2:
+        iq2 = preq2 / d.step
+        if iq2 != int(iq2) or not (0 <= iq2 < g.nq // g.nq1):
+            return -1
+        iq += int(iq2) * g.nq1
     return int((int(iq) * g.nx + int(ix)) * g.nc + ic)
 
 
@@ -79,6 +84,45 @@ def test_c_oracle_equals_pure_python_translation(oracle, make):
         s = f.make_state(int(m["period"][i]), m["x"][i], m["cash"][i], m["preq"][i])
         assert cv[s] == m["values"][i]
         assert ca[s] == m["actions"][i]
+
+
+def test_pipeline_oracle_equals_pure_python_translation(oracle):
+    """Lead time 2 is a generalisation the reference does not have (its LeadtimeState carries one pipeline
+    quantity); the oracle's version of it is checked against a literal memoised recursion written here:
+    Leadtime.java:50-81's lambdas with the queue (q1, q2) shifting by one per period."""
+    import sys
+    w = cases.f2_pipeline(T=3)
+    f, pmf, T = w.functor, w.pmf, 3
+    cache, act = {}, {}
+
+    def value(t, x, q1, q2):
+        key = (t, x, q1, q2)
+        if key in cache:
+            return cache[key]
+        val, best = sys.float_info.max, 0.0
+        for k in range(int(f.maxOrderQuantity / f.stepSize) + 1):
+            a = k * f.stepSize
+            q = 0.0
+            for d, p in pmf[t - 1]:
+                level = x + q1 - d
+                fixed = f.fixedOrderingCost if a > 0 else 0.0
+                q += p * (fixed + f.variOrderingCost * a + f.holdingCost * max(level, 0.0) + f.penaltyCost * max(-level, 0.0))
+                if t < T:
+                    nx = f.maxInventory if level > f.maxInventory else level
+                    nx = f.minInventory if nx < f.minInventory else nx
+                    q += p * value(t + 1, nx, q2, a)
+            if q < val:
+                val, best = q, a
+        cache[key], act[key] = val, best
+        return val
+
+    root = value(1, f.iniInventory, f.iniPreQ, f.iniPreQ2)
+    m = _problem(oracle, w).memo()
+    assert m["value"] == root and m["n"] == len(cache)
+    assert m["action"] == act[(1, f.iniInventory, f.iniPreQ, f.iniPreQ2)]
+    for i in range(m["n"]):
+        key = (int(m["period"][i]), m["x"][i], m["preq"][i], m["preq2"][i])
+        assert cache[key] == m["values"][i] and act[key] == m["actions"][i]
 
 
 def test_hand_computed_one_period(oracle):
