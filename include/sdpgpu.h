@@ -24,7 +24,8 @@
  *                            in-scope drivers close over (see sdpgpu_desc).
  *   sdpgpu_set_pmf           the `double[][][] pmf` constructor argument
  *                            (Recursion.java:38,54): pmf[t][j] = {demand, prob}.
- *   sdpgpu_solve             the first `getExpectedValue(initialState)` call
+ *                            Also RiskRecursion.java:31-46 (family SURVIVAL).
+ *   sdpgpu_solve             the first `getExpectedValue(initialState)` / `getSurvProb(initialState)` call
  *                            (Recursion.java:89-163, CLSP.java:88-138,
  *                            LeadtimeRecursion.java:47-75, CashRecursion.java:79-140,
  *                            CashLeadtimeRecursion.java:48-79): fills the value and
@@ -87,7 +88,13 @@ typedef enum sdpgpu_family {
   /* state (x, cash). CashOverdraft.java:72-118.  Piecewise overdraft interest. */
   SDPGPU_FAMILY_OVERDRAFT = 4,
   /* state (x, cash, preQ). SingleProductLeadtime.java:72-119. */
-  SDPGPU_FAMILY_CASH_LEADTIME = 5
+  SDPGPU_FAMILY_CASH_LEADTIME = 5,
+  /* state (x, cash). The survival-probability recursion: RiskRecursion.getSurvProb (RiskRecursion.java:65-108)
+   * == CashRecursion.getSurvProb (CashRecursion.java:143-194, which also multiplies by discount_factor) with the
+   * lambdas of cashSurvival.java:98-143: orders limited by cash / variCost, no penalty term.  The value is
+   * P(final cash >= 0 and no negative cash on the way) under the best policy, MAX only; a successor with
+   * negative cash contributes 0 and is not visited. */
+  SDPGPU_FAMILY_SURVIVAL = 6
 } sdpgpu_family;
 
 /* OptDirection, Recursion.java:44-47 / CashRecursion.java:34-37. */

@@ -86,7 +86,7 @@ static double overhead_at(const ctx_t* c, int32_t period) {
 
 static int has_cash(int family) {
   return family == SDPGPU_FAMILY_CASH || family == SDPGPU_FAMILY_OVERDRAFT ||
-         family == SDPGPU_FAMILY_CASH_LEADTIME;
+         family == SDPGPU_FAMILY_CASH_LEADTIME || family == SDPGPU_FAMILY_SURVIVAL;
 }
 static int has_preq(int family) {
   return family == SDPGPU_FAMILY_LEADTIME || family == SDPGPU_FAMILY_CASH_LEADTIME;
@@ -113,6 +113,11 @@ static int32_t n_actions(const ctx_t* c, const st_t* s) {
     }
     case SDPGPU_FAMILY_OVERDRAFT: /* CashOverdraft.java:72-75 */
       return jd2i(d->max_order_quantity) + 1;
+    case SDPGPU_FAMILY_SURVIVAL: { /* cashSurvival.java:98-105 (bankruptBefore is always false, RiskState.java:17) */
+      double maxQ = jmin(s->cash / d->unit_order_cost, d->max_order_quantity);
+      maxQ = jmax(maxQ, 0);
+      return jd2i(maxQ) + 1; /* limit((int) maxQ + 1) */
+    }
     case SDPGPU_FAMILY_CASH_LEADTIME: { /* SingleProductLeadtime.java:72-77 */
       double maxQ = d->max_order_quantity;
       if (d->zero_order_last_period && s->period == c->T) maxQ = 0;
@@ -182,6 +187,18 @@ static double imm_value(const ctx_t* c, const st_t* s, double action, double ran
       if (endCash < 0) {
         cashIncrement += d->penalty_cost * endCash;
       }
+      return cashIncrement;
+    }
+    case SDPGPU_FAMILY_SURVIVAL: { /* cashSurvival.java:112-125 */
+      double revenue = d->price * jmin(s->x + action, randomDemand);
+      double fixedCost = action > 0 ? d->fixed_order_cost : 0;
+      double variableCost = d->unit_order_cost * action;
+      double deposite = (s->cash - fixedCost - variableCost) * (1 + d->deposit_rate);
+      double inventoryLevel = s->x + action - randomDemand;
+      double holdCosts = d->holding_cost * jmax(inventoryLevel, 0);
+      double cashIncrement = revenue + deposite - holdCosts - overhead_at(c, s->period) - s->cash;
+      double salValue = s->period == c->T ? d->salvage_value * jmax(inventoryLevel, 0) : 0;
+      cashIncrement += salValue;
       return cashIncrement;
     }
     case SDPGPU_FAMILY_OVERDRAFT: { /* CashOverdraft.java:80-104 */
@@ -255,6 +272,7 @@ static void transition(const ctx_t* c, const st_t* s, double action, double rand
       return;
     }
     case SDPGPU_FAMILY_CASH:       /* CashConstraint.java:122-133 */
+    case SDPGPU_FAMILY_SURVIVAL:   /* cashSurvival.java:128-143 (same statements; `Math.round(nextCash * 1) / 1`) */
     case SDPGPU_FAMILY_OVERDRAFT: { /* CashOverdraft.java:107-118 */
       double nextInventory = jmax(0, s->x + action - randomDemand);
       double nextCash = s->cash + imm_value(c, s, action, randomDemand);
@@ -304,6 +322,45 @@ static void eval_state(const ctx_t* c, const st_t* s, vlook_fn vlook, void* env,
   double val = maxdir ? -DBL_MAX : DBL_MAX; /* Recursion.java:132-133 */
   double bestOrderQty = 0;                  /* Recursion.java:134 */
   int32_t bestk = 0;
+  if (d->family == SDPGPU_FAMILY_SURVIVAL) {
+    /* RiskRecursion.getSurvProb, RiskRecursion.java:65-108 (== CashRecursion.java:143-194, whose line 174 also
+     * multiplies by discountFactor: p * 1.0 == p, so discount_factor = 1 is RiskRecursion exactly). */
+    val = -DBL_MAX; /* :70 */
+    for (int32_t i = 0; i < nA; i++) {
+      double orderQty = action_value(c, i);
+      double thisQProb = 0;
+      for (int32_t j = 0; j < n; j++) {
+        double randomDemand = dem[j];
+        double dProb = prob[j];
+        if (s->period == c->T) { /* :82-86 */
+          double thisDFinalCash = s->cash + imm_value(c, s, orderQty, randomDemand);
+          double thisDProb = thisDFinalCash >= 0 ? 1 : 0;
+          thisQProb += dProb * thisDProb;
+        }
+        if (s->period < c->T) { /* :87-97 */
+          st_t newState;
+          transition(c, s, orderQty, dem[j], &newState);
+          double thisDProb = 0;
+          if (newState.cash < 0) {
+            thisDProb = 0;
+          } else {
+            thisDProb = vlook(env, &newState);
+          }
+          thisQProb += prob[j] * d->discount_factor * thisDProb;
+        }
+      }
+      if (thisQProb > val) { /* :101-104 */
+        val = thisQProb;
+        bestOrderQty = orderQty;
+        bestk = i;
+      }
+    }
+    if (cells) *cells += (int64_t)nA * n;
+    *val_out = val;
+    if (best_out) *best_out = bestOrderQty;
+    if (bestk_out) *bestk_out = bestk;
+    return;
+  }
   for (int32_t i = 0; i < nA; i++) {
     double orderQty = action_value(c, i);
     double thisQValue = 0;
@@ -597,6 +654,10 @@ int sdpref_simulate(const sdpgpu_desc* d, const int32_t* pmf_off, const double* 
   }
   ctx_t c = {d, pmf_off, pmf_d, pmf_p, overhead, d->periods};
   int32_t T = d->periods;
+  if (d->family == SDPGPU_FAMILY_SURVIVAL) { /* RiskSimulation is a different loop; not restated */
+    free(grids);
+    return 4;
+  }
   for (int64_t i = 0; i < n_paths; i++) {
     double sum = 0;
     st_t state = {1, ini_x, has_cash(d->family) ? ini_cash : 0, has_preq(d->family) ? ini_preq : 0,
@@ -672,6 +733,7 @@ int sdpref_reachable(const sdpgpu_desc* d, const int32_t* pmf_off, const double*
         for (int32_t j = 0; j < n; j++) {
           st_t nx;
           transition(&c, &s, action_value(&c, i), pmf_d[pmf_off[period - 1] + j], &nx);
+          if (d->family == SDPGPU_FAMILY_SURVIVAL && nx.cash < 0) continue; /* RiskRecursion.java:90-92: not visited */
           int64_t ni = index_of(d, &grids[period], &nx);
           if (ni < 0) {
             free(grids);

@@ -198,7 +198,7 @@ class Problem:
         ix = (idx // g.nc) % g.nx
         iq = idx // (g.nc * g.nx)
         x = g.x_lo + ix * d.step
-        if d.family in (3, 4, 5):
+        if d.family in (3, 4, 5, 6):
             k = (g.k_lo + ic).astype(np.float64)
             cash = k if d.cash_round_int_div else k / d.cash_round_div
         else:

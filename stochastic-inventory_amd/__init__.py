@@ -6,21 +6,21 @@ The directory name carries a hyphen (it is fixed by the build contract); import 
 """
 from . import _abi
 from ._abi import (FAMILY_BACKORDER, FAMILY_CASH, FAMILY_CASH_LEADTIME, FAMILY_LEADTIME, FAMILY_OVERDRAFT,
-                   KERNEL_AUTO, KERNEL_GATHER, KERNEL_WINDOW, SdpgpuDesc, SdpgpuError, SdpgpuStats, desc_defaults)
+                   FAMILY_SURVIVAL,                   KERNEL_AUTO, KERNEL_GATHER, KERNEL_WINDOW, SdpgpuDesc, SdpgpuError, SdpgpuStats, desc_defaults)
 from .engine import SdpEngine
 from .functors import (BackorderFunctor, CashFunctor, CashLeadtimeFunctor, LeadtimeFunctor, OverdraftFunctor,
-                       java_round)
+                       SurvivalFunctor, java_round)
 from .multiitem import MultiLeadResult, multilead_solve
 from .pmf import DiscreteDistribution, GetPmf, NormalDist, PoissonDist, UniformIntDist
-from .recursion import CLSP, CashLeadtimeRecursion, CashRecursion, LeadtimeRecursion, Recursion
+from .recursion import CLSP, CashLeadtimeRecursion, CashRecursion, LeadtimeRecursion, Recursion, RiskRecursion
 from .simulation import Sampling, Simulation
-from .states import CashLeadtimeState, CashState, LeadtimeState, OptDirection, State
+from .states import CashLeadtimeState, CashState, LeadtimeState, OptDirection, RiskState, State
 
 __all__ = [
     "SdpEngine", "SdpgpuDesc", "SdpgpuError", "SdpgpuStats", "desc_defaults",
-    "BackorderFunctor", "LeadtimeFunctor", "CashFunctor", "OverdraftFunctor", "CashLeadtimeFunctor",
-    "Recursion", "CLSP", "LeadtimeRecursion", "CashRecursion", "CashLeadtimeRecursion",
+    "BackorderFunctor", "LeadtimeFunctor", "CashFunctor", "OverdraftFunctor", "CashLeadtimeFunctor", "SurvivalFunctor",
+    "Recursion", "CLSP", "LeadtimeRecursion", "CashRecursion", "CashLeadtimeRecursion", "RiskRecursion",
     "multilead_solve", "MultiLeadResult",
     "GetPmf", "PoissonDist", "NormalDist", "UniformIntDist", "DiscreteDistribution", "Simulation", "Sampling",
-    "State", "LeadtimeState", "CashState", "CashLeadtimeState", "OptDirection", "java_round",
+    "State", "LeadtimeState", "CashState", "CashLeadtimeState", "RiskState", "OptDirection", "java_round",
 ]

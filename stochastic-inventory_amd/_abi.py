@@ -19,6 +19,7 @@ FAMILY_LEADTIME = 2
 FAMILY_CASH = 3
 FAMILY_OVERDRAFT = 4
 FAMILY_CASH_LEADTIME = 5
+FAMILY_SURVIVAL = 6
 
 MIN = 0
 MAX = 1
@@ -190,6 +191,30 @@ class SdpgpuError(RuntimeError):
         self.message = message
 
 
+def _share_hip_runtime_with_torch():
+    """One HIP runtime per process.  libsdpgpu.so needs `libamdhip64.so.7` (the system ROCm's); PyTorch's
+    libraries need the unversioned `libamdhip64.so` and find their own bundled copy through RPATH.  If this
+    library is loaded first the process ends up with two runtimes and the second one to initialise sees no
+    GPU ("No HIP GPUs are available").  Loading PyTorch's copy first (when PyTorch is installed; it is not
+    imported here) makes both resolve to the same object, because its SONAME is libamdhip64.so.7."""
+    import importlib.util
+    import sys
+    if "torch" in sys.modules:
+        return  # already loaded: our DT_NEEDED resolves to it by SONAME
+    try:
+        spec = importlib.util.find_spec("torch")
+    except (ImportError, ValueError):
+        spec = None
+    if spec is None or not spec.origin:
+        return
+    cand = os.path.join(os.path.dirname(spec.origin), "lib", "libamdhip64.so")
+    if os.path.exists(cand):
+        try:
+            C.CDLL(cand, mode=C.RTLD_GLOBAL)
+        except OSError:
+            pass  # fall back to the system runtime
+
+
 def load():
     """Load libsdpgpu.so and type every export.  Raises if the extension is not built."""
     global _lib
@@ -200,6 +225,7 @@ def load():
             f"{LIB_PATH} is missing: build the HIP extension first "
             "(python -c 'import __graft_entry__ as g; g.build()'); there is no CPU fallback"
         )
+    _share_hip_runtime_with_torch()
     lib = C.CDLL(LIB_PATH)
     for name, (res, args) in EXPORTS.items():
         fn = getattr(lib, name)  # AttributeError if the library lacks a declared symbol

@@ -16,6 +16,7 @@ constexpr int FAM_LEADTIME = 2;
 constexpr int FAM_CASH = 3;
 constexpr int FAM_OVERDRAFT = 4;
 constexpr int FAM_CASH_LEADTIME = 5;
+constexpr int FAM_SURVIVAL = 6;  // RiskRecursion.getSurvProb over the lambdas of cashSurvival.java
 
 struct Grid {
   double x_lo;   // inventory value of ix = 0
@@ -73,6 +74,11 @@ __device__ __forceinline__ int n_actions(const DevParams& P, const StateT& s) {
     double m = jmin(P.max_order_quantity, jmax(0.0, (s.cash - P.overhead - P.K) / P.v));
     int mq = (m != m) ? 0 : (int)m;  // Java (int)NaN == 0
     return mq + 1;
+  } else if constexpr (FAM == FAM_SURVIVAL) {
+    // cashSurvival.java:98-105: maxQ = Math.min(cash / variCost, maxOrderQuantity); maxQ = Math.max(maxQ, 0)
+    double m = jmax(jmin(s.cash / P.v, P.max_order_quantity), 0.0);
+    int mq = (m != m) ? 0 : (int)m;
+    return mq + 1;
   } else {
     return P.n_actions_full;
   }
@@ -124,7 +130,7 @@ __device__ __forceinline__ void action_setup(const DevParams& P, const StateT& s
       c.next_q_off = ((int64_t)k * P.next.nq1 + (int64_t)(s.preq2 * P.inv_step)) * P.next.nx;
     else
       c.next_q_off = (int64_t)k * P.next.nx * P.next.nc;
-  } else if constexpr (FAM == FAM_CASH) {
+  } else if constexpr (FAM == FAM_CASH || FAM == FAM_SURVIVAL) {
     c.base = s.x + c.a;
     c.deposit = (s.cash - c.fixed - c.var) * P.one_plus_deposit;
   } else if constexpr (FAM == FAM_OVERDRAFT) {
@@ -197,6 +203,25 @@ __device__ __forceinline__ double cell(const DevParams& P, const StateT& s, cons
       ninv = ninv > P.max_inventory ? P.max_inventory : ninv;
       ninv = ninv < P.min_inventory ? P.min_inventory : ninv;
       next_idx = (int64_t)inv_index(P, ninv) * P.next.nc + cash_index(P, ncash);
+    }
+    return inc;
+  } else if constexpr (FAM == FAM_SURVIVAL) {
+    // cashSurvival.java:112-125 (immediate value) and :128-143 (transition)
+    double revenue = P.price * jmin(c.base, d);
+    double level = c.base - d;
+    double hold = P.h * jmax(level, 0.0);
+    double inc = revenue + c.deposit - hold - P.overhead - s.cash;
+    double sal = is_last ? P.salvage * jmax(level, 0.0) : 0.0;
+    inc += sal;
+    if (!is_last) {
+      double ninv = jmax(0.0, level);
+      double ncash = s.cash + inc;
+      ninv = ninv > P.max_inventory ? P.max_inventory : ninv;
+      ninv = ninv < P.min_inventory ? P.min_inventory : ninv;
+      const int ci = cash_index(P, ncash);
+      // RiskRecursion.java:90-92: a successor with negative cash is worth 0 and is never visited.  The rounded
+      // cash is negative exactly when its integer key is.
+      next_idx = (int64_t)ci + P.next.k_lo < 0 ? -1 : (int64_t)inv_index(P, ninv) * P.next.nc + ci;
     }
     return inc;
   } else {

@@ -79,7 +79,24 @@ __global__ __launch_bounds__(256) void gather_period_kernel(DevParams P, const d
     ActionCtx c;
     action_setup<FAM>(P, s, k, c);
     double acc = 0.0;
-    if (P.is_last) {
+    if constexpr (FAM == FAM_SURVIVAL) {
+      // RiskRecursion.java:78-98: probability of ending with non-negative cash
+      if (P.is_last) {
+        for (int j = 0; j < nD; ++j) {
+          double2 dp = s_pmf[j];
+          int64_t ni;
+          double fin = s.cash + cell<FAM, 1>(P, s, c, dp.x, ni);
+          acc += dp.y * (fin >= 0 ? 1.0 : 0.0);
+        }
+      } else {
+        for (int j = 0; j < nD; ++j) {
+          double2 dp = s_pmf[j];
+          int64_t ni = 0;
+          (void)cell<FAM, 0>(P, s, c, dp.x, ni);
+          acc += (dp.y * P.gamma) * (ni < 0 ? 0.0 : v_next[ni]);
+        }
+      }
+    } else if (P.is_last) {
       for (int j = 0; j < nD; ++j) {
         double2 dp = s_pmf[j];
         int64_t ni;
@@ -172,7 +189,7 @@ __global__ __launch_bounds__(256) void reach_kernel(DevParams P, const uint8_t* 
     for (int j = 0; j < P.n_demand; ++j) {
       int64_t ni = 0;
       (void)cell<FAM>(P, s, c, pmf_d[j], ni);
-      mask_next[ni] = 1;
+      if (ni >= 0) mask_next[ni] = 1;  // (negative only in the survival family: bankrupt successors are not visited)
     }
   }
 }

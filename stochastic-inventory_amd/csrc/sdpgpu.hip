@@ -122,7 +122,10 @@ int fail(sdpgpu_handle* h, int code, const char* fmt, ...) {
     if (e_ != hipSuccess) return fail(h, SDPGPU_ERR_DEVICE, "%s: %s", #expr, hipGetErrorString(e_)); \
   } while (0)
 
-bool has_cash(int f) { return f == SDPGPU_FAMILY_CASH || f == SDPGPU_FAMILY_OVERDRAFT || f == SDPGPU_FAMILY_CASH_LEADTIME; }
+bool has_cash(int f) {
+  return f == SDPGPU_FAMILY_CASH || f == SDPGPU_FAMILY_OVERDRAFT || f == SDPGPU_FAMILY_CASH_LEADTIME ||
+         f == SDPGPU_FAMILY_SURVIVAL;
+}
 bool has_preq(int f) { return f == SDPGPU_FAMILY_LEADTIME || f == SDPGPU_FAMILY_CASH_LEADTIME; }
 
 // Java semantics needed on the host for the layout only.
@@ -152,7 +155,7 @@ bool is_pow2_int(double s) {
 
 int validate(const sdpgpu_desc& d) {
   if (d.abi_version != SDPGPU_ABI_VERSION) return fail(nullptr, SDPGPU_ERR_ARG, "abi_version %d != %d", d.abi_version, SDPGPU_ABI_VERSION);
-  if (d.family < 1 || d.family > 5) return fail(nullptr, SDPGPU_ERR_ARG, "unknown family %d", d.family);
+  if (d.family < 1 || d.family > 6) return fail(nullptr, SDPGPU_ERR_ARG, "unknown family %d", d.family);
   if (d.direction != SDPGPU_MIN && d.direction != SDPGPU_MAX) return fail(nullptr, SDPGPU_ERR_ARG, "bad direction %d", d.direction);
   if (d.periods < 1 || d.periods > 4096) return fail(nullptr, SDPGPU_ERR_ARG, "periods %d out of range", d.periods);
   if (!is_pow2_int(d.step)) return fail(nullptr, SDPGPU_ERR_UNSUPPORTED, "step %g: only power-of-two integer step sizes are supported (every in-scope driver uses 1)", d.step);
@@ -178,6 +181,7 @@ int validate(const sdpgpu_desc& d) {
     if (!d.clamp_inventory) return fail(nullptr, SDPGPU_ERR_UNSUPPORTED, "lead_time 2 needs clamp_inventory = 1");
   }
   if ((d.family == SDPGPU_FAMILY_LEADTIME) && d.direction != SDPGPU_MIN) return fail(nullptr, SDPGPU_ERR_ARG, "LeadtimeRecursion is MIN only (LeadtimeRecursion.java:52,66)");
+  if ((d.family == SDPGPU_FAMILY_SURVIVAL) && d.direction != SDPGPU_MAX) return fail(nullptr, SDPGPU_ERR_ARG, "getSurvProb maximises (RiskRecursion.java:70,101)");
   if ((d.family == SDPGPU_FAMILY_CASH_LEADTIME) && d.direction != SDPGPU_MAX) return fail(nullptr, SDPGPU_ERR_ARG, "CashLeadtimeRecursion is MAX only (CashLeadtimeRecursion.java:53,70)");
   return SDPGPU_OK;
 }
@@ -324,7 +328,7 @@ DevParams make_params(const sdpgpu_handle* h, int period) {
   P.one_minus_overhead_rate = 1 - d.overhead_rate;
   // Recursion / LeadtimeRecursion / CashLeadtimeRecursion have no discount (p * V); p * 1.0 == p
   // exactly, so one code path serves both loop shapes.
-  bool cash_loop = d.family == SDPGPU_FAMILY_CASH || d.family == SDPGPU_FAMILY_OVERDRAFT;
+  bool cash_loop = d.family == SDPGPU_FAMILY_CASH || d.family == SDPGPU_FAMILY_OVERDRAFT || d.family == SDPGPU_FAMILY_SURVIVAL;
   P.gamma = cash_loop ? d.discount_factor : 1.0;
   P.min_cash = d.min_cash;
   P.max_cash = d.max_cash;
@@ -383,6 +387,7 @@ hipError_t launch_gather(const DevParams& P, const double* v_next, double* v_cur
     SDP_CASE(sdp::FAM_CASH)
     SDP_CASE(sdp::FAM_OVERDRAFT)
     SDP_CASE(sdp::FAM_CASH_LEADTIME)
+    SDP_CASE(sdp::FAM_SURVIVAL)
   }
 #undef SDP_CASE
   return hipErrorInvalidValue;
@@ -395,7 +400,7 @@ void count_cells(sdpgpu_handle* h, int period) {
   int64_t nD = p.nD;
   auto range_cells = [&](int64_t lo, int64_t hi) -> int64_t {
     if (hi <= lo) return 0;
-    if (d.family != SDPGPU_FAMILY_CASH) {
+    if (d.family != SDPGPU_FAMILY_CASH && d.family != SDPGPU_FAMILY_SURVIVAL) {
       int64_t nA = h->n_actions_full;
       if (d.family == SDPGPU_FAMILY_CASH_LEADTIME && d.zero_order_last_period && period == h->T) nA = 1;
       return (hi - lo) * nA * nD;
@@ -407,6 +412,7 @@ void count_cells(sdpgpu_handle* h, int period) {
       double k = (double)(p.g.k_lo + ic);
       double cash = d.cash_round_int_div ? k : k / d.cash_round_div;
       double m = std::fmin(d.max_order_quantity, std::fmax(0.0, (cash - p.overhead - d.fixed_order_cost) / d.unit_order_cost));
+      if (d.family == SDPGPU_FAMILY_SURVIVAL) m = std::fmax(std::fmin(cash / d.unit_order_cost, d.max_order_quantity), 0.0);
       int64_t nA = (int64_t)java_d2i(m) + 1;
       pre[(size_t)ic + 1] = pre[(size_t)ic] + nA;
     }
@@ -565,6 +571,7 @@ hipError_t launch_reach(const DevParams& P, const uint8_t* mcur, uint8_t* mnext,
     case sdp::FAM_CASH: return launch_reach_fam<sdp::FAM_CASH>(P, mcur, mnext, pmf_d, n, q, query, st);
     case sdp::FAM_OVERDRAFT: return launch_reach_fam<sdp::FAM_OVERDRAFT>(P, mcur, mnext, pmf_d, n, q, query, st);
     case sdp::FAM_CASH_LEADTIME: return launch_reach_fam<sdp::FAM_CASH_LEADTIME>(P, mcur, mnext, pmf_d, n, q, query, st);
+    case sdp::FAM_SURVIVAL: return launch_reach_fam<sdp::FAM_SURVIVAL>(P, mcur, mnext, pmf_d, n, q, query, st);
   }
   return hipErrorInvalidValue;
 }
@@ -1611,6 +1618,7 @@ int sdpgpu_simulate(sdpgpu_handle* h, int64_t n_paths, const double* demand, con
   h->err.clear();
   if (n_paths < 0 || !demand || !discount || !out_sum || !out_valid) return fail(h, SDPGPU_ERR_ARG, "simulate: bad argument");
   if (h->d.world_size != 1) return fail(h, SDPGPU_ERR_STATE, "simulate needs the whole policy on one GPU (world_size 1)");
+  if (h->d.family == SDPGPU_FAMILY_SURVIVAL) return fail(h, SDPGPU_ERR_UNSUPPORTED, "simulate: RiskSimulation's rollout is not part of this library");
   if (!h->allocated) return fail(h, SDPGPU_ERR_STATE, "simulate: nothing has been solved");
   for (int t = 0; t < h->T; ++t)
     if (!h->policy_done[t]) return fail(h, SDPGPU_ERR_STATE, "simulate: period %d has not been computed", t + 1);

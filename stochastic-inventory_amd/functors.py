@@ -17,7 +17,7 @@ from dataclasses import dataclass, field
 from typing import List, Optional
 
 from . import _abi
-from .states import CashLeadtimeState, CashState, LeadtimeState, OptDirection, State
+from .states import CashLeadtimeState, CashState, LeadtimeState, OptDirection, RiskState, State
 
 
 def java_round(x: float) -> int:
@@ -280,6 +280,54 @@ class CashFunctor(_Base):
         nextInventory = self.minInventoryState if nextInventory < self.minInventoryState else nextInventory
         nextCash = self._round_cash(nextCash)
         return CashState(s.getPeriod() + 1, nextInventory, nextCash)
+
+
+@dataclass
+class SurvivalFunctor(CashFunctor):
+    """F6: the lambdas of cashSurvival.java:98-143 under RiskRecursion.getSurvProb (RiskRecursion.java:65-108):
+    orders limited by cash / variCost (no overhead or fixed cost in the bound), immediate value without the
+    end-cash penalty, `Math.round(nextCash * 1) / 1`.  price / variCost are arrays there, filled with one value
+    (cashSurvival.java:52-55); scalars here."""
+
+    cashRoundMult: float = 1.0
+    cashRoundDiv: float = 1.0
+    cashRoundIntDiv: bool = True
+
+    state_type = RiskState
+    family = _abi.FAMILY_SURVIVAL
+
+    def make_state(self, period, x, cash=0.0, preq=0.0):
+        return RiskState(period, x, cash, False)
+
+    def feasibleActions(self, s, T=None):
+        v = self.variCost
+        c = s.getIniCash()
+        q = (math.nan if c == 0 else math.copysign(math.inf, c)) if v == 0 else c / v
+        maxQ = min(q, self.maxOrderQuantity) if q == q else math.nan
+        maxQ = max(maxQ, 0.0) if maxQ == maxQ else math.nan
+        return [k * self.stepSize for k in range(_d2i(maxQ) + 1)]
+
+    def immediateValue(self, s, action, randomDemand, T=None):
+        revenue = self.price * min(s.getIniInventory() + action, randomDemand)
+        fixedCost = self.fixOrderCost if action > 0 else 0.0
+        variableCost = self.variCost * action
+        deposite = (s.getIniCash() - fixedCost - variableCost) * (1 + self.depositeRate)
+        inventoryLevel = s.getIniInventory() + action - randomDemand
+        holdCosts = self.holdingCost * max(inventoryLevel, 0.0)
+        cashIncrement = revenue + deposite - holdCosts - self._oh(s.getPeriod()) - s.getIniCash()
+        salValue = self.salvageValue * max(inventoryLevel, 0.0) if s.getPeriod() == T else 0.0
+        cashIncrement += salValue
+        return cashIncrement
+
+    def stateTransition(self, s, action, randomDemand, T=None):
+        nextInventory = max(0.0, s.getIniInventory() + action - randomDemand)
+        nextCash = s.getIniCash() + self.immediateValue(s, action, randomDemand, T)
+        nextCash = self.maxCashState if nextCash > self.maxCashState else nextCash
+        nextCash = self.minCashState if nextCash < self.minCashState else nextCash
+        nextInventory = self.maxInventoryState if nextInventory > self.maxInventoryState else nextInventory
+        nextInventory = self.minInventoryState if nextInventory < self.minInventoryState else nextInventory
+        nextCash = self._round_cash(nextCash)
+        return RiskState(s.getPeriod() + 1, nextInventory, nextCash, nextCash < 0)
 
 
 @dataclass

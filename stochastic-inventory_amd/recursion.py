@@ -275,6 +275,36 @@ class CashRecursion(_GpuRecursionBase):
         return 4
 
 
+class RiskRecursion(CashRecursion):
+    """sdp.cash.RiskRecursion (RiskRecursion.java:31-46): the survival-probability recursion, MAX only, no
+    discount; `getSurvProb` (:65-108) takes the place of getExpectedValue.  Rows of getOptTable are
+    {period, x, cash, bankruptBefore, Q} (:123-132; the flag is always 0, RiskState.java:17)."""
+
+    def __init__(self, pmf, getFeasibleAction=None, stateTransition=None, immediateValue=None, *, functor=None,
+                 device: int = -1, kernel: int = 0):
+        super().__init__(OptDirection.MAX, pmf, getFeasibleAction, stateTransition, immediateValue, 1.0,
+                         functor=functor, device=device, kernel=kernel)
+
+    def getSurvProb(self, state) -> float:
+        return self._lookup(state)[0]
+
+    def getExpectedValue(self, state):
+        raise AttributeError("RiskRecursion has getSurvProb, not getExpectedValue (RiskRecursion.java:65)")
+
+    def _opt_columns(self, period, idx, q):
+        c = super()._opt_columns(period, idx, q)
+        return np.concatenate([c[:, :3], np.zeros((len(idx), 1)), c[:, 3:]], axis=1)
+
+    def _row_tuple(self, r):
+        return (r[1], r[2])
+
+    def _row_of_state(self, s, action):
+        return np.array([[float(s.getPeriod()), s.getIniInventory(), s.getIniCash(), 0.0, action]])
+
+    def _ncols(self):
+        return 5
+
+
 class CashLeadtimeRecursion(_GpuRecursionBase):
     """sdp.cash.CashLeadtimeRecursion (CashLeadtimeRecursion.java:28-46): MAX only, no discount;
     rows {period, x, cash, preQ, Q} (:97-106).  The reference's comparator (:37-41) is malformed

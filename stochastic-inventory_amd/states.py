@@ -4,6 +4,7 @@ State            src/sdp/inventory/State.java:12-76
 LeadtimeState    src/sdp/inventory/LeadtimeState.java:10-52
 CashState        src/sdp/cash/CashState.java:12-48
 CashLeadtimeState src/sdp/cash/CashLeadtimeState.java:11-46
+RiskState        src/sdp/cash/RiskState.java:12-52
 
 Equality is exact `==` on the doubles, as in the reference's equals(); the objects are
 immutable and hashable so they can key Python dicts the way they key the Java maps.
@@ -81,6 +82,23 @@ class CashState(State):
 
     def __repr__(self):
         return f"period = {self.period}, iniInventory = {self.initialInventory}, iniCash = {self.iniCash}"
+
+
+class RiskState(CashState):
+    """RiskState.java:12-52.  The constructor there ignores its `bankruptBefore` argument (`:17` assigns the
+    literal false), and RiskRecursion's comparator (RiskRecursion.java:39-42) does not look at the flag."""
+    __slots__ = ("bankruptBefore",)
+
+    def __init__(self, period: int, initialInventory: float, iniCash: float, bankruptBefore: bool = False):
+        super().__init__(period, initialInventory, iniCash)
+        object.__setattr__(self, "bankruptBefore", False)
+
+    def getBankruptBefore(self) -> bool:
+        return self.bankruptBefore
+
+    def __repr__(self):
+        return (f"period = {self.period}, iniInventory = {self.initialInventory}, iniCash = {self.iniCash}, "
+                f"bankuptBefore = {self.bankruptBefore}")
 
 
 class CashLeadtimeState(CashState):

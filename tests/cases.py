@@ -2,7 +2,7 @@
 import numpy as np
 
 from stochastic_inventory_amd.functors import (BackorderFunctor, CashFunctor, CashLeadtimeFunctor, LeadtimeFunctor,
-                                                OverdraftFunctor)
+                                                OverdraftFunctor, SurvivalFunctor)
 from stochastic_inventory_amd.states import OptDirection
 from stochastic_inventory_amd.workloads import Workload, truncated_poisson_tile
 
@@ -149,6 +149,24 @@ def f5_cash_leadtime(T=3):
     return Workload("f5_cash_leadtime", f, OptDirection.MAX, _pmf([3, 3, 3][:T], 6))
 
 
+def f6_survival(T=4):
+    """cashSurvival.java shape (survival-probability objective): price 4, unit cost 1, overhead per period,
+    integer cash, orders limited by cash; negative-cash successors are worth 0."""
+    f = SurvivalFunctor(price=4, fixOrderCost=0, variCost=1, holdingCost=0, depositeRate=0, salvageValue=0.5,
+                        maxOrderQuantity=30, minInventoryState=0, maxInventoryState=25, minCashState=-20,
+                        maxCashState=150, iniInventory=0, iniCash=12, overheadCosts=[14.0, 20.0, 9.0, 16.0][:T])
+    return Workload("f6_survival", f, OptDirection.MAX, _pmf([4, 6, 3, 5][:T], 10))
+
+
+def f6_survival_gamma(T=3):
+    """CashRecursion.getSurvProb shape (CashRecursion.java:174 multiplies by discountFactor), fractional costs."""
+    f = SurvivalFunctor(price=3.5, fixOrderCost=1.5, variCost=1.25, holdingCost=0.2, depositeRate=0.02,
+                        salvageValue=0.4, discountFactor=0.97, maxOrderQuantity=12, minInventoryState=0,
+                        maxInventoryState=15, minCashState=-8, maxCashState=70, iniInventory=1, iniCash=9,
+                        overheadCost=7.5)
+    return Workload("f6_survival_gamma", f, OptDirection.MAX, _pmf([3, 5, 4][:T], 9))
+
+
 ALL = [f1_small, f1_max, f1_gapped, f1_unclamped, f1_edge_single, f2_unclamped, f2_clamped, f2_pipeline, f3_tenths, f3_testing, f3_dyadic, f3_min_gamma,
-       f4_overdraft, f5_cash_leadtime]
+       f4_overdraft, f5_cash_leadtime, f6_survival, f6_survival_gamma]
 TINY = [f1_small, f1_max, f1_gapped, f1_unclamped, f2_unclamped, f3_testing, f3_min_gamma, f4_overdraft]

@@ -46,3 +46,35 @@ def memo_recursion(functor, pmf, direction, ini_state, cash_loop=False, gamma=1.
 
     root = get_expected_value(ini_state)
     return root, cache_values, cache_actions
+
+
+def surv_recursion(functor, pmf, ini_state, gamma=1.0):
+    """RiskRecursion.getSurvProb (RiskRecursion.java:65-108; CashRecursion.java:143-194 with the discount)."""
+    T = len(pmf)
+    cache_values, cache_actions = {}, {}
+
+    def get_surv_prob(s):
+        if s in cache_values:
+            return cache_values[s]
+        feasible = functor.feasibleActions(s, T)
+        d_and_p = pmf[s.getPeriod() - 1]
+        val, best = -DBL_MAX, 0.0
+        for order_qty in feasible:
+            q = 0.0
+            for dp in d_and_p:
+                d, p = float(dp[0]), float(dp[1])
+                if s.getPeriod() == T:
+                    final_cash = s.getIniCash() + functor.immediateValue(s, order_qty, d, T)
+                    q += p * (1 if final_cash >= 0 else 0)
+                if s.getPeriod() < T:
+                    ns = functor.stateTransition(s, order_qty, d, T)
+                    this_prob = 0 if ns.getIniCash() < 0 else get_surv_prob(ns)
+                    q += p * gamma * this_prob
+            if q > val:
+                val, best = q, order_qty
+        cache_values[s] = val
+        cache_actions[s] = best
+        return val
+
+    root = get_surv_prob(ini_state)
+    return root, cache_values, cache_actions

@@ -134,7 +134,8 @@ def test_pipeline_eval_reachable_simulate(sia, oracle):
     eng.close()
 
 
-@pytest.mark.parametrize("make", [cases.f1_small, cases.f3_tenths, cases.f5_cash_leadtime, cases.f2_unclamped],
+@pytest.mark.parametrize("make", [cases.f1_small, cases.f3_tenths, cases.f5_cash_leadtime, cases.f2_unclamped,
+                                  cases.f6_survival_gamma],
                          ids=lambda f: f.__name__)
 def test_eval_states_off_grid(sia, oracle, make):
     """getExpectedValue(state) for states that are not grid points (off-grid initial cash etc.)."""
@@ -145,7 +146,7 @@ def test_eval_states_off_grid(sia, oracle, make):
         x, cash, preq = P.state_arrays(period)
         pick = rng.integers(0, len(x), size=37)
         xs, cs, qs = x[pick].copy(), cash[pick].copy(), preq[pick].copy()
-        if w.desc().family in (3, 4, 5):
+        if w.desc().family in (3, 4, 5, 6):
             cs = cs + 0.013  # off the cash grid
         v_next = V[period] if period < w.T else None
         ov, oa = P.eval_states(period, v_next, xs, cs, qs)
@@ -154,7 +155,8 @@ def test_eval_states_off_grid(sia, oracle, make):
     eng.close()
 
 
-@pytest.mark.parametrize("make", [cases.f1_small, cases.f2_unclamped, cases.f3_testing, cases.f5_cash_leadtime],
+@pytest.mark.parametrize("make", [cases.f1_small, cases.f2_unclamped, cases.f3_testing, cases.f5_cash_leadtime,
+                                  cases.f6_survival],
                          ids=lambda f: f.__name__)
 def test_reachable_set(sia, oracle, make):
     w = make()
@@ -195,7 +197,7 @@ def test_ping_pong_tables(sia, oracle, make):
 @pytest.mark.parametrize("make,world", [(cases.f3_tenths, 3), (cases.f2_clamped, 3), (cases.f2_unclamped, 2),
                                         (cases.f1_small, 2), (cases.f1_clsp_main, 4), (cases.f1_unclamped, 2),
                                         (cases.f3_testing, 3), (cases.f3_dyadic, 2), (cases.f5_cash_leadtime, 2),
-                                        (cases.f2_pipeline, 3)],
+                                        (cases.f2_pipeline, 3), (cases.f6_survival, 3)],
                          ids=lambda v: getattr(v, "__name__", str(v)))
 def test_sharded_periods_single_process(sia, oracle, make, world):
     """world_size N slabs driven from one process: each rank computes its slab into its own copy of
@@ -313,6 +315,32 @@ def test_mirror_cash_and_leadtime(sia, oracle):
     ini3 = sia.CashLeadtimeState(1, 0.0, 0.0, 0.0)
     assert cl.getExpectedValue(ini3) == m3["value"] and cl.getAction(ini3) == m3["action"]
     assert cl.getOptTable().shape == (m3["n"], 5)
+
+
+def test_mirror_risk_recursion(sia, oracle):
+    """RiskRecursion.getSurvProb (cashSurvival.java's driver shape): survival probability, first-period order,
+    opt table over the visited (never bankrupt) states; ties between actions are the rule here (many actions
+    reach probability 1), so the lowest-index rule is exercised on nearly every state."""
+    w = cases.f6_survival()
+    f = w.functor
+    T = w.T
+    rec = sia.RiskRecursion(w.pmf, lambda s: f.feasibleActions(s, T), lambda s, a, r: f.stateTransition(s, a, r, T),
+                            lambda s, a, r: f.immediateValue(s, a, r, T), functor=f)
+    rec.setTreeMapCacheAction()
+    assert rec.validateFunctor(64) == 64
+    ini = sia.RiskState(1, f.iniInventory, f.iniCash, False)
+    m = oracle.Problem(w.desc(), w.pmf, w.overhead()).memo()
+    assert 0.0 < m["value"] < 1.0
+    assert rec.getSurvProb(ini) == m["value"] and rec.getAction(ini) == m["action"]
+    t = rec.getOptTable()
+    assert t.shape == (m["n"], 5) and not t[:, 3].any() and (t[:, 2] >= 0).all()
+    order = np.lexsort((m["cash"], m["x"], m["period"]))
+    assert np.array_equal(t[:, 1], m["x"][order]) and np.array_equal(t[:, 2], m["cash"][order])
+    assert np.array_equal(t[:, 4], m["actions"][order])
+    with pytest.raises(AttributeError):
+        rec.getExpectedValue(ini)
+    with pytest.raises(sia.SdpgpuError):
+        rec.engine.simulate(np.zeros((1, T)), np.ones(T), 0.0, 12.0)
 
 
 def test_cfg2_full_horizon_properties(sia, oracle):

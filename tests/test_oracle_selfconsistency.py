@@ -48,7 +48,7 @@ def _index(P, period, x, cash, preq, preq2=0.0):
     if ix != int(ix) or not (0 <= ix < g.nx):
         return -1
     ic = iq = 0
-    if d.family in (3, 4, 5):
+    if d.family in (3, 4, 5, 6):
         k = int(cash) if d.cash_round_int_div else round(cash * d.cash_round_mult)
         back = float(k) if d.cash_round_int_div else k / d.cash_round_div
         if back != cash:
@@ -84,6 +84,21 @@ def test_c_oracle_equals_pure_python_translation(oracle, make):
         s = f.make_state(int(m["period"][i]), m["x"][i], m["cash"][i], m["preq"][i])
         assert cv[s] == m["values"][i]
         assert ca[s] == m["actions"][i]
+
+
+@pytest.mark.parametrize("make", [cases.f6_survival, cases.f6_survival_gamma], ids=lambda f: f.__name__)
+def test_survival_oracle_equals_pure_python_translation(oracle, make):
+    w = make(T=3)
+    P = _problem(oracle, w)
+    f = w.functor
+    ini = f.make_state(1, f.iniInventory, f.iniCash)
+    root, cv, ca = pyref.surv_recursion(f, w.pmf, ini, f.discountFactor)
+    m = P.memo()
+    assert 0.0 < root <= 1.0 and m["value"] == root and m["action"] == ca[ini] and m["n"] == len(cv)
+    assert all(s.getIniCash() >= 0 for s in cv)  # bankrupt states are never visited
+    for i in range(m["n"]):
+        s = f.make_state(int(m["period"][i]), m["x"][i], m["cash"][i])
+        assert cv[s] == m["values"][i] and ca[s] == m["actions"][i]
 
 
 def test_pipeline_oracle_equals_pure_python_translation(oracle):
