@@ -77,6 +77,13 @@ class CashState : public inventory::State {
   double iniCash;
 };
 
+class RiskState : public CashState {  // RiskState.java:12-52 (the constructor there stores `false`, :17)
+ public:
+  RiskState(int period, double initialInventory, double iniCash, bool /*bankruptBefore*/)
+      : CashState(period, initialInventory, iniCash) {}
+  bool getBankruptBefore() const { return false; }
+};
+
 class CashLeadtimeState : public CashState {
  public:
   CashLeadtimeState(int period, double initialInventory, double iniCash, double preQ)
@@ -170,6 +177,18 @@ struct CashFunctor {  // CashConstraint.java:95-133 (cashFormula 0), CashConstra
     d.r3 = r3;
     d.overdraft_limit = limit;
     d.interest_free_amount = interestFreeAmount;
+  }
+};
+
+struct SurvivalFunctor : CashFunctor {  // cashSurvival.java:98-143 under RiskRecursion.getSurvProb
+  SurvivalFunctor() {
+    cashRoundMult = 1;  // Math.round(nextCash * 1) / 1
+    cashRoundDiv = 1;
+    cashRoundIntDiv = true;
+  }
+  void fill(sdpgpu_desc& d) const {
+    CashFunctor::fill(d);
+    d.family = SDPGPU_FAMILY_SURVIVAL;
   }
 };
 
@@ -430,6 +449,63 @@ class CashRecursion {
     sdpgpu_desc d = make_desc(dir);
     f.fill(d);
     d.discount_factor = discountFactor;
+    return d;
+  }
+  double step_;
+  Engine engine_;
+};
+
+// ---- sdp.cash.RiskRecursion (survival probability, RiskRecursion.java:31-46, :65-108) -----------------
+class RiskRecursion {
+ public:
+  using State = cash::RiskState;
+  using Trans = StateTransitionFunction<State, double, double, State>;
+  using Imm = ImmediateValueFunction<State, double, double, double>;
+  using Actions = std::function<std::vector<double>(const State&)>;
+
+  RiskRecursion(const Pmf& pmf, Actions getFeasibleAction, Trans stateTransition, Imm immediateValue,
+                const SurvivalFunctor& functor)
+      : getFeasibleActions(std::move(getFeasibleAction)), stateTransition(std::move(stateTransition)),
+        immediateValue(std::move(immediateValue)), step_(functor.stepSize),
+        engine_(desc_of(functor), pmf, functor.overheadCosts) {}
+
+  Trans getStateTransitionFunction() const { return stateTransition; }
+  Imm getImmediateValueFunction() const { return immediateValue; }
+  void setTreeMapCacheAction() {}
+
+  double getSurvProb(const State& s) {
+    return engine_.lookup(s.getPeriod(), s.getIniInventory(), s.getIniCash(), 0).first;
+  }
+  double getAction(const State& s) {
+    return engine_.lookup(s.getPeriod(), s.getIniInventory(), s.getIniCash(), 0).second * step_;
+  }
+  /** rows {period, inventory, cash, bankruptBefore (always 0), Q} (RiskRecursion.java:123-132). */
+  std::vector<std::array<double, 5>> getOptTable() {
+    std::vector<std::array<double, 5>> rows;
+    for (int period = 1; period <= engine_.periods(); ++period) {
+      const auto mask = engine_.reachable(period);
+      const auto& pol = engine_.policy(period);
+      double x_lo;
+      int64_t nx, nc, nq;
+      engine_.check(sdpgpu_grid(engine_.handle(), period, &x_lo, &nx, &nc, &nq));
+      for (size_t i = 0; i < mask.size(); ++i)
+        if (mask[i])
+          rows.push_back({(double)period, x_lo + (double)(i / (size_t)nc) * step_,
+                          sdpgpu_cash_value(engine_.handle(), (int64_t)(i % (size_t)nc)), 0.0, pol[i] * step_});
+    }
+    return rows;
+  }
+  Engine& engine() { return engine_; }
+
+  Actions getFeasibleActions;
+  Trans stateTransition;
+  Imm immediateValue;
+
+ private:
+  static sdpgpu_desc desc_of(const SurvivalFunctor& f) {
+    sdpgpu_desc d = make_desc(OptDirection::MAX);
+    f.fill(d);
+    d.discount_factor = 1;
     return d;
   }
   double step_;

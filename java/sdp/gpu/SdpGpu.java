@@ -23,7 +23,7 @@ public final class SdpGpu {
 
 	/** Families: the closed-form lambda families of the in-scope drivers (sdpgpu_family). */
 	public static final int FAMILY_BACKORDER = 1, FAMILY_LEADTIME = 2, FAMILY_CASH = 3, FAMILY_OVERDRAFT = 4,
-			FAMILY_CASH_LEADTIME = 5;
+			FAMILY_CASH_LEADTIME = 5, FAMILY_SURVIVAL = 6;
 	public static final int MIN = 0, MAX = 1;
 
 	/**

@@ -1,4 +1,4 @@
-// mirror_drivers.cpp -- three driver programs in the shape of the reference's mains, written in C++ over include/sdpgpu_mirror.hpp:
+// mirror_drivers.cpp -- four driver programs in the shape of the reference's mains, written in C++ over include/sdpgpu_mirror.hpp:
 // same local variable names, same lambdas, one constructor swapped (Recursion -> sdp::gpu::Recursion + a
 // functor descriptor).  tests/test_gpu_cpp_mirror.py compiles this with g++, runs it on the GPU and
 // compares what it prints with the CPU oracle.
@@ -6,6 +6,7 @@
 //   clsp       capacitated.CLSPTesting.main   (src/capacitated/CLSPTesting.java:52-119, one parameter set)
 //   leadtime   leadtime.Leadtime.main         (src/leadtime/Leadtime.java:25-99)
 //   cash       cash.singleItem.CashConstraint.main (src/cash/singleItem/CashConstraint.java:44-146), smaller grid
+//   survival   cash.risk.cashSurvival.main    (src/cash/risk/cashSurvival.java:45-163), smaller grid
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
@@ -205,6 +206,68 @@ static int cash_constraint(const Pmf& pmf) {
   return 0;
 }
 
+static int cash_survival(const Pmf& pmf) {
+  using cash::RiskState;
+  const int T = (int)pmf.size();
+  double iniI = 0, iniCash = 150, fixOrderCost = 0, price = 4, variCost = 1, depositeRate = 0, salvageValue = 0.5;
+  double holdingCost = 0, overheadCosts = 100, maxOrderQuantity = 200, stepSize = 1;
+  double minInventoryState = 0, maxInventoryState = 200, minCashState = -100, maxCashState = 1500;
+
+  auto getFeasibleAction = [=](const RiskState& s) {
+    double maxQ = std::fmin(s.getIniCash() / variCost, maxOrderQuantity);
+    if (s.getBankruptBefore() == true) maxQ = 0;
+    maxQ = std::fmax(maxQ, 0);
+    std::vector<double> a((size_t)((int)maxQ + 1));
+    for (size_t i = 0; i < a.size(); ++i) a[i] = (double)i * stepSize;
+    return a;
+  };
+  auto immediateValue = [=](const RiskState& state, double action, double randomDemand) {
+    double revenue = price * std::fmin(state.getIniInventory() + action, randomDemand);
+    double fixedCost = action > 0 ? fixOrderCost : 0;
+    double variableCost = variCost * action;
+    double deposite = (state.getIniCash() - fixedCost - variableCost) * (1 + depositeRate);
+    double inventoryLevel = state.getIniInventory() + action - randomDemand;
+    double holdCosts = holdingCost * std::fmax(inventoryLevel, 0);
+    double cashIncrement = revenue + deposite - holdCosts - overheadCosts - state.getIniCash();
+    double salValue = state.getPeriod() == T ? salvageValue * std::fmax(inventoryLevel, 0) : 0;
+    cashIncrement += salValue;
+    return cashIncrement;
+  };
+  auto stateTransition = [=](const RiskState& state, double action, double randomDemand) {
+    double nextInventory = std::fmax(0, state.getIniInventory() + action - randomDemand);
+    double nextCash = state.getIniCash() + immediateValue(state, action, randomDemand);
+    nextCash = nextCash > maxCashState ? maxCashState : nextCash;
+    nextCash = nextCash < minCashState ? minCashState : nextCash;
+    nextInventory = nextInventory > maxInventoryState ? maxInventoryState : nextInventory;
+    nextInventory = nextInventory < minInventoryState ? minInventoryState : nextInventory;
+    nextCash = (double)(java_round(nextCash * 1) / 1);
+    return RiskState(state.getPeriod() + 1, nextInventory, nextCash, nextCash < 0);
+  };
+  gpu::SurvivalFunctor functor;
+  functor.price = price;
+  functor.fixOrderCost = fixOrderCost;
+  functor.variCost = variCost;
+  functor.holdingCost = holdingCost;
+  functor.depositeRate = depositeRate;
+  functor.overheadCost = overheadCosts;
+  functor.salvageValue = salvageValue;
+  functor.maxOrderQuantity = maxOrderQuantity;
+  functor.minInventoryState = minInventoryState;
+  functor.maxInventoryState = maxInventoryState;
+  functor.minCashState = minCashState;
+  functor.maxCashState = maxCashState;
+  functor.iniInventory = iniI;
+  functor.iniCash = iniCash;
+  gpu::RiskRecursion recursion(pmf, getFeasibleAction, stateTransition, immediateValue, functor);
+  RiskState initialState(1, iniI, iniCash, false);
+  recursion.setTreeMapCacheAction();
+  double finalValue = recursion.getSurvProb(initialState);
+  std::printf("survival probability for this initial state is: %.17g\n", finalValue);
+  std::printf("optimal order quantity in the first priod is : %.17g\n", recursion.getAction(initialState));
+  std::printf("visited states %zu\n", recursion.getOptTable().size());
+  return 0;
+}
+
 int main(int argc, char** argv) {
   if (argc < 3) return 1;
   try {
@@ -213,6 +276,7 @@ int main(int argc, char** argv) {
     if (which == "clsp") return clsp(pmf);
     if (which == "leadtime") return leadtime(pmf);
     if (which == "cash") return cash_constraint(pmf);
+    if (which == "survival") return cash_survival(pmf);
   } catch (const std::exception& e) {
     std::fprintf(stderr, "error: %s\n", e.what());
     return 2;

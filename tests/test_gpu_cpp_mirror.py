@@ -91,3 +91,19 @@ def test_cash_constraint_main(exe, tmp_path, sia, oracle):
     s1 = f.stateTransition(sia.CashState(1, 0.0, 100.0), q, d, 4)
     idx = int(s1.getIniInventory()) * 6001 + int(round(s1.getIniCash() * 10))
     assert _last_number(lines[2]) == V[1][idx]
+
+
+def test_cash_survival_main(exe, tmp_path, sia, oracle):
+    """cashSurvival.main's lambdas and parameters (mean demands {14, 23, 33, 46, 50}, overhead 100, price 4) on a
+    smaller state box and with initial cash 150 instead of 80 (80 goes bankrupt in period 1 with probability
+    0.995): survival probability, first order, number of visited states."""
+    tiles = sia.GetPmf([sia.PoissonDist(m) for m in (14, 23, 33, 46, 50)], 0.99, 1).getpmf()
+    lines = _run(exe, "survival", tiles, tmp_path)
+    f = sia.SurvivalFunctor(price=4, fixOrderCost=0, variCost=1, holdingCost=0, depositeRate=0, overheadCost=100,
+                            salvageValue=0.5, maxOrderQuantity=200, minInventoryState=0, maxInventoryState=200,
+                            minCashState=-100, maxCashState=1500, iniInventory=0, iniCash=150)
+    m = oracle.Problem(f.to_desc(5, sia.OptDirection.MAX), tiles).memo(cap=1 << 23)
+    assert 0.0 < m["value"] < 1.0
+    assert _last_number(lines[0]) == m["value"]
+    assert _last_number(lines[1]) == m["action"]
+    assert int(lines[2].split()[-1]) == m["n"]
