@@ -110,6 +110,7 @@ class ShardedSolver:
         # host (used to rehearse N ranks on ONE GPU; the production path is RCCL on device memory)
         self.stage_through_host = stage_through_host
         self.force_split = False  # rehearsal/testing: take the interior + boundary path after a blocking exchange too
+        self.force_exchange = False  # measurement only: issue the collective even at world_size 1 (tools/exchange_overhead.py)
         self.world = dist.get_world_size(group) if dist.is_initialized() else 1
         self.rank = dist.get_rank(group) if dist.is_initialized() else 0
         self.gathered_bytes = 0
@@ -118,7 +119,7 @@ class ShardedSolver:
         """All-gather the row of `period`.  With async_op the collective runs on the communicator's own
         stream (ordered after everything already queued on the compute stream) and the returned work's
         wait() makes the compute stream wait for it -- the host never blocks."""
-        if self.world == 1:
+        if self.world == 1 and not self.force_exchange:
             return None
         pad, lo, hi = self.backend.slab(period)
         full = self.backend.table(period)
