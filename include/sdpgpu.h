@@ -196,6 +196,40 @@ void sdpgpu_desc_init(sdpgpu_desc* d);
 int sdpgpu_create(const sdpgpu_desc* desc, sdpgpu_handle** out);
 void sdpgpu_destroy(sdpgpu_handle* h);
 
+/*
+ * User-defined lambdas.  The reference injects a problem as three Java lambdas (Recursion.java:49-52):
+ * `Function<State, double[]>` feasible actions, StateTransitionFunction (StateTransition.java:20-22) and
+ * ImmediateValueFunction (ImmediateValue.java:23-25).  The built-in families cover the in-scope drivers; any
+ * other driver's lambdas are handed over here as HIP device source, compiled at this call with hipRTC for gfx950
+ * under the library's numerics contract (-ffp-contract=off) around the same loop (accumulation order,
+ * strict-compare arg-opt, discount, survival objective) as the built-in kernels.
+ *
+ * `functor_source` defines exactly these three device functions (the text may define helpers and constants too):
+ *
+ *   __device__ int    sdp_feasible_count(const sdp_ctx& c, double x, double cash, double preq);
+ *       getFeasibleActions.apply(state).length; action k is k * c.step (DoubleStream.iterate(0, i -> i + stepSize))
+ *   __device__ double sdp_immediate(const sdp_ctx& c, double x, double cash, double preq, double action, double demand);
+ *       immediateValue.apply(state, action, randomDemand)
+ *   __device__ void   sdp_transition(const sdp_ctx& c, double x, double cash, double preq, double action, double demand,
+ *                                    double& next_x, double& next_cash, double& next_preq);
+ *       stateTransition.apply(state, action, randomDemand), clamped and rounded as the Java lambda does it: the
+ *       result must be a grid point of the next period, otherwise the next read of results fails with
+ *       SDPGPU_ERR_ARG.
+ *
+ * with `struct sdp_ctx { int period; int T; double step; const double* params; }` (period = state.getPeriod(),
+ * params = the n_params doubles given here: the constants the Java lambdas close over) and the helpers
+ * sdp_max / sdp_min / sdp_round / sdp_trunc (java.lang.Math.max / min / round and the (int) cast).
+ *
+ * `desc->family` selects the STATE SHAPE and the loop, not the formulas: BACKORDER = (x) under Recursion,
+ * LEADTIME = (x, preQ) under LeadtimeRecursion, CASH / OVERDRAFT = (x, cash) under CashRecursion (discounted),
+ * CASH_LEADTIME = (x, cash, preQ), SURVIVAL = (x, cash) under getSurvProb.  The grid fields of the descriptor
+ * (step, inventory bounds and clamp flag, cash bounds and rounding, max_order_quantity = longest pipeline
+ * quantity, ini_*) keep their meaning; the cost fields are ignored.  sdpgpu_simulate is not available (the
+ * lambdas also exist on the host, where the reference's simulators call them).
+ */
+int sdpgpu_create_custom(const sdpgpu_desc* desc, const char* functor_source, const double* params, int32_t n_params,
+                         sdpgpu_handle** out);
+
 /* Never NULL; empty string when the last call on h succeeded.  h may be NULL to
  * read the message of a failed sdpgpu_create. */
 const char* sdpgpu_last_error(const sdpgpu_handle* h);

@@ -80,6 +80,34 @@ typedef struct ctx {
   int32_t T;
 } ctx_t;
 
+/* User-defined lambdas (the counterpart of sdpgpu_create_custom): the SAME three functions the product
+ * compiles with hipRTC, compiled for the host by the test harness (oracle/sdpref.py: compile_custom) and
+ * registered here as function pointers.  While registered they replace n_actions / imm_value / transition
+ * for every family; desc->family then only selects the state shape and the loop. */
+typedef struct sdpref_user_ctx {
+  int period;
+  int T;
+  double step;
+  const double* params;
+} sdpref_user_ctx;
+typedef int (*sdpref_user_count_fn)(const sdpref_user_ctx*, double, double, double);
+typedef double (*sdpref_user_imm_fn)(const sdpref_user_ctx*, double, double, double, double, double);
+typedef void (*sdpref_user_trans_fn)(const sdpref_user_ctx*, double, double, double, double, double, double*, double*,
+                                     double*);
+static struct {
+  sdpref_user_count_fn count;
+  sdpref_user_imm_fn imm;
+  sdpref_user_trans_fn trans;
+  const double* params;
+} g_user = {0, 0, 0, 0};
+
+void sdpref_register_custom(void* count, void* imm, void* trans, const double* params) {
+  g_user.count = (sdpref_user_count_fn)count;
+  g_user.imm = (sdpref_user_imm_fn)imm;
+  g_user.trans = (sdpref_user_trans_fn)trans;
+  g_user.params = params;
+}
+
 static double overhead_at(const ctx_t* c, int32_t period) {
   return c->oh ? c->oh[period - 1] : c->d->overhead_cost;
 }
@@ -101,6 +129,10 @@ static int32_t full_action_count(const sdpgpu_desc* d) {
 /* getFeasibleActions.apply(state).length */
 static int32_t n_actions(const ctx_t* c, const st_t* s) {
   const sdpgpu_desc* d = c->d;
+  if (g_user.count) {
+    sdpref_user_ctx u = {s->period, c->T, d->step, g_user.params};
+    return g_user.count(&u, s->x, s->cash, s->preq);
+  }
   switch (d->family) {
     case SDPGPU_FAMILY_BACKORDER: /* CLSP.java:251-253, CLSPTesting.java:78-86 */
     case SDPGPU_FAMILY_LEADTIME:  /* Leadtime.java:50-58 */
@@ -149,6 +181,10 @@ static double overdraft_interest(const sdpgpu_desc* d, double cashBalanceBefore)
 /* immediateValue.apply(state, action, randomDemand) */
 static double imm_value(const ctx_t* c, const st_t* s, double action, double randomDemand) {
   const sdpgpu_desc* d = c->d;
+  if (g_user.imm) {
+    sdpref_user_ctx u = {s->period, c->T, d->step, g_user.params};
+    return g_user.imm(&u, s->x, s->cash, s->preq, action, randomDemand);
+  }
   switch (d->family) {
     case SDPGPU_FAMILY_BACKORDER: { /* CLSP.java:263-272 == CLSPTesting.java:97-106 */
       double fixedCost = action > 0 ? d->fixed_order_cost : 0;
@@ -246,6 +282,11 @@ static void transition(const ctx_t* c, const st_t* s, double action, double rand
   out->cash = 0;
   out->preq = 0;
   out->preq2 = 0;
+  if (g_user.trans) {
+    sdpref_user_ctx u = {s->period, c->T, d->step, g_user.params};
+    g_user.trans(&u, s->x, s->cash, s->preq, action, randomDemand, &out->x, &out->cash, &out->preq);
+    return;
+  }
   switch (d->family) {
     case SDPGPU_FAMILY_BACKORDER: { /* CLSP.java:255-260 == CLSPTesting.java:89-94 */
       double nextInventory = s->x + action - randomDemand;

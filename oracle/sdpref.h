@@ -100,6 +100,10 @@ typedef struct sdpref_multilead {
 int sdpref_kat_multilead(const sdpref_multilead* k, double* final_value, int32_t* q1, int32_t* q2,
                          int64_t* states_visited, int64_t* cells);
 
+/* User-defined lambdas: host-compiled versions of the three functions sdpgpu_create_custom takes (signatures in
+ * sdpref.c).  Pass NULLs to return to the built-in families.  Not thread-safe: test harness use only. */
+void sdpref_register_custom(void* count_fn, void* imm_fn, void* trans_fn, const double* params);
+
 /* Java arithmetic helpers, exported so tests can probe their corner cases. */
 int64_t sdpref_java_round(double x);
 double sdpref_java_max(double a, double b);

@@ -236,3 +236,64 @@ def kat_multilead(**kw):
     if rc:
         raise RuntimeError(f"sdpref_kat_multilead failed: {rc}")
     return fv.value, q1.value, q2.value, ns.value, nc.value
+
+
+# ---------------------------------------------------------------------------------------------------------
+# User-defined lambdas: the SAME source text the product hands to hipRTC, compiled for the host with g++
+# (-ffp-contract=off) and registered with the oracle as function pointers.
+# ---------------------------------------------------------------------------------------------------------
+_HOST_PRELUDE = r"""
+#include <cmath>
+#define __device__
+typedef long long sdp_i64;
+struct sdp_ctx { int period; int T; double step; const double* params; };
+// java.lang.Math.max / min (a zero of either sign: max prefers +0, min prefers -0), round, (int)
+static inline double sdp_max(double a, double b) { if (a != a) return a; if (a == 0 && b == 0) return std::signbit(a) ? b : a; return a > b ? a : b; }
+static inline double sdp_min(double a, double b) { if (a != a) return a; if (a == 0 && b == 0) return std::signbit(a) ? a : b; return a < b ? a : b; }
+static inline double sdp_round(double x) { double f = std::floor(x); return (x - f >= 0.5) ? f + 1.0 : f; }
+static inline double sdp_trunc(double x) { return std::trunc(x); }
+using std::fmax; using std::fmin; using std::floor; using std::trunc; using std::fabs;
+#line 1 "user_functor"
+"""
+_HOST_WRAPPERS = r"""
+extern "C" int sdpref_user_count(const sdp_ctx* c, double x, double cash, double preq) {
+  return sdp_feasible_count(*c, x, cash, preq);
+}
+extern "C" double sdpref_user_imm(const sdp_ctx* c, double x, double cash, double preq, double a, double d) {
+  return sdp_immediate(*c, x, cash, preq, a, d);
+}
+extern "C" void sdpref_user_trans(const sdp_ctx* c, double x, double cash, double preq, double a, double d, double* nx,
+                                  double* nc, double* nq) {
+  sdp_transition(*c, x, cash, preq, a, d, *nx, *nc, *nq);
+}
+"""
+
+
+class custom_functor:
+    """Context manager: compile `source` for the host and make it the oracle's lambdas while the block runs."""
+
+    def __init__(self, source: str, params=()):
+        import hashlib
+        import tempfile
+        text = _HOST_PRELUDE + source + "\n" + _HOST_WRAPPERS
+        tag = hashlib.sha1(text.encode()).hexdigest()[:16]
+        d = os.path.join(tempfile.gettempdir(), "sdpref_custom")
+        os.makedirs(d, exist_ok=True)
+        self.so = os.path.join(d, f"user_{tag}.so")
+        if not os.path.exists(self.so):
+            cpp = os.path.join(d, f"user_{tag}.cpp")
+            with open(cpp, "w") as f:
+                f.write(text)
+            subprocess.run(["g++", "-O2", "-std=c++17", "-ffp-contract=off", "-fPIC", "-shared", "-o", self.so, cpp],
+                           check=True)
+        self.user = C.CDLL(self.so)
+        self.params = np.ascontiguousarray(params, dtype=np.float64)
+
+    def __enter__(self):
+        f = [C.cast(getattr(self.user, n), C.c_void_p) for n in ("sdpref_user_count", "sdpref_user_imm",
+                                                                  "sdpref_user_trans")]
+        lib().sdpref_register_custom(*f, _dp(self.params) if len(self.params) else None)
+        return self
+
+    def __exit__(self, *exc):
+        lib().sdpref_register_custom(None, None, None, None)

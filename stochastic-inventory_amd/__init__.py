@@ -8,7 +8,7 @@ from . import _abi
 from ._abi import (FAMILY_BACKORDER, FAMILY_CASH, FAMILY_CASH_LEADTIME, FAMILY_LEADTIME, FAMILY_OVERDRAFT,
                    FAMILY_SURVIVAL,                   KERNEL_AUTO, KERNEL_GATHER, KERNEL_WINDOW, SdpgpuDesc, SdpgpuError, SdpgpuStats, desc_defaults)
 from .engine import SdpEngine
-from .functors import (BackorderFunctor, CashFunctor, CashLeadtimeFunctor, LeadtimeFunctor, OverdraftFunctor,
+from .functors import (BackorderFunctor, CashFunctor, CashLeadtimeFunctor, CustomFunctor, LeadtimeFunctor, OverdraftFunctor,
                        SurvivalFunctor, java_round)
 from .multiitem import MultiLeadResult, multilead_solve
 from .pmf import DiscreteDistribution, GetPmf, NormalDist, PoissonDist, UniformIntDist
@@ -18,7 +18,7 @@ from .states import CashLeadtimeState, CashState, LeadtimeState, OptDirection, R
 
 __all__ = [
     "SdpEngine", "SdpgpuDesc", "SdpgpuError", "SdpgpuStats", "desc_defaults",
-    "BackorderFunctor", "LeadtimeFunctor", "CashFunctor", "OverdraftFunctor", "CashLeadtimeFunctor", "SurvivalFunctor",
+    "BackorderFunctor", "LeadtimeFunctor", "CashFunctor", "OverdraftFunctor", "CashLeadtimeFunctor", "SurvivalFunctor", "CustomFunctor",
     "Recursion", "CLSP", "LeadtimeRecursion", "CashRecursion", "CashLeadtimeRecursion", "RiskRecursion",
     "multilead_solve", "MultiLeadResult",
     "GetPmf", "PoissonDist", "NormalDist", "UniformIntDist", "DiscreteDistribution", "Simulation", "Sampling",

@@ -142,6 +142,7 @@ EXPORTS = {
     "sdpgpu_abi_version": (C.c_int, []),
     "sdpgpu_desc_init": (None, [C.POINTER(SdpgpuDesc)]),
     "sdpgpu_create": (C.c_int, [C.POINTER(SdpgpuDesc), C.POINTER(_P)]),
+    "sdpgpu_create_custom": (C.c_int, [C.POINTER(SdpgpuDesc), C.c_char_p, _DP, C.c_int32, C.POINTER(_P)]),
     "sdpgpu_destroy": (None, [_P]),
     "sdpgpu_last_error": (C.c_char_p, [_P]),
     "sdpgpu_set_pmf": (C.c_int, [_P, C.c_int32, _DP, _DP, C.c_int32]),

@@ -50,7 +50,7 @@ def build(force: bool = False, extra_flags=(), verbose: bool = True) -> str:
     if not force and up_to_date():
         return OUT
     hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
-    cmd = [hipcc, *HIPCC_FLAGS, *extra_flags, "-o", OUT, *sources()]
+    cmd = [hipcc, *HIPCC_FLAGS, *extra_flags, "-o", OUT, *sources(), "-lhiprtc"]
     if verbose:
         print("+", " ".join(cmd), flush=True)
     subprocess.run(cmd, check=True)

@@ -1,0 +1,252 @@
+// sdp_custom_src.hpp -- device source of the USER-DEFINED functor path, compiled at sdpgpu_create_custom()
+// time with hipRTC for gfx950 (-ffp-contract=off, like the rest of the library).
+//
+// The reference injects a problem as three Java lambdas (Recursion.java:49-52: feasible actions,
+// StateTransition.java:20-22, ImmediateValue.java:23-25).  The built-in families cover the in-scope drivers;
+// any other driver's lambdas are handed over as three HIP device functions (see include/sdpgpu.h,
+// sdpgpu_create_custom) and this engine source is compiled around them: same loop, same accumulation
+// order, same strict-compare arg-opt as sdp_gather.hpp.
+//
+// Three pieces of text: kCustomPrelude (what the user's functions may use), the user's source, kCustomEngine.
+#pragma once
+
+namespace sdp {
+
+// NOTE: struct CustomParams below (host) and `struct CParams` in kCustomEngine (device) must stay identical;
+// both sides static_assert the size.
+struct CustomGrid {
+  double x_lo;
+  long long nx, nc, nq, k_lo;
+};
+struct CustomParams {
+  int has_cash, has_preq, maxdir, is_last;
+  int n_demand, survival, cash_int_div, period;
+  int T, pad0;
+  double step, inv_step, gamma, round_mult, round_div;
+  CustomGrid cur, next;
+  const double* user;
+};
+static_assert(sizeof(CustomParams) == 168, "CustomParams layout is mirrored in kCustomEngine");
+
+static const char* const kCustomPrelude = R"SDPSRC(
+typedef long long sdp_i64;
+// what the three user functions receive besides the state tuple
+struct sdp_ctx {
+  int period;            // 1-based period of the state (State.getPeriod())
+  int T;                 // horizon, pmf.length
+  double step;           // stepSize
+  const double* params;  // the doubles given to sdpgpu_create_custom (the constants the lambdas close over)
+};
+// java.lang.Math.max / min / round for the operands that occur here (round: nearest, ties toward +infinity,
+// returned as an integer-valued double)
+__device__ inline double sdp_max(double a, double b) { return fmax(a, b); }
+__device__ inline double sdp_min(double a, double b) { return fmin(a, b); }
+__device__ inline double sdp_round(double x) { double f = floor(x); return (x - f >= 0.5) ? f + 1.0 : f; }
+__device__ inline double sdp_trunc(double x) { return trunc(x); }  // (int) / (long) casts, long division
+#line 1 "user_functor"
+)SDPSRC";
+
+static const char* const kCustomEngine = R"SDPSRC(
+#line 1 "sdp_custom_engine"
+struct CGrid { double x_lo; sdp_i64 nx, nc, nq, k_lo; };
+struct CParams {
+  int has_cash, has_preq, maxdir, is_last;
+  int n_demand, survival, cash_int_div, period;
+  int T, pad0;
+  double step, inv_step, gamma, round_mult, round_div;
+  CGrid cur, next;
+  const double* user;
+};
+static_assert(sizeof(CParams) == 168, "CParams layout is mirrored in sdp_custom_src.hpp");
+
+struct CState { double x, cash, preq; };
+
+__device__ inline void c_decode(const CParams& P, sdp_i64 idx, CState& s) {
+  sdp_i64 ic = idx % P.cur.nc;
+  sdp_i64 r = idx / P.cur.nc;
+  sdp_i64 ix = r % P.cur.nx;
+  sdp_i64 iq = r / P.cur.nx;
+  s.x = P.cur.x_lo + (double)ix * P.step;
+  double k = (double)(P.cur.k_lo + ic);
+  s.cash = P.has_cash ? (P.cash_int_div ? k : k / P.round_div) : 0.0;
+  s.preq = P.has_preq ? (double)iq * P.step : 0.0;
+}
+
+// Flat index of the state the user's transition returned, which must be a grid point of period + 1 (the Java
+// lambda clamps and rounds itself).  Anything else raises the error flag and reads index 0.
+__device__ inline sdp_i64 c_next_index(const CParams& P, double nx, double ncash, double npreq, int* err) {
+  double fx = (nx - P.next.x_lo) * P.inv_step;
+  sdp_i64 ix = (sdp_i64)fx;
+  bool ok = (double)ix == fx && ix >= 0 && ix < P.next.nx;
+  sdp_i64 ic = 0, iq = 0;
+  if (P.has_cash) {
+    sdp_i64 k;
+    double back;
+    if (P.cash_int_div) {
+      k = (sdp_i64)ncash;
+      back = (double)k;
+    } else {
+      k = (sdp_i64)sdp_round(ncash * P.round_mult);
+      back = (double)k / P.round_div;
+    }
+    ic = k - P.next.k_lo;
+    ok = ok && back == ncash && ic >= 0 && ic < P.next.nc;
+  }
+  if (P.has_preq) {
+    double fq = npreq * P.inv_step;
+    iq = (sdp_i64)fq;
+    ok = ok && (double)iq == fq && iq >= 0 && iq < P.next.nq;
+  }
+  if (!ok) {
+    atomicOr(err, 1);
+    return 0;
+  }
+  return (iq * P.next.nx + ix) * P.next.nc + ic;
+}
+
+__device__ inline bool c_better(bool maxdir, double v2, int k2, double v, int k) {
+  return maxdir ? (v2 > v || (v2 == v && k2 < k)) : (v2 < v || (v2 == v && k2 < k));
+}
+
+// One period: 256 threads = 16 consecutive states x 16 action slots; a lane walks its actions and, per action,
+// the demand index serially in the reference's order (Recursion.java:138-144).  q* != nullptr: evaluate the
+// given state tuples instead of grid states (getExpectedValue on an off-grid state).
+extern "C" __global__ __launch_bounds__(256) void sdp_custom_period(
+    CParams P, const double* __restrict__ v_next, double* __restrict__ v_cur, int* __restrict__ pol,
+    const double* __restrict__ pmf_d, const double* __restrict__ pmf_p, sdp_i64 lo, sdp_i64 hi,
+    const double* __restrict__ qx, const double* __restrict__ qcash, const double* __restrict__ qpreq,
+    unsigned long long* __restrict__ cells, int* __restrict__ err) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  double2* s_pmf = reinterpret_cast<double2*>(smem);
+  double* s_val = reinterpret_cast<double*>(smem + (size_t)P.n_demand * 16);
+  int* s_k = reinterpret_cast<int*>(s_val + 4 * 16);
+  const int tid = threadIdx.x;
+  for (int j = tid; j < P.n_demand; j += 256) s_pmf[j] = make_double2(pmf_d[j], pmf_p[j]);
+  __syncthreads();
+
+  const int sx = tid & 15;
+  const int as = tid >> 4;
+  const sdp_i64 idx = lo + (sdp_i64)blockIdx.x * 16 + sx;
+  const bool live = idx < hi;
+  CState s;
+  if (qx) {
+    s.x = live ? qx[idx] : 0.0;
+    s.cash = (live && qcash) ? qcash[idx] : 0.0;
+    s.preq = (live && qpreq) ? qpreq[idx] : 0.0;
+  } else {
+    c_decode(P, live ? idx : lo, s);
+  }
+  sdp_ctx U;
+  U.period = P.period;
+  U.T = P.T;
+  U.step = P.step;
+  U.params = P.user;
+  const int nA = live ? sdp_feasible_count(U, s.x, s.cash, s.preq) : 0;
+  const int nD = P.n_demand;
+
+  double best = P.maxdir ? -1.7976931348623157e308 : 1.7976931348623157e308;
+  int bestk = 0;
+  for (int k = as; k < nA; k += 16) {
+    const double a = (double)k * P.step;
+    double acc = 0.0;
+    for (int j = 0; j < nD; ++j) {
+      const double2 dp = s_pmf[j];
+      const double imm = sdp_immediate(U, s.x, s.cash, s.preq, a, dp.x);
+      if (P.survival) {  // RiskRecursion.java:78-98
+        if (P.is_last) {
+          acc += dp.y * ((s.cash + imm) >= 0 ? 1.0 : 0.0);
+        } else {
+          double nx, nc, nq;
+          sdp_transition(U, s.x, s.cash, s.preq, a, dp.x, nx, nc, nq);
+          acc += (dp.y * P.gamma) * (nc < 0 ? 0.0 : v_next[c_next_index(P, nx, nc, nq, err)]);
+        }
+      } else {
+        acc += dp.y * imm;
+        if (!P.is_last) {
+          double nx, nc, nq;
+          sdp_transition(U, s.x, s.cash, s.preq, a, dp.x, nx, nc, nq);
+          acc += (dp.y * P.gamma) * v_next[c_next_index(P, nx, nc, nq, err)];
+        }
+      }
+    }
+    if (P.maxdir ? (acc > best) : (acc < best)) {
+      best = acc;
+      bestk = k;
+    }
+  }
+  // the four action slots of a state that live in this wave (lanes sx, sx+16, sx+32, sx+48)
+  for (int off = 16; off < 64; off <<= 1) {
+    double ov = __shfl_xor(best, off, 64);
+    int ok = __shfl_xor(bestk, off, 64);
+    if (c_better(P.maxdir, ov, ok, best, bestk)) {
+      best = ov;
+      bestk = ok;
+    }
+  }
+  const int wave = tid >> 6;
+  const int lane = tid & 63;
+  if (lane < 16) {
+    s_val[wave * 16 + lane] = best;
+    s_k[wave * 16 + lane] = bestk;
+  }
+  __syncthreads();
+  if (tid < 16) {
+    double bv = s_val[tid];
+    int bk = s_k[tid];
+    for (int w = 1; w < 4; ++w) {
+      double ov = s_val[w * 16 + tid];
+      int ok = s_k[w * 16 + tid];
+      if (c_better(P.maxdir, ov, ok, bv, bk)) {
+        bv = ov;
+        bk = ok;
+      }
+    }
+    if (live) {
+      v_cur[idx] = bv;
+      pol[idx] = bk;
+    }
+    // cells of this workgroup = sum over its states of nA * D (tid < 16 holds as == 0: nA of state sx)
+    unsigned long long c = live ? (unsigned long long)nA * (unsigned long long)nD : 0ull;
+    for (int off = 8; off > 0; off >>= 1) c += __shfl_down(c, off, 64);
+    if (tid == 0 && cells) atomicAdd(cells, c);
+  }
+}
+
+// Forward reachable set (Recursion.java:90's key set): successors of every marked state over all feasible
+// actions and all demands; bankrupt successors of the survival loop are not visited.
+extern "C" __global__ __launch_bounds__(256) void sdp_custom_reach(
+    CParams P, const unsigned char* __restrict__ mask_cur, unsigned char* __restrict__ mask_next,
+    const double* __restrict__ pmf_d, sdp_i64 n, const double* __restrict__ qx, const double* __restrict__ qcash,
+    const double* __restrict__ qpreq, int* __restrict__ err) {
+  const int sx = threadIdx.x & 63;
+  const int as = threadIdx.x >> 6;
+  const sdp_i64 idx = (sdp_i64)blockIdx.x * 64 + sx;
+  if (idx >= n) return;
+  CState s;
+  if (qx) {
+    s.x = qx[idx];
+    s.cash = qcash ? qcash[idx] : 0.0;
+    s.preq = qpreq ? qpreq[idx] : 0.0;
+  } else {
+    if (!mask_cur[idx]) return;
+    c_decode(P, idx, s);
+  }
+  sdp_ctx U;
+  U.period = P.period;
+  U.T = P.T;
+  U.step = P.step;
+  U.params = P.user;
+  const int nA = sdp_feasible_count(U, s.x, s.cash, s.preq);
+  for (int k = as; k < nA; k += 4) {
+    const double a = (double)k * P.step;
+    for (int j = 0; j < P.n_demand; ++j) {
+      double nx, nc, nq;
+      sdp_transition(U, s.x, s.cash, s.preq, a, pmf_d[j], nx, nc, nq);
+      if (P.survival && nc < 0) continue;
+      mask_next[c_next_index(P, nx, nc, nq, err)] = 1;
+    }
+  }
+}
+)SDPSRC";
+
+}  // namespace sdp

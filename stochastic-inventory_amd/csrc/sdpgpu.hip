@@ -7,6 +7,7 @@
 #include "../../include/sdpgpu.h"
 
 #include <hip/hip_runtime.h>
+#include <hip/hiprtc.h>
 
 #include <cmath>
 #include <cstdarg>
@@ -22,6 +23,7 @@
 #include "sdp_gather.hpp"
 #include "sdp_window.hpp"
 #include "sdp_cash.hpp"
+#include "sdp_custom_src.hpp"
 
 using sdp::DevParams;
 using sdp::Grid;
@@ -97,6 +99,16 @@ struct sdpgpu_handle {
   uint8_t* d_reach = nullptr;      // reachable masks, period t at reach_off[t-1]
   std::vector<size_t> reach_off;
   bool reach_done = false;
+  // user-defined functor (sdpgpu_create_custom): code object compiled by hipRTC at create time, loaded at
+  // first use; every period then runs sdp_custom_period instead of a built-in kernel
+  bool custom = false;
+  std::vector<char> custom_code;
+  std::vector<double> custom_params;
+  hipModule_t custom_mod = nullptr;
+  hipFunction_t custom_period = nullptr, custom_reach = nullptr;
+  double* d_custom_params = nullptr;
+  unsigned long long* d_custom_cells = nullptr;  // [T]
+  int* d_custom_err = nullptr;
   std::string err;
   int device = -1;
 };
@@ -257,6 +269,10 @@ int layout(sdpgpu_handle* h) {
   return SDPGPU_OK;
 }
 
+// A dispatch carries at most 2^32 - 1 work-items (AQL grid_size is 32 bits); beyond that the launch is
+// silently truncated.  Every launcher below sends 256-thread workgroups and refuses a grid over the limit.
+inline bool grid_ok(int64_t blocks) { return blocks > 0 && blocks * 256 < 4294967296LL; }
+
 int ensure_device(sdpgpu_handle* h) {
   if (h->device >= 0) HIP_TRY(h, hipSetDevice(h->device));
   return SDPGPU_OK;
@@ -294,7 +310,97 @@ int allocate(sdpgpu_handle* h) {
   HIP_TRY(h, hipMemcpy(h->d_pmf, host.data(), pmf_elems * sizeof(double), hipMemcpyHostToDevice));
   HIP_TRY(h, hipEventCreate(&h->ev_solve0));
   HIP_TRY(h, hipEventCreate(&h->ev_solve1));
+  if (h->custom) {
+    HIP_TRY(h, hipModuleLoadData(&h->custom_mod, h->custom_code.data()));
+    HIP_TRY(h, hipModuleGetFunction(&h->custom_period, h->custom_mod, "sdp_custom_period"));
+    HIP_TRY(h, hipModuleGetFunction(&h->custom_reach, h->custom_mod, "sdp_custom_reach"));
+    HIP_TRY(h, hipMalloc((void**)&h->d_custom_params, std::max<size_t>(h->custom_params.size(), 1) * sizeof(double)));
+    if (!h->custom_params.empty())
+      HIP_TRY(h, hipMemcpy(h->d_custom_params, h->custom_params.data(), h->custom_params.size() * sizeof(double), hipMemcpyHostToDevice));
+    HIP_TRY(h, hipMalloc((void**)&h->d_custom_cells, (size_t)h->T * sizeof(unsigned long long)));
+    HIP_TRY(h, hipMemset(h->d_custom_cells, 0, (size_t)h->T * sizeof(unsigned long long)));
+    HIP_TRY(h, hipMalloc((void**)&h->d_custom_err, sizeof(int)));
+    HIP_TRY(h, hipMemset(h->d_custom_err, 0, sizeof(int)));
+  }
   h->allocated = true;
+  return SDPGPU_OK;
+}
+
+// ---- user-defined functor: parameter block and launches ---------------------------------------------
+sdp::CustomParams make_custom_params(const sdpgpu_handle* h, int period) {
+  const sdpgpu_desc& d = h->d;
+  const PeriodInfo& p = h->per[period - 1];
+  sdp::CustomParams C{};
+  C.has_cash = has_cash(d.family);
+  C.has_preq = has_preq(d.family);
+  C.maxdir = d.direction == SDPGPU_MAX;
+  C.is_last = period == h->T;
+  C.n_demand = p.nD;
+  C.survival = d.family == SDPGPU_FAMILY_SURVIVAL;
+  C.cash_int_div = d.cash_round_int_div;
+  C.period = period;
+  C.T = h->T;
+  C.step = d.step;
+  C.inv_step = 1.0 / d.step;
+  const bool cash_loop = d.family == SDPGPU_FAMILY_CASH || d.family == SDPGPU_FAMILY_OVERDRAFT || d.family == SDPGPU_FAMILY_SURVIVAL;
+  C.gamma = cash_loop ? d.discount_factor : 1.0;
+  C.round_mult = d.cash_round_mult;
+  C.round_div = d.cash_round_div;
+  auto grid_of = [](const Grid& g) { return sdp::CustomGrid{g.x_lo, (long long)g.nx, (long long)g.nc, (long long)g.nq, (long long)g.k_lo}; };
+  C.cur = grid_of(p.g);
+  if (period < h->T) C.next = grid_of(h->per[period].g);
+  C.user = h->d_custom_params;
+  return C;
+}
+
+hipError_t launch_custom_period(sdpgpu_handle* h, int period, const double* v_next, double* v_cur, int32_t* pol,
+                                int64_t lo, int64_t hi, const double* qx, const double* qcash, const double* qpreq,
+                                bool count) {
+  if (hi <= lo) return hipSuccess;
+  const PeriodInfo& p = h->per[period - 1];
+  sdp::CustomParams C = make_custom_params(h, period);
+  const double* pd = h->d_pmf + p.pmf_off;
+  const double* pp = pd + p.nD;
+  long long llo = lo, lhi = hi;
+  unsigned long long* cells = count ? h->d_custom_cells + (period - 1) : nullptr;
+  if (count) {
+    hipError_t e0 = hipMemsetAsync(cells, 0, sizeof(unsigned long long), h->stream);
+    if (e0 != hipSuccess) return e0;
+  }
+  int* err = h->d_custom_err;
+  void* args[] = {&C, &v_next, &v_cur, &pol, &pd, &pp, &llo, &lhi, &qx, &qcash, &qpreq, &cells, &err};
+  const int64_t blocks = (hi - lo + 15) / 16;
+  if (!grid_ok(blocks)) return hipErrorInvalidValue;
+  const size_t smem = (size_t)p.nD * 16 + 4 * 16 * (sizeof(double) + sizeof(int));
+  return hipModuleLaunchKernel(h->custom_period, (unsigned)blocks, 1, 1, 256, 1, 1, (unsigned)smem, h->stream, args, nullptr);
+}
+
+hipError_t launch_custom_reach(sdpgpu_handle* h, int period, const uint8_t* mcur, uint8_t* mnext, int64_t n,
+                               const double* qx, const double* qcash, const double* qpreq) {
+  if (n <= 0) return hipSuccess;
+  const PeriodInfo& p = h->per[period - 1];
+  sdp::CustomParams C = make_custom_params(h, period);
+  const double* pd = h->d_pmf + p.pmf_off;
+  long long ln = n;
+  int* err = h->d_custom_err;
+  void* args[] = {&C, &mcur, &mnext, &pd, &ln, &qx, &qcash, &qpreq, &err};
+  const int64_t blocks = (n + 63) / 64;
+  if (!grid_ok(blocks)) return hipErrorInvalidValue;
+  return hipModuleLaunchKernel(h->custom_reach, (unsigned)blocks, 1, 1, 256, 1, 1, 0, h->stream, args, nullptr);
+}
+
+// After a synchronisation point: did a user transition return a state that is not a grid point?
+int custom_check(sdpgpu_handle* h) {
+  if (!h->custom || !h->d_custom_err) return SDPGPU_OK;
+  int flag = 0;
+  HIP_TRY(h, hipStreamSynchronize(h->stream));
+  HIP_TRY(h, hipMemcpy(&flag, h->d_custom_err, sizeof flag, hipMemcpyDeviceToHost));
+  if (flag) {
+    (void)hipMemset(h->d_custom_err, 0, sizeof(int));
+    return fail(h, SDPGPU_ERR_ARG,
+                "user functor: sdp_transition returned a state that is not a grid point of the next period "
+                "(the lambda must clamp and round as the descriptor says; results are invalid)");
+  }
   return SDPGPU_OK;
 }
 
@@ -346,9 +452,6 @@ DevParams make_params(const sdpgpu_handle* h, int period) {
 
 // ---- launch helpers --------------------------------------------------------------------------
 
-// A dispatch carries at most 2^32 - 1 work-items (AQL grid_size is 32 bits); beyond that the launch is
-// silently truncated.  Every launcher below sends 256-thread workgroups and refuses a grid over the limit.
-inline bool grid_ok(int64_t blocks) { return blocks > 0 && blocks * 256 < 4294967296LL; }
 
 template <int FAM, bool MAXDIR, int SX, bool QUERY>
 hipError_t launch_gather_sx(const DevParams& P, const double* v_next, double* v_cur, int32_t* pol, const double* pmf_d,
@@ -396,6 +499,7 @@ hipError_t launch_gather(const DevParams& P, const double* v_next, double* v_cur
 // cells of one period: sum over states of nA(s) * D  (host arithmetic, no device work)
 void count_cells(sdpgpu_handle* h, int period) {
   PeriodInfo& p = h->per[period - 1];
+  if (h->custom) return;  // counted on the device (sdpgpu_stats_get)
   const sdpgpu_desc& d = h->d;
   int64_t nD = p.nD;
   auto range_cells = [&](int64_t lo, int64_t hi) -> int64_t {
@@ -456,6 +560,22 @@ int run_period_impl(sdpgpu_handle* h, int period, int part = SDPGPU_PART_ALL) {
       HIP_TRY(h, hipEventCreate(&p.ev1));
     }
     HIP_TRY(h, hipEventRecord(p.ev0, h->stream));
+  }
+  if (h->custom) {
+    if (part == SDPGPU_PART_INTERIOR) return SDPGPU_OK;  // no bounded footprint is known for user lambdas
+    hipError_t ec = launch_custom_period(h, period, v_next, v_cur, pol, p.lo, p.hi, nullptr, nullptr, nullptr, true);
+    if (ec != hipSuccess) return fail(h, SDPGPU_ERR_DEVICE, "period %d user-functor kernel: %s", period, hipGetErrorString(ec));
+    p.kernel_used = SDPGPU_KERNEL_GATHER;
+    if (h->profiling) {
+      HIP_TRY(h, hipEventRecord(p.ev1, h->stream));
+      p.timed = true;
+    } else {
+      p.timed = false;
+    }
+    h->period_done[period - 1] = 1;
+    h->policy_done[period - 1] = 1;
+    if (!h->d.store_all_values && period + 2 <= h->T) h->period_done[period + 1] = 0;
+    return SDPGPU_OK;
   }
   if (h->d.kernel == SDPGPU_KERNEL_SEPARABLE) {
     if (h->d.family != SDPGPU_FAMILY_BACKORDER) return fail(h, SDPGPU_ERR_UNSUPPORTED, "the separable mode exists for the backorder family only");
@@ -608,7 +728,10 @@ int compute_reachable(sdpgpu_handle* h) {
     const PeriodInfo& p = h->per[period - 1];
     const double* pd = h->d_pmf + p.pmf_off;
     uint8_t* mnext = h->d_reach + h->reach_off[period];
-    if (period == 1)
+    if (h->custom)
+      e = period == 1 ? launch_custom_reach(h, 1, nullptr, mnext, 1, d_ini, d_ini + 1, d_ini + 2)
+                      : launch_custom_reach(h, period, h->d_reach + h->reach_off[period - 1], mnext, p.S, nullptr, nullptr, nullptr);
+    else if (period == 1)
       e = launch_reach(P, nullptr, mnext, pd, 1, sdp::QueryStates{d_ini, d_ini + 1, d_ini + 2, d_ini + 3}, true, h->stream);
     else
       e = launch_reach(P, h->d_reach + h->reach_off[period - 1], mnext, pd, p.S, sdp::QueryStates{nullptr, nullptr, nullptr, nullptr}, false, h->stream);
@@ -616,6 +739,8 @@ int compute_reachable(sdpgpu_handle* h) {
   if (e == hipSuccess) e = hipStreamSynchronize(h->stream);
   (void)hipFree(d_ini);
   if (e != hipSuccess) return fail(h, SDPGPU_ERR_DEVICE, "reachable: %s", hipGetErrorString(e));
+  rc = custom_check(h);
+  if (rc) return rc;
   h->reach_done = true;
   return SDPGPU_OK;
 }
@@ -627,6 +752,7 @@ bool dyadic(double x, double scale, double max_abs) { return std::fabs(x) <= max
 // cash quantum is a power of two and every parameter is a multiple of 2^-10 of bounded size.
 bool cash_shift_eligible(const sdpgpu_handle* h, int period) {
   const sdpgpu_desc& d = h->d;
+  if (h->custom) return false;
   if (d.family != SDPGPU_FAMILY_CASH || !d.clamp_inventory) return false;
   if (d.deposit_rate != 0 || d.overhead_rate != 0 || d.penalty_cost != 0) return false;
   double q;
@@ -709,6 +835,7 @@ struct WinPlan {
 
 // F1 / F2 with a unit-stride demand grid: d_j = d_0 + j*step.
 bool window_eligible(const sdpgpu_handle* h, int period) {
+  if (h->custom) return false;
   if (h->d.family != SDPGPU_FAMILY_BACKORDER && h->d.family != SDPGPU_FAMILY_LEADTIME) return false;
   const std::vector<double>& d = h->pmf_d[period - 1];
   for (size_t j = 1; j < d.size(); ++j)
@@ -1162,6 +1289,7 @@ bool keys_needed(sdpgpu_handle* h) {
 }
 
 int flush_api(sdpgpu_handle* h) {
+  if (h->custom) return custom_check(h);
   if (h->n_pending == 0) return SDPGPU_OK;
   int rc = ensure_device(h);
   if (rc) return rc;
@@ -1226,6 +1354,44 @@ int sdpgpu_create(const sdpgpu_desc* desc, sdpgpu_handle** out) {
   return SDPGPU_OK;
 }
 
+int sdpgpu_create_custom(const sdpgpu_desc* desc, const char* functor_source, const double* params, int32_t n_params,
+                         sdpgpu_handle** out) {
+  g_create_error.clear();
+  if (!desc || !out || !functor_source || n_params < 0 || (n_params > 0 && !params)) return fail(nullptr, SDPGPU_ERR_ARG, "null argument");
+  *out = nullptr;
+  if (desc->lead_time == 2) return fail(nullptr, SDPGPU_ERR_UNSUPPORTED, "a user functor has one pipeline quantity at most (lead_time 2 is a built-in shape)");
+  if (desc->kernel != SDPGPU_KERNEL_AUTO && desc->kernel != SDPGPU_KERNEL_GATHER) return fail(nullptr, SDPGPU_ERR_UNSUPPORTED, "a user functor runs on the generic kernel only");
+  // compile: prelude + the user's three device functions + the engine kernels, strict fp64 (no FMA)
+  std::string src = std::string(sdp::kCustomPrelude) + functor_source + "\n" + sdp::kCustomEngine;
+  hiprtcProgram prog = nullptr;
+  if (hiprtcCreateProgram(&prog, src.c_str(), "sdp_custom.hip", 0, nullptr, nullptr) != HIPRTC_SUCCESS)
+    return fail(nullptr, SDPGPU_ERR_DEVICE, "hiprtcCreateProgram failed");
+  const char* opts[] = {"--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fno-fast-math"};
+  hiprtcResult cr = hiprtcCompileProgram(prog, 5, opts);
+  if (cr != HIPRTC_SUCCESS) {
+    size_t n = 0;
+    (void)hiprtcGetProgramLogSize(prog, &n);
+    std::string log(n, '\0');
+    if (n) (void)hiprtcGetProgramLog(prog, &log[0]);
+    (void)hiprtcDestroyProgram(&prog);
+    if (log.size() > 400) log.resize(400);
+    return fail(nullptr, SDPGPU_ERR_ARG, "user functor does not compile: %s", log.c_str());
+  }
+  size_t code_size = 0;
+  (void)hiprtcGetCodeSize(prog, &code_size);
+  std::vector<char> code(code_size);
+  hiprtcResult gr = hiprtcGetCode(prog, code.data());
+  (void)hiprtcDestroyProgram(&prog);
+  if (gr != HIPRTC_SUCCESS || code.empty()) return fail(nullptr, SDPGPU_ERR_DEVICE, "hiprtcGetCode failed");
+  int rc = sdpgpu_create(desc, out);
+  if (rc) return rc;
+  sdpgpu_handle* h = *out;
+  h->custom = true;
+  h->custom_code.swap(code);
+  h->custom_params.assign(params, params + n_params);
+  return SDPGPU_OK;
+}
+
 void sdpgpu_destroy(sdpgpu_handle* h) {
   if (!h) return;
   if (h->allocated || h->d_policy || h->d_pmf) {
@@ -1250,6 +1416,10 @@ void sdpgpu_destroy(sdpgpu_handle* h) {
   if (h->d_chunk_val) (void)hipFree(h->d_chunk_val);
   if (h->d_chunk_idx) (void)hipFree(h->d_chunk_idx);
   if (h->d_jobs) (void)hipFree(h->d_jobs);
+  if (h->d_custom_params) (void)hipFree(h->d_custom_params);
+  if (h->d_custom_cells) (void)hipFree(h->d_custom_cells);
+  if (h->d_custom_err) (void)hipFree(h->d_custom_err);
+  if (h->custom_mod) (void)hipModuleUnload(h->custom_mod);
   if (h->stream && h->own_stream) (void)hipStreamDestroy(h->stream);
   delete h;
 }
@@ -1588,7 +1758,10 @@ int sdpgpu_eval_states2(sdpgpu_handle* h, int32_t period, int64_t n, const doubl
     const double* v_next = period < h->T ? h->d_values + h->per[period].v_off : nullptr;
     const double* pd = h->d_pmf + p.pmf_off;
     sdp::QueryStates q{d_in, cash ? d_in + nn : nullptr, preq ? d_in + 2 * nn : nullptr, preq2 ? d_in + 3 * nn : nullptr};
-    e = launch_gather<true>(P, v_next, d_val, d_act, pd, pd + p.nD, 0, n, q, h->stream);
+    if (h->custom)
+      e = launch_custom_period(h, period, v_next, d_val, d_act, 0, n, q.x, q.cash, q.preq, false);
+    else
+      e = launch_gather<true>(P, v_next, d_val, d_act, pd, pd + p.nD, 0, n, q, h->stream);
   }
   if (e == hipSuccess) e = hipStreamSynchronize(h->stream);
   if (e == hipSuccess) e = hipMemcpy(out_value, d_val, nn * sizeof(double), hipMemcpyDeviceToHost);
@@ -1597,7 +1770,7 @@ int sdpgpu_eval_states2(sdpgpu_handle* h, int32_t period, int64_t n, const doubl
   (void)hipFree(d_val);
   (void)hipFree(d_act);
   if (e != hipSuccess) return fail(h, SDPGPU_ERR_DEVICE, "eval_states: %s", hipGetErrorString(e));
-  return SDPGPU_OK;
+  return custom_check(h);
 }
 
 int sdpgpu_reachable(sdpgpu_handle* h, int32_t period, uint8_t* out, int64_t n) {
@@ -1619,6 +1792,7 @@ int sdpgpu_simulate(sdpgpu_handle* h, int64_t n_paths, const double* demand, con
   if (n_paths < 0 || !demand || !discount || !out_sum || !out_valid) return fail(h, SDPGPU_ERR_ARG, "simulate: bad argument");
   if (h->d.world_size != 1) return fail(h, SDPGPU_ERR_STATE, "simulate needs the whole policy on one GPU (world_size 1)");
   if (h->d.family == SDPGPU_FAMILY_SURVIVAL) return fail(h, SDPGPU_ERR_UNSUPPORTED, "simulate: RiskSimulation's rollout is not part of this library");
+  if (h->custom) return fail(h, SDPGPU_ERR_UNSUPPORTED, "simulate: a user functor's lambdas live on the host; roll the policy tables forward there");
   if (!h->allocated) return fail(h, SDPGPU_ERR_STATE, "simulate: nothing has been solved");
   for (int t = 0; t < h->T; ++t)
     if (!h->policy_done[t]) return fail(h, SDPGPU_ERR_STATE, "simulate: period %d has not been computed", t + 1);
@@ -1705,6 +1879,16 @@ int sdpgpu_stats_get(sdpgpu_handle* h, sdpgpu_stats* out) {
   out->kernel_used = h->per[0].kernel_used;
   if (h->allocated) {
     (void)ensure_device(h);
+    if (h->custom && h->d_custom_cells && hipStreamSynchronize(h->stream) == hipSuccess) {
+      // the action count of a user functor is only known on the device: the kernel counted its cells
+      std::vector<unsigned long long> c((size_t)h->T, 0);
+      if (hipMemcpy(c.data(), h->d_custom_cells, c.size() * sizeof(unsigned long long), hipMemcpyDeviceToHost) == hipSuccess) {
+        out->cells_evaluated = 0;
+        for (int t = 0; t < h->T; ++t)
+          if (h->period_done[t]) out->cells_evaluated += (int64_t)c[(size_t)t];
+        out->cells_all_ranks = h->d.world_size == 1 ? out->cells_evaluated : 0;
+      }
+    }
     if (h->solve_timed && hipStreamSynchronize(h->stream) == hipSuccess) {
       float ms = 0;
       if (hipEventElapsedTime(&ms, h->ev_solve0, h->ev_solve1) == hipSuccess) out->solve_ms = ms;

@@ -35,14 +35,22 @@ def split_pmf(pmf):
 class SdpEngine:
     """One backward-recursion problem on one GPU (or one rank's state slab of it)."""
 
-    def __init__(self, desc: SdpgpuDesc, pmf, overhead: Optional[Sequence[float]] = None):
+    def __init__(self, desc: SdpgpuDesc, pmf, overhead: Optional[Sequence[float]] = None,
+                 custom_source: Optional[str] = None, custom_params: Optional[Sequence[float]] = None):
+        """custom_source: HIP device text of the three lambdas (see sdpgpu_create_custom in include/sdpgpu.h),
+        custom_params: the doubles they read through `c.params`."""
         self._lib = _abi.load()
         self._h = C.c_void_p()
         self.desc = desc
         tiles = split_pmf(pmf)
         if len(tiles) != desc.periods:
             raise ValueError(f"pmf has {len(tiles)} periods, descriptor says {desc.periods}")
-        rc = self._lib.sdpgpu_create(C.byref(desc), C.byref(self._h))
+        if custom_source is None:
+            rc = self._lib.sdpgpu_create(C.byref(desc), C.byref(self._h))
+        else:
+            prm = np.ascontiguousarray(custom_params if custom_params is not None else [], dtype=np.float64)
+            rc = self._lib.sdpgpu_create_custom(C.byref(desc), custom_source.encode(), _dp(prm) if len(prm) else None,
+                                                len(prm), C.byref(self._h))
         if rc:
             raise SdpgpuError(rc, self._lib.sdpgpu_last_error(None).decode())
         try:

@@ -418,3 +418,45 @@ class CashLeadtimeFunctor(OverdraftFunctor):
         nextInventory = self.minInventoryState if nextInventory < self.minInventoryState else nextInventory
         nextCash = self._round_cash(nextCash)
         return CashLeadtimeState(s.getPeriod() + 1, nextInventory, nextCash, action)
+
+
+@dataclass
+class CustomFunctor(_Base):
+    """User-defined lambdas (sdpgpu_create_custom): `source` is the HIP device text of sdp_feasible_count /
+    sdp_immediate / sdp_transition, `params` the doubles it reads through c.params, `shape` the built-in functor
+    whose STATE SHAPE, grid fields and loop it borrows (its cost fields are ignored).  The Python callables
+    restate the same lambdas on the host for the mirror classes (policy read-out, validateFunctor); they take
+    and return the reference's state objects, exactly like the Java lambdas."""
+
+    shape: object = None
+    source: str = ""
+    params: List[float] = field(default_factory=list)
+    getFeasibleAction: Optional[object] = None   # state -> list of actions
+    stateTransitionFn: Optional[object] = None   # (state, action, demand) -> state
+    immediateValueFn: Optional[object] = None    # (state, action, demand) -> float
+
+    def __getattr__(self, name):  # stepSize, iniInventory, ... come from the shape
+        if name in ("shape", "source", "params"):
+            raise AttributeError(name)
+        return getattr(self.shape, name)
+
+    def to_desc(self, T, direction=OptDirection.MIN):
+        return self.shape.to_desc(T, direction)
+
+    def overheads(self, T):
+        return self.shape.overheads(T) if hasattr(self.shape, "overheads") else None
+
+    def make_state(self, *a, **k):
+        return self.shape.make_state(*a, **k)
+
+    def tuple_of(self, s):
+        return self.shape.tuple_of(s)
+
+    def feasibleActions(self, s, T=None):
+        return list(self.getFeasibleAction(s))
+
+    def immediateValue(self, s, action, randomDemand, T=None):
+        return self.immediateValueFn(s, action, randomDemand)
+
+    def stateTransition(self, s, action, randomDemand, T=None):
+        return self.stateTransitionFn(s, action, randomDemand)

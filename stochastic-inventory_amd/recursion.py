@@ -47,13 +47,16 @@ class _GpuRecursionBase:
         self.stateTransition = stateTransition or (lambda s, a, r: functor.stateTransition(s, a, r, T))
         self.immediateValue = immediateValue or (lambda s, a, r: functor.immediateValue(s, a, r, T))
         self.discountFactor = discountFactor
-        if hasattr(functor, "discountFactor"):
-            functor.discountFactor = discountFactor
+        holder = getattr(functor, "shape", None) or functor  # a CustomFunctor borrows its grid from `shape`
+        if hasattr(holder, "discountFactor"):
+            holder.discountFactor = discountFactor
         desc = functor.to_desc(T, optDirection)
         desc.device = device
         desc.kernel = kernel
         overhead = functor.overheads(T) if hasattr(functor, "overheads") else None
-        self._engine = SdpEngine(desc, pmf, overhead)
+        source = getattr(functor, "source", None) or None  # CustomFunctor: the lambdas as HIP device text
+        self._engine = SdpEngine(desc, pmf, overhead, custom_source=source,
+                                 custom_params=getattr(functor, "params", None) if source else None)
         self._solved = False
         self._values: Dict[int, np.ndarray] = {}
         self._policy: Dict[int, np.ndarray] = {}

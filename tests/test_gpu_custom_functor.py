@@ -1,0 +1,141 @@
+"""User-defined lambdas on the GPU (sdpgpu_create_custom): the three Java lambdas of a driver written as HIP
+device text, compiled by hipRTC around the engine's loop.  Parity: (i) a built-in family restated as user text
+gives the built-in kernels' tables bit for bit; (ii) a driver OUTSIDE the built-in families
+(CashOverdraftLimit.java) equals the oracle running the same text compiled for the host."""
+import numpy as np
+import pytest
+
+import cases
+import custom_sources as cs
+from test_custom_functor import _params_backorder
+
+pytestmark = pytest.mark.gpu
+
+
+def _tables_equal(eng, V, pol, what):
+    for period in range(1, len(V) + 1):
+        gv, gp = eng.values(period), eng.policy(period)
+        assert np.array_equal(gp, pol[period - 1]), f"{what} t={period}: policy indices differ"
+        assert np.all(np.abs(gv - V[period - 1]) <= 1e-9 * np.maximum(np.abs(V[period - 1]), 1e-300))
+        assert np.array_equal(gv, V[period - 1]), f"{what} t={period}: values not bit-identical"
+
+
+@pytest.mark.parametrize("make,src", [(cases.f1_small, cs.BACKORDER), (cases.f1_max, cs.BACKORDER),
+                                      (cases.f1_clsp_main, cs.BACKORDER), (cases.f2_clamped, cs.LEADTIME)],
+                         ids=["f1_small", "f1_max", "f1_clsp_main", "f2_clamped"])
+def test_builtin_family_as_user_text(sia, oracle, make, src):
+    w = make()
+    prm = _params_backorder(w.functor)
+    eng = sia.SdpEngine(w.desc(), w.pmf, custom_source=src, custom_params=prm)
+    eng.solve()
+    builtin = sia.SdpEngine(w.desc(), w.pmf)
+    builtin.solve()
+    V, pol, cells = oracle.Problem(w.desc(), w.pmf).solve()
+    _tables_equal(eng, V, pol, f"{w.name} custom")
+    _tables_equal(builtin, V, pol, f"{w.name} builtin")
+    assert eng.stats().cells_evaluated == cells == builtin.stats().cells_evaluated
+    for period in (1, w.T):
+        assert np.array_equal(eng.reachable(period), builtin.reachable(period))
+    eng.close()
+    builtin.close()
+
+
+def _overdraft_limit_case(sia, T=4):
+    """CashOverdraftLimit.main's shape on a small box: cash in integers (`/ 10` long division), overhead per
+    period, interest 10 % on a negative balance before revenue, no deposit interest."""
+    shape = sia.OverdraftFunctor(price=6, fixOrderCost=2, variCost=1, salvageValue=0.5, maxOrderQuantity=14,
+                                 minInventoryState=0, maxInventoryState=18, minCashState=-40, maxCashState=120,
+                                 cashRoundMult=10.0, cashRoundDiv=10.0, cashRoundIntDiv=True, iniInventory=0,
+                                 iniCash=10)
+    overhead = [9.0, 12.0, 7.0, 10.0][:T]
+    params = [6, 2, 1, 0.25, 0.1, 0.0, 0.5, 14, 0, 18, -40, 120] + overhead
+    pmf = cases._pmf([4, 6, 3, 5][:T], 10)
+    return shape, params, pmf
+
+
+def test_driver_outside_the_builtin_families(sia, oracle):
+    shape, params, pmf = _overdraft_limit_case(sia)
+    T = len(pmf)
+    desc = shape.to_desc(T, sia.OptDirection.MAX)
+    desc.discount_factor = 0.98
+    eng = sia.SdpEngine(desc, pmf, custom_source=cs.OVERDRAFT_LIMIT, custom_params=params)
+    eng.solve()
+    P = oracle.Problem(desc, pmf)
+    with oracle.custom_functor(cs.OVERDRAFT_LIMIT, params):
+        V, pol, cells = P.solve(nthreads=4)
+        m = P.memo()
+        reach = P.reachable()
+        xs, cs_, _ = P.state_arrays(2)
+        pick = np.arange(0, len(xs), 97)
+        ov, oa = P.eval_states(2, V[2], xs[pick], cs_[pick] + 0.37, None)
+    _tables_equal(eng, V, pol, "overdraft-limit")
+    assert eng.stats().cells_evaluated == cells
+    for period in range(1, T + 1):
+        assert np.array_equal(eng.reachable(period), reach[period - 1])
+    gv, ga = eng.eval_states(2, xs[pick], cs_[pick] + 0.37)
+    assert np.array_equal(gv, ov) and np.array_equal(ga, oa)
+    i0 = eng.state_index(1, 0.0, 10.0)
+    assert eng.values(1)[i0] == m["value"] and eng.policy(1)[i0] == m["action"]
+    # the built-in OVERDRAFT family (CashOverdraft.java's piecewise schedule) is a different model
+    other = sia.SdpEngine(desc, pmf, [9.0, 12.0, 7.0, 10.0])
+    other.solve()
+    assert not np.array_equal(other.values(1), V[0])
+    eng.close()
+    other.close()
+
+
+def test_mirror_class_over_user_lambdas(sia, oracle):
+    """CashRecursion with the driver's own lambdas on both sides: Python callables for the host mirror, device
+    text for the engine; validateFunctor cross-checks the two on sampled cells through the GPU tables."""
+    shape, params, pmf = _overdraft_limit_case(sia, T=3)
+    T = 3
+    price, fix, vari, hold, rate, dep, sal, maxQ, minI, maxI, minC, maxC = params[:12]
+    overhead = params[12:]
+
+    def feasible(s):
+        return [float(k) for k in range(int(maxQ) + 1)]
+
+    def imm(s, action, d):
+        revenue = price * min(s.getIniInventory() + action, d)
+        fixedCost = fix if action > 0 else 0
+        level = s.getIniInventory() + action - d
+        before = s.getIniCash() - fixedCost - vari * action - hold * max(level, 0) - overhead[s.getPeriod() - 1]
+        after = before - rate * max(-before, 0) + dep * max(before, 0) + revenue
+        inc = after - s.getIniCash()
+        inc += sal * max(level, 0) if s.getPeriod() == T else 0
+        return inc
+
+    def trans(s, action, d):
+        nx = max(0, s.getIniInventory() + action - d)
+        nc = s.getIniCash() + imm(s, action, d)
+        nc = maxC if nc > maxC else nc
+        nc = minC if nc < minC else nc
+        nx = maxI if nx > maxI else nx
+        nx = minI if nx < minI else nx
+        r = sia.java_round(nc * 10)
+        nc = float(abs(r) // 10 * (1 if r >= 0 else -1))
+        return sia.CashState(s.getPeriod() + 1, nx, nc)
+
+    functor = sia.CustomFunctor(shape=shape, source=cs.OVERDRAFT_LIMIT, params=params, getFeasibleAction=feasible,
+                                stateTransitionFn=trans, immediateValueFn=imm)
+    rec = sia.CashRecursion(sia.OptDirection.MAX, pmf, feasible, trans, imm, 1.0, functor=functor)
+    ini = sia.CashState(1, 0.0, 10.0)
+    P = oracle.Problem(shape.to_desc(T, sia.OptDirection.MAX), pmf)
+    with oracle.custom_functor(cs.OVERDRAFT_LIMIT, params):
+        m = P.memo()
+    assert rec.getExpectedValue(ini) == m["value"] and rec.getAction(ini) == m["action"]
+    assert rec.getOptTable().shape == (m["n"], 4)
+    # host lambdas == device text, cell by cell, on the successor the GPU tables were built from
+    s1 = trans(ini, rec.getAction(ini), float(pmf[0][3][0]))
+    order = {(int(p), x, c): v for p, x, c, v in zip(m["period"], m["x"], m["cash"], m["values"])}
+    assert rec.getExpectedValue(s1) == order[(2, s1.getIniInventory(), s1.getIniCash())]
+
+
+def test_transition_that_leaves_the_grid_is_reported(sia):
+    w = cases.f1_small()
+    eng = sia.SdpEngine(w.desc(), w.pmf, custom_source=cs.BROKEN_TRANSITION, custom_params=_params_backorder(w.functor))
+    with pytest.raises(sia.SdpgpuError, match="not a grid point"):
+        eng.solve()
+    with pytest.raises(sia.SdpgpuError, match="host"):
+        eng.simulate(np.zeros((1, w.T)), np.ones(w.T), 0.0)
+    eng.close()
