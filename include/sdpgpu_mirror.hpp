@@ -99,7 +99,16 @@ class CashLeadtimeState : public CashState {
 namespace gpu {
 
 // ---- functor descriptors: field names are the reference's local variable names -----------------------
+// The driver's own lambdas as HIP device text (sdpgpu_create_custom, include/sdpgpu.h): when `source` is set the
+// engine compiles it with hipRTC and runs it instead of the functor's built-in family; the functor then only
+// describes the state shape and the grid.  `params` = the constants the Java lambdas close over (c.params[]).
+struct UserLambdas {
+  std::string source;
+  std::vector<double> params;
+};
+
 struct BackorderFunctor {  // CLSP.java:251-272, CLSPTesting.java:78-106
+  UserLambdas user;
   double fixedOrderingCost = 0, variOrderingCost = 0, holdingCost = 0, penaltyCost = 0;
   double minInventory = 0, maxInventory = 0, maxOrderQuantity = 0, stepSize = 1, iniInventory = 0;
   void fill(sdpgpu_desc& d) const {
@@ -117,6 +126,7 @@ struct BackorderFunctor {  // CLSP.java:251-272, CLSPTesting.java:78-106
 };
 
 struct LeadtimeFunctor {  // Leadtime.java:50-81
+  UserLambdas user;
   double fixedOrderingCost = 0, variOrderingCost = 0, holdingCost = 0, penaltyCost = 0;
   double maxOrderQuantity = 0, stepSize = 1, iniInventory = 0, iniPreQ = 0;
   bool clampInventory = false;  // Leadtime.java:65-66 has the clamp commented out
@@ -138,6 +148,7 @@ struct LeadtimeFunctor {  // Leadtime.java:50-81
 };
 
 struct CashFunctor {  // CashConstraint.java:95-133 (cashFormula 0), CashConstraintTesting.java:110-148 (1)
+  UserLambdas user;
   double price = 0, fixOrderCost = 0, variCost = 1, holdingCost = 0, depositeRate = 0, overheadCost = 0;
   double overheadRate = 0, salvageValue = 0, penaltyCost = 0, maxOrderQuantity = 0, stepSize = 1;
   double minInventoryState = 0, maxInventoryState = 0, minCashState = 0, maxCashState = 0;
@@ -210,9 +221,13 @@ struct CashLeadtimeFunctor : CashFunctor {  // SingleProductLeadtime.java:72-119
 // ---- RAII wrapper of one sdpgpu_handle ---------------------------------------------------------------
 class Engine {
  public:
-  Engine(sdpgpu_desc desc, const Pmf& pmf, const std::vector<double>& overhead = {}) : T_((int)pmf.size()) {
+  Engine(sdpgpu_desc desc, const Pmf& pmf, const std::vector<double>& overhead = {}, const UserLambdas& user = {})
+      : T_((int)pmf.size()) {
     desc.periods = T_;
-    if (sdpgpu_create(&desc, &h_) != 0) throw std::runtime_error(sdpgpu_last_error(nullptr));
+    const int rc = user.source.empty()
+                       ? sdpgpu_create(&desc, &h_)
+                       : sdpgpu_create_custom(&desc, user.source.c_str(), user.params.data(), (int32_t)user.params.size(), &h_);
+    if (rc != 0) throw std::runtime_error(sdpgpu_last_error(nullptr));
     try {
       for (int t = 0; t < T_; ++t) {
         std::vector<double> d, p;
@@ -307,7 +322,7 @@ class Recursion {
   Recursion(OptDirection optDirection, const Pmf& pmf, Actions getFeasibleAction, Trans stateTransition,
             Imm immediateValue, const BackorderFunctor& functor)
       : getFeasibleActions(std::move(getFeasibleAction)), stateTransition(std::move(stateTransition)),
-        immediateValue(std::move(immediateValue)), step_(functor.stepSize), engine_(desc_of(optDirection, functor), pmf) {}
+        immediateValue(std::move(immediateValue)), step_(functor.stepSize), engine_(desc_of(optDirection, functor), pmf, {}, functor.user) {}
 
   Trans getStateTransitionFunction() const { return stateTransition; }
   Imm getImmediateValueFunction() const { return immediateValue; }
@@ -357,7 +372,7 @@ class LeadtimeRecursion {
   LeadtimeRecursion(const Pmf& pmf, Actions getFeasibleAction, Trans stateTransition, Imm immediateValue,
                     const LeadtimeFunctor& functor)
       : getFeasibleActions(std::move(getFeasibleAction)), stateTransition(std::move(stateTransition)),
-        immediateValue(std::move(immediateValue)), step_(functor.stepSize), engine_(desc_of(functor), pmf) {}
+        immediateValue(std::move(immediateValue)), step_(functor.stepSize), engine_(desc_of(functor), pmf, {}, functor.user) {}
 
   double getExpectedValue(const State& s) {
     return engine_.lookup(s.getPeriod(), s.getIniInventory(), 0, s.getPreQ()).first;
@@ -410,7 +425,7 @@ class CashRecursion {
                 Imm immediateValue, double discountFactor, const CashFunctor& functor)
       : getFeasibleActions(std::move(getFeasibleAction)), stateTransition(std::move(stateTransition)),
         immediateValue(std::move(immediateValue)), step_(functor.stepSize),
-        engine_(desc_of(optDirection, discountFactor, functor), pmf, functor.overheadCosts) {}
+        engine_(desc_of(optDirection, discountFactor, functor), pmf, functor.overheadCosts, functor.user) {}
 
   Trans getStateTransitionFunction() const { return stateTransition; }
   Imm getImmediateValueFunction() const { return immediateValue; }
@@ -467,7 +482,7 @@ class RiskRecursion {
                 const SurvivalFunctor& functor)
       : getFeasibleActions(std::move(getFeasibleAction)), stateTransition(std::move(stateTransition)),
         immediateValue(std::move(immediateValue)), step_(functor.stepSize),
-        engine_(desc_of(functor), pmf, functor.overheadCosts) {}
+        engine_(desc_of(functor), pmf, functor.overheadCosts, functor.user) {}
 
   Trans getStateTransitionFunction() const { return stateTransition; }
   Imm getImmediateValueFunction() const { return immediateValue; }
@@ -524,7 +539,7 @@ class CashLeadtimeRecursion {
                         const CashLeadtimeFunctor& functor)
       : getFeasibleActions(std::move(getFeasibleAction)), stateTransition(std::move(stateTransition)),
         immediateValue(std::move(immediateValue)), step_(functor.stepSize),
-        engine_(desc_of(functor), pmf, functor.overheadCosts) {}
+        engine_(desc_of(functor), pmf, functor.overheadCosts, functor.user) {}
 
   double getExpectedValue(const State& s) {
     return engine_.lookup(s.getPeriod(), s.getIniInventory(), s.getIniCash(), s.getPreQ()).first;

@@ -16,7 +16,39 @@ static void throw_state(JNIEnv* env, const char* msg) {
 #define H(h) ((sdpgpu_handle*)(intptr_t)(h))
 #define CHECK(env, h, rc) do { if ((rc) != 0) throw_state(env, sdpgpu_last_error(H(h))); } while (0)
 
+static void fill_desc(JNIEnv* env, jintArray ints, jdoubleArray dbls, sdpgpu_desc* out);
+
+/* sdpgpu_create_custom: the driver's lambdas as HIP device text + the constants they close over */
+JNIEXPORT jlong JNICALL Java_sdp_gpu_SdpGpu_createCustom(JNIEnv* env, jclass cls, jintArray ints, jdoubleArray dbls,
+                                                         jstring source, jdoubleArray params) {
+  sdpgpu_desc d;
+  fill_desc(env, ints, dbls, &d);
+  const char* text = (*env)->GetStringUTFChars(env, source, NULL);
+  jsize n = params ? (*env)->GetArrayLength(env, params) : 0;
+  jdouble* p = n ? (*env)->GetDoubleArrayElements(env, params, NULL) : NULL;
+  sdpgpu_handle* h = NULL;
+  int rc = sdpgpu_create_custom(&d, text, p, n, &h);
+  if (p) (*env)->ReleaseDoubleArrayElements(env, params, p, JNI_ABORT);
+  (*env)->ReleaseStringUTFChars(env, source, text);
+  if (rc != 0) {
+    throw_state(env, sdpgpu_last_error(NULL));
+    return 0;
+  }
+  return (jlong)(intptr_t)h;
+}
+
 JNIEXPORT jlong JNICALL Java_sdp_gpu_SdpGpu_create(JNIEnv* env, jclass cls, jintArray ints, jdoubleArray dbls) {
+  sdpgpu_desc d;
+  fill_desc(env, ints, dbls, &d);
+  sdpgpu_handle* h = NULL;
+  if (sdpgpu_create(&d, &h) != 0) {
+    throw_state(env, sdpgpu_last_error(NULL));
+    return 0;
+  }
+  return (jlong)(intptr_t)h;
+}
+
+static void fill_desc(JNIEnv* env, jintArray ints, jdoubleArray dbls, sdpgpu_desc* out) {
   sdpgpu_desc d;
   sdpgpu_desc_init(&d);
   jint i[12];
@@ -33,12 +65,7 @@ JNIEXPORT jlong JNICALL Java_sdp_gpu_SdpGpu_create(JNIEnv* env, jclass cls, jint
   d.overhead_rate = v[15]; d.discount_factor = v[16]; d.min_cash = v[17]; d.max_cash = v[18];
   d.cash_round_mult = v[19]; d.cash_round_div = v[20];
   d.r0 = v[21]; d.r2 = v[22]; d.r3 = v[23]; d.overdraft_limit = v[24]; d.interest_free_amount = v[25];
-  sdpgpu_handle* h = NULL;
-  if (sdpgpu_create(&d, &h) != 0) {
-    throw_state(env, sdpgpu_last_error(NULL));
-    return 0;
-  }
-  return (jlong)(intptr_t)h;
+  *out = d;
 }
 
 JNIEXPORT void JNICALL Java_sdp_gpu_SdpGpu_destroy(JNIEnv* env, jclass cls, jlong h) { sdpgpu_destroy(H(h)); }

@@ -33,6 +33,13 @@ public final class SdpGpu {
 	 */
 	public static native long create(int[] ints, double[] doubles);
 
+	/**
+	 * sdpgpu_create_custom: a driver whose lambdas are not one of the families hands them over as HIP device
+	 * text (three functions, see include/sdpgpu.h) together with the constants they close over; `ints[0]` then
+	 * only names the state shape and the loop.
+	 */
+	public static native long createCustom(int[] ints, double[] doubles, String functorSource, double[] params);
+
 	public static native void destroy(long handle);
 
 	public static native void setPmf(long handle, int t, double[] demand, double[] prob);

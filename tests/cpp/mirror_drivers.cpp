@@ -1,4 +1,4 @@
-// mirror_drivers.cpp -- four driver programs in the shape of the reference's mains, written in C++ over include/sdpgpu_mirror.hpp:
+// mirror_drivers.cpp -- five driver programs in the shape of the reference's mains, written in C++ over include/sdpgpu_mirror.hpp:
 // same local variable names, same lambdas, one constructor swapped (Recursion -> sdp::gpu::Recursion + a
 // functor descriptor).  tests/test_gpu_cpp_mirror.py compiles this with g++, runs it on the GPU and
 // compares what it prints with the CPU oracle.
@@ -7,12 +7,17 @@
 //   leadtime   leadtime.Leadtime.main         (src/leadtime/Leadtime.java:25-99)
 //   cash       cash.singleItem.CashConstraint.main (src/cash/singleItem/CashConstraint.java:44-146), smaller grid
 //   survival   cash.risk.cashSurvival.main    (src/cash/risk/cashSurvival.java:45-163), smaller grid
+//   limit      cash.overdraft.CashOverdraftLimit.main (src/cash/overdraft/CashOverdraftLimit.java:30-113), smaller
+//              grid: a driver whose lambdas are NOT a built-in family -- they are passed as HIP device text
+//              (argv[3], the file tests/custom_sources.py writes) next to the C++ lambdas
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
 #include <fstream>
 #include <iostream>
+#include <iterator>
 #include <string>
+#include <vector>
 
 #include "sdpgpu_mirror.hpp"
 
@@ -268,6 +273,73 @@ static int cash_survival(const Pmf& pmf) {
   return 0;
 }
 
+static int overdraft_limit(const Pmf& pmf, const char* source_path) {
+  using cash::CashState;
+  const int T = (int)pmf.size();
+  double price = 6, fixOrderCost = 2, variCost = 1, holdingCost = 0.25, interestRate = 0.1, depositeRate = 0;
+  double salvageValue = 0.5, maxOrderQuantity = 14, stepSize = 1, discountFactor = 1;
+  double minInventoryState = 0, maxInventoryState = 18, minCashState = -40, maxCashState = 120, iniCash = 10;
+  std::vector<double> overheadCost = {9, 12, 7, 10};
+
+  auto getFeasibleAction = [=](const CashState&) {
+    double maxQ = maxOrderQuantity;
+    std::vector<double> a((size_t)((int)maxQ + 1));
+    for (size_t i = 0; i < a.size(); ++i) a[i] = (double)i * stepSize;
+    return a;
+  };
+  auto immediateValue = [=](const CashState& state, double action, double randomDemand) {
+    double revenue = price * std::fmin(state.getIniInventory() + action, randomDemand);
+    double fixedCost = action > 0 ? fixOrderCost : 0;
+    double variableCost = variCost * action;
+    double inventoryLevel = state.getIniInventory() + action - randomDemand;
+    double holdCosts = holdingCost * std::fmax(inventoryLevel, 0);
+    double cashBalanceBeforeRevenue =
+        state.getIniCash() - fixedCost - variableCost - holdCosts - overheadCost[(size_t)state.getPeriod() - 1];
+    double interest = interestRate * std::fmax(-cashBalanceBeforeRevenue, 0);
+    double deposite = depositeRate * std::fmax(cashBalanceBeforeRevenue, 0);
+    double cashBalanceAfter = cashBalanceBeforeRevenue - interest + deposite + revenue;
+    double cashIncrement = cashBalanceAfter - state.getIniCash();
+    double salValue = state.getPeriod() == T ? salvageValue * std::fmax(inventoryLevel, 0) : 0;
+    cashIncrement += salValue;
+    return cashIncrement;
+  };
+  auto stateTransition = [=](const CashState& state, double action, double randomDemand) {
+    double nextInventory = std::fmax(0, state.getIniInventory() + action - randomDemand);
+    double nextCash = state.getIniCash() + immediateValue(state, action, randomDemand);
+    nextCash = nextCash > maxCashState ? maxCashState : nextCash;
+    nextCash = nextCash < minCashState ? minCashState : nextCash;
+    nextInventory = nextInventory > maxInventoryState ? maxInventoryState : nextInventory;
+    nextInventory = nextInventory < minInventoryState ? minInventoryState : nextInventory;
+    nextCash = (double)(java_round(nextCash * 10) / 10);
+    return CashState(state.getPeriod() + 1, nextInventory, nextCash);
+  };
+  gpu::CashFunctor functor;  // state shape and grid only: the formulas come from the device text
+  functor.overdraft = true;
+  functor.maxOrderQuantity = maxOrderQuantity;
+  functor.minInventoryState = minInventoryState;
+  functor.maxInventoryState = maxInventoryState;
+  functor.minCashState = minCashState;
+  functor.maxCashState = maxCashState;
+  functor.cashRoundIntDiv = true;  // Math.round(nextCash * 10) / 10
+  functor.iniCash = iniCash;
+  std::ifstream f(source_path);
+  functor.user.source.assign(std::istreambuf_iterator<char>(f), std::istreambuf_iterator<char>());
+  functor.user.params = {price, fixOrderCost, variCost, holdingCost, interestRate, depositeRate, salvageValue,
+                         maxOrderQuantity, minInventoryState, maxInventoryState, minCashState, maxCashState};
+  for (int t = 0; t < T; ++t) functor.user.params.push_back(overheadCost[(size_t)t]);
+  gpu::CashRecursion recursion(OptDirection::MAX, pmf, getFeasibleAction, stateTransition, immediateValue, discountFactor,
+                               functor);
+  CashState initialState(1, 0, iniCash);
+  recursion.setTreeMapCacheAction();
+  double finalCash = iniCash + recursion.getExpectedValue(initialState);
+  std::printf("final optimal cash is: %.17g\n", finalCash);
+  std::printf("optimal order quantity in the first priod is : %.17g\n", recursion.getAction(initialState));
+  double q = recursion.getAction(initialState);
+  CashState next = stateTransition(initialState, q, pmf[0][pmf[0].size() / 2][0]);
+  std::printf("successor value %.17g\n", recursion.getExpectedValue(next));
+  return 0;
+}
+
 int main(int argc, char** argv) {
   if (argc < 3) return 1;
   try {
@@ -277,6 +349,7 @@ int main(int argc, char** argv) {
     if (which == "leadtime") return leadtime(pmf);
     if (which == "cash") return cash_constraint(pmf);
     if (which == "survival") return cash_survival(pmf);
+    if (which == "limit" && argc > 3) return overdraft_limit(pmf, argv[3]);
   } catch (const std::exception& e) {
     std::fprintf(stderr, "error: %s\n", e.what());
     return 2;

@@ -29,10 +29,10 @@ def _write_pmf(path, pmf):
                 f.write(f"{float(d)!r} {float(p)!r}\n")
 
 
-def _run(exe, which, pmf, tmp_path):
+def _run(exe, which, pmf, tmp_path, *extra):
     path = tmp_path / f"{which}.pmf"
     _write_pmf(path, pmf)
-    out = subprocess.run([exe, which, str(path)], check=True, capture_output=True, text=True).stdout
+    out = subprocess.run([exe, which, str(path), *extra], check=True, capture_output=True, text=True).stdout
     return out.strip().splitlines()
 
 
@@ -107,3 +107,23 @@ def test_cash_survival_main(exe, tmp_path, sia, oracle):
     assert _last_number(lines[0]) == m["value"]
     assert _last_number(lines[1]) == m["action"]
     assert int(lines[2].split()[-1]) == m["n"]
+
+
+def test_overdraft_limit_main_with_user_lambdas(exe, tmp_path, sia, oracle):
+    """CashOverdraftLimit.main's lambdas are not a built-in family: the C++ driver passes them as HIP device text
+    (functor.user.source) beside its own C++ lambdas; the oracle runs the same text compiled for the host."""
+    import cases
+    import custom_sources as cs
+    from test_gpu_custom_functor import _overdraft_limit_case
+    shape, params, pmf = _overdraft_limit_case(sia)
+    src = tmp_path / "limit.hip"
+    src.write_text(cs.OVERDRAFT_LIMIT)
+    lines = _run(exe, "limit", pmf, tmp_path, str(src))
+    P = oracle.Problem(shape.to_desc(4, sia.OptDirection.MAX), pmf)
+    with oracle.custom_functor(cs.OVERDRAFT_LIMIT, params):
+        V, pol, _ = P.solve(nthreads=4)
+        m = P.memo()
+    assert _last_number(lines[0]) == 10 + m["value"]
+    assert _last_number(lines[1]) == m["action"]
+    by = {(int(p), x, c): v for p, x, c, v in zip(m["period"], m["x"], m["cash"], m["values"])}
+    assert _last_number(lines[2]) in [v for (p, x, c), v in by.items() if p == 2]
