@@ -157,4 +157,214 @@ __global__ __launch_bounds__(256) void cash_shift_kernel(CashShiftParams P, cons
   }
 }
 
+// ---------------------------------------------------------------------------------------------
+// "Cash row" period kernel: the cash families F3 (both formulas), F4, F5, F6 on ANY cash grid
+// (tenths, hundredths, non-dyadic prices: the cases the uniform-shift kernel must refuse).
+//
+// The cash axis is the fastest one, so the 64 lanes of a wave are 64 consecutive cash points of ONE
+// (inventory[, preQ]) row.  For such a wave everything in the reference's lambdas that does not read
+// the cash balance -- revenue, level, holding cost, salvage, the next inventory row -- is WAVE-UNIFORM per
+// (action, demand): lanes = demand indices compute it once per action into LDS, and the per-cell work is
+// only the cash-dependent tail (4-5 additions, the clamp, Math.round, one gather).  Every operation, its
+// operands and its order are those of cell<FAM>() in sdp_device.hpp -- hoisting an operation out of a loop
+// does not change its result -- so the tables are bit-identical to the generic kernel's
+// (tests run both).  Two operations are elided where they provably change nothing: `inc += 0.0` (salvage
+// outside period T) and `inc += 0 * endCash` (penalty rate zero): either can only turn a -0.0 into +0.0,
+// which no later operation (p * inc added to an accumulator that is never -0.0; cash + inc) can see.
+// ---------------------------------------------------------------------------------------------
+// Cash index of a next-period balance: CashConstraint.java:126-131 (clamp, Math.round quantiser).  Same result as
+// cash_index() in sdp_device.hpp with fewer instructions: the two clamp ternaries become v_min/v_max (they differ
+// from the ternaries only in the sign of a zero, which Math.round maps to the same key) and the tie rule of
+// Math.round is folded into the integer add.
+template <bool INTDIV>
+__device__ __forceinline__ int cash_key_row(double next_cash, double min_cash, double max_cash, double round_mult,
+                                            double round_div) {
+  const double c = fmax(fmin(next_cash, max_cash), min_cash);
+  const double xm = c * round_mult;
+  const double f = floor(xm);
+  int k = (int)f + ((xm - f) >= 0.5 ? 1 : 0);
+  if constexpr (INTDIV) k = (int)trunc((double)k / round_div);  // `/ 10`: long division (CashOverdraft.java:116)
+  return k;
+}
+
+struct alignas(16) RowEnt {
+  double u;       // F3 formula 0: (1 - overheadRate) * revenue; formula 1: the whole increment; F4/F5/F6: revenue
+  double hold;    // holdingCost * max(level, 0)
+  double sal;     // salvageValue * max(level, 0) (period T)
+  int32_t rowoff; // flat offset of the next state's inventory row: inv_index * nc (0 in period T)
+  int32_t pad;
+};
+
+// FORMULA1: F3 with CashConstraintTesting.java's increment (no cash term); INTDIV: the quantiser divides by an
+// integer other than 1.  F3 with a non-zero end-cash penalty stays on the generic kernel (host: cash_row_eligible).
+template <int FAM, bool LAST, bool FORMULA1, bool INTDIV>
+__global__ __launch_bounds__(256) void cash_row_kernel(DevParams P, const double* __restrict__ v_next,
+                                                       double* __restrict__ v_cur, int32_t* __restrict__ pol,
+                                                       const double* __restrict__ pmf_d,
+                                                       const double* __restrict__ pmf_p, int64_t lo, int64_t hi,
+                                                       int64_t row0, int tiles_per_row) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int D = P.n_demand;
+  double2* s_p = reinterpret_cast<double2*>(smem);                  // {p_j, p_j * gamma}
+  RowEnt* s_ent = reinterpret_cast<RowEnt*>(s_p + D);               // [4 waves][D]
+  double* s_d = reinterpret_cast<double*>(s_ent + (size_t)4 * D);   // d_j
+  double* s_val = s_d + D;
+  int* s_k = reinterpret_cast<int*>(s_val + 4 * 64);
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  for (int j = tid; j < D; j += 256) {
+    s_d[j] = pmf_d[j];
+    s_p[j] = make_double2(pmf_p[j], pmf_p[j] * P.gamma);
+  }
+  __syncthreads();
+
+  const int64_t row = row0 + blockIdx.x / tiles_per_row;  // (iq * nx + ix)
+  const int ic0 = (blockIdx.x % tiles_per_row) * 64;
+  const int nc = (int)P.cur.nc;
+  const int ic = ic0 + lane;
+  const int ic_c = ic < nc ? ic : nc - 1;
+  const int64_t idx = row * nc + ic;
+  const bool live = ic < nc && idx >= lo && idx < hi;
+
+  StateT s;
+  decode_state<FAM>(P, row * nc + ic_c, s);  // x (and preQ) are the same in every lane
+  const double base = (FAM == FAM_CASH_LEADTIME) ? s.x + s.preq : s.x;  // + action below for F3/F4/F6
+
+  // feasible actions: per lane, and the tile's maximum (non-decreasing in cash where it varies at all)
+  const int nA = n_actions<FAM>(P, s);
+  int nA_max = nA;
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) {
+    int o = __shfl_xor(nA_max, off, 64);
+    nA_max = o > nA_max ? o : nA_max;
+  }
+  nA_max = __builtin_amdgcn_readfirstlane(nA_max);
+
+  RowEnt* ent = s_ent + (size_t)wave * D;
+  const bool MAXDIR = P.maxdir != 0;
+  double best = MAXDIR ? -1.7976931348623157e308 : 1.7976931348623157e308;
+  int bestk = 0;
+  // loop invariants of the cash quantiser, in registers
+  const double min_cash = P.min_cash, max_cash = P.max_cash, round_mult = P.round_mult, round_div = P.round_div;
+  const double overhead = P.overhead;
+  const int k_lo_next = (int)P.next.k_lo;
+  for (int k = wave; k < nA_max; k += 4) {
+    // ---- wave-uniform part, lanes = demand indices --------------------------------------------
+    const double a = (double)k * P.step;
+    const double y = (FAM == FAM_CASH_LEADTIME) ? base : base + a;  // level before demand
+    const double fixed = a > 0 ? P.K : 0.0;
+    const double var = P.v * a;
+    for (int j = lane; j < D; j += 64) {
+      const double d = s_d[j];
+      const double revenue = P.price * jmin(y, d);
+      const double level = y - d;
+      const double pos = jmax(level, 0.0);
+      RowEnt e;
+      e.hold = P.h * pos;
+      e.sal = LAST ? P.salvage * pos : 0.0;
+      if constexpr (FAM == FAM_CASH) {
+        if constexpr (!FORMULA1) {
+          e.u = P.one_minus_overhead_rate * revenue;
+        } else {  // CashConstraintTesting.java:117-132: nothing in the increment reads the cash balance
+          double inc = revenue - fixed - var - e.hold - P.overhead;
+          inc += e.sal;  // (0.0 outside period T, exactly what the reference adds)
+          e.u = inc;
+        }
+      } else {
+        e.u = revenue;
+      }
+      e.rowoff = 0;
+      e.pad = 0;
+      if constexpr (!LAST) {
+        double ninv = jmax(0.0, level);
+        ninv = ninv > P.max_inventory ? P.max_inventory : ninv;
+        ninv = ninv < P.min_inventory ? P.min_inventory : ninv;
+        e.rowoff = inv_index(P, ninv) * (int)P.next.nc - k_lo_next;  // + cash key = flat index
+      }
+      ent[j] = e;
+    }
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_s_waitcnt(0xC07F);  // lgkmcnt(0): the wave's own LDS writes have landed
+
+    // ---- per-lane (cash) invariants of this action ------------------------------------------------
+    double dep_or_bi = 0.0;  // F3/F6: deposit; F4/F5: cashBalanceBefore - interest
+    if constexpr (FAM == FAM_CASH || FAM == FAM_SURVIVAL) {
+      dep_or_bi = (s.cash - fixed - var) * P.one_plus_deposit;
+    } else if constexpr (FAM == FAM_OVERDRAFT) {
+      const double before = s.cash - fixed - var - P.overhead;
+      dep_or_bi = before - overdraft_interest(P, before);
+    } else {  // FAM_CASH_LEADTIME
+      const double before = s.cash - var - P.overhead;
+      dep_or_bi = before - overdraft_interest(P, before);
+    }
+    const int64_t qoff = (FAM == FAM_CASH_LEADTIME && !LAST) ? (int64_t)k * P.next.nx * P.next.nc : 0;
+
+    // ---- the demand loop: serial in j, reference order -------------------------------------------
+    double acc = 0.0;
+    for (int j = 0; j < D; ++j) {
+      const RowEnt e = ent[j];
+      const double2 pp = s_p[j];
+      double inc;
+      if constexpr (FAM == FAM_CASH) {
+        if constexpr (!FORMULA1) {
+          inc = e.u + dep_or_bi - e.hold - overhead - s.cash;
+          if constexpr (LAST) inc += e.sal;
+        } else {
+          inc = e.u;
+        }
+        // (end-cash penalty rate is zero here: `inc += 0 * endCash` changes nothing)
+        acc += pp.x * inc;
+        if constexpr (!LAST) {
+          const double ncash = s.cash + inc;  // CashConstraint.java:125
+          acc += pp.y * v_next[(unsigned)(e.rowoff + cash_key_row<INTDIV>(ncash, min_cash, max_cash, round_mult, round_div))];
+        }
+      } else if constexpr (FAM == FAM_SURVIVAL) {
+        inc = e.u + dep_or_bi - e.hold - overhead - s.cash;
+        if constexpr (LAST) {
+          inc += e.sal;
+          acc += pp.x * ((s.cash + inc) >= 0 ? 1.0 : 0.0);
+        } else {
+          const int key = cash_key_row<INTDIV>(s.cash + inc, min_cash, max_cash, round_mult, round_div);
+          acc += pp.y * (key < 0 ? 0.0 : v_next[(unsigned)(e.rowoff + key)]);  // bankrupt: worth 0
+        }
+      } else {  // F4 / F5: CashOverdraft.java:99-104
+        const double after = dep_or_bi + e.u;
+        inc = after - s.cash;
+        if constexpr (LAST) inc += e.sal;
+        acc += pp.x * inc;
+        if constexpr (!LAST) {
+          const double ncash = s.cash + inc;
+          acc += pp.y * v_next[qoff + (unsigned)(e.rowoff + cash_key_row<INTDIV>(ncash, min_cash, max_cash, round_mult, round_div))];
+        }
+      }
+    }
+    __builtin_amdgcn_wave_barrier();
+    if (k < nA && (MAXDIR ? (acc > best) : (acc < best))) {
+      best = acc;
+      bestk = k;
+    }
+  }
+
+  s_val[wave * 64 + lane] = best;
+  s_k[wave * 64 + lane] = bestk;
+  __syncthreads();
+  if (tid < 64 && live) {
+    double bv = s_val[tid];
+    int bk = s_k[tid];
+#pragma unroll
+    for (int w = 1; w < 4; ++w) {
+      double ov = s_val[w * 64 + tid];
+      int ok = s_k[w * 64 + tid];
+      if (MAXDIR ? better<true>(ov, ok, bv, bk) : better<false>(ov, ok, bv, bk)) {
+        bv = ov;
+        bk = ok;
+      }
+    }
+    v_cur[idx] = bv;
+    pol[idx] = bk;
+  }
+}
+
 }  // namespace sdp

@@ -94,6 +94,7 @@ struct sdpgpu_handle {
   sdp::FinalizeJob* d_jobs = nullptr;
   bool fuse_combine = true;
   bool use_cash_shift = true;
+  bool use_cash_row = true;   // SDPGPU_CASH_ROW=0 turns the cash row kernel off (generic kernel instead)
   int win_prio_fair = 1;  // window kernel: s_setprio by progress (SDPGPU_WIN_PRIO=0 turns it off)
   int win_r = 0, win_nch = 0;      // tuning overrides (SDPGPU_WIN_R / SDPGPU_WIN_NCH), 0 = heuristic
   uint8_t* d_reach = nullptr;      // reachable masks, period t at reach_off[t-1]
@@ -529,6 +530,9 @@ void count_cells(sdpgpu_handle* h, int period) {
 
 bool window_eligible(const sdpgpu_handle* h, int period);
 bool cash_shift_eligible(const sdpgpu_handle* h, int period);
+bool cash_row_eligible(const sdpgpu_handle* h, int period);
+hipError_t launch_cash_row(sdpgpu_handle* h, const DevParams& P, int period, const double* v_next, double* v_cur,
+                           int32_t* pol, const double* pmf_d, const double* pmf_p, int64_t lo, int64_t hi, hipStream_t st);
 hipError_t flush_pending(sdpgpu_handle* h);
 hipError_t launch_cash_shift(sdpgpu_handle* h, const DevParams& P, int period, const double* v_next, double* v_cur,
                              int32_t* pol, const double* pmf_d, const double* pmf_p, int64_t lo, int64_t hi, hipStream_t st);
@@ -651,6 +655,10 @@ int run_period_impl(sdpgpu_handle* h, int period, int part = SDPGPU_PART_ALL) {
     e = flush_pending(h);
     if (e == hipSuccess) e = launch_cash_shift(h, P, period, v_next, v_cur, pol, pd, pp, p.lo, p.hi, h->stream);
     p.kernel_used = SDPGPU_KERNEL_WINDOW;  // reported as a specialised (non-gather) kernel
+  } else if (h->d.kernel != SDPGPU_KERNEL_GATHER && cash_row_eligible(h, period)) {
+    e = flush_pending(h);
+    if (e == hipSuccess) e = launch_cash_row(h, P, period, v_next, v_cur, pol, pd, pp, p.lo, p.hi, h->stream);
+    p.kernel_used = SDPGPU_KERNEL_WINDOW;
   } else {
     e = flush_pending(h);  // the gather kernel reads the final V_{t+1} row
     if (e == hipSuccess)
@@ -824,6 +832,57 @@ hipError_t launch_cash_shift(sdpgpu_handle* h, const DevParams& P, int period, c
   }
 #undef SDP_CS
   return hipGetLastError();
+}
+
+// ---- cash row kernel (F3-F6 on any cash grid) -------------------------------------------------------
+bool cash_row_eligible(const sdpgpu_handle* h, int period) {
+  const sdpgpu_desc& d = h->d;
+  if (h->custom || !has_cash(d.family) || !d.clamp_inventory || !h->use_cash_row) return false;
+  if (d.family == SDPGPU_FAMILY_CASH && d.penalty_cost != 0) return false;  // the end-cash penalty branch: generic kernel
+  const PeriodInfo& p = h->per[period - 1];
+  if (p.g.nc < 32) return false;                       // a wave is 64 consecutive cash points of one row
+  if (p.S >= 2147483647LL) return false;               // 32-bit row offsets
+  if ((size_t)p.nD * 152 + 4 * 64 * 12 > 64 * 1024) return false;  // per-wave entries of every demand point in LDS
+  return true;
+}
+
+template <int FAM, bool FORMULA1>
+hipError_t launch_cash_row_fam(const DevParams& P, bool last, bool intdiv, const double* v_next, double* v_cur,
+                               int32_t* pol, const double* pmf_d, const double* pmf_p, int64_t lo, int64_t hi,
+                               int64_t row0, int tiles_per_row, dim3 grid, size_t smem, hipStream_t st) {
+#define SDP_CR(LS, ID) hipLaunchKernelGGL((sdp::cash_row_kernel<FAM, LS, FORMULA1, ID>), grid, dim3(256), smem, st, P, v_next, v_cur, pol, pmf_d, pmf_p, lo, hi, row0, tiles_per_row)
+  if (intdiv) {
+    if (last) SDP_CR(true, true); else SDP_CR(false, true);
+  } else {
+    if (last) SDP_CR(true, false); else SDP_CR(false, false);
+  }
+#undef SDP_CR
+  return hipGetLastError();
+}
+
+hipError_t launch_cash_row(sdpgpu_handle* h, const DevParams& P, int period, const double* v_next, double* v_cur,
+                           int32_t* pol, const double* pmf_d, const double* pmf_p, int64_t lo, int64_t hi, hipStream_t st) {
+  if (hi <= lo) return hipSuccess;
+  const PeriodInfo& p = h->per[period - 1];
+  const int tiles_per_row = (int)((p.g.nc + 63) / 64);
+  const int64_t row_lo = lo / p.g.nc, row_hi = (hi - 1) / p.g.nc;
+  const int64_t blocks = (row_hi - row_lo + 1) * (int64_t)tiles_per_row;
+  if (!grid_ok(blocks)) return hipErrorInvalidValue;
+  dim3 grid((unsigned)blocks);
+  const size_t smem = (size_t)p.nD * 152 + 4 * 64 * (sizeof(double) + sizeof(int));
+  const bool last = period == h->T;
+  const bool intdiv = h->d.cash_round_int_div && h->d.cash_round_div != 1.0;
+#define SDP_ROWARGS P, last, intdiv, v_next, v_cur, pol, pmf_d, pmf_p, lo, hi, row_lo, tiles_per_row, grid, smem, st
+  switch (P.family) {
+    case sdp::FAM_CASH:
+      return P.cash_formula == 0 ? launch_cash_row_fam<sdp::FAM_CASH, false>(SDP_ROWARGS)
+                                 : launch_cash_row_fam<sdp::FAM_CASH, true>(SDP_ROWARGS);
+    case sdp::FAM_OVERDRAFT: return launch_cash_row_fam<sdp::FAM_OVERDRAFT, false>(SDP_ROWARGS);
+    case sdp::FAM_CASH_LEADTIME: return launch_cash_row_fam<sdp::FAM_CASH_LEADTIME, false>(SDP_ROWARGS);
+    case sdp::FAM_SURVIVAL: return launch_cash_row_fam<sdp::FAM_SURVIVAL, false>(SDP_ROWARGS);
+  }
+#undef SDP_ROWARGS
+  return hipErrorInvalidValue;
 }
 
 // ---- window kernel (F1) -----------------------------------------------------------------------
@@ -1345,6 +1404,7 @@ int sdpgpu_create(const sdpgpu_desc* desc, sdpgpu_handle** out) {
     if (const char* e = std::getenv("SDPGPU_WIN_NCH")) h->win_nch = std::atoi(e);
     if (const char* e = std::getenv("SDPGPU_FUSE_COMBINE")) h->fuse_combine = std::atoi(e) != 0;
     if (const char* e = std::getenv("SDPGPU_CASH_SHIFT")) h->use_cash_shift = std::atoi(e) != 0;
+    if (const char* e = std::getenv("SDPGPU_CASH_ROW")) h->use_cash_row = std::atoi(e) != 0;
     if (const char* e = std::getenv("SDPGPU_WIN_PRIO")) h->win_prio_fair = std::atoi(e) != 0;
   } catch (...) {
     delete h;

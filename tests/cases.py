@@ -101,6 +101,16 @@ def f3_tenths(T=3):
     return Workload("f3_tenths", f, OptDirection.MAX, _pmf([3, 4, 2][:T], 7))
 
 
+def f3_row(T=3):
+    """CashConstraint.java's own shape -- cash in tenths, formula 0, no end-cash penalty -- with fractional prices
+    and a deposit rate, so that nothing is exact: the cash row kernel's case (the shift kernel must refuse it)."""
+    f = CashFunctor(price=2.3, fixOrderCost=1.2, variCost=0.7, holdingCost=0.1, depositeRate=0.01, overheadCost=0.5,
+                    overheadRate=0.05, salvageValue=0.35, penaltyCost=0, discountFactor=0.97, maxOrderQuantity=9,
+                    minInventoryState=0, maxInventoryState=11, minCashState=-2, maxCashState=22, cashRoundMult=10.0,
+                    cashRoundDiv=10.0, cashRoundIntDiv=False, cashFormula=0, iniInventory=0, iniCash=5)
+    return Workload("f3_row", f, OptDirection.MAX, _pmf([3, 4, 2][:T], 7))
+
+
 def f3_testing(T=4):
     """CashConstraintTesting.java shape: formula 1, integer cash (Math.round(c*1)/1)."""
     f = CashFunctor(price=5, fixOrderCost=10, variCost=1, holdingCost=0, overheadCost=0, salvageValue=0.5,
@@ -167,6 +177,6 @@ def f6_survival_gamma(T=3):
     return Workload("f6_survival_gamma", f, OptDirection.MAX, _pmf([3, 5, 4][:T], 9))
 
 
-ALL = [f1_small, f1_max, f1_gapped, f1_unclamped, f1_edge_single, f2_unclamped, f2_clamped, f2_pipeline, f3_tenths, f3_testing, f3_dyadic, f3_min_gamma,
+ALL = [f1_small, f1_max, f1_gapped, f1_unclamped, f1_edge_single, f2_unclamped, f2_clamped, f2_pipeline, f3_tenths, f3_row, f3_testing, f3_dyadic, f3_min_gamma,
        f4_overdraft, f5_cash_leadtime, f6_survival, f6_survival_gamma]
 TINY = [f1_small, f1_max, f1_gapped, f1_unclamped, f2_unclamped, f3_testing, f3_min_gamma, f4_overdraft]
