@@ -1,0 +1,128 @@
+"""Randomised parity: seeded random instances of every built-in family (parameters, grid bounds, rounding mode,
+PMF support), each solved by the automatically selected kernel, by the generic kernel and by the CPU oracle.
+All three must agree bit for bit (values) and exactly (policy indices); the north-star tolerance (1e-9 relative)
+is implied.  Sizes are kept small so that the whole file takes seconds."""
+import numpy as np
+import pytest
+
+from stochastic_inventory_amd.functors import (BackorderFunctor, CashFunctor, CashLeadtimeFunctor, LeadtimeFunctor,
+                                                OverdraftFunctor, SurvivalFunctor)
+from stochastic_inventory_amd.states import OptDirection
+from stochastic_inventory_amd.workloads import Workload
+
+pytestmark = pytest.mark.gpu
+
+
+def _pmf(rng, T, unit_stride=True, d_max=9):
+    tiles = []
+    for _ in range(T):
+        n = int(rng.integers(1, d_max + 1))
+        if unit_stride:
+            d = np.arange(n, dtype=np.float64) + float(rng.integers(0, 3))
+        else:
+            d = np.sort(rng.choice(np.arange(0, 3 * d_max), size=n, replace=False)).astype(np.float64)
+        p = rng.random(n) + 0.05
+        p /= p.sum()
+        tiles.append(np.stack([d, p], axis=1))
+    return tiles
+
+
+def _money(rng, lo, hi, kind):
+    """A cost parameter: integer, dyadic fraction or an arbitrary decimal."""
+    v = rng.uniform(lo, hi)
+    if kind == "int":
+        return float(round(v))
+    if kind == "dyadic":
+        return round(v * 8) / 8
+    return round(v, 2)
+
+
+def _rounding(rng):
+    mode = rng.integers(0, 4)
+    if mode == 0:
+        return dict(cashRoundMult=1.0, cashRoundDiv=1.0, cashRoundIntDiv=True)      # Math.round(c * 1) / 1
+    if mode == 1:
+        return dict(cashRoundMult=10.0, cashRoundDiv=10.0, cashRoundIntDiv=False)   # Math.round(c * 10) / 10.0
+    if mode == 2:
+        return dict(cashRoundMult=10.0, cashRoundDiv=10.0, cashRoundIntDiv=True)    # Math.round(c * 10) / 10
+    return dict(cashRoundMult=2.0, cashRoundDiv=2.0, cashRoundIntDiv=False)         # halves
+
+
+def make_instance(family, seed):
+    rng = np.random.default_rng(1000 * family + seed)
+    T = int(rng.integers(1, 5))
+    kind = ["int", "dyadic", "decimal"][int(rng.integers(0, 3))]
+    if family == 1:
+        clamp = bool(rng.integers(0, 4))
+        f = BackorderFunctor(fixedOrderingCost=_money(rng, 0, 30, kind), variOrderingCost=_money(rng, 0, 3, kind),
+                             holdingCost=_money(rng, 0, 3, kind), penaltyCost=_money(rng, 0, 12, kind),
+                             minInventory=-float(rng.integers(0, 80)), maxInventory=float(rng.integers(1, 400)),
+                             maxOrderQuantity=float(rng.integers(0, 70)), iniInventory=float(rng.integers(-3, 4)),
+                             clampInventory=clamp)
+        direction = OptDirection.MIN if rng.integers(0, 4) else OptDirection.MAX
+        return Workload(f"fuzz_f1_{seed}", f, direction,
+                        _pmf(rng, T, unit_stride=bool(rng.integers(0, 3)), d_max=int(rng.integers(3, 30))))
+    if family == 2:
+        lead2 = bool(rng.integers(0, 2))
+        clamp = True if lead2 else bool(rng.integers(0, 2))
+        f = LeadtimeFunctor(fixedOrderingCost=_money(rng, 0, 10, kind), variOrderingCost=_money(rng, 0, 3, kind),
+                            holdingCost=_money(rng, 0, 3, kind), penaltyCost=_money(rng, 0, 12, kind),
+                            maxOrderQuantity=float(rng.integers(0, 9 if lead2 else 14)), clampInventory=clamp,
+                            minInventory=-float(rng.integers(0, 15)), maxInventory=float(rng.integers(1, 70)),
+                            iniInventory=float(rng.integers(0, 3)), iniPreQ=0.0, leadTime=2 if lead2 else 1)
+        return Workload(f"fuzz_f2_{seed}", f, OptDirection.MIN, _pmf(rng, T, unit_stride=bool(rng.integers(0, 3))))
+    common = dict(price=_money(rng, 2, 12, kind), variCost=max(0.25, _money(rng, 0.5, 3, kind)),
+                  salvageValue=_money(rng, 0, 1, kind), maxOrderQuantity=float(rng.integers(0, 14)),
+                  minInventoryState=0.0, maxInventoryState=float(rng.integers(1, 16)),
+                  minCashState=-float(rng.integers(0, 40)), maxCashState=float(rng.integers(20, 90)),
+                  iniInventory=0.0, iniCash=float(rng.integers(0, 15)))
+    overheads = [_money(rng, 0, 8, kind) for _ in range(T)]
+    if family == 3:
+        f = CashFunctor(fixOrderCost=_money(rng, 0, 5, kind), holdingCost=_money(rng, 0, 1, kind),
+                        depositeRate=float(rng.choice([0, 0, 0.01])), overheadRate=float(rng.choice([0, 0, 0.05])),
+                        penaltyCost=float(rng.choice([0, 0, 0.3])), discountFactor=float(rng.choice([1.0, 0.95])),
+                        cashFormula=int(rng.integers(0, 2)), overheadCosts=overheads, **_rounding(rng), **common)
+        direction = OptDirection.MAX if rng.integers(0, 4) else OptDirection.MIN
+        return Workload(f"fuzz_f3_{seed}", f, direction, _pmf(rng, T, unit_stride=bool(rng.integers(0, 2))))
+    if family == 4:
+        f = OverdraftFunctor(fixOrderCost=_money(rng, 0, 5, kind), r0=float(rng.choice([0, 0.01])), r2=0.1,
+                             r3=float(rng.choice([1.0, 2.0])), limit=float(rng.integers(10, 40)),
+                             interestFreeAmount=float(rng.integers(0, 10)), discountFactor=float(rng.choice([1.0, 0.9])),
+                             overheadCosts=overheads, **_rounding(rng), **common)
+        return Workload(f"fuzz_f4_{seed}", f, OptDirection.MAX, _pmf(rng, T))
+    if family == 5:
+        common["maxOrderQuantity"] = float(rng.integers(0, 7))
+        common["maxCashState"] = float(rng.integers(10, 30))
+        common["minCashState"] = -float(rng.integers(0, 15))
+        rnd = _rounding(rng)
+        f = CashLeadtimeFunctor(r0=float(rng.choice([0, 0.01])), r2=0.1, r3=2.0, limit=float(rng.integers(5, 20)),
+                                interestFreeAmount=float(rng.integers(0, 5)), iniPreQ=0.0,
+                                overheadCosts=overheads[:min(T, 3)], **rnd, **common)
+        return Workload(f"fuzz_f5_{seed}", f, OptDirection.MAX, _pmf(rng, min(T, 3), d_max=6))
+    f = SurvivalFunctor(fixOrderCost=_money(rng, 0, 3, kind), holdingCost=_money(rng, 0, 1, kind),
+                        depositeRate=float(rng.choice([0, 0.02])), discountFactor=float(rng.choice([1.0, 0.97])),
+                        overheadCosts=[o + 4 for o in overheads], **common)
+    return Workload(f"fuzz_f6_{seed}", f, OptDirection.MAX, _pmf(rng, T))
+
+
+@pytest.mark.parametrize("family", [1, 2, 3, 4, 5, 6])
+def test_random_instances_bit_exact(sia, oracle, family):
+    n = 16 if family == 5 else 40
+    kernels_seen = set()
+    for seed in range(n):
+        w = make_instance(family, seed)
+        P = oracle.Problem(w.desc(), w.pmf, w.overhead())
+        V, pol, cells = P.solve(nthreads=4)
+        for kernel in (0, 1):
+            d = w.desc()
+            d.kernel = kernel
+            with sia.SdpEngine(d, w.pmf, w.overhead()) as eng:
+                eng.solve()
+                if kernel == 0:
+                    kernels_seen.add(eng.stats().kernel_used)
+                assert eng.stats().cells_evaluated == cells, w.name
+                for period in range(1, w.T + 1):
+                    gv, gp = eng.values(period), eng.policy(period)
+                    assert np.array_equal(gp, pol[period - 1]), f"{w.name} kernel {kernel} t={period}: policy"
+                    assert np.array_equal(gv, V[period - 1]), f"{w.name} kernel {kernel} t={period}: values"
+    assert 2 in kernels_seen or family == 0  # the specialised kernels took part
