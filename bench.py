@@ -285,14 +285,22 @@ def main():
             },
         }
         if int(st.kernel_used) == 2 and args.workload in ("cfg2", "cfg5"):
-            # the bound that actually limits the window kernel: fp64 add/mul issue (no FMA by contract).
-            # 5 ops per cell with a future term, 3 in the last period; peak = 16 lanes/clk/SIMD x 1024 SIMDs
-            # x 2.4 GHz (tools/valu_probe.hip measures 3.8e13 of it at the clock the chip holds).
-            ops_per_sweep = cells_step_rank * (5.0 * (T - 1) + 3.0) / T
+            # the bound that actually limits the window kernel: fp64 add/mul issue (no FMA by contract);
+            # peak = 16 lanes/clk/SIMD x 1024 SIMDs x 2.4 GHz (tools/valu_probe.hip measures 3.8e13 of it at the
+            # clock the chip holds).
+            # Operations the kernel executes per cell with R actions x S adjacent states per lane (sdp_window.hpp):
+            # c0 + M once per (action, m): 1/S; p * imm: 1; p * V once per window entry: (R + S - 1)/(R S); two
+            # accumulations: 2.  The last period has no future term.  Every one is an operation of the reference.
+            R_, S_ = max(int(st.window_r), 1), max(int(st.window_s), 1)
+            ops_future = 3.0 + 1.0 / S_ + (R_ + S_ - 1.0) / (R_ * S_)
+            ops_last = 2.0 + 1.0 / S_
+            ops_per_sweep = cells_step_rank * (ops_future * (T - 1) + ops_last) / T
             lane_ops = ops_per_sweep * args.steps / (dev_ms * 1e-3)
             out["valu_roofline"] = {"bound": "fp64 add/mul issue", "achieved": lane_ops / 1e12, "peak": 39.3,
                                     "unit": "T lane-op/s", "frac": lane_ops / 39.3e12,
-                                    "ops_per_cell": [5, 3], "note": "secondary: the north star prices this path against HBM"}
+                                    "ops_per_cell": [round(ops_future, 4), round(ops_last, 4)],
+                                    "register_block": {"actions": R_, "states_per_lane": S_},
+                                    "note": "secondary: the north star prices this path against HBM"}
         if check is not None:
             out["check_vs_single_rank"] = check
         if not args.no_cpu_baseline:

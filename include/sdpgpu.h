@@ -181,6 +181,8 @@ typedef struct sdpgpu_stats {
   double  kernel_ms_sum;    /* sum of per-period kernel times when profiling is on, else 0 */
   int32_t periods_run;
   int32_t kernel_used;      /* SDPGPU_KERNEL_* actually launched for the last period run */
+  int32_t window_r;         /* F1 window kernel: actions per register block ... */
+  int32_t window_s;         /* ... and adjacent states per lane of the plan used for period 1 (0: other kernel) */
 } sdpgpu_stats;
 
 typedef struct sdpgpu_handle sdpgpu_handle;

@@ -92,6 +92,8 @@ class SdpgpuStats(C.Structure):
         ("kernel_ms_sum", C.c_double),
         ("periods_run", C.c_int32),
         ("kernel_used", C.c_int32),
+        ("window_r", C.c_int32),
+        ("window_s", C.c_int32),
     ]
 
 

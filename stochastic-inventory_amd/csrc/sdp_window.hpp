@@ -34,17 +34,19 @@ struct WinParams {
   int32_t idx_off;    // m -> next-grid index offset: (lev0 - x_lo(next)) / step
   int32_t next_last;  // nx(next) - 1
   int32_t n_actions;  // A
-  int32_t d_pad;      // demand steps rounded up to a multiple of R (sizes the LDS window)
-  int32_t d_main;     // demand steps handled by full blocks of R: floor(D / R) * R
+  int32_t d_pad;      // demand steps rounded up to a multiple of NW = R + S - 1 (sizes the LDS window)
+  int32_t d_main;     // demand steps handled by full blocks of NW: floor(D / NW) * NW
   int32_t n_demand;   // D
   int32_t n_chunks;   // tasks per state tile: the action range is cut into n_chunks runs of R-blocks
   int32_t chunk_blocks;   // R-blocks per task
-  int32_t n_tiles;        // state tiles of 64 covered by THIS launch
+  int32_t n_tiles;        // state tiles (64 * S states each) covered by THIS launch
   int32_t n_tasks;        // n_tiles * n_chunks (one task per wave)
   int32_t tile_first;     // launch tile u maps to slab tile tile_first + u (+ tile_gap when u >= tile_gap_at):
   int32_t tile_gap_at;    // lets one launch cover the interior run of tiles, or the two boundary runs
   int32_t tile_gap;
   int32_t prio_fair;      // s_setprio by progress: resident waves of a SIMD advance together
+  int32_t maxdir;         // OptDirection.MAX
+  int32_t pad0;
   int64_t partial_stride; // elements between chunk rows of the partial tables
 };
 
@@ -84,18 +86,27 @@ __device__ __forceinline__ double2 window_entry(const WinParams& W, const double
   return e;
 }
 
-// One TASK per wave: (state tile of 64, run of R-blocks of the action axis).  Tasks are numbered
+// One TASK per wave: (state tile of 64*S, run of R-blocks of the action axis).  Tasks are numbered
 // chunk-major (task = chunk * n_tiles + tile) and packed four to a workgroup regardless of tile, so
 // every workgroup carries four equal tasks -- one per SIMD -- and a launch of n_tasks/4 workgroups
 // loads the 1024 SIMDs evenly (the measured timeline of one SIMD is strictly task after task).  Each
 // wave stages its OWN window in its own LDS region: there is no workgroup barrier in this kernel.
+//
+// S ADJACENT STATES PER LANE (lane l owns states S*l .. S*l+S-1 of the tile).  The cells (state s, action r,
+// demand j) and (s+1, r, j+1) have the same m AND the same action, hence the same immediate cost
+// c0[r] + M(m) -- the identical fp64 add on identical operands.  It is computed once, for state 0 of the
+// lane, and handed down the lane's states one demand step at a time (immc[s][r]); only p_j * imm and the
+// two accumulations are per cell.  Operations per cell: (5 + 4*(S-1)) / S = 5, 4.5, 4.25 for S = 1, 2, 4,
+// every one of them an operation the reference performs, in its order.  The register window has
+// R + S - 1 entries (state s, action r reads entry r + s) and still slides by ONE ds_read_b128 per
+// demand step: LDS traffic is 16 B per R*S cells.
 //
 // When a tile is shared by several tasks (n_chunks > 1, small grids) a task publishes its best value
 // with a 64-bit atomic min/max on the order-preserving key of V_t (exact), and stores its
 // (value, action) pair in its chunk row; the arg-opt ACTION is resolved later, off the critical
 // path, by finalize_kernel: the lowest chunk whose value equals V_t holds the lowest optimal action
 // index (chunks are ascending action ranges), which is the reference's tie rule.
-template <int R, bool MAXDIR, bool FUTURE, bool KEYED_IN>
+template <int R, int S, bool FUTURE, bool KEYED_IN>
 __global__ __launch_bounds__(256) void window_f1_kernel(WinParams W, const double* __restrict__ v_next,
                                                         const unsigned long long* __restrict__ k_next,
                                                         double* __restrict__ out_val, int32_t* __restrict__ out_idx,
@@ -105,34 +116,42 @@ __global__ __launch_bounds__(256) void window_f1_kernel(WinParams W, const doubl
                                                         , unsigned long long* stamps
 #endif
 ) {
+  constexpr int NW = R + S - 1;  // register window entries = demand steps per unrolled block
+  constexpr int TS = 64 * S;     // states per tile
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int tid = threadIdx.x;
   const int lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int task = blockIdx.x * 4 + wave;
   if (task >= W.n_tasks) return;  // no barriers below: a wave may leave on its own
+  const bool MAXDIR = W.maxdir != 0;
   const int chunk = task / W.n_tiles;
   int tile = task - chunk * W.n_tiles;
   tile = W.tile_first + tile + (tile >= W.tile_gap_at ? W.tile_gap : 0);
   const int chunk_actions = W.chunk_blocks * R;
-  const int span = 64 + chunk_actions + W.d_pad;  // entries [0, span): slot 0 is a spare
+  const int span = TS + chunk_actions + W.d_pad + S;  // entries [0, span): slot 0 is a spare
   double2* s_win = reinterpret_cast<double2*>(smem) + (size_t)wave * span;
-  const int64_t i0 = lo + (int64_t)tile * 64;
+  const int64_t i0 = lo + (int64_t)tile * TS;
   const int kA = chunk * chunk_actions;
 #ifdef SDP_STAMPS  // diagnostic build only (tools/stamp_window.py): per-wave timeline, never in the product
   unsigned long long st_t0 = __builtin_amdgcn_s_memrealtime();
 #endif
 
-  // stage this wave's window: slot s holds m = m_lo + s, m_lo = i0 + kA - d_pad
+  // stage this wave's window: slot q holds m = m_lo + q, m_lo = i0 + kA - d_pad
   const int m_lo = (int)i0 + kA - W.d_pad;
-  for (int s = lane; s < span; s += 64) s_win[s] = window_entry<FUTURE, KEYED_IN>(W, v_next, k_next, m_lo + s);
+  for (int q = lane; q < span; q += 64) s_win[q] = window_entry<FUTURE, KEYED_IN>(W, v_next, k_next, m_lo + q);
   __builtin_amdgcn_wave_barrier();
 #ifdef SDP_STAMPS
   unsigned long long st_t1 = __builtin_amdgcn_s_memrealtime();
 #endif
 
-  double best = MAXDIR ? -1.7976931348623157e308 : 1.7976931348623157e308;
-  int bestk = 0;
+  double best[S];
+  int bestk[S];
+#pragma unroll
+  for (int s = 0; s < S; ++s) {
+    best[s] = MAXDIR ? -1.7976931348623157e308 : 1.7976931348623157e308;
+    bestk[s] = 0;
+  }
   for (int rb = 0; rb < W.chunk_blocks; ++rb) {
     const int k0 = kA + rb * R;
     if (k0 >= W.n_actions) break;
@@ -142,17 +161,23 @@ __global__ __launch_bounds__(256) void window_f1_kernel(WinParams W, const doubl
       double a = (double)(k0 + r) * W.step;
       c0[r] = (a > 0 ? W.K : 0.0) + W.v * a;  // fixedCost + variableCost (wave-uniform)
     }
-    // slot of (lane, r, j):  lane + (k0 - kA) + r - j + d_pad
-    const int base = lane + (k0 - kA) + W.d_pad;
-    double2 win[R];
-    double acc[R];
+    // slot of (lane, s, r, j):  S*lane + s + (k0 - kA) + r - j + d_pad;  window entry q at step j: base - j + q
+    const int base = S * lane + (k0 - kA) + W.d_pad;
+    double2 win[NW];
+    double acc[S][R];
+    double immc[S][R];  // immc[s][r], s >= 1: immediate cost of (state s, action r) at the current demand step
+#pragma unroll
+    for (int q = 0; q < NW; ++q) win[q] = s_win[base + q];
 #pragma unroll
     for (int r = 0; r < R; ++r) {
-      win[r] = s_win[base + r];
-      acc[r] = 0.0;
+#pragma unroll
+      for (int s = 0; s < S; ++s) {
+        acc[s][r] = 0.0;
+        immc[s][r] = c0[r] + win[r + s].x;  // (s = 0 unused)
+      }
     }
 #pragma unroll 1
-    for (int jb = 0; jb < W.d_main; jb += R) {
+    for (int jb = 0; jb < W.d_main; jb += NW) {
       if (W.prio_fair) {
         // The SIMD issues by priority, then age: left alone, the oldest resident wave runs ahead and the
         // last task of a SIMD ends up alone (one wave sustains 76 % of the fp64 issue rate, four 94 %).
@@ -165,62 +190,85 @@ __global__ __launch_bounds__(256) void window_f1_kernel(WinParams W, const doubl
         else if (pr == 2) __builtin_amdgcn_s_setprio(2);
         else __builtin_amdgcn_s_setprio(3);
       }
-      const double2* nxt = s_win + (base - jb - R);  // slots base-jb-R ... base-jb-1
+      const double2* nxt = s_win + (base - jb - NW);  // slots base-jb-NW ... base-jb-1
 #pragma unroll
-      for (int t = 0; t < R; ++t) {
+      for (int t = 0; t < NW; ++t) {
         const double p = pmf_p[jb + t];  // wave-uniform -> scalar load
 #pragma unroll
         for (int r = 0; r < R; ++r) {
-          const double2 w = win[(r - t + R) % R];
-          double imm = c0[r] + w.x;
-          acc[r] += p * imm;
-          if constexpr (FUTURE) acc[r] += p * w.y;
+          const double2 w0 = win[(r - t + NW) % NW];
+          const double imm0 = c0[r] + w0.x;
+          acc[0][r] += p * imm0;
+          if constexpr (FUTURE) acc[0][r] += p * w0.y;
+#pragma unroll
+          for (int s = 1; s < S; ++s) {
+            acc[s][r] += p * immc[s][r];
+            // (cells with the same r + s read the same entry: the product p * V is formed once for them)
+            if constexpr (FUTURE) acc[s][r] += p * win[(r + s - t + NW) % NW].y;
+          }
+#pragma unroll
+          for (int s = S - 1; s > 1; --s) immc[s][r] = immc[s - 1][r];
+          if constexpr (S > 1) immc[1][r] = imm0;
         }
-        // slide: the entry for (r = 0, j + 1) replaces the one (r = R-1, j) just used
-        win[(R - 1 - t) % R] = nxt[R - 1 - t];
+        // slide: the entry for (s = 0, r = 0, j + 1) replaces the one (s = S-1, r = R-1, j) just used
+        win[(NW - 1 - t) % NW] = nxt[NW - 1 - t];
       }
     }
-    // the last D mod R demand steps: the same unrolled body under wave-uniform guards (the register
+    // the last D mod NW demand steps: the same unrolled body under wave-uniform guards (the register
     // window is back in its canonical rotation after every full block)
     if (W.d_main < W.n_demand) {
       const int jb = W.d_main;
       const int rem = W.n_demand - W.d_main;
-      const double2* nxt = s_win + (base - jb - R);
+      const double2* nxt = s_win + (base - jb - NW);
 #pragma unroll
-      for (int t = 0; t < R - 1; ++t) {
+      for (int t = 0; t < NW - 1; ++t) {
         if (t < rem) {
           const double p = pmf_p[jb + t];
 #pragma unroll
           for (int r = 0; r < R; ++r) {
-            const double2 w = win[(r - t + R) % R];
-            double imm = c0[r] + w.x;
-            acc[r] += p * imm;
-            if constexpr (FUTURE) acc[r] += p * w.y;
+            const double2 w0 = win[(r - t + NW) % NW];
+            const double imm0 = c0[r] + w0.x;
+            acc[0][r] += p * imm0;
+            if constexpr (FUTURE) acc[0][r] += p * w0.y;
+#pragma unroll
+            for (int s = 1; s < S; ++s) {
+              acc[s][r] += p * immc[s][r];
+              if constexpr (FUTURE) acc[s][r] += p * win[(r + s - t + NW) % NW].y;
+            }
+#pragma unroll
+            for (int s = S - 1; s > 1; --s) immc[s][r] = immc[s - 1][r];
+            if constexpr (S > 1) immc[1][r] = imm0;
           }
-          win[(R - 1 - t) % R] = nxt[R - 1 - t];
+          win[(NW - 1 - t) % NW] = nxt[NW - 1 - t];
         }
       }
     }
 #pragma unroll
     for (int r = 0; r < R; ++r) {
       const int k = k0 + r;
-      if (k < W.n_actions && (MAXDIR ? (acc[r] > best) : (acc[r] < best))) {
-        best = acc[r];
-        bestk = k;
+#pragma unroll
+      for (int s = 0; s < S; ++s) {
+        if (k < W.n_actions && (MAXDIR ? (acc[s][r] > best[s]) : (acc[s][r] < best[s]))) {
+          best[s] = acc[s][r];
+          bestk[s] = k;
+        }
       }
     }
   }
 
-  const int64_t idx = i0 + lane;
-  if (idx < hi) {
-    const int64_t o = (int64_t)chunk * W.partial_stride + idx;
-    out_val[o] = best;
-    out_idx[o] = bestk;
-    if (W.n_chunks > 1) {
-      if (MAXDIR)
-        atomicMax(k_cur + idx, f64_key(best));
-      else
-        atomicMin(k_cur + idx, f64_key(best));
+#pragma unroll
+  for (int s = 0; s < S; ++s) {
+    const int64_t idx = i0 + (int64_t)S * lane + s;
+    if (idx < hi) {
+      const int64_t o = (int64_t)chunk * W.partial_stride + idx;
+      out_val[o] = best[s];
+      out_idx[o] = bestk[s];
+      if (W.n_chunks > 1) {
+        if (MAXDIR)
+          atomicMax(k_cur + idx, f64_key(best[s]));
+        else
+          atomicMin(k_cur + idx, f64_key(best[s]));
+      }
     }
   }
 #ifdef SDP_STAMPS

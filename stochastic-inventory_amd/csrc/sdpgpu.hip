@@ -96,7 +96,7 @@ struct sdpgpu_handle {
   bool use_cash_shift = true;
   bool use_cash_row = true;   // SDPGPU_CASH_ROW=0 turns the cash row kernel off (generic kernel instead)
   int win_prio_fair = 1;  // window kernel: s_setprio by progress (SDPGPU_WIN_PRIO=0 turns it off)
-  int win_r = 0, win_nch = 0;      // tuning overrides (SDPGPU_WIN_R / SDPGPU_WIN_NCH), 0 = heuristic
+  int win_r = 0, win_nch = 0, win_s = 0;  // tuning overrides (SDPGPU_WIN_R / SDPGPU_WIN_NCH / SDPGPU_WIN_S), 0 = heuristic
   uint8_t* d_reach = nullptr;      // reachable masks, period t at reach_off[t-1]
   std::vector<size_t> reach_off;
   bool reach_done = false;
@@ -888,8 +888,9 @@ hipError_t launch_cash_row(sdpgpu_handle* h, const DevParams& P, int period, con
 // ---- window kernel (F1) -----------------------------------------------------------------------
 
 struct WinPlan {
-  int R = 0, d_pad = 0, n_chunks = 1, chunk_blocks = 0, n_tiles = 0, n_tasks = 0;
+  int R = 0, S = 1, d_pad = 0, n_chunks = 1, chunk_blocks = 0, n_tiles = 0, n_tasks = 0;
   size_t smem = 0;
+  int tile_states() const { return 64 * S; }
 };
 
 // F1 / F2 with a unit-stride demand grid: d_j = d_0 + j*step.
@@ -905,50 +906,57 @@ bool window_eligible(const sdpgpu_handle* h, int period) {
   return true;
 }
 
-// One task = one wave = (tile of 64 states, run of R-blocks).  The measured timeline of a SIMD is task
+// One task = one wave = (tile of 64*S states, run of R-blocks).  The measured timeline of a SIMD is task
 // after task, so a launch costs  rounds x task time  with rounds = ceil(tasks / 1024 SIMDs): pick the
-// register block R and the number of chunks per tile that minimise it (fewest chunks on ties: fewer
-// chunk rows, less staging).
+// register block R, the states per lane S and the number of chunks per tile that minimise it (fewest chunks
+// on ties: fewer chunk rows, less staging).  More states per lane = fewer fp64 operations per cell
+// ((5 + 4(S-1)) / S, see window_f1_kernel) but bigger, fewer tasks: small grids keep S low.
 WinPlan plan_window(const sdpgpu_handle* h, int period, int64_t lo, int64_t hi) {
   const PeriodInfo& p = h->per[period - 1];
   const int A = h->n_actions_full, D = p.nD;
   WinPlan best;
   double best_cost = -1;
-  // The plan (register block, chunks per tile) is chosen from the NOMINAL slab S_pad / world_size, which is
-  // the same on every rank: ranks must agree on whether a period's row is exchanged as keys or as fp64
-  // values, whatever their own (possibly clipped or empty) slab looks like.
+  // The plan is chosen from the NOMINAL slab S_pad / world_size, which is the same on every rank: ranks
+  // must agree on whether a period's row is exchanged as keys or as fp64 values, whatever their own
+  // (possibly clipped or empty) slab looks like.
   const int64_t nominal = p.S_pad / std::max(1, h->d.world_size);
-  const int64_t n_tiles = std::max<int64_t>(1, (nominal + 63) / 64);
-  const int64_t own_tiles = (hi - lo + 63) / 64;
   auto rup = [](int v, int r) { return (v + r - 1) / r * r; };
-  const int cand[3] = {8, 5, 4};
+  struct Cand {
+    int r, s, occupancy;  // occupancy: waves a SIMD can hold within the register budget
+  };
+  // (84 / 62 / 54 VGPRs for S = 1, R = 8 / 5 / 4; 134 / 116 / 96 for S = 2; 130 for R = 4, S = 4)
+  const Cand cand[] = {{8, 1, 6}, {5, 1, 8}, {4, 1, 9}, {8, 2, 3}, {4, 2, 5}, {4, 4, 3}};
   const bool may_chunk = h->fuse_combine && h->d.store_all_values;
-  for (int r : cand) {
+  for (const Cand& c : cand) {
+    const int r = c.r, sl = c.s, nw = r + sl - 1, ts = 64 * sl;
     if (h->win_r && r != h->win_r) continue;
-    const int d_pad = rup(D, r);
+    if (h->win_s && sl != h->win_s) continue;
+    const int64_t n_tiles = std::max<int64_t>(1, (nominal + ts - 1) / ts);
+    const int64_t own_tiles = (hi - lo + ts - 1) / ts;
+    const int d_pad = rup(D, nw);
     const int blocks_total = rup(A, r) / r;
-    // cost of one R-block on one SIMD, in fp64-instruction units: 5 ops per cell plus a per-step overhead
-    // (LDS read, scalar load, waits) that a wider register block amortises better
-    const double block_cost = (double)D * (5.0 * r + 3.0) + 60.0;
-    // register budget -> waves a SIMD can hold (76 / 86 / 65 VGPRs for R = 8 / 5 / 4)
-    const int occupancy = r == 8 ? 6 : (r == 5 ? 5 : 7);
+    // cost of one R-block on one SIMD, in fp64-instruction units per lane: (5 + 4(S-1)) ops per S cells of an
+    // action plus a per-step overhead (LDS read, scalar load, waits) that a bigger register block amortises
+    const double block_cost = (double)D * ((5.0 + 4.0 * (sl - 1)) * r + 3.0) + 60.0 + 2.0 * (sl - 1) * r;
     for (int nch = 1; nch <= blocks_total; ++nch) {
       if (h->win_nch && nch != std::min(h->win_nch, blocks_total)) continue;
       const int bpc = (blocks_total + nch - 1) / nch;
       if ((blocks_total + bpc - 1) / bpc != nch) continue;  // same plan as a smaller nch
       if (nch > 1 && !may_chunk) continue;  // chunk rows need the deferred key/finalize scheme
-      const size_t smem = (size_t)4 * (64 + bpc * r + d_pad) * 16;
+      const int span = ts + bpc * r + d_pad + sl;
+      const size_t smem = (size_t)4 * span * 16;
       if (smem > 64 * 1024) continue;
       const int64_t tasks = n_tiles * nch;
       const int64_t rounds = (tasks + 1023) / 1024;  // tasks the busiest SIMD runs, one after the other
       // fp64 issue rate one SIMD sustains with w resident waves (tools/valu_probe): 0.76 / 0.86 / 0.94 / 0.97
-      const int64_t w = std::min<int64_t>(rounds, occupancy);
+      const int64_t w = std::min<int64_t>(rounds, c.occupancy);
       const double eff = w >= 8 ? 0.97 : (w >= 4 ? 0.94 : (w >= 3 ? 0.90 : (w >= 2 ? 0.86 : 0.76)));
-      const double staging = 400.0 + 4.0 * (64 + bpc * r + d_pad);
+      const double staging = 400.0 + 4.0 * span;
       const double cost = (double)rounds * (bpc * block_cost + staging) / eff;
       if (best_cost < 0 || cost < best_cost * 0.999) {
         best_cost = cost;
         best.R = r;
+        best.S = sl;
         best.d_pad = d_pad;
         best.n_chunks = nch;
         best.chunk_blocks = bpc;
@@ -1133,14 +1141,15 @@ bool window_interior_tiles(const sdpgpu_handle* h, int period, int64_t lo, int64
   if (h->d.family != SDPGPU_FAMILY_BACKORDER || period >= h->T || h->d.world_size == 1) return false;
   const PeriodInfo& p = h->per[period - 1];
   const PeriodInfo& pn = h->per[period];
-  const int64_t n_tiles = (hi - lo + 63) / 64;
+  const int64_t ts = plan_window(h, period, lo, hi).tile_states();
+  const int64_t n_tiles = (hi - lo + ts - 1) / ts;
   const double lev0 = p.g.x_lo - h->pmf_d[period - 1][0];
   const int64_t idx_off = (int64_t)((lev0 - pn.g.x_lo) / h->d.step);
   const int64_t A = h->n_actions_full, D = p.nD;
   int64_t f = -1, c = 0;
   for (int64_t u = 0; u < n_tiles; ++u) {
-    const int64_t i0 = lo + u * 64;
-    int64_t a = i0 + idx_off - (D - 1), b = i0 + 63 + idx_off + A - 1;
+    const int64_t i0 = lo + u * ts;
+    int64_t a = i0 + idx_off - (D - 1), b = i0 + ts - 1 + idx_off + A - 1;
     a = std::max<int64_t>(0, std::min<int64_t>(a, pn.g.nx - 1));  // the kernel clamps reads to the grid
     b = std::max<int64_t>(0, std::min<int64_t>(b, pn.g.nx - 1));
     const bool inside = a >= pn.lo && b < pn.hi;
@@ -1168,6 +1177,9 @@ hipError_t launch_window(sdpgpu_handle* h, const DevParams& P, int period, const
   PeriodInfo& p = h->per[period - 1];
   WinPlan pl = plan_window(h, period, lo, hi);
   if (!pl.R) return hipErrorInvalidValue;
+  if (period == h->T && std::getenv("SDPGPU_DEBUG_PLAN"))
+    std::fprintf(stderr, "[sdpgpu] window plan: R=%d S=%d chunks=%d blocks/chunk=%d tiles=%d tasks=%d lds=%zu\n", pl.R, pl.S,
+                 pl.n_chunks, pl.chunk_blocks, pl.n_tiles, pl.n_tasks, pl.smem);
   const bool future = period < h->T;
   const bool chunked = pl.n_chunks > 1;
   // a period is never re-run on top of its own pending rows, and a new sweep (period T) first
@@ -1230,7 +1242,8 @@ hipError_t launch_window(sdpgpu_handle* h, const DevParams& P, int period, const
   }
   W.n_actions = h->n_actions_full;
   W.d_pad = pl.d_pad;
-  W.d_main = p.nD / pl.R * pl.R;
+  W.d_main = p.nD / (pl.R + pl.S - 1) * (pl.R + pl.S - 1);
+  W.maxdir = P.maxdir;
   W.n_demand = p.nD;
   W.n_chunks = pl.n_chunks;
   W.chunk_blocks = pl.chunk_blocks;
@@ -1276,34 +1289,27 @@ hipError_t launch_window(sdpgpu_handle* h, const DevParams& P, int period, const
 #define SDP_STAMP_ARG
 #endif
   if (W.n_tasks > 0) {
-#define SDP_WIN_GO(RR, MX, FU, KI)                                                                                      \
-  hipLaunchKernelGGL((sdp::window_f1_kernel<RR, MX, FU, KI>), grid, dim3(256), pl.smem, st, W, v_next, k_next, out_val, \
+#define SDP_WIN_GO(RR, SS, FU, KI)                                                                                      \
+  hipLaunchKernelGGL((sdp::window_f1_kernel<RR, SS, FU, KI>), grid, dim3(256), pl.smem, st, W, v_next, k_next, out_val, \
                      out_idx, k_cur, pmf_p, lo, hi SDP_STAMP_ARG)
-#define SDP_WIN_R(RR)                                       \
-  case RR:                                                  \
-    if (P.maxdir) {                                         \
-      if (!future)                                          \
-        SDP_WIN_GO(RR, true, false, false);                 \
-      else if (keyed_in)                                    \
-        SDP_WIN_GO(RR, true, true, true);                   \
-      else                                                  \
-        SDP_WIN_GO(RR, true, true, false);                  \
-    } else {                                                \
-      if (!future)                                          \
-        SDP_WIN_GO(RR, false, false, false);                \
-      else if (keyed_in)                                    \
-        SDP_WIN_GO(RR, false, true, true);                  \
-      else                                                  \
-        SDP_WIN_GO(RR, false, true, false);                 \
-    }                                                       \
-    break;
-  switch (pl.R) {
-    SDP_WIN_R(8)
-    SDP_WIN_R(5)
-    SDP_WIN_R(4)
-    default:
-      return hipErrorInvalidValue;
+#define SDP_WIN_R(RR, SS)                      \
+  if (pl.R == RR && pl.S == SS) {              \
+    if (!future)                               \
+      SDP_WIN_GO(RR, SS, false, false);        \
+    else if (keyed_in)                         \
+      SDP_WIN_GO(RR, SS, true, true);          \
+    else                                       \
+      SDP_WIN_GO(RR, SS, true, false);         \
+    launched = true;                           \
   }
+  bool launched = false;
+  SDP_WIN_R(8, 1)
+  SDP_WIN_R(5, 1)
+  SDP_WIN_R(4, 1)
+  SDP_WIN_R(8, 2)
+  SDP_WIN_R(4, 2)
+  SDP_WIN_R(4, 4)
+  if (!launched) return hipErrorInvalidValue;
 #undef SDP_WIN_R
 #undef SDP_WIN_GO
 #undef SDP_STAMP_ARG
@@ -1402,6 +1408,7 @@ int sdpgpu_create(const sdpgpu_desc* desc, sdpgpu_handle** out) {
     h->pending_chunks.assign((size_t)h->T + 1, 0);
     if (const char* e = std::getenv("SDPGPU_WIN_R")) h->win_r = std::atoi(e);
     if (const char* e = std::getenv("SDPGPU_WIN_NCH")) h->win_nch = std::atoi(e);
+    if (const char* e = std::getenv("SDPGPU_WIN_S")) h->win_s = std::atoi(e);
     if (const char* e = std::getenv("SDPGPU_FUSE_COMBINE")) h->fuse_combine = std::atoi(e) != 0;
     if (const char* e = std::getenv("SDPGPU_CASH_SHIFT")) h->use_cash_shift = std::atoi(e) != 0;
     if (const char* e = std::getenv("SDPGPU_CASH_ROW")) h->use_cash_row = std::atoi(e) != 0;
@@ -1937,6 +1944,12 @@ int sdpgpu_stats_get(sdpgpu_handle* h, sdpgpu_stats* out) {
     if (h->period_done[t]) out->periods_run++;
   }
   out->kernel_used = h->per[0].kernel_used;
+  if (!h->custom && h->d.family == SDPGPU_FAMILY_BACKORDER && h->per[0].kernel_used == SDPGPU_KERNEL_WINDOW &&
+      window_eligible(h, 1)) {
+    const WinPlan pl = plan_window(h, 1, h->per[0].lo, h->per[0].hi);
+    out->window_r = pl.R;
+    out->window_s = pl.S;
+  }
   if (h->allocated) {
     (void)ensure_device(h);
     if (h->custom && h->d_custom_cells && hipStreamSynchronize(h->stream) == hipSuccess) {
