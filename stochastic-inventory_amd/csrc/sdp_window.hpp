@@ -358,16 +358,22 @@ struct RowParams {
   int64_t partial_stride;
 };
 
-template <int R, bool MAXDIR, bool FUTURE>
+// S ADJACENT STATES PER LANE, as in the F1 kernel: the cell (state s+1, action r, demand j+1) has the level AND
+// the plane of (s, r, j), i.e. the same immediate cost c0[r] + M(m) and the same V_{t+1} entry.  Both are
+// formed / read once, for state 0 of the lane, and reused by state s at step j + s (a ring of S register
+// sets, the demand loop unrolled by S so that the ring needs no moves): 4 + 1/S fp64 operations and
+// 8(R+1)/(R S) B of LDS per cell.
+template <int R, int S, bool MAXDIR, bool FUTURE>
 __global__ __launch_bounds__(256) void window_f2_kernel(RowParams W, const double* __restrict__ v_next,
                                                         double* __restrict__ out_val, int32_t* __restrict__ out_idx,
                                                         const double* __restrict__ pmf_p, int64_t lo, int64_t hi) {
+  constexpr int TS = 64 * S;
   extern __shared__ __attribute__((aligned(16))) char smem[];
-  const int span = 64 + W.d_pad + 1;                   // slots per row segment (slot 0 spare)
+  const int span = TS + W.d_pad + 1;                   // slots per row segment (slot 0 spare)
   double* s_m = reinterpret_cast<double*>(smem);       // M(m)
   double* s_v = s_m + span;                            // [chunk_actions][span]
   double* s_val = s_v + (size_t)(FUTURE ? W.chunk_actions : 0) * span;
-  int* s_k = reinterpret_cast<int*>(s_val + 4 * 64);
+  int* s_k = reinterpret_cast<int*>(s_val + 4 * TS);
 
   const int tid = threadIdx.x;
   const int lane = tid & 63;
@@ -375,25 +381,25 @@ __global__ __launch_bounds__(256) void window_f2_kernel(RowParams W, const doubl
   const int chunk = blockIdx.x / W.n_tiles;
   const int tile = W.tile0 + (blockIdx.x - chunk * W.n_tiles);
   const int iq = tile / W.tiles_per_row;
-  const int ix0 = (tile - iq * W.tiles_per_row) * 64;
+  const int ix0 = (tile - iq * W.tiles_per_row) * TS;
   const int kA = chunk * W.chunk_actions;
   const int iq2 = iq / W.nq1;
   const int iq1 = iq - iq2 * W.nq1;     // the quantity arriving this period
-  const int m_lo = ix0 + iq1 - W.d_pad;  // slot s <-> m = m_lo + s
+  const int m_lo = ix0 + iq1 - W.d_pad;  // slot q <-> m = m_lo + q
   const int64_t row_off = (int64_t)iq2 * W.next_nx;
 
-  for (int s = tid; s < span; s += 256) {
-    double l = W.lev0 + (double)(m_lo + s) * W.step;
-    s_m[s] = W.h * jmax(l, 0.0) + W.pi * jmax(-l, 0.0);
+  for (int q = tid; q < span; q += 256) {
+    double l = W.lev0 + (double)(m_lo + q) * W.step;
+    s_m[q] = W.h * jmax(l, 0.0) + W.pi * jmax(-l, 0.0);
   }
   if constexpr (FUTURE) {
     const int total = W.chunk_actions * span;
     for (int e = tid; e < total; e += 256) {
       const int row = e / span;
-      const int s = e - row * span;
+      const int q = e - row * span;
       int k = kA + row;
       k = k < W.n_actions ? k : W.n_actions - 1;  // padded actions read a valid plane, never selected
-      int idx = m_lo + s + W.idx_off;
+      int idx = m_lo + q + W.idx_off;
       idx = idx > W.next_last ? W.next_last : idx;
       idx = idx < 0 ? 0 : idx;
       s_v[e] = v_next[(int64_t)k * W.plane_stride + row_off + idx];
@@ -401,61 +407,91 @@ __global__ __launch_bounds__(256) void window_f2_kernel(RowParams W, const doubl
   }
   __syncthreads();
 
-  double best = MAXDIR ? -1.7976931348623157e308 : 1.7976931348623157e308;
-  int bestk = 0;
+  double best[S];
+  int bestk[S];
+#pragma unroll
+  for (int s = 0; s < S; ++s) {
+    best[s] = MAXDIR ? -1.7976931348623157e308 : 1.7976931348623157e308;
+    bestk[s] = 0;
+  }
   const int blocks_in_chunk = W.chunk_actions / R;
-  const int base = lane + W.d_pad;  // slot of (lane, j): base - j
+  const int base = S * lane + W.d_pad;  // slot of (lane, s, j): base + s - j
   for (int rb = wave; rb < blocks_in_chunk; rb += 4) {
     const int k0 = kA + rb * R;
     if (k0 >= W.n_actions) break;
-    double c0[R], acc[R];
+    double c0[R], acc[S][R];
+    // ring[u][r]: {imm, V} of state 0 at the step j with j mod S == u; state s at step j uses ring[(j - s) mod S]
+    double ring_i[S][R], ring_v[S][R];
+    const double* rows = s_v + (size_t)(rb * R) * span + base;
 #pragma unroll
     for (int r = 0; r < R; ++r) {
       double a = (double)(k0 + r) * W.step;
       c0[r] = (a > 0 ? W.K : 0.0) + W.v * a;
-      acc[r] = 0.0;
-    }
-    const double* rows = s_v + (size_t)(rb * R) * span + base;
-    for (int j = 0; j < W.d_pad; ++j) {
-      const double p = pmf_p[j];
-      const double mj = s_m[base - j];
 #pragma unroll
-      for (int r = 0; r < R; ++r) {
-        double imm = c0[r] + mj;
-        acc[r] += p * imm;
-        if constexpr (FUTURE) acc[r] += p * rows[r * span - j];
+      for (int s = 0; s < S; ++s) acc[s][r] = 0.0;
+      // what state s needs at step 0 is "state 0 at step -s": the entry at slot base + s
+#pragma unroll
+      for (int s = 1; s < S; ++s) {
+        ring_i[(S - s) % S][r] = c0[r] + s_m[base + s];
+        ring_v[(S - s) % S][r] = FUTURE ? rows[r * span + s] : 0.0;
+      }
+    }
+    for (int jb = 0; jb < W.d_pad; jb += S) {
+#pragma unroll
+      for (int u = 0; u < S; ++u) {
+        const int j = jb + u;
+        const double p = pmf_p[j];
+        const double mj = s_m[base - j];
+#pragma unroll
+        for (int r = 0; r < R; ++r) {
+          ring_i[u][r] = c0[r] + mj;
+          if constexpr (FUTURE) ring_v[u][r] = rows[r * span - j];
+#pragma unroll
+          for (int s = 0; s < S; ++s) {
+            acc[s][r] += p * ring_i[(u - s + S) % S][r];
+            if constexpr (FUTURE) acc[s][r] += p * ring_v[(u - s + S) % S][r];
+          }
+        }
       }
     }
 #pragma unroll
     for (int r = 0; r < R; ++r) {
       const int k = k0 + r;
-      if (k < W.n_actions && (MAXDIR ? (acc[r] > best) : (acc[r] < best))) {
-        best = acc[r];
-        bestk = k;
+#pragma unroll
+      for (int s = 0; s < S; ++s) {
+        if (k < W.n_actions && (MAXDIR ? (acc[s][r] > best[s]) : (acc[s][r] < best[s]))) {
+          best[s] = acc[s][r];
+          bestk[s] = k;
+        }
       }
     }
   }
 
-  s_val[wave * 64 + lane] = best;
-  s_k[wave * 64 + lane] = bestk;
-  __syncthreads();
-  const int ix = ix0 + tid;
-  const int64_t idx = (int64_t)iq * W.cur_nx + ix;
-  if (tid < 64 && ix < W.cur_nx && idx >= lo && idx < hi) {
-    double bv = s_val[tid];
-    int bk = s_k[tid];
 #pragma unroll
-    for (int w = 1; w < 4; ++w) {
-      double ov = s_val[w * 64 + tid];
-      int ok = s_k[w * 64 + tid];
-      if (better<MAXDIR>(ov, ok, bv, bk)) {
-        bv = ov;
-        bk = ok;
+  for (int s = 0; s < S; ++s) {
+    s_val[wave * TS + S * lane + s] = best[s];
+    s_k[wave * TS + S * lane + s] = bestk[s];
+  }
+  __syncthreads();
+  for (int q = tid; q < TS; q += 256) {
+    const int ix = ix0 + q;
+    const int64_t idx = (int64_t)iq * W.cur_nx + ix;
+    if (ix < W.cur_nx && idx >= lo && idx < hi) {
+      double bv = s_val[q];
+      int bk = s_k[q];
+#pragma unroll
+      for (int w = 1; w < 4; ++w) {
+        double ov = s_val[w * TS + q];
+        int ok = s_k[w * TS + q];
+        if (better<MAXDIR>(ov, ok, bv, bk)) {
+          bv = ov;
+          bk = ok;
+        }
       }
+      const int64_t o = (int64_t)chunk * W.partial_stride + idx;
+      out_val[o] = bv;
+      out_idx[o] = bk;
     }
-    const int64_t o = (int64_t)chunk * W.partial_stride + idx;
-    out_val[o] = bv;
-    out_idx[o] = bk;
   }
 }
 

@@ -1037,15 +1037,15 @@ hipError_t flush_pending(sdpgpu_handle* h) {
 }
 
 // ---- row-window kernel (F2) ---------------------------------------------------------------
-template <int R, bool MAXDIR>
+template <int R, int S, bool MAXDIR>
 hipError_t launch_row_r(const sdp::RowParams& W, size_t smem, bool future, const double* v_next, double* out_val,
                         int32_t* out_idx, const double* pmf_p, int64_t lo, int64_t hi, hipStream_t st) {
   if (!grid_ok((int64_t)W.n_tiles * W.n_chunks)) return hipErrorInvalidValue;
   dim3 grid((unsigned)((int64_t)W.n_tiles * W.n_chunks));
   if (future)
-    hipLaunchKernelGGL((sdp::window_f2_kernel<R, MAXDIR, true>), grid, dim3(256), smem, st, W, v_next, out_val, out_idx, pmf_p, lo, hi);
+    hipLaunchKernelGGL((sdp::window_f2_kernel<R, S, MAXDIR, true>), grid, dim3(256), smem, st, W, v_next, out_val, out_idx, pmf_p, lo, hi);
   else
-    hipLaunchKernelGGL((sdp::window_f2_kernel<R, MAXDIR, false>), grid, dim3(256), smem, st, W, v_next, out_val, out_idx, pmf_p, lo, hi);
+    hipLaunchKernelGGL((sdp::window_f2_kernel<R, S, MAXDIR, false>), grid, dim3(256), smem, st, W, v_next, out_val, out_idx, pmf_p, lo, hi);
   return hipGetLastError();
 }
 
@@ -1070,6 +1070,11 @@ hipError_t launch_row_window(sdpgpu_handle* h, const DevParams& P, int period, c
     }
   }
   if (!R) R = 8;
+  // states per lane: 2 (tiles of 128) unless the inventory axis is short or overridden (SDPGPU_WIN_S)
+  int SL = h->win_s ? h->win_s : (p.g.nx >= 96 ? 2 : 1);
+  if (SL != 1 && SL != 2 && SL != 4) SL = 2;
+  if (SL == 4 && R == 8) SL = 2;  // (no 8 x 4 instantiation: too many registers)
+  const int TSZ = 64 * SL;
   const bool future = period < h->T;
   sdp::RowParams W{};
   W.lev0 = p.g.x_lo - h->pmf_d[period - 1][0];
@@ -1086,21 +1091,21 @@ hipError_t launch_row_window(sdpgpu_handle* h, const DevParams& P, int period, c
   W.cur_nx = (int32_t)p.g.nx;
   W.nq1 = (int32_t)p.g.nq1;
   W.plane_stride = P.lead2 ? (int64_t)W.nq1 * W.next_nx : (int64_t)W.next_nx;
-  W.tiles_per_row = (int32_t)((p.g.nx + 63) / 64);
+  W.tiles_per_row = (int32_t)((p.g.nx + TSZ - 1) / TSZ);
   W.n_actions = A;
-  W.d_pad = rup(D, R);
-  const int span = 64 + W.d_pad + 1;
+  W.d_pad = rup(D, 4);  // the demand loop is unrolled by S (1, 2 or 4); padded steps carry p = 0
+  const int span = TSZ + W.d_pad + 1;
   const int blocks_total = rup(A, R) / R;
   // one R-block per wave: chunks of 4 R-blocks, fewer if the LDS budget (rows of `span` doubles) says so
   int bpc = std::min(4, blocks_total);
   if (h->win_nch) bpc = std::max(1, (blocks_total + h->win_nch - 1) / h->win_nch);
-  auto lds = [&](int b) { return (size_t)span * 8 * (1 + (future ? b * R : 0)) + 4 * 64 * 12; };
+  auto lds = [&](int b) { return (size_t)span * 8 * (1 + (future ? b * R : 0)) + (size_t)4 * TSZ * 12; };
   while (bpc > 1 && lds(bpc) > 60 * 1024) --bpc;
   if (lds(bpc) > 64 * 1024) return hipErrorInvalidValue;
   W.chunk_actions = bpc * R;
   W.n_chunks = (blocks_total + bpc - 1) / bpc;
   // the run of row tiles that covers [lo, hi)
-  auto tile_of = [&](int64_t idx) { return (int32_t)((idx / p.g.nx) * W.tiles_per_row + (idx % p.g.nx) / 64); };
+  auto tile_of = [&](int64_t idx) { return (int32_t)((idx / p.g.nx) * W.tiles_per_row + (idx % p.g.nx) / TSZ); };
   W.tile0 = tile_of(lo);
   W.n_tiles = tile_of(hi - 1) - W.tile0 + 1;
   double* out_val = v_cur;
@@ -1116,16 +1121,13 @@ hipError_t launch_row_window(sdpgpu_handle* h, const DevParams& P, int period, c
   }
   hipError_t e = hipErrorInvalidValue;
   size_t smem = lds(bpc);
-#define SDP_ROW(RR)                                                                                         \
-  case RR:                                                                                                  \
-    e = P.maxdir ? launch_row_r<RR, true>(W, smem, future, v_next, out_val, out_idx, pmf_p, lo, hi, st)      \
-                 : launch_row_r<RR, false>(W, smem, future, v_next, out_val, out_idx, pmf_p, lo, hi, st);    \
-    break;
-  switch (R) {
-    SDP_ROW(8)
-    SDP_ROW(5)
-    SDP_ROW(4)
-  }
+#define SDP_ROW(RR, SS)                                                                                          \
+  if (R == RR && SL == SS)                                                                                       \
+    e = P.maxdir ? launch_row_r<RR, SS, true>(W, smem, future, v_next, out_val, out_idx, pmf_p, lo, hi, st)      \
+                 : launch_row_r<RR, SS, false>(W, smem, future, v_next, out_val, out_idx, pmf_p, lo, hi, st);
+  SDP_ROW(8, 1) SDP_ROW(5, 1) SDP_ROW(4, 1)
+  SDP_ROW(8, 2) SDP_ROW(5, 2) SDP_ROW(4, 2)
+  SDP_ROW(5, 4) SDP_ROW(4, 4)
 #undef SDP_ROW
   if (e != hipSuccess) return e;
   if (W.n_chunks > 1)
