@@ -10,17 +10,16 @@
 // The span is staged ONCE in LDS (16 B per entry); HBM/L2 sees each V_{t+1} element once per
 // workgroup instead of once per cell.
 //
-// Thread mapping (wave64): lane = state, each lane carries R consecutive actions in registers
-// and walks the demand index j = 0..D-1 serially, in the reference's order
-// (Recursion.java:138-144): per cell
-//     imm = c0[r] + W.x;  t = p_j*imm;  acc[r] += t;  u = p_j*W.y;  acc[r] += u;      (5 fp64 ops)
-// with separate multiplies and adds (no FMA).  Cells (r, j) and (r+1, j+1) read the same W
-// entry, so the R-entry register window slides by ONE new ds_read_b128 per demand step:
-// LDS traffic is 16 B per R cells.  p_j is wave-uniform and comes through the scalar cache.
-// The five VALU ops per cell are the floor for this operation order; the kernel is bound by
-// fp64 VALU issue (4 cycles per wave64 instruction per SIMD), not by memory.
+// Thread mapping (wave64): a lane owns S adjacent states and carries R consecutive actions in registers; it
+// walks the demand index j = 0..D-1 serially, in the reference's order (Recursion.java:138-144): per cell
+//     imm = c0[r] + W.x;  t = p_j*imm;  acc += t;  u = p_j*W.y;  acc += u;
+// with separate multiplies and adds (no FMA).  Neighbouring cells repeat some of these operations on the
+// very same operands (see window_f1_kernel), and those are executed once: 3 + 1/S + (R+S-1)/(RS) operations
+// per cell instead of 5.  The register window of R + S - 1 entries slides by ONE new ds_read_b128 per demand
+// step: LDS traffic is 16 B per R*S cells.  p_j is wave-uniform and comes through the scalar cache.
+// The kernel is bound by fp64 VALU issue (4 cycles per wave64 instruction per SIMD), not by memory.
 //
-// Small grids (configs[1] has only 157 state tiles) do not fill 1024 SIMDs with whole-action tasks,
+// Small grids (configs[1] has only 79 tiles of 128 states) do not fill 1024 SIMDs with whole-action tasks,
 // so the action range of a tile is cut into chunks handled by different waves (see window_f1_kernel).
 #pragma once
 #include "sdp_device.hpp"
@@ -256,18 +255,36 @@ __global__ __launch_bounds__(256) void window_f1_kernel(WinParams W, const doubl
     }
   }
 
+  // Results leave through the wave's own LDS region (its window is dead by now) so that every store
+  // instruction writes 64 CONSECUTIVE states: lane l owns states S*l .. S*l+S-1, but stores state 64*u + l.
+  if constexpr (S > 1) {
+    __builtin_amdgcn_wave_barrier();
+    double* t_val = reinterpret_cast<double*>(s_win);
+    int* t_idx = reinterpret_cast<int*>(t_val + TS);
 #pragma unroll
-  for (int s = 0; s < S; ++s) {
-    const int64_t idx = i0 + (int64_t)S * lane + s;
+    for (int s = 0; s < S; ++s) {
+      t_val[S * lane + s] = best[s];
+      t_idx[S * lane + s] = bestk[s];
+    }
+    __builtin_amdgcn_wave_barrier();
+#pragma unroll
+    for (int u = 0; u < S; ++u) {
+      best[u] = t_val[64 * u + lane];
+      bestk[u] = t_idx[64 * u + lane];
+    }
+  }
+#pragma unroll
+  for (int u = 0; u < S; ++u) {
+    const int64_t idx = i0 + (S > 1 ? 64 * u + lane : lane);
     if (idx < hi) {
       const int64_t o = (int64_t)chunk * W.partial_stride + idx;
-      out_val[o] = best[s];
-      out_idx[o] = bestk[s];
+      out_val[o] = best[u];
+      out_idx[o] = bestk[u];
       if (W.n_chunks > 1) {
         if (MAXDIR)
-          atomicMax(k_cur + idx, f64_key(best[s]));
+          atomicMax(k_cur + idx, f64_key(best[u]));
         else
-          atomicMin(k_cur + idx, f64_key(best[s]));
+          atomicMin(k_cur + idx, f64_key(best[u]));
       }
     }
   }
