@@ -180,6 +180,28 @@ def main():
             dist.barrier()
         torch.cuda.synchronize(dev)
 
+    schedule = "single rank"
+    if world > 1:
+        schedule = "blocking all-gather" if args.no_overlap else "all-gather overlapped with the interior tiles"
+    if world > 1 and not args.no_overlap and not args.split and (args.backend == "nccl" or os.environ.get("SDP_BENCH_CALIBRATE")):
+        # Which schedule is faster depends on how the all-gather latency of THIS node compares with a period's
+        # compute (30 us at the configs[1] slab): the overlapped one pays two cross-stream waits per period, the
+        # blocking one pays the collective's latency.  Measure both (untimed, before the warm-up) and keep the
+        # faster; every rank takes the same decision (max over ranks of each timing).
+        timing = []
+        for mode in (True, False):
+            solver.solve(overlap=mode)
+            barrier()
+            t0c = time.perf_counter()
+            solver.solve(overlap=mode)
+            solver.solve(overlap=mode)
+            barrier()
+            tc = torch.tensor([time.perf_counter() - t0c], dtype=torch.float64, device=dev)
+            dist.all_reduce(tc, op=dist.ReduceOp.MAX)
+            timing.append(float(tc.item()))
+        overlap = timing[0] <= timing[1]
+        schedule = ("all-gather overlapped with the interior tiles" if overlap else "blocking all-gather") + \
+                   f" (calibrated: {timing[0] / 2 * 1e3:.3f} ms overlapped vs {timing[1] / 2 * 1e3:.3f} ms blocking per sweep)"
     for _ in range(args.warmup):
         solver.solve(overlap=overlap)
     barrier()
@@ -267,6 +289,7 @@ def main():
                 "demands": len(w.pmf[0]), "periods": T,
                 "cells_per_step": cells_step_all,
                 "parallelism": f"state-sharded x{world}, all-gather V_t per period" if world > 1 else "single GPU",
+                "exchange": schedule,
                 "kernel": {0: "auto", 1: "gather", 2: "window", 3: "separable (opt-in, not the graded path)"}[int(st.kernel_used)],
             },
             "roofline": {

@@ -1262,6 +1262,25 @@ hipError_t launch_window(sdpgpu_handle* h, const DevParams& P, int period, const
       W.tile_first = first;
       W.n_tiles = count;
     } else {  // the tiles below and above the interior run, in one launch
+      // The boundary runs are a handful of tiles on the critical path behind the exchange: cut them finer than
+      // the plan does (64-state tiles, 4-action register blocks -- same chunks, so the chunk rows line up) so
+      // that the few tasks spread over more SIMDs and each is short.
+      const int ratio = pl.S;  // plan tiles are ratio x 64 states
+      const int fine_r = (pl.R % 4 == 0) ? 4 : pl.R;
+      if (ratio > 1 || fine_r != pl.R) {
+        const int chunk_actions = pl.chunk_blocks * pl.R;
+        pl.n_tiles = (int)((hi - lo + 63) / 64);
+        first *= ratio;
+        count = std::min(count * ratio, pl.n_tiles - first);  // (the last plan tile may be a partial one)
+        pl.chunk_blocks = chunk_actions / fine_r;
+        pl.R = fine_r;
+        pl.S = 1;
+        pl.d_pad = (p.nD + fine_r - 1) / fine_r * fine_r;
+        pl.smem = (size_t)4 * (64 + chunk_actions + pl.d_pad + 1) * 16;
+        W.d_pad = pl.d_pad;
+        W.d_main = p.nD / fine_r * fine_r;
+        W.chunk_blocks = pl.chunk_blocks;
+      }
       W.n_tiles = pl.n_tiles - count;
       W.tile_gap_at = first;
       W.tile_gap = count;
