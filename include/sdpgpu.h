@@ -326,7 +326,10 @@ int sdpgpu_reachable(sdpgpu_handle* h, int32_t period, uint8_t* out, int64_t n);
  * discount[t] multiplies the immediate value of period t+1 (Math.pow(discountFactor, t) in CashSimulation,
  * all 1.0 for the undiscounted classes).  out_sum[i] = sum_t discount[t] * imm_t; out_valid[i] = 0 when
  * the path left the grid (possible only for unclamped families with demands outside the PMF support).
- * The start state is (1, ini_x, ini_cash, ini_preq[, desc.ini_preq2 with lead_time 2]); world_size must be 1. */
+ * The start state is (1, ini_x, ini_cash, ini_preq[, desc.ini_preq2 with lead_time 2]); world_size must be 1.
+ * Family SURVIVAL rolls RiskSimulation.simulateLostSale instead (RiskSimulation.java:213-234): out_sum[i] = 1 when
+ * path i held negative cash at some point (else 0), bit 1 of out_valid[i] is set when a demand was lost on it, and
+ * the order is forced to 0 in a state with negative cash; `discount` is ignored. */
 int sdpgpu_simulate(sdpgpu_handle* h, int64_t n_paths, const double* demand, const double* discount, double ini_x,
                     double ini_cash, double ini_preq, double* out_sum, uint8_t* out_valid);
 

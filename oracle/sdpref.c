@@ -695,9 +695,43 @@ int sdpref_simulate(const sdpgpu_desc* d, const int32_t* pmf_off, const double* 
   }
   ctx_t c = {d, pmf_off, pmf_d, pmf_p, overhead, d->periods};
   int32_t T = d->periods;
-  if (d->family == SDPGPU_FAMILY_SURVIVAL) { /* RiskSimulation is a different loop; not restated */
+  if (d->family == SDPGPU_FAMILY_SURVIVAL) {
+    /* RiskSimulation.simulateLostSale, RiskSimulation.java:213-234: out_sum[i] = simuValues[i] (1 when the path
+     * held negative cash at some point), out_valid[i] = 1 | 2 * (a demand was lost at some point). */
+    for (int64_t i = 0; i < n_paths; i++) {
+      st_t state = {1, ini_x, ini_cash, 0, 0};
+      int countBefore = 0, countBeforeBankrupt = 0, valid = 1;
+      double simuValue = 0;
+      for (int32_t t = 0; t < T; t++) {
+        int64_t idx = index_of(d, &grids[t], &state);
+        double optQ;
+        if (idx >= 0) {
+          optQ = action_value(&c, policy[values_off[t] + idx]);
+        } else if (t == 0) { /* recursion.getSurvProb(state); recursion.getAction(state) */
+          dense_env env = {d, T > 1 ? &grids[1] : NULL, T > 1 ? values + values_off[1] : NULL, 0};
+          double val;
+          eval_state(&c, &state, dense_look, &env, &val, &optQ, NULL, NULL);
+        } else {
+          valid = 0;
+          break;
+        }
+        if (state.cash < 0) optQ = 0; /* :221-222 */
+        double randomDemand = demand[i * T + t];
+        if (state.x + optQ < randomDemand && !countBefore) countBefore = 1; /* :224-227 */
+        double thisValue = state.cash + imm_value(&c, &state, optQ, randomDemand);
+        st_t next;
+        transition(&c, &state, optQ, randomDemand, &next);
+        state = next;
+        if (thisValue < 0 && !countBeforeBankrupt) { /* :230-233 */
+          simuValue = 1;
+          countBeforeBankrupt = 1;
+        }
+      }
+      out_sum[i] = simuValue;
+      out_valid[i] = (uint8_t)(valid | (countBefore << 1));
+    }
     free(grids);
-    return 4;
+    return 0;
   }
   for (int64_t i = 0; i < n_paths; i++) {
     double sum = 0;

@@ -187,7 +187,8 @@ class Problem:
                                    C.c_double(ini_preq), _dp(out), valid.ctypes.data_as(C.POINTER(C.c_uint8)))
         if rc:
             raise RuntimeError(f"sdpref_simulate failed: {rc}")
-        return out, valid.astype(bool)
+        self.last_sim_flags = valid
+        return out, (valid & 1).astype(bool)
 
     def state_arrays(self, period: int):
         """(x, cash, preq) value arrays of every grid state of `period`, in flat-index order."""

@@ -13,7 +13,7 @@ from .functors import (BackorderFunctor, CashFunctor, CashLeadtimeFunctor, Custo
 from .multiitem import MultiLeadResult, multilead_solve
 from .pmf import DiscreteDistribution, GetPmf, NormalDist, PoissonDist, UniformIntDist
 from .recursion import CLSP, CashLeadtimeRecursion, CashRecursion, LeadtimeRecursion, Recursion, RiskRecursion
-from .simulation import Sampling, Simulation
+from .simulation import RiskSimulation, Sampling, Simulation
 from .states import CashLeadtimeState, CashState, LeadtimeState, OptDirection, RiskState, State
 
 __all__ = [
@@ -21,6 +21,6 @@ __all__ = [
     "BackorderFunctor", "LeadtimeFunctor", "CashFunctor", "OverdraftFunctor", "CashLeadtimeFunctor", "SurvivalFunctor", "CustomFunctor",
     "Recursion", "CLSP", "LeadtimeRecursion", "CashRecursion", "CashLeadtimeRecursion", "RiskRecursion",
     "multilead_solve", "MultiLeadResult",
-    "GetPmf", "PoissonDist", "NormalDist", "UniformIntDist", "DiscreteDistribution", "Simulation", "Sampling",
+    "GetPmf", "PoissonDist", "NormalDist", "UniformIntDist", "DiscreteDistribution", "Simulation", "RiskSimulation", "Sampling",
     "State", "LeadtimeState", "CashState", "CashLeadtimeState", "RiskState", "OptDirection", "java_round",
 ]

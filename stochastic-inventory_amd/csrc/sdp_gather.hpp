@@ -215,6 +215,7 @@ __global__ __launch_bounds__(256) void simulate_kernel(const SimPeriod* __restri
   int64_t idx = idx0;
   StateT s = ini;
   bool valid = true;
+  bool lost = false;
   for (int t = 0; t < T && valid; ++t) {
     const DevParams& P = per[t].P;
     int k;
@@ -223,6 +224,25 @@ __global__ __launch_bounds__(256) void simulate_kernel(const SimPeriod* __restri
     } else {
       decode_state<FAM>(P, idx, s);
       k = pol[per[t].pol_off + idx];
+    }
+    if constexpr (FAM == FAM_SURVIVAL) {
+      // RiskSimulation.simulateLostSale (RiskSimulation.java:213-234): sum = 1 once the path has held negative
+      // cash, bit 1 of the flags once a demand was lost; the walk itself continues through bankrupt states
+      if (s.cash < 0) k = 0;
+      ActionCtx c;
+      action_setup<FAM>(P, s, k, c);
+      const double d = demand[i * T + t];
+      if (c.base < d) lost = true;
+      int64_t ni = 0;
+      const double imm = cell<FAM>(P, s, c, d, ni);
+      if (s.cash + imm < 0) sum = 1.0;
+      if (!P.is_last) {  // cell() marks a bankrupt successor with -1: the rollout needs its index all the same
+        double ninv = jmax(0.0, c.base - d);
+        ninv = ninv > P.max_inventory ? P.max_inventory : ninv;
+        ninv = ninv < P.min_inventory ? P.min_inventory : ninv;
+        idx = (int64_t)inv_index(P, ninv) * P.next.nc + cash_index(P, s.cash + imm);
+      }
+      continue;
     }
     ActionCtx c;
     action_setup<FAM>(P, s, k, c);
@@ -240,7 +260,7 @@ __global__ __launch_bounds__(256) void simulate_kernel(const SimPeriod* __restri
     }
   }
   out_sum[i] = sum;
-  out_valid[i] = valid ? 1 : 0;
+  out_valid[i] = (valid ? 1 : 0) | (lost ? 2 : 0);
 }
 
 }  // namespace sdp

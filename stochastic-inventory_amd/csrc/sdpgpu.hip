@@ -1879,7 +1879,6 @@ int sdpgpu_simulate(sdpgpu_handle* h, int64_t n_paths, const double* demand, con
   h->err.clear();
   if (n_paths < 0 || !demand || !discount || !out_sum || !out_valid) return fail(h, SDPGPU_ERR_ARG, "simulate: bad argument");
   if (h->d.world_size != 1) return fail(h, SDPGPU_ERR_STATE, "simulate needs the whole policy on one GPU (world_size 1)");
-  if (h->d.family == SDPGPU_FAMILY_SURVIVAL) return fail(h, SDPGPU_ERR_UNSUPPORTED, "simulate: RiskSimulation's rollout is not part of this library");
   if (h->custom) return fail(h, SDPGPU_ERR_UNSUPPORTED, "simulate: a user functor's lambdas live on the host; roll the policy tables forward there");
   if (!h->allocated) return fail(h, SDPGPU_ERR_STATE, "simulate: nothing has been solved");
   for (int t = 0; t < h->T; ++t)
@@ -1933,6 +1932,7 @@ int sdpgpu_simulate(sdpgpu_handle* h, int64_t n_paths, const double* demand, con
         SDP_SIM(sdp::FAM_CASH)
         SDP_SIM(sdp::FAM_OVERDRAFT)
         SDP_SIM(sdp::FAM_CASH_LEADTIME)
+        SDP_SIM(sdp::FAM_SURVIVAL)
       }
 #undef SDP_SIM
       e = hipGetLastError();

@@ -213,7 +213,8 @@ class SdpEngine:
         valid = np.empty(n, dtype=np.uint8)
         self._check(self._lib.sdpgpu_simulate(self._h, n, _dp(dem), _dp(disc), float(ini_x), float(ini_cash),
                                               float(ini_preq), _dp(out), valid.ctypes.data_as(C.POINTER(C.c_uint8))))
-        return out, valid.astype(bool)
+        self.last_sim_flags = valid  # bit 0: path stayed on the grid; bit 1 (family SURVIVAL): a demand was lost
+        return out, (valid & 1).astype(bool)
 
     def stats(self) -> SdpgpuStats:
         st = SdpgpuStats()

@@ -131,3 +131,58 @@ class Simulation:
                 state = self.stateTransition(state, optQ, float(d))
             out[i] = total
         return out
+
+
+class RiskSimulation:
+    """sdp.cash.RiskSimulation(distributions, sampleNum, recursion): `simulateLostSale` (RiskSimulation.java:206-241),
+    the validation run of the survival-probability recursion -- roll the policy along LHS demand paths, count the
+    paths that ever hold negative cash and the paths that ever lose a demand.  The walk runs on the device
+    (`sdpgpu_simulate`, family SURVIVAL); sampling and the two ratios stay on the host."""
+
+    def __init__(self, distributions: Sequence, sampleNum: int, recursion, seed: int = 12345):
+        self.distributions = list(distributions)
+        self.sampleNum = int(sampleNum)
+        self.recursion = recursion
+        self.sampling = Sampling(seed)
+        self.last_flags = None
+
+    def simulateLostSale(self, iniState, immediateValue=None):
+        """Returns [simulated survival probability, lost-sale rate] (RiskSimulation.java:237-240)."""
+        samples = self.sampling.generateLHSamples(self.distributions, self.sampleNum)
+        return self.simulateLostSaleOnDemands(iniState, round_demands(samples))
+
+    def simulateLostSaleOnDemands(self, iniState, demands: np.ndarray):
+        rec = self.recursion
+        rec.getSurvProb(iniState)
+        x, cash, _ = rec.functor.tuple_of(iniState)
+        went_bankrupt, valid = rec.engine.simulate(demands, np.ones(rec.T), x, cash, 0.0)
+        if not valid.all():
+            raise RuntimeError("a sample path left the state grid")
+        flags = rec.engine.last_sim_flags
+        self.last_flags = flags
+        lost = int(((flags >> 1) & 1).sum())
+        sim_final = 1 - math.fsum(went_bankrupt.tolist()) / float(len(went_bankrupt))
+        return [sim_final, lost / float(self.sampleNum)]
+
+    def simulateOnHost(self, iniState, demands: np.ndarray):
+        """The reference's loop verbatim through the host lambdas and getAction, for a few paths."""
+        rec = self.recursion
+        bankrupt = np.zeros(len(demands))
+        lost = 0
+        for i, row in enumerate(demands):
+            state = iniState
+            countBefore, countBeforeBankrupt = False, state.getBankruptBefore()
+            for d in row:
+                rec.getSurvProb(state)
+                optQ = rec.getAction(state)
+                if state.getIniCash() < 0:
+                    optQ = 0.0
+                if state.getIniInventory() + optQ < d and not countBefore:
+                    lost += 1
+                    countBefore = True
+                thisValue = state.getIniCash() + rec.immediateValue(state, optQ, float(d))
+                state = rec.stateTransition(state, optQ, float(d))
+                if thisValue < 0 and not countBeforeBankrupt:
+                    bankrupt[i] = 1
+                    countBeforeBankrupt = True
+        return [1 - bankrupt.sum() / float(len(demands)), lost / float(len(demands))]

@@ -339,8 +339,20 @@ def test_mirror_risk_recursion(sia, oracle):
     assert np.array_equal(t[:, 4], m["actions"][order])
     with pytest.raises(AttributeError):
         rec.getExpectedValue(ini)
-    with pytest.raises(sia.SdpgpuError):
-        rec.engine.simulate(np.zeros((1, T)), np.ones(T), 0.0, 12.0)
+    # RiskSimulation.simulateLostSale: device rollout == oracle rollout == the reference's loop on the host lambdas
+    P = oracle.Problem(w.desc(), w.pmf, w.overhead())
+    V, pol, _ = P.solve()
+    rng = np.random.default_rng(5)
+    dem = rng.integers(0, 11, size=(300, T)).astype(np.float64)
+    osum, ovalid = P.simulate(V, pol, dem, np.ones(T), f.iniInventory, f.iniCash)
+    gsum, gvalid = rec.engine.simulate(dem, np.ones(T), f.iniInventory, f.iniCash)
+    assert np.array_equal(gsum, osum) and np.array_equal(rec.engine.last_sim_flags, P.last_sim_flags)
+    assert 0 < gsum.sum() < len(gsum) and ((P.last_sim_flags >> 1) & 1).any()
+    sim = sia.RiskSimulation([sia.PoissonDist(m) for m in (4, 6, 3, 5)], 300, rec)
+    res = sim.simulateLostSaleOnDemands(ini, dem)
+    assert res[0] == 1 - osum.sum() / 300 and res == sim.simulateOnHost(ini, dem)
+    est = sim.simulateLostSale(ini)  # LHS paths from the Poisson quantiles: close to the computed probability
+    assert abs(est[0] - m["value"]) < 0.12
 
 
 def test_cfg2_full_horizon_properties(sia, oracle):
