@@ -48,6 +48,9 @@ __device__ inline double sdp_trunc(double x) { return trunc(x); }  // (int) / (l
 
 static const char* const kCustomEngine = R"SDPSRC(
 #line 1 "sdp_custom_engine"
+#ifndef SDP_NP
+#define SDP_NP 1  // number of user parameters (-DSDP_NP=n at compile time)
+#endif
 struct CGrid { double x_lo; sdp_i64 nx, nc, nq, k_lo; };
 struct CParams {
   int has_cash, has_preq, maxdir, is_last;
@@ -73,35 +76,38 @@ __device__ inline void c_decode(const CParams& P, sdp_i64 idx, CState& s) {
 }
 
 // Flat index of the state the user's transition returned, which must be a grid point of period + 1 (the Java
-// lambda clamps and rounds itself).  Anything else raises the error flag and reads index 0.
-__device__ inline sdp_i64 c_next_index(const CParams& P, double nx, double ncash, double npreq, int* err) {
-  double fx = (nx - P.next.x_lo) * P.inv_step;
-  sdp_i64 ix = (sdp_i64)fx;
-  bool ok = (double)ix == fx && ix >= 0 && ix < P.next.nx;
-  sdp_i64 ic = 0, iq = 0;
+// lambda clamps and rounds itself).  Anything else sets `bad` and reads index 0.  (`bad` is a register: an atomic
+// inside the demand loop would make the compiler reload the user's parameters after every cell.)
+__device__ inline sdp_i64 c_next_index(const CParams& P, double nx, double ncash, double npreq, bool& bad) {
+  // (32-bit conversions: every axis is shorter than 2^31 points and cash keys fit 32 bits, checked at create;
+  // a value out of int range saturates and fails the range test)
+  const double fx = (nx - P.next.x_lo) * P.inv_step;
+  const int ix = (int)fx;
+  bool ok = (double)ix == fx && ix >= 0 && ix < (int)P.next.nx;
+  int ic = 0, iq = 0;
   if (P.has_cash) {
-    sdp_i64 k;
+    int k;
     double back;
     if (P.cash_int_div) {
-      k = (sdp_i64)ncash;
+      k = (int)ncash;
       back = (double)k;
     } else {
-      k = (sdp_i64)sdp_round(ncash * P.round_mult);
+      k = (int)sdp_round(ncash * P.round_mult);
       back = (double)k / P.round_div;
     }
-    ic = k - P.next.k_lo;
-    ok = ok && back == ncash && ic >= 0 && ic < P.next.nc;
+    ic = k - (int)P.next.k_lo;
+    ok = ok && back == ncash && ic >= 0 && ic < (int)P.next.nc;
   }
   if (P.has_preq) {
-    double fq = npreq * P.inv_step;
-    iq = (sdp_i64)fq;
-    ok = ok && (double)iq == fq && iq >= 0 && iq < P.next.nq;
+    const double fq = npreq * P.inv_step;
+    iq = (int)fq;
+    ok = ok && (double)iq == fq && iq >= 0 && iq < (int)P.next.nq;
   }
   if (!ok) {
-    atomicOr(err, 1);
+    bad = true;
     return 0;
   }
-  return (iq * P.next.nx + ix) * P.next.nc + ic;
+  return ((sdp_i64)iq * P.next.nx + ix) * P.next.nc + ic;
 }
 
 __device__ inline bool c_better(bool maxdir, double v2, int k2, double v, int k) {
@@ -136,16 +142,23 @@ extern "C" __global__ __launch_bounds__(256) void sdp_custom_period(
   } else {
     c_decode(P, live ? idx : lo, s);
   }
+  // The user's constants are copied into a private array first: constant indices then become registers, a
+  // period-dependent index one hoisted load -- read through the global pointer, every use inside a branch of the
+  // user's code would be a scalar load with a full wait in the demand loop (the compiler may not speculate it).
+  double prm[SDP_NP];
+#pragma unroll
+  for (int i = 0; i < SDP_NP; ++i) prm[i] = P.user[i];
   sdp_ctx U;
   U.period = P.period;
   U.T = P.T;
   U.step = P.step;
-  U.params = P.user;
+  U.params = prm;
   const int nA = live ? sdp_feasible_count(U, s.x, s.cash, s.preq) : 0;
   const int nD = P.n_demand;
 
   double best = P.maxdir ? -1.7976931348623157e308 : 1.7976931348623157e308;
   int bestk = 0;
+  bool bad = false;
   for (int k = as; k < nA; k += 16) {
     const double a = (double)k * P.step;
     double acc = 0.0;
@@ -158,14 +171,14 @@ extern "C" __global__ __launch_bounds__(256) void sdp_custom_period(
         } else {
           double nx, nc, nq;
           sdp_transition(U, s.x, s.cash, s.preq, a, dp.x, nx, nc, nq);
-          acc += (dp.y * P.gamma) * (nc < 0 ? 0.0 : v_next[c_next_index(P, nx, nc, nq, err)]);
+          acc += (dp.y * P.gamma) * (nc < 0 ? 0.0 : v_next[c_next_index(P, nx, nc, nq, bad)]);
         }
       } else {
         acc += dp.y * imm;
         if (!P.is_last) {
           double nx, nc, nq;
           sdp_transition(U, s.x, s.cash, s.preq, a, dp.x, nx, nc, nq);
-          acc += (dp.y * P.gamma) * v_next[c_next_index(P, nx, nc, nq, err)];
+          acc += (dp.y * P.gamma) * v_next[c_next_index(P, nx, nc, nq, bad)];
         }
       }
     }
@@ -174,6 +187,7 @@ extern "C" __global__ __launch_bounds__(256) void sdp_custom_period(
       bestk = k;
     }
   }
+  if (bad) atomicOr(err, 1);
   // the four action slots of a state that live in this wave (lanes sx, sx+16, sx+32, sx+48)
   for (int off = 16; off < 64; off <<= 1) {
     double ov = __shfl_xor(best, off, 64);
@@ -231,21 +245,29 @@ extern "C" __global__ __launch_bounds__(256) void sdp_custom_reach(
     if (!mask_cur[idx]) return;
     c_decode(P, idx, s);
   }
+  // The user's constants are copied into a private array first: constant indices then become registers, a
+  // period-dependent index one hoisted load -- read through the global pointer, every use inside a branch of the
+  // user's code would be a scalar load with a full wait in the demand loop (the compiler may not speculate it).
+  double prm[SDP_NP];
+#pragma unroll
+  for (int i = 0; i < SDP_NP; ++i) prm[i] = P.user[i];
   sdp_ctx U;
   U.period = P.period;
   U.T = P.T;
   U.step = P.step;
-  U.params = P.user;
+  U.params = prm;
   const int nA = sdp_feasible_count(U, s.x, s.cash, s.preq);
+  bool bad = false;
   for (int k = as; k < nA; k += 4) {
     const double a = (double)k * P.step;
     for (int j = 0; j < P.n_demand; ++j) {
       double nx, nc, nq;
       sdp_transition(U, s.x, s.cash, s.preq, a, pmf_d[j], nx, nc, nq);
       if (P.survival && nc < 0) continue;
-      mask_next[c_next_index(P, nx, nc, nq, err)] = 1;
+      mask_next[c_next_index(P, nx, nc, nq, bad)] = 1;
     }
   }
+  if (bad) atomicOr(err, 1);
 }
 )SDPSRC";
 

@@ -1445,7 +1445,8 @@ int sdpgpu_create(const sdpgpu_desc* desc, sdpgpu_handle** out) {
 int sdpgpu_create_custom(const sdpgpu_desc* desc, const char* functor_source, const double* params, int32_t n_params,
                          sdpgpu_handle** out) {
   g_create_error.clear();
-  if (!desc || !out || !functor_source || n_params < 0 || (n_params > 0 && !params)) return fail(nullptr, SDPGPU_ERR_ARG, "null argument");
+  if (!desc || !out || !functor_source || n_params < 0 || n_params > 256 || (n_params > 0 && !params))
+    return fail(nullptr, SDPGPU_ERR_ARG, "null argument, or more than 256 user parameters");
   *out = nullptr;
   if (desc->lead_time == 2) return fail(nullptr, SDPGPU_ERR_UNSUPPORTED, "a user functor has one pipeline quantity at most (lead_time 2 is a built-in shape)");
   if (desc->kernel != SDPGPU_KERNEL_AUTO && desc->kernel != SDPGPU_KERNEL_GATHER) return fail(nullptr, SDPGPU_ERR_UNSUPPORTED, "a user functor runs on the generic kernel only");
@@ -1454,8 +1455,9 @@ int sdpgpu_create_custom(const sdpgpu_desc* desc, const char* functor_source, co
   hiprtcProgram prog = nullptr;
   if (hiprtcCreateProgram(&prog, src.c_str(), "sdp_custom.hip", 0, nullptr, nullptr) != HIPRTC_SUCCESS)
     return fail(nullptr, SDPGPU_ERR_DEVICE, "hiprtcCreateProgram failed");
-  const char* opts[] = {"--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fno-fast-math"};
-  hiprtcResult cr = hiprtcCompileProgram(prog, 5, opts);
+  const std::string np_def = "-DSDP_NP=" + std::to_string(std::max(1, (int)n_params));
+  const char* opts[] = {"--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fno-fast-math", np_def.c_str()};
+  hiprtcResult cr = hiprtcCompileProgram(prog, 6, opts);
   if (cr != HIPRTC_SUCCESS) {
     size_t n = 0;
     (void)hiprtcGetProgramLogSize(prog, &n);
