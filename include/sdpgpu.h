@@ -63,6 +63,9 @@
 #ifdef __cplusplus
 extern "C" {
 #endif
+#if defined(__GNUC__)
+#pragma GCC visibility push(default) /* the library is built with -fvisibility=hidden: only this header is exported */
+#endif
 
 #define SDPGPU_ABI_VERSION 2
 
@@ -368,6 +371,9 @@ const char* sdpgpu_multilead_last_error(void);
 /* Kernel time of period t of the last solve (ms), needs sdpgpu_set_profiling(h, 1). */
 double sdpgpu_period_ms(sdpgpu_handle* h, int32_t period);
 
+#if defined(__GNUC__)
+#pragma GCC visibility pop
+#endif
 #ifdef __cplusplus
 }
 #endif

@@ -29,7 +29,8 @@ HIPCC_FLAGS = [
 
 
 def sources():
-    return [os.path.join(CSRC, "sdpgpu.hip"), os.path.join(CSRC, "sdpgpu_sparse.hip")]
+    return [os.path.join(CSRC, f) for f in ("sdpgpu.hip", "sdpgpu_generic.hip", "sdpgpu_window.hip", "sdpgpu_cash.hip",
+                                            "sdpgpu_sparse.hip")]
 
 
 def deps():
@@ -47,10 +48,27 @@ def up_to_date() -> bool:
 
 
 def build(force: bool = False, extra_flags=(), verbose: bool = True) -> str:
+    """Compile every translation unit (in parallel) and link libsdpgpu.so.  Only the entry points of
+    include/sdpgpu.h are exported (-fvisibility=hidden + the visibility pragma in that header)."""
     if not force and up_to_date():
         return OUT
+    from concurrent.futures import ThreadPoolExecutor
     hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
-    cmd = [hipcc, *HIPCC_FLAGS, *extra_flags, "-o", OUT, *sources(), "-lhiprtc"]
+    objdir = os.path.join(HERE, "_build")
+    os.makedirs(objdir, exist_ok=True)
+    compile_flags = [f for f in HIPCC_FLAGS if f != "-shared"] + ["-fvisibility=hidden", *extra_flags]
+
+    def compile_one(src):
+        obj = os.path.join(objdir, os.path.basename(src) + ".o")
+        cmd = [hipcc, *compile_flags, "-c", "-o", obj, src]
+        if verbose:
+            print("+", " ".join(cmd), flush=True)
+        subprocess.run(cmd, check=True)
+        return obj
+
+    with ThreadPoolExecutor(max_workers=min(5, os.cpu_count() or 1)) as ex:
+        objs = list(ex.map(compile_one, sources()))
+    cmd = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", OUT, *objs, "-lhiprtc"]
     if verbose:
         print("+", " ".join(cmd), flush=True)
     subprocess.run(cmd, check=True)

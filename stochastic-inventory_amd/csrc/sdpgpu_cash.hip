@@ -1,0 +1,139 @@
+// sdpgpu_cash.hip -- host side of the two cash-family kernels (sdp_cash.hpp).
+#include "sdpgpu_internal.hpp"
+#include "sdp_cash.hpp"
+
+namespace sdpgpu_detail {
+
+// ---- uniform-shift kernel (F3 on dyadic grids) ---------------------------------------------------
+bool dyadic(double x, double scale, double max_abs) { return std::fabs(x) <= max_abs && x * scale == std::floor(x * scale); }
+
+// All arithmetic of the F3 lambdas is exact (see sdp_cash.hpp) iff the rates and the penalty are zero, the
+// cash quantum is a power of two and every parameter is a multiple of 2^-10 of bounded size.
+bool cash_shift_eligible(const sdpgpu_handle* h, int period) {
+  const sdpgpu_desc& d = h->d;
+  if (h->custom) return false;
+  if (d.family != SDPGPU_FAMILY_CASH || !d.clamp_inventory) return false;
+  if (d.deposit_rate != 0 || d.overhead_rate != 0 || d.penalty_cost != 0) return false;
+  double q;
+  if (d.cash_round_int_div) {
+    if (d.cash_round_mult != 1.0 || d.cash_round_div != 1.0) return false;
+    q = 1.0;
+  } else {
+    q = d.cash_round_div;  // == mult (validated at create)
+  }
+  if (!is_pow2_int(q) || q > 1024) return false;
+  const PeriodInfo& p = h->per[period - 1];
+  const double S = 1024.0, M = 4096.0;
+  if (!dyadic(d.price, S, M) || !dyadic(d.fixed_order_cost, S, M) || !dyadic(d.unit_order_cost, S, M) ||
+      !dyadic(d.holding_cost, S, M) || !dyadic(d.salvage_value, S, M) || !dyadic(p.overhead, S, 1048576.0))
+    return false;
+  if (!(d.unit_order_cost != 0)) return false;
+  if (!dyadic(d.min_cash, q, 1e9) || !dyadic(d.max_cash, q, 1e9)) return false;
+  if (!dyadic(d.discount_factor, 1.0, 1.0) && d.discount_factor != 1.0) {
+    // gamma only multiplies p_j (inexact anyway, same product as the general kernel): any value is fine
+  }
+  double ymax = std::fabs(d.max_inventory) + std::fabs(d.min_inventory) + d.max_order_quantity * d.step;
+  double dmax = 0;
+  for (double v : h->pmf_d[period - 1]) dmax = std::max(dmax, std::fabs(v));
+  if (ymax > 1048576.0 || dmax > 1048576.0) return false;
+  double incmax = (std::fabs(d.price) + std::fabs(d.holding_cost) + std::fabs(d.salvage_value)) * (ymax + dmax) +
+                  std::fabs(d.fixed_order_cost) + std::fabs(d.unit_order_cost) * d.max_order_quantity * d.step + std::fabs(p.overhead);
+  if (incmax * q > 1.0e9) return false;
+  if (p.S >= 2147483647LL || p.nD > 2000) return false;
+  return true;
+}
+
+hipError_t launch_cash_shift(sdpgpu_handle* h, const DevParams& P, int period, const double* v_next, double* v_cur,
+                             int32_t* pol, const double* pmf_d, const double* pmf_p, int64_t lo, int64_t hi, hipStream_t st) {
+  if (hi <= lo) return hipSuccess;
+  const sdpgpu_desc& d = h->d;
+  const PeriodInfo& p = h->per[period - 1];
+  sdp::CashShiftParams C{};
+  C.price = d.price;
+  C.K = d.fixed_order_cost;
+  C.v = d.unit_order_cost;
+  C.h = d.holding_cost;
+  C.overhead = p.overhead;
+  C.salvage = d.salvage_value;
+  C.gamma = P.gamma;
+  C.step = d.step;
+  C.x_lo = p.g.x_lo;
+  C.min_inventory = d.min_inventory;
+  C.max_inventory = d.max_inventory;
+  C.next_x_lo = period < h->T ? h->per[period].g.x_lo : p.g.x_lo;
+  C.q = d.cash_round_int_div ? 1.0 : d.cash_round_div;
+  C.k_lo = p.g.k_lo;
+  C.nx = (int32_t)p.g.nx;
+  C.nc = (int32_t)p.g.nc;
+  C.n_demand = p.nD;
+  C.max_order_quantity = d.max_order_quantity;
+  C.is_last = period == h->T;
+  C.tiles_per_row = (int32_t)((p.g.nc + 63) / 64);
+  const int64_t row_lo = lo / p.g.nc, row_hi = (hi - 1) / p.g.nc;
+  C.row0 = (int32_t)row_lo;
+  if (!grid_ok((row_hi - row_lo + 1) * (int64_t)C.tiles_per_row)) return hipErrorInvalidValue;
+  dim3 grid((unsigned)((row_hi - row_lo + 1) * C.tiles_per_row));
+  size_t smem = (size_t)p.nD * 16 * 5 + 4 * 64 * (sizeof(double) + sizeof(int));
+  const bool last = period == h->T;
+#define SDP_CS(MX, LS) hipLaunchKernelGGL((sdp::cash_shift_kernel<MX, LS>), grid, dim3(256), smem, st, C, v_next, v_cur, pol, pmf_d, pmf_p, lo, hi)
+  if (P.maxdir) {
+    if (last) SDP_CS(true, true); else SDP_CS(true, false);
+  } else {
+    if (last) SDP_CS(false, true); else SDP_CS(false, false);
+  }
+#undef SDP_CS
+  return hipGetLastError();
+}
+
+// ---- cash row kernel (F3-F6 on any cash grid) -------------------------------------------------------
+bool cash_row_eligible(const sdpgpu_handle* h, int period) {
+  const sdpgpu_desc& d = h->d;
+  if (h->custom || !has_cash(d.family) || !d.clamp_inventory || !h->use_cash_row) return false;
+  if (d.family == SDPGPU_FAMILY_CASH && d.penalty_cost != 0) return false;  // the end-cash penalty branch: generic kernel
+  const PeriodInfo& p = h->per[period - 1];
+  if (p.g.nc < 32) return false;                       // a wave is 64 consecutive cash points of one row
+  if (p.S >= 2147483647LL) return false;               // 32-bit row offsets
+  if ((size_t)p.nD * 152 + 4 * 64 * 12 > 64 * 1024) return false;  // per-wave entries of every demand point in LDS
+  return true;
+}
+
+template <int FAM, bool FORMULA1>
+hipError_t launch_cash_row_fam(const DevParams& P, bool last, bool intdiv, const double* v_next, double* v_cur,
+                               int32_t* pol, const double* pmf_d, const double* pmf_p, int64_t lo, int64_t hi,
+                               int64_t row0, int tiles_per_row, dim3 grid, size_t smem, hipStream_t st) {
+#define SDP_CR(LS, ID) hipLaunchKernelGGL((sdp::cash_row_kernel<FAM, LS, FORMULA1, ID>), grid, dim3(256), smem, st, P, v_next, v_cur, pol, pmf_d, pmf_p, lo, hi, row0, tiles_per_row)
+  if (intdiv) {
+    if (last) SDP_CR(true, true); else SDP_CR(false, true);
+  } else {
+    if (last) SDP_CR(true, false); else SDP_CR(false, false);
+  }
+#undef SDP_CR
+  return hipGetLastError();
+}
+
+hipError_t launch_cash_row(sdpgpu_handle* h, const DevParams& P, int period, const double* v_next, double* v_cur,
+                           int32_t* pol, const double* pmf_d, const double* pmf_p, int64_t lo, int64_t hi, hipStream_t st) {
+  if (hi <= lo) return hipSuccess;
+  const PeriodInfo& p = h->per[period - 1];
+  const int tiles_per_row = (int)((p.g.nc + 63) / 64);
+  const int64_t row_lo = lo / p.g.nc, row_hi = (hi - 1) / p.g.nc;
+  const int64_t blocks = (row_hi - row_lo + 1) * (int64_t)tiles_per_row;
+  if (!grid_ok(blocks)) return hipErrorInvalidValue;
+  dim3 grid((unsigned)blocks);
+  const size_t smem = (size_t)p.nD * 152 + 4 * 64 * (sizeof(double) + sizeof(int));
+  const bool last = period == h->T;
+  const bool intdiv = h->d.cash_round_int_div && h->d.cash_round_div != 1.0;
+#define SDP_ROWARGS P, last, intdiv, v_next, v_cur, pol, pmf_d, pmf_p, lo, hi, row_lo, tiles_per_row, grid, smem, st
+  switch (P.family) {
+    case sdp::FAM_CASH:
+      return P.cash_formula == 0 ? launch_cash_row_fam<sdp::FAM_CASH, false>(SDP_ROWARGS)
+                                 : launch_cash_row_fam<sdp::FAM_CASH, true>(SDP_ROWARGS);
+    case sdp::FAM_OVERDRAFT: return launch_cash_row_fam<sdp::FAM_OVERDRAFT, false>(SDP_ROWARGS);
+    case sdp::FAM_CASH_LEADTIME: return launch_cash_row_fam<sdp::FAM_CASH_LEADTIME, false>(SDP_ROWARGS);
+    case sdp::FAM_SURVIVAL: return launch_cash_row_fam<sdp::FAM_SURVIVAL, false>(SDP_ROWARGS);
+  }
+#undef SDP_ROWARGS
+  return hipErrorInvalidValue;
+}
+
+}  // namespace sdpgpu_detail

@@ -1,0 +1,210 @@
+// sdpgpu_internal.hpp -- what the translation units of libsdpgpu.so share: the handle, the per-period layout
+// record, small host helpers and the functions one unit offers the others.  Not installed, not part of the ABI.
+//
+//   sdpgpu.hip          descriptor validation, grid layout, device tables, period dispatch, the C ABI
+//   sdpgpu_generic.hip  generic per-cell kernel (every family), reachable set, rollout, user-defined functors
+//   sdpgpu_window.hip   F1 window kernel (plan, chunk/key bookkeeping, finalize) and F2 row-window kernel
+//   sdpgpu_cash.hip     F3 uniform-shift kernel and the cash row kernel (F3-F6)
+//   sdpgpu_sparse.hip   reachable-set engine of the two-product lead-time family (own entry point)
+#pragma once
+#include "../../include/sdpgpu.h"
+
+#include <hip/hip_runtime.h>
+
+#include <cmath>
+#include <cstdarg>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <algorithm>
+#include <new>
+#include <string>
+#include <vector>
+
+#include "sdp_device.hpp"
+
+namespace sdp {
+struct FinalizeJob;
+struct QueryStates;
+struct SimPeriod;
+}  // namespace sdp
+
+using sdp::DevParams;
+using sdp::Grid;
+
+
+
+constexpr size_t kPmfPad = 16;  // zero-probability tail: demand loop in blocks of R <= 8, one block of prefetch
+
+struct PeriodInfo {
+  Grid g{};
+  int64_t S = 0;      // grid states
+  int64_t S_pad = 0;  // padded to a multiple of world_size
+  int64_t lo = 0, hi = 0;  // this rank's slab
+  int32_t nD = 0;
+  size_t pmf_off = 0;   // element offset of this period's demand array inside d_pmf
+  size_t v_off = 0;     // element offset of V_t inside the value arena
+  size_t pol_off = 0;   // element offset of this rank's policy slab
+  double overhead = 0;
+  bool overhead_set = false;
+  int64_t cells_rank = 0, cells_all = 0;
+  hipEvent_t ev0 = nullptr, ev1 = nullptr;
+  bool timed = false;
+  int32_t kernel_used = 0;
+};
+
+struct sdpgpu_handle {
+  sdpgpu_desc d{};
+  int32_t T = 0;
+  int32_t n_actions_full = 0;
+  std::vector<PeriodInfo> per;  // index period-1
+  std::vector<std::vector<double>> pmf_d, pmf_p;
+  std::vector<char> pmf_set;
+  bool laid_out = false;
+  bool allocated = false;
+  double* d_pmf = nullptr;
+  double* d_values = nullptr;
+  size_t values_elems = 0;
+  bool values_external = false;
+  int32_t* d_policy = nullptr;
+  size_t policy_elems = 0;
+  hipStream_t stream = nullptr;
+  bool own_stream = false;
+  bool stream_given = false;  // sdpgpu_set_stream was called (NULL then means the legacy default stream)
+  bool profiling = false;
+  hipEvent_t ev_solve0 = nullptr, ev_solve1 = nullptr;
+  bool solve_timed = false;
+  std::vector<char> period_done;  // V_t valid (a ping-pong table may have been overwritten since)
+  std::vector<char> policy_done;  // the policy slab of period t has been computed
+  double* d_part_val[2] = {nullptr, nullptr};  // window kernels: partial arg-opt rows [chunk][slab], by period parity
+  int32_t* d_part_idx[2] = {nullptr, nullptr};
+  size_t part_elems[2] = {0, 0};
+  // F1 window kernel with several tasks per tile (small grids): V_t is reduced into order-preserving
+  // keys by atomics and the (value, action) rows of the chunks are kept until flush_pending() turns
+  // them into the final V_t / policy rows in ONE launch (see sdp_window.hpp finalize_kernel).
+  unsigned long long* d_keys = nullptr;  // [T][key_stride]
+  bool keys_external = false;            // caller memory (sdpgpu_attach_keys), e.g. a tensor RCCL can address
+  size_t key_stride = 0;
+  std::vector<char> key_row_clean;       // row t holds the reduction identity (+-Double.MAX_VALUE)
+  double* d_chunk_val = nullptr;         // arena of chunk rows, period t at chunk_off[t-1]
+  int32_t* d_chunk_idx = nullptr;
+  std::vector<size_t> chunk_off;
+  std::vector<int> pending_chunks;       // >0: period's final rows not written yet (value = n_chunks)
+  int n_pending = 0;
+  sdp::FinalizeJob* d_jobs = nullptr;
+  bool fuse_combine = true;
+  bool use_cash_shift = true;
+  bool use_cash_row = true;   // SDPGPU_CASH_ROW=0 turns the cash row kernel off (generic kernel instead)
+  int win_prio_fair = 1;  // window kernel: s_setprio by progress (SDPGPU_WIN_PRIO=0 turns it off)
+  int win_r = 0, win_nch = 0, win_s = 0;  // tuning overrides (SDPGPU_WIN_R / SDPGPU_WIN_NCH / SDPGPU_WIN_S), 0 = heuristic
+  uint8_t* d_reach = nullptr;      // reachable masks, period t at reach_off[t-1]
+  std::vector<size_t> reach_off;
+  bool reach_done = false;
+  // user-defined functor (sdpgpu_create_custom): code object compiled by hipRTC at create time, loaded at
+  // first use; every period then runs sdp_custom_period instead of a built-in kernel
+  bool custom = false;
+  std::vector<char> custom_code;
+  std::vector<double> custom_params;
+  hipModule_t custom_mod = nullptr;
+  hipFunction_t custom_period = nullptr, custom_reach = nullptr;
+  double* d_custom_params = nullptr;
+  unsigned long long* d_custom_cells = nullptr;  // [T]
+  int* d_custom_err = nullptr;
+  std::string err;
+  int device = -1;
+};
+
+namespace sdpgpu_detail {
+
+extern thread_local std::string g_create_error;
+int fail(sdpgpu_handle* h, int code, const char* fmt, ...);
+
+#define HIP_TRY(h, expr)                                                                        \
+  do {                                                                                          \
+    hipError_t e_ = (expr);                                                                     \
+    if (e_ != hipSuccess) return fail(h, SDPGPU_ERR_DEVICE, "%s: %s", #expr, hipGetErrorString(e_)); \
+  } while (0)
+
+inline bool has_cash(int f) {
+  return f == SDPGPU_FAMILY_CASH || f == SDPGPU_FAMILY_OVERDRAFT || f == SDPGPU_FAMILY_CASH_LEADTIME ||
+         f == SDPGPU_FAMILY_SURVIVAL;
+}
+inline bool has_preq(int f) { return f == SDPGPU_FAMILY_LEADTIME || f == SDPGPU_FAMILY_CASH_LEADTIME; }
+
+// Java semantics needed on the host for the layout only.
+inline int64_t java_round(double x) {
+  double f = std::floor(x);
+  return (int64_t)((x - f >= 0.5) ? f + 1.0 : f);
+}
+inline int32_t java_d2i(double x) {
+  if (x != x) return 0;
+  if (x >= 2147483647.0) return INT32_MAX;
+  if (x <= -2147483648.0) return INT32_MIN;
+  return (int32_t)x;
+}
+
+inline int64_t cash_key_of_bound(const sdpgpu_desc& d, double bound) {
+  // key of the grid point the reference's rounding maps `bound` to
+  int64_t r = java_round(bound * d.cash_round_mult);
+  if (d.cash_round_int_div) return r / (int64_t)d.cash_round_div;
+  return r;
+}
+
+inline bool is_pow2_int(double s) {
+  if (!(s >= 1) || s != std::floor(s) || s > 1073741824.0) return false;
+  int64_t v = (int64_t)s;
+  return (v & (v - 1)) == 0;
+}
+
+// A dispatch carries at most 2^32 - 1 work-items (AQL grid_size is 32 bits); beyond that the launch is
+// silently truncated.  Every launcher below sends 256-thread workgroups and refuses a grid over the limit.
+inline bool grid_ok(int64_t blocks) { return blocks > 0 && blocks * 256 < 4294967296LL; }
+
+// register block / chunking of the F1 window kernel for one period (sdpgpu_window.hip)
+struct WinPlan {
+  int R = 0, S = 1, d_pad = 0, n_chunks = 1, chunk_blocks = 0, n_tiles = 0, n_tasks = 0;
+  size_t smem = 0;
+  int tile_states() const { return 64 * S; }
+};
+
+// ---- sdpgpu.hip ----------------------------------------------------------------------------------------
+int layout(sdpgpu_handle* h);
+int ensure_device(sdpgpu_handle* h);
+int allocate(sdpgpu_handle* h);
+DevParams make_params(const sdpgpu_handle* h, int period);
+
+// ---- sdpgpu_generic.hip ----------------------------------------------------------------------------------
+hipError_t launch_gather_grid(const DevParams& P, const double* v_next, double* v_cur, int32_t* pol, const double* pmf_d,
+                              const double* pmf_p, int64_t lo, int64_t hi, hipStream_t st);
+hipError_t launch_gather_query(const DevParams& P, const double* v_next, double* out_val, int32_t* out_act,
+                               const double* pmf_d, const double* pmf_p, int64_t n, const double* x, const double* cash,
+                               const double* preq, const double* preq2, hipStream_t st);
+hipError_t launch_custom_period(sdpgpu_handle* h, int period, const double* v_next, double* v_cur, int32_t* pol,
+                                int64_t lo, int64_t hi, const double* qx, const double* qcash, const double* qpreq,
+                                bool count);
+int custom_check(sdpgpu_handle* h);
+int compute_reachable(sdpgpu_handle* h);
+hipError_t launch_simulate(sdpgpu_handle* h, const sdp::SimPeriod* d_per, const double* d_dem, const double* d_disc,
+                           int64_t n_paths, int64_t idx0, double ini_x, double ini_cash, double ini_preq,
+                           double ini_preq2, int first_k, double* d_sum, uint8_t* d_valid);
+
+// ---- sdpgpu_cash.hip ---------------------------------------------------------------------------------------
+bool cash_shift_eligible(const sdpgpu_handle* h, int period);
+hipError_t launch_cash_shift(sdpgpu_handle* h, const DevParams& P, int period, const double* v_next, double* v_cur,
+                             int32_t* pol, const double* pmf_d, const double* pmf_p, int64_t lo, int64_t hi, hipStream_t st);
+bool cash_row_eligible(const sdpgpu_handle* h, int period);
+hipError_t launch_cash_row(sdpgpu_handle* h, const DevParams& P, int period, const double* v_next, double* v_cur,
+                           int32_t* pol, const double* pmf_d, const double* pmf_p, int64_t lo, int64_t hi, hipStream_t st);
+
+// ---- sdpgpu_window.hip -------------------------------------------------------------------------------------
+bool window_eligible(const sdpgpu_handle* h, int period);
+WinPlan plan_window(const sdpgpu_handle* h, int period, int64_t lo, int64_t hi);
+hipError_t flush_pending(sdpgpu_handle* h);
+bool window_interior_tiles(const sdpgpu_handle* h, int period, int64_t lo, int64_t hi, int* first, int* count);
+hipError_t launch_separable(sdpgpu_handle* h, const DevParams& P, int period, const double* v_next, double* v_cur,
+                            int32_t* pol, const double* pd, const double* pp, bool* too_big);
+hipError_t launch_window(sdpgpu_handle* h, const DevParams& P, int period, const double* v_next, double* v_cur,
+                         int32_t* pol, const double* pmf_d, const double* pmf_p, int64_t lo, int64_t hi, hipStream_t st,
+                         int part);
+
+}  // namespace sdpgpu_detail

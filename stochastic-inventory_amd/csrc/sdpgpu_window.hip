@@ -1,0 +1,521 @@
+// sdpgpu_window.hip -- host side of the F1 window kernel (plan, chunk rows and key rows, deferred finalize)
+// and of the F2 row-window kernel (sdp_window.hpp).
+#include "sdpgpu_internal.hpp"
+#include "sdp_window.hpp"
+
+namespace sdpgpu_detail {
+
+// ---- window kernel (F1) -----------------------------------------------------------------------
+
+
+// F1 / F2 with a unit-stride demand grid: d_j = d_0 + j*step.
+bool window_eligible(const sdpgpu_handle* h, int period) {
+  if (h->custom) return false;
+  if (h->d.family != SDPGPU_FAMILY_BACKORDER && h->d.family != SDPGPU_FAMILY_LEADTIME) return false;
+  const std::vector<double>& d = h->pmf_d[period - 1];
+  for (size_t j = 1; j < d.size(); ++j)
+    if (d[j] - d[j - 1] != h->d.step) return false;
+  const PeriodInfo& p = h->per[period - 1];
+  if (p.S >= 2147483647LL - 4096) return false;
+  if (h->n_actions_full + p.nD > 3500) return false;
+  return true;
+}
+
+// One task = one wave = (tile of 64*S states, run of R-blocks).  The measured timeline of a SIMD is task
+// after task, so a launch costs  rounds x task time  with rounds = ceil(tasks / 1024 SIMDs): pick the
+// register block R, the states per lane S and the number of chunks per tile that minimise it (fewest chunks
+// on ties: fewer chunk rows, less staging).  More states per lane = fewer fp64 operations per cell
+// ((5 + 4(S-1)) / S, see window_f1_kernel) but bigger, fewer tasks: small grids keep S low.
+WinPlan plan_window(const sdpgpu_handle* h, int period, int64_t lo, int64_t hi) {
+  const PeriodInfo& p = h->per[period - 1];
+  const int A = h->n_actions_full, D = p.nD;
+  WinPlan best;
+  double best_cost = -1;
+  // The plan is chosen from the NOMINAL slab S_pad / world_size, which is the same on every rank: ranks
+  // must agree on whether a period's row is exchanged as keys or as fp64 values, whatever their own
+  // (possibly clipped or empty) slab looks like.
+  const int64_t nominal = p.S_pad / std::max(1, h->d.world_size);
+  auto rup = [](int v, int r) { return (v + r - 1) / r * r; };
+  struct Cand {
+    int r, s, occupancy;  // occupancy: waves a SIMD can hold within the register budget
+  };
+  // (84 / 62 / 54 VGPRs for S = 1, R = 8 / 5 / 4; 134 / 116 / 96 for S = 2; 130 for R = 4, S = 4)
+  const Cand cand[] = {{8, 1, 6}, {5, 1, 8}, {4, 1, 9}, {8, 2, 3}, {4, 2, 5}, {4, 4, 3}};
+  const bool may_chunk = h->fuse_combine && h->d.store_all_values;
+  for (const Cand& c : cand) {
+    const int r = c.r, sl = c.s, nw = r + sl - 1, ts = 64 * sl;
+    if (h->win_r && r != h->win_r) continue;
+    if (h->win_s && sl != h->win_s) continue;
+    const int64_t n_tiles = std::max<int64_t>(1, (nominal + ts - 1) / ts);
+    const int64_t own_tiles = (hi - lo + ts - 1) / ts;
+    const int d_pad = rup(D, nw);
+    const int blocks_total = rup(A, r) / r;
+    // cost of one R-block on one SIMD, in fp64-instruction units per lane: (5 + 4(S-1)) ops per S cells of an
+    // action plus a per-step overhead (LDS read, scalar load, waits) that a bigger register block amortises
+    const double block_cost = (double)D * ((5.0 + 4.0 * (sl - 1)) * r + 3.0) + 60.0 + 2.0 * (sl - 1) * r;
+    for (int nch = 1; nch <= blocks_total; ++nch) {
+      if (h->win_nch && nch != std::min(h->win_nch, blocks_total)) continue;
+      const int bpc = (blocks_total + nch - 1) / nch;
+      if ((blocks_total + bpc - 1) / bpc != nch) continue;  // same plan as a smaller nch
+      if (nch > 1 && !may_chunk) continue;  // chunk rows need the deferred key/finalize scheme
+      const int span = ts + bpc * r + d_pad + sl;
+      const size_t smem = (size_t)4 * span * 16;
+      if (smem > 64 * 1024) continue;
+      const int64_t tasks = n_tiles * nch;
+      const int64_t rounds = (tasks + 1023) / 1024;  // tasks the busiest SIMD runs, one after the other
+      // fp64 issue rate one SIMD sustains with w resident waves (tools/valu_probe): 0.76 / 0.86 / 0.94 / 0.97
+      const int64_t w = std::min<int64_t>(rounds, c.occupancy);
+      const double eff = w >= 8 ? 0.97 : (w >= 4 ? 0.94 : (w >= 3 ? 0.90 : (w >= 2 ? 0.86 : 0.76)));
+      const double staging = 400.0 + 4.0 * span;
+      const double cost = (double)rounds * (bpc * block_cost + staging) / eff;
+      if (best_cost < 0 || cost < best_cost * 0.999) {
+        best_cost = cost;
+        best.R = r;
+        best.S = sl;
+        best.d_pad = d_pad;
+        best.n_chunks = nch;
+        best.chunk_blocks = bpc;
+        best.n_tiles = (int)own_tiles;
+        best.n_tasks = (int)(own_tiles * nch);
+        best.smem = smem;
+      }
+    }
+  }
+  return best;
+}
+
+hipError_t ensure_partials(sdpgpu_handle* h, int b, size_t need) {
+  if (need <= h->part_elems[b]) return hipSuccess;
+  // (re)allocation frees a buffer earlier launches may still read: drain the stream first
+  hipError_t e = hipStreamSynchronize(h->stream);
+  if (e != hipSuccess) return e;
+  if (h->d_part_val[b]) (void)hipFree(h->d_part_val[b]);
+  if (h->d_part_idx[b]) (void)hipFree(h->d_part_idx[b]);
+  h->d_part_val[b] = nullptr;
+  h->d_part_idx[b] = nullptr;
+  h->part_elems[b] = 0;
+  e = hipMalloc((void**)&h->d_part_val[b], need * sizeof(double));
+  if (e != hipSuccess) return e;
+  e = hipMalloc((void**)&h->d_part_idx[b], need * sizeof(int32_t));
+  if (e != hipSuccess) return e;
+  h->part_elems[b] = need;
+  return hipSuccess;
+}
+
+template <bool MAXDIR>
+hipError_t launch_combine(const double* pv, const int32_t* pi, int n_chunks, int64_t stride, double* v_cur, int32_t* pol,
+                          int64_t lo, int64_t hi, hipStream_t st) {
+  unsigned blocks = (unsigned)((hi - lo + 255) / 256);
+  hipLaunchKernelGGL((sdp::window_combine_kernel<MAXDIR>), dim3(blocks), dim3(256), 0, st, pv, pi, n_chunks, stride, v_cur, pol, lo, hi);
+  return hipGetLastError();
+}
+
+// Turn every pending period's keys + chunk rows into its final V_t / policy rows: one launch.
+hipError_t flush_pending(sdpgpu_handle* h) {
+  if (h->n_pending == 0) return hipSuccess;
+  std::vector<sdp::FinalizeJob> jobs;
+  int64_t total = 0;
+  for (int t = 0; t < h->T; ++t) {
+    if (h->pending_chunks[t] <= 0) continue;
+    const PeriodInfo& p = h->per[t];
+    sdp::FinalizeJob J{};
+    J.keys = h->d_keys + (size_t)t * h->key_stride;
+    J.part_val = h->d_chunk_val + h->chunk_off[t] - p.lo;
+    J.part_idx = h->d_chunk_idx + h->chunk_off[t] - p.lo;
+    J.v_out = h->d_values + p.v_off;
+    J.pol_out = h->d_policy + p.pol_off - p.lo;
+    J.stride = p.hi - p.lo;
+    J.lo = p.lo;
+    J.hi = p.hi;
+    // V_t is decoded over the whole row (after the all-gather every rank holds all keys), the policy
+    // only for this rank's slab
+    J.vlo = h->d.world_size > 1 ? 0 : p.lo;
+    J.vhi = h->d.world_size > 1 ? p.S : p.hi;
+    J.first = total;
+    J.n_chunks = h->pending_chunks[t];
+    total += J.vhi - J.vlo;
+    jobs.push_back(J);
+    h->pending_chunks[t] = 0;
+  }
+  h->n_pending = 0;
+  if (jobs.empty() || total == 0) return hipSuccess;
+  if (!h->d_jobs) {
+    hipError_t e = hipMalloc((void**)&h->d_jobs, (size_t)h->T * sizeof(sdp::FinalizeJob));
+    if (e != hipSuccess) return e;
+  }
+  // pageable source: HIP stages the bytes before hipMemcpyAsync returns, so `jobs` may go out of scope
+  hipError_t e = hipMemcpyAsync(h->d_jobs, jobs.data(), jobs.size() * sizeof(sdp::FinalizeJob), hipMemcpyHostToDevice, h->stream);
+  if (e != hipSuccess) return e;
+  hipLaunchKernelGGL(sdp::finalize_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, h->stream, h->d_jobs,
+                     (int)jobs.size(), total);
+  return hipGetLastError();
+}
+
+// ---- row-window kernel (F2) ---------------------------------------------------------------
+template <int R, int S, bool MAXDIR>
+hipError_t launch_row_r(const sdp::RowParams& W, size_t smem, bool future, const double* v_next, double* out_val,
+                        int32_t* out_idx, const double* pmf_p, int64_t lo, int64_t hi, hipStream_t st) {
+  if (!grid_ok((int64_t)W.n_tiles * W.n_chunks)) return hipErrorInvalidValue;
+  dim3 grid((unsigned)((int64_t)W.n_tiles * W.n_chunks));
+  if (future)
+    hipLaunchKernelGGL((sdp::window_f2_kernel<R, S, MAXDIR, true>), grid, dim3(256), smem, st, W, v_next, out_val, out_idx, pmf_p, lo, hi);
+  else
+    hipLaunchKernelGGL((sdp::window_f2_kernel<R, S, MAXDIR, false>), grid, dim3(256), smem, st, W, v_next, out_val, out_idx, pmf_p, lo, hi);
+  return hipGetLastError();
+}
+
+hipError_t launch_row_window(sdpgpu_handle* h, const DevParams& P, int period, const double* v_next, double* v_cur,
+                             int32_t* pol, const double* pmf_p, int64_t lo, int64_t hi, hipStream_t st) {
+  {
+    hipError_t ef = flush_pending(h);
+    if (ef != hipSuccess) return ef;
+  }
+  const PeriodInfo& p = h->per[period - 1];
+  const int A = h->n_actions_full, D = p.nD;
+  auto rup = [](int v, int r) { return (v + r - 1) / r * r; };
+  int R = 0;
+  int64_t best_cost = -1;
+  const int cand[3] = {8, 5, 4};
+  for (int r : cand) {
+    if (h->win_r && r != h->win_r) continue;
+    int64_t cost = (int64_t)rup(A, r) * rup(D, r);
+    if (best_cost < 0 || cost < best_cost) {
+      best_cost = cost;
+      R = r;
+    }
+  }
+  if (!R) R = 8;
+  // states per lane: 2 (tiles of 128) unless the inventory axis is short or overridden (SDPGPU_WIN_S)
+  int SL = h->win_s ? h->win_s : (p.g.nx >= 96 ? 2 : 1);
+  if (SL != 1 && SL != 2 && SL != 4) SL = 2;
+  if (SL == 4 && R == 8) SL = 2;  // (no 8 x 4 instantiation: too many registers)
+  const int TSZ = 64 * SL;
+  const bool future = period < h->T;
+  sdp::RowParams W{};
+  W.lev0 = p.g.x_lo - h->pmf_d[period - 1][0];
+  W.step = h->d.step;
+  W.h = h->d.holding_cost;
+  W.pi = h->d.penalty_cost;
+  W.K = h->d.fixed_order_cost;
+  W.v = h->d.unit_order_cost;
+  if (future) {
+    W.idx_off = (int32_t)((W.lev0 - h->per[period].g.x_lo) / h->d.step);
+    W.next_last = (int32_t)(h->per[period].g.nx - 1);
+    W.next_nx = (int32_t)h->per[period].g.nx;
+  }
+  W.cur_nx = (int32_t)p.g.nx;
+  W.nq1 = (int32_t)p.g.nq1;
+  W.plane_stride = P.lead2 ? (int64_t)W.nq1 * W.next_nx : (int64_t)W.next_nx;
+  W.tiles_per_row = (int32_t)((p.g.nx + TSZ - 1) / TSZ);
+  W.n_actions = A;
+  W.d_pad = rup(D, 4);  // the demand loop is unrolled by S (1, 2 or 4); padded steps carry p = 0
+  const int span = TSZ + W.d_pad + 1;
+  const int blocks_total = rup(A, R) / R;
+  // one R-block per wave: chunks of 4 R-blocks, fewer if the LDS budget (rows of `span` doubles) says so
+  int bpc = std::min(4, blocks_total);
+  if (h->win_nch) bpc = std::max(1, (blocks_total + h->win_nch - 1) / h->win_nch);
+  auto lds = [&](int b) { return (size_t)span * 8 * (1 + (future ? b * R : 0)) + (size_t)4 * TSZ * 12; };
+  while (bpc > 1 && lds(bpc) > 60 * 1024) --bpc;
+  if (lds(bpc) > 64 * 1024) return hipErrorInvalidValue;
+  W.chunk_actions = bpc * R;
+  W.n_chunks = (blocks_total + bpc - 1) / bpc;
+  // the run of row tiles that covers [lo, hi)
+  auto tile_of = [&](int64_t idx) { return (int32_t)((idx / p.g.nx) * W.tiles_per_row + (idx % p.g.nx) / TSZ); };
+  W.tile0 = tile_of(lo);
+  W.n_tiles = tile_of(hi - 1) - W.tile0 + 1;
+  double* out_val = v_cur;
+  int32_t* out_idx = pol;
+  if (W.n_chunks > 1) {
+    int64_t slab = hi - lo;
+    const int b = period & 1;
+    hipError_t e = ensure_partials(h, b, (size_t)W.n_chunks * (size_t)slab);
+    if (e != hipSuccess) return e;
+    W.partial_stride = slab;
+    out_val = h->d_part_val[b] - lo;
+    out_idx = h->d_part_idx[b] - lo;
+  }
+  hipError_t e = hipErrorInvalidValue;
+  size_t smem = lds(bpc);
+#define SDP_ROW(RR, SS)                                                                                          \
+  if (R == RR && SL == SS)                                                                                       \
+    e = P.maxdir ? launch_row_r<RR, SS, true>(W, smem, future, v_next, out_val, out_idx, pmf_p, lo, hi, st)      \
+                 : launch_row_r<RR, SS, false>(W, smem, future, v_next, out_val, out_idx, pmf_p, lo, hi, st);
+  SDP_ROW(8, 1) SDP_ROW(5, 1) SDP_ROW(4, 1)
+  SDP_ROW(8, 2) SDP_ROW(5, 2) SDP_ROW(4, 2)
+  SDP_ROW(5, 4) SDP_ROW(4, 4)
+#undef SDP_ROW
+  if (e != hipSuccess) return e;
+  if (W.n_chunks > 1)
+    e = P.maxdir ? launch_combine<true>(out_val, out_idx, W.n_chunks, W.partial_stride, v_cur, pol, lo, hi, st)
+                 : launch_combine<false>(out_val, out_idx, W.n_chunks, W.partial_stride, v_cur, pol, lo, hi, st);
+  return e;
+}
+
+// The interior run of slab tiles of a period: tiles whose whole V_{t+1} footprint
+// [i0 + idx_off - (D-1), i0 + 63 + idx_off + A - 1] (before the clamp to the grid) lies inside this rank's
+// slab of the next period's row, or is clamped at a grid edge this rank owns.
+bool window_interior_tiles(const sdpgpu_handle* h, int period, int64_t lo, int64_t hi, int* first, int* count) {
+  if (h->d.family != SDPGPU_FAMILY_BACKORDER || period >= h->T || h->d.world_size == 1) return false;
+  const PeriodInfo& p = h->per[period - 1];
+  const PeriodInfo& pn = h->per[period];
+  const int64_t ts = plan_window(h, period, lo, hi).tile_states();
+  const int64_t n_tiles = (hi - lo + ts - 1) / ts;
+  const double lev0 = p.g.x_lo - h->pmf_d[period - 1][0];
+  const int64_t idx_off = (int64_t)((lev0 - pn.g.x_lo) / h->d.step);
+  const int64_t A = h->n_actions_full, D = p.nD;
+  int64_t f = -1, c = 0;
+  for (int64_t u = 0; u < n_tiles; ++u) {
+    const int64_t i0 = lo + u * ts;
+    int64_t a = i0 + idx_off - (D - 1), b = i0 + ts - 1 + idx_off + A - 1;
+    a = std::max<int64_t>(0, std::min<int64_t>(a, pn.g.nx - 1));  // the kernel clamps reads to the grid
+    b = std::max<int64_t>(0, std::min<int64_t>(b, pn.g.nx - 1));
+    const bool inside = a >= pn.lo && b < pn.hi;
+    if (inside) {
+      if (f < 0) f = u;
+      if (u != f + c) return false;  // not one contiguous run: do not split
+      ++c;
+    }
+  }
+  if (c <= 0) return false;
+  if (first) *first = (int)f;
+  if (count) *count = (int)c;
+  return true;
+}
+
+hipError_t launch_window(sdpgpu_handle* h, const DevParams& P, int period, const double* v_next, double* v_cur,
+                         int32_t* pol, const double* pmf_d, const double* pmf_p, int64_t lo, int64_t hi, hipStream_t st,
+                         int part) {
+  (void)pmf_d;
+  if (h->d.family == SDPGPU_FAMILY_LEADTIME) {
+    if (hi <= lo) return hipSuccess;
+    return launch_row_window(h, P, period, v_next, v_cur, pol, pmf_p, lo, hi, st);
+  }
+  // (an empty slab still goes through the bookkeeping below: every rank must treat the row alike)
+  PeriodInfo& p = h->per[period - 1];
+  WinPlan pl = plan_window(h, period, lo, hi);
+  if (!pl.R) return hipErrorInvalidValue;
+  if (period == h->T && std::getenv("SDPGPU_DEBUG_PLAN"))
+    std::fprintf(stderr, "[sdpgpu] window plan: R=%d S=%d chunks=%d blocks/chunk=%d tiles=%d tasks=%d lds=%zu\n", pl.R, pl.S,
+                 pl.n_chunks, pl.chunk_blocks, pl.n_tiles, pl.n_tasks, pl.smem);
+  const bool future = period < h->T;
+  const bool chunked = pl.n_chunks > 1;
+  // a period is never re-run on top of its own pending rows, and a new sweep (period T) first
+  // finalizes what the previous one left: the key rows are about to be reset
+  // (the BOUNDARY half of a split period continues what its INTERIOR half started: no reset there)
+  const bool continuing = part == SDPGPU_PART_BOUNDARY;
+  if (!continuing && h->n_pending > 0 && (h->pending_chunks[period - 1] > 0 || period == h->T)) {
+    hipError_t e = flush_pending(h);
+    if (e != hipSuccess) return e;
+  }
+  // where V_{t+1} comes from: its key row while that period is still pending, else the final fp64 row
+  const bool keyed_in = future && h->pending_chunks[period] > 0;
+  if (chunked) {
+    if (!h->d_chunk_val) {  // one-time arenas: a key row per period, the chunk rows of every chunked period
+      size_t stride = 0;
+      for (const PeriodInfo& q : h->per) stride = std::max<size_t>(stride, (size_t)q.S_pad);
+      hipError_t e = hipSuccess;
+      if (!h->d_keys) e = hipMalloc((void**)&h->d_keys, (size_t)h->T * stride * sizeof(unsigned long long));
+      if (e != hipSuccess) return e;
+      h->key_stride = stride;
+      h->key_row_clean.assign((size_t)h->T, 0);
+      h->chunk_off.assign((size_t)h->T, 0);
+      size_t total = 0;
+      for (int t = 0; t < h->T; ++t) {
+        const PeriodInfo& q = h->per[t];
+        h->chunk_off[t] = total;
+        if (window_eligible(h, t + 1))
+          total += (size_t)plan_window(h, t + 1, q.lo, q.hi).n_chunks * (size_t)std::max<int64_t>(q.hi - q.lo, 0);
+      }
+      e = hipMalloc((void**)&h->d_chunk_val, std::max<size_t>(total, 1) * sizeof(double));
+      if (e == hipSuccess) e = hipMalloc((void**)&h->d_chunk_idx, std::max<size_t>(total, 1) * sizeof(int32_t));
+      if (e != hipSuccess) return e;
+    }
+    if (!continuing && !h->key_row_clean[period - 1]) {
+      // reset key rows to the reduction identity: all of them when nothing is pending (the usual case:
+      // period T of a new sweep), else only this period's row (periods re-run out of order)
+      const bool all = h->n_pending == 0;
+      const int64_t n = (all ? (int64_t)h->T : 1) * (int64_t)h->key_stride;
+      unsigned long long* base = all ? h->d_keys : h->d_keys + (size_t)(period - 1) * h->key_stride;
+      hipLaunchKernelGGL(sdp::key_fill_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, base, n, (int)P.maxdir);
+      hipError_t e = hipGetLastError();
+      if (e != hipSuccess) return e;
+      if (all)
+        std::fill(h->key_row_clean.begin(), h->key_row_clean.end(), 1);
+      else
+        h->key_row_clean[period - 1] = 1;
+    }
+  }
+  sdp::WinParams W{};
+  const double d0 = h->pmf_d[period - 1][0];
+  W.lev0 = p.g.x_lo - d0;
+  W.step = h->d.step;
+  W.h = h->d.holding_cost;
+  W.pi = h->d.penalty_cost;
+  W.K = h->d.fixed_order_cost;
+  W.v = h->d.unit_order_cost;
+  if (future) {
+    W.idx_off = (int32_t)((W.lev0 - h->per[period].g.x_lo) / h->d.step);
+    W.next_last = (int32_t)(h->per[period].g.nx - 1);
+  }
+  W.n_actions = h->n_actions_full;
+  W.d_pad = pl.d_pad;
+  W.d_main = p.nD / (pl.R + pl.S - 1) * (pl.R + pl.S - 1);
+  W.maxdir = P.maxdir;
+  W.n_demand = p.nD;
+  W.n_chunks = pl.n_chunks;
+  W.chunk_blocks = pl.chunk_blocks;
+  W.n_tiles = pl.n_tiles;
+  W.n_tasks = pl.n_tasks;
+  W.tile_first = 0;
+  W.prio_fair = h->win_prio_fair;
+  W.tile_gap_at = pl.n_tiles;  // no gap
+  W.tile_gap = 0;
+  if (part != SDPGPU_PART_ALL) {
+    int first = 0, count = 0;
+    if (!window_interior_tiles(h, period, lo, hi, &first, &count)) return hipErrorInvalidValue;
+    if (part == SDPGPU_PART_INTERIOR) {
+      W.tile_first = first;
+      W.n_tiles = count;
+    } else {  // the tiles below and above the interior run, in one launch
+      // The boundary runs are a handful of tiles on the critical path behind the exchange: cut them finer than
+      // the plan does (64-state tiles, 4-action register blocks -- same chunks, so the chunk rows line up) so
+      // that the few tasks spread over more SIMDs and each is short.
+      const int ratio = pl.S;  // plan tiles are ratio x 64 states
+      const int fine_r = (pl.R % 4 == 0) ? 4 : pl.R;
+      if (ratio > 1 || fine_r != pl.R) {
+        const int chunk_actions = pl.chunk_blocks * pl.R;
+        pl.n_tiles = (int)((hi - lo + 63) / 64);
+        first *= ratio;
+        count = std::min(count * ratio, pl.n_tiles - first);  // (the last plan tile may be a partial one)
+        pl.chunk_blocks = chunk_actions / fine_r;
+        pl.R = fine_r;
+        pl.S = 1;
+        pl.d_pad = (p.nD + fine_r - 1) / fine_r * fine_r;
+        pl.smem = (size_t)4 * (64 + chunk_actions + pl.d_pad + 1) * 16;
+        W.d_pad = pl.d_pad;
+        W.d_main = p.nD / fine_r * fine_r;
+        W.chunk_blocks = pl.chunk_blocks;
+      }
+      W.n_tiles = pl.n_tiles - count;
+      W.tile_gap_at = first;
+      W.tile_gap = count;
+    }
+    W.n_tasks = W.n_tiles * pl.n_chunks;
+    W.tile_gap_at = std::min(W.tile_gap_at, W.n_tiles);
+    if (W.n_tiles == 0) return hipSuccess;
+  }
+  double* out_val = v_cur;
+  int32_t* out_idx = pol;
+  unsigned long long* k_cur = nullptr;
+  const unsigned long long* k_next = keyed_in ? h->d_keys + (size_t)period * h->key_stride : nullptr;
+  if (chunked) {
+    W.partial_stride = hi - lo;
+    out_val = h->d_chunk_val + h->chunk_off[period - 1] - lo;  // the kernel indexes rows by flat state index
+    out_idx = h->d_chunk_idx + h->chunk_off[period - 1] - lo;
+    k_cur = h->d_keys + (size_t)(period - 1) * h->key_stride;
+  }
+  if (W.n_tasks > 0 && !grid_ok((W.n_tasks + 3) / 4)) return hipErrorInvalidValue;
+  const dim3 grid((unsigned)std::max(1, (W.n_tasks + 3) / 4));
+#ifdef SDP_STAMPS
+  static unsigned long long* d_stamps = nullptr;
+  if (!d_stamps) (void)hipMalloc((void**)&d_stamps, (size_t)1 << 24);
+  unsigned long long* stamps = (period == 2) ? d_stamps : nullptr;  // record one mid-sweep launch
+#define SDP_STAMP_ARG , stamps
+#else
+#define SDP_STAMP_ARG
+#endif
+  if (W.n_tasks > 0) {
+#define SDP_WIN_GO(RR, SS, FU, KI)                                                                                      \
+  hipLaunchKernelGGL((sdp::window_f1_kernel<RR, SS, FU, KI>), grid, dim3(256), pl.smem, st, W, v_next, k_next, out_val, \
+                     out_idx, k_cur, pmf_p, lo, hi SDP_STAMP_ARG)
+#define SDP_WIN_R(RR, SS)                      \
+  if (pl.R == RR && pl.S == SS) {              \
+    if (!future)                               \
+      SDP_WIN_GO(RR, SS, false, false);        \
+    else if (keyed_in)                         \
+      SDP_WIN_GO(RR, SS, true, true);          \
+    else                                       \
+      SDP_WIN_GO(RR, SS, true, false);         \
+    launched = true;                           \
+  }
+  bool launched = false;
+  SDP_WIN_R(8, 1)
+  SDP_WIN_R(5, 1)
+  SDP_WIN_R(4, 1)
+  SDP_WIN_R(8, 2)
+  SDP_WIN_R(4, 2)
+  SDP_WIN_R(4, 4)
+  if (!launched) return hipErrorInvalidValue;
+#undef SDP_WIN_R
+#undef SDP_WIN_GO
+#undef SDP_STAMP_ARG
+  }
+  hipError_t e = hipGetLastError();
+  if (e != hipSuccess) return e;
+#ifdef SDP_STAMPS
+  if (period == 1) {
+    std::vector<unsigned long long> hs((size_t)pl.n_tasks * 5);
+    (void)hipStreamSynchronize(st);
+    (void)hipMemcpy(hs.data(), d_stamps, hs.size() * 8, hipMemcpyDeviceToHost);
+    if (FILE* f = std::fopen("gpurun_out/stamps.txt", "w")) {
+      for (size_t i = 0; i + 4 < hs.size(); i += 5)
+        std::fprintf(f, "%zu %llu %llu %llu %llu %llu\n", i / 5, hs[i], hs[i + 1], hs[i + 2], hs[i + 3], hs[i + 4]);
+      std::fclose(f);
+    }
+  }
+#endif
+  if (chunked && h->pending_chunks[period - 1] == 0) {
+    h->pending_chunks[period - 1] = pl.n_chunks;
+    h->n_pending++;
+    h->key_row_clean[period - 1] = 0;  // holds data now; re-filled when the next sweep starts
+  }
+  return e;
+}
+
+// OPT-IN separable mode (SDPGPU_KERNEL_SEPARABLE, F1 only): one launch per period, see sdp_window.hpp
+hipError_t launch_separable(sdpgpu_handle* h, const DevParams& P, int period, const double* v_next, double* v_cur,
+                            int32_t* pol, const double* pd, const double* pp, bool* too_big) {
+  const PeriodInfo& p = h->per[period - 1];
+  hipError_t es = flush_pending(h);
+  if (es == hipSuccess) {
+    sdp::SepParams S{};
+    S.x_lo = p.g.x_lo;
+    S.step = h->d.step;
+    S.h = h->d.holding_cost;
+    S.pi = h->d.penalty_cost;
+    S.K = h->d.fixed_order_cost;
+    S.v = h->d.unit_order_cost;
+    S.inv_step = 1.0 / h->d.step;
+    S.min_inventory = h->d.min_inventory;
+    S.max_inventory = h->d.max_inventory;
+    S.clamp_inventory = h->d.clamp_inventory;
+    S.n_actions = h->n_actions_full;
+    S.n_demand = p.nD;
+    S.d_min = h->pmf_d[period - 1].front();  // demands are strictly ascending (checked at set_pmf)
+    S.d_range = (int32_t)((h->pmf_d[period - 1].back() - S.d_min) / h->d.step);
+    const bool future = period < h->T;
+    if (future) {
+      S.next_x_lo = h->per[period].g.x_lo;
+      S.next_last = (int32_t)(h->per[period].g.nx - 1);
+    }
+    const int64_t n = p.hi - p.lo;
+    if (n > 0) {
+      dim3 grid((unsigned)((n + 63) / 64));
+      size_t smem = (size_t)(64 + S.n_actions + S.d_range) * 16 + (size_t)(64 + S.n_actions) * 8 +
+                    4 * 64 * (sizeof(double) + sizeof(int));
+      if (smem > 64 * 1024) {
+        *too_big = true;
+        return hipSuccess;
+      }
+      const bool mx = P.maxdir != 0;
+      if (mx && future) hipLaunchKernelGGL((sdp::separable_f1_kernel<true, true>), grid, dim3(256), smem, h->stream, S, v_next, v_cur, pol, pd, pp, p.lo, p.hi);
+      else if (mx) hipLaunchKernelGGL((sdp::separable_f1_kernel<true, false>), grid, dim3(256), smem, h->stream, S, v_next, v_cur, pol, pd, pp, p.lo, p.hi);
+      else if (future) hipLaunchKernelGGL((sdp::separable_f1_kernel<false, true>), grid, dim3(256), smem, h->stream, S, v_next, v_cur, pol, pd, pp, p.lo, p.hi);
+      else hipLaunchKernelGGL((sdp::separable_f1_kernel<false, false>), grid, dim3(256), smem, h->stream, S, v_next, v_cur, pol, pd, pp, p.lo, p.hi);
+      es = hipGetLastError();
+    }
+  }
+  return es;
+}
+
+}  // namespace sdpgpu_detail
