@@ -24,3 +24,14 @@ def test_1e7_state_pipeline_grid_sampled_parity():
                          capture_output=True, text=True, timeout=600)
     assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-2000:]
     assert out.stdout.count("bit-identical") == 3
+
+
+@pytest.mark.parametrize("name,periods", [("cfg3", 4), ("cfg4", 4)])
+def test_full_size_config_sampled_parity(name, periods):
+    """configs[2] (1e6 cash states x <=300 actions x 150 demands, 6 periods) and configs[3] in the reference's
+    (period, x, preQ) shape (50 periods x 1000 x 200) at full size: sampled states of four periods against the
+    oracle fed the GPU's own V_{t+1}."""
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "sampled_grid_check.py"), name, "1500"],
+                         capture_output=True, text=True, timeout=900)
+    assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-2000:]
+    assert out.stdout.count("bit-identical") == periods
