@@ -101,6 +101,28 @@ def test_slabs_partition_the_grid(sia):
     assert all(seen[i][1] == seen[i + 1][0] for i in range(2))
 
 
+def test_create_rejects_the_new_descriptor_fields_misused(sia, lib):
+    h = C.c_void_p()
+    d = sia.desc_defaults()
+    d.lead_time = 2  # a two-stage pipeline exists for the LEADTIME family only
+    assert lib.sdpgpu_create(C.byref(d), C.byref(h)) == 4 and b"LEADTIME" in lib.sdpgpu_last_error(None)
+    d.family, d.clamp_inventory = sia.FAMILY_LEADTIME, 0
+    assert lib.sdpgpu_create(C.byref(d), C.byref(h)) == 4 and b"clamp" in lib.sdpgpu_last_error(None)
+    d.lead_time = 3
+    assert lib.sdpgpu_create(C.byref(d), C.byref(h)) == 1
+    d = sia.desc_defaults()
+    d.family, d.direction = sia.FAMILY_SURVIVAL, 0  # getSurvProb maximises
+    d.cash_round_mult = d.cash_round_div = 1.0
+    d.max_cash = 10.0
+    assert lib.sdpgpu_create(C.byref(d), C.byref(h)) == 1 and b"maximises" in lib.sdpgpu_last_error(None)
+    d.direction = 1
+    assert lib.sdpgpu_create(C.byref(d), C.byref(h)) == 0
+    lib.sdpgpu_destroy(h)
+    prm = (C.c_double * 300)()
+    assert lib.sdpgpu_create_custom(C.byref(d), b"", prm, 300, C.byref(h)) == 1  # more than 256 parameters
+    assert lib.sdpgpu_create_custom(C.byref(d), None, prm, 1, C.byref(h)) == 1
+
+
 def test_errors_are_reported_not_thrown(sia):
     w = cases.f1_small()
     with pytest.raises(ValueError):
@@ -130,6 +152,9 @@ def test_compute_fails_loudly_without_a_gpu(sia):
 
 
 def test_host_mirror_keeps_the_reference_api(sia):
+    assert callable(sia.RiskRecursion.getSurvProb) and callable(sia.RiskSimulation.simulateLostSale)
+    r = sia.RiskState(1, 0.0, 5.0, True)
+    assert r.getBankruptBefore() is False and r == sia.RiskState(1, 0.0, 5.0, False)  # RiskState.java:17
     for cls in (sia.Recursion, sia.CashRecursion, sia.LeadtimeRecursion, sia.CashLeadtimeRecursion):
         for name in ("getExpectedValue", "getAction", "getCacheActions", "getOptTable",
                      "getStateTransitionFunction", "getImmediateValueFunction", "setTreeMapCacheAction"):
