@@ -14,17 +14,24 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 @pytest.mark.parametrize("extra", [["--periods", "6"], ["--workload", "cfg5", "--states", "100000", "--periods", "3"],
                                    ["--periods", "6", "--split"],
-                                   ["--workload", "cfg5", "--states", "100000", "--periods", "3", "--split"]],
+                                   ["--workload", "cfg5", "--states", "100000", "--periods", "3", "--split"],
+                                   ["--periods", "6", "CALIBRATE"]],
                          ids=["cfg2_small_slabs_key_rows", "f1_large_slabs", "cfg2_interior_boundary_split",
-                              "f1_large_interior_boundary_split"])
+                              "f1_large_interior_boundary_split", "cfg2_schedule_calibration"])
 def test_two_ranks_match_single_rank(extra):
+    env = dict(os.environ)
+    if "CALIBRATE" in extra:  # the N > 1 schedule calibration bench.py runs under RCCL, rehearsed over gloo
+        extra = [e for e in extra if e != "CALIBRATE"]
+        env["SDP_BENCH_CALIBRATE"] = "1"
     port = 29600 + os.getpid() % 300
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr",
            "127.0.0.1", "--master-port", str(port), os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2",
            "--warmup", "1", "--backend", "gloo", "--check", "--no-cpu-baseline", *extra]
-    out = subprocess.run(cmd, capture_output=True, text=True, timeout=240, cwd=ROOT)
+    out = subprocess.run(cmd, capture_output=True, text=True, timeout=240, cwd=ROOT, env=env)
     assert out.returncode == 0, out.stderr[-2000:]
     line = [l for l in out.stdout.splitlines() if l.startswith("{")][-1]
     rec = json.loads(line)
     assert rec["n_gpus"] == 2 and rec["check_vs_single_rank"] is True
     assert rec["scaling"] == "weak" and rec["value"] > 0
+    if "SDP_BENCH_CALIBRATE" in env:
+        assert "calibrated" in rec["config"]["exchange"]
