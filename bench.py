@@ -324,6 +324,17 @@ def main():
                                     "ops_per_cell": [round(ops_future, 4), round(ops_last, 4)],
                                     "register_block": {"actions": R_, "states_per_lane": S_},
                                     "note": "secondary: the north star prices this path against HBM"}
+        # SURVEY.md section 8(d) asks for four numbers side by side
+        flops_per_cell = {"cfg2": 14, "cfg5": 14, "cfg4": 14, "cfg4p": 14, "cfg3": 25}.get(args.workload, 14)
+        out["side_by_side"] = {
+            "cells_per_s": out["value"],
+            "algorithmic_GBps": achieved * (world if world > 1 else 1),
+            "hbm_measured_GBps": (traffic / (avg_launch_ms * 1e-3) / 1e9) if (traffic and avg_launch_ms > 0) else None,
+            "fp64_TFLOPs_at_reference_op_count": out["value"] * flops_per_cell / 1e12,
+            "reference_fp64_ops_per_cell": flops_per_cell,
+            "note": "the reference's formulas spend 14 (F1/F2) / 25 (F3) fp64 operations per cell; the kernels execute fewer "
+                    "(identical operations are formed once), see valu_roofline",
+        }
         if check is not None:
             out["check_vs_single_rank"] = check
         if not args.no_cpu_baseline:
