@@ -101,6 +101,20 @@ int layout(sdpgpu_handle* h) {
     p.nD = (int32_t)h->pmf_d[t].size();
     p.pmf_off = pmf_off;
     pmf_off += 2 * (size_t)p.nD + kPmfPad;  // probabilities are followed by kPmfPad zeros (window kernel)
+    {
+      const std::vector<double>& dv = h->pmf_d[t];
+      const double span = (dv.back() - dv.front()) / d.step;  // demands are multiples of step (set_pmf)
+      const int64_t dense = (int64_t)span + 1;
+      p.nD_win = 0;
+      p.pmf_win_off = p.pmf_off + (size_t)p.nD;
+      if (dense == p.nD) {
+        p.nD_win = p.nD;
+      } else if (dense <= 3 * (int64_t)p.nD + 16 && dense <= 4000) {  // beyond ~3x padding the generic kernel wins
+        p.nD_win = (int32_t)dense;
+        p.pmf_win_off = pmf_off;
+        pmf_off += (size_t)dense + kPmfPad;
+      }
+    }
     p.v_off = v_off;
     p.pol_off = pol_off;
     pol_off += (size_t)slab;
@@ -156,13 +170,16 @@ int allocate(sdpgpu_handle* h) {
   }
   HIP_TRY(h, hipMalloc((void**)&h->d_policy, std::max<size_t>(h->policy_elems, 1) * sizeof(int32_t)));
   size_t pmf_elems = 0;
-  for (auto& p : h->per) pmf_elems += 2 * (size_t)p.nD + kPmfPad;
+  for (auto& p : h->per) pmf_elems += 2 * (size_t)p.nD + kPmfPad + (p.nD_win > p.nD ? (size_t)p.nD_win + kPmfPad : 0);
   HIP_TRY(h, hipMalloc((void**)&h->d_pmf, std::max<size_t>(pmf_elems, 1) * sizeof(double)));
   std::vector<double> host(pmf_elems, 0.0);
   for (int t = 0; t < h->T; ++t) {
     const PeriodInfo& p = h->per[t];
     std::memcpy(&host[p.pmf_off], h->pmf_d[t].data(), (size_t)p.nD * sizeof(double));
     std::memcpy(&host[p.pmf_off + p.nD], h->pmf_p[t].data(), (size_t)p.nD * sizeof(double));
+    if (p.nD_win > p.nD)  // unit-stride layout of a support with gaps
+      for (int j = 0; j < p.nD; ++j)
+        host[p.pmf_win_off + (size_t)((h->pmf_d[t][(size_t)j] - h->pmf_d[t][0]) / h->d.step)] = h->pmf_p[t][(size_t)j];
   }
   HIP_TRY(h, hipMemcpy(h->d_pmf, host.data(), pmf_elems * sizeof(double), hipMemcpyHostToDevice));
   HIP_TRY(h, hipEventCreate(&h->ev_solve0));
@@ -335,7 +352,7 @@ int run_period_impl(sdpgpu_handle* h, int period, int part = SDPGPU_PART_ALL) {
   }
   hipError_t e;
   if (use_window) {
-    e = launch_window(h, P, period, v_next, v_cur, pol, pd, pp, p.lo, p.hi, h->stream, part);
+    e = launch_window(h, P, period, v_next, v_cur, pol, pd, h->d_pmf + p.pmf_win_off, p.lo, p.hi, h->stream, part);
     p.kernel_used = SDPGPU_KERNEL_WINDOW;
   } else if (h->d.kernel != SDPGPU_KERNEL_GATHER && h->use_cash_shift && cash_shift_eligible(h, period)) {
     e = flush_pending(h);

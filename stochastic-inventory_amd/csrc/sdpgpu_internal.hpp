@@ -43,6 +43,11 @@ struct PeriodInfo {
   int64_t lo = 0, hi = 0;  // this rank's slab
   int32_t nD = 0;
   size_t pmf_off = 0;   // element offset of this period's demand array inside d_pmf
+  // The window kernels index demands by j = (d - d_0) / step.  A support with gaps (DiscreteDistribution-style
+  // {2, 5, 9}) is laid out on the unit-stride grid with probability 0 in the gaps: a zero-probability step adds
+  // exact zeros to the accumulator, so the sums are unchanged.  nD_win = 0: too sparse, generic kernel instead.
+  int32_t nD_win = 0;      // demand steps of the unit-stride layout
+  size_t pmf_win_off = 0;  // element offset of its probability array (== pmf_off + nD when there are no gaps)
   size_t v_off = 0;     // element offset of V_t inside the value arena
   size_t pol_off = 0;   // element offset of this rank's policy slab
   double overhead = 0;

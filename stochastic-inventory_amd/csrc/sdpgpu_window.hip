@@ -8,16 +8,14 @@ namespace sdpgpu_detail {
 // ---- window kernel (F1) -----------------------------------------------------------------------
 
 
-// F1 / F2 with a unit-stride demand grid: d_j = d_0 + j*step.
+// F1 / F2 on a unit-stride demand grid d_j = d_0 + j*step (supports with gaps are laid out on one, see PeriodInfo).
 bool window_eligible(const sdpgpu_handle* h, int period) {
   if (h->custom) return false;
   if (h->d.family != SDPGPU_FAMILY_BACKORDER && h->d.family != SDPGPU_FAMILY_LEADTIME) return false;
-  const std::vector<double>& d = h->pmf_d[period - 1];
-  for (size_t j = 1; j < d.size(); ++j)
-    if (d[j] - d[j - 1] != h->d.step) return false;
   const PeriodInfo& p = h->per[period - 1];
+  if (p.nD_win <= 0) return false;
   if (p.S >= 2147483647LL - 4096) return false;
-  if (h->n_actions_full + p.nD > 3500) return false;
+  if (h->n_actions_full + p.nD_win > 3500) return false;
   return true;
 }
 
@@ -28,7 +26,7 @@ bool window_eligible(const sdpgpu_handle* h, int period) {
 // ((5 + 4(S-1)) / S, see window_f1_kernel) but bigger, fewer tasks: small grids keep S low.
 WinPlan plan_window(const sdpgpu_handle* h, int period, int64_t lo, int64_t hi) {
   const PeriodInfo& p = h->per[period - 1];
-  const int A = h->n_actions_full, D = p.nD;
+  const int A = h->n_actions_full, D = p.nD_win;
   WinPlan best;
   double best_cost = -1;
   // The plan is chosen from the NOMINAL slab S_pad / world_size, which is the same on every rank: ranks
@@ -171,7 +169,7 @@ hipError_t launch_row_window(sdpgpu_handle* h, const DevParams& P, int period, c
     if (ef != hipSuccess) return ef;
   }
   const PeriodInfo& p = h->per[period - 1];
-  const int A = h->n_actions_full, D = p.nD;
+  const int A = h->n_actions_full, D = p.nD_win;
   auto rup = [](int v, int r) { return (v + r - 1) / r * r; };
   int R = 0;
   int64_t best_cost = -1;
@@ -262,7 +260,7 @@ bool window_interior_tiles(const sdpgpu_handle* h, int period, int64_t lo, int64
   const int64_t n_tiles = (hi - lo + ts - 1) / ts;
   const double lev0 = p.g.x_lo - h->pmf_d[period - 1][0];
   const int64_t idx_off = (int64_t)((lev0 - pn.g.x_lo) / h->d.step);
-  const int64_t A = h->n_actions_full, D = p.nD;
+  const int64_t A = h->n_actions_full, D = p.nD_win;
   int64_t f = -1, c = 0;
   for (int64_t u = 0; u < n_tiles; ++u) {
     const int64_t i0 = lo + u * ts;
@@ -359,9 +357,9 @@ hipError_t launch_window(sdpgpu_handle* h, const DevParams& P, int period, const
   }
   W.n_actions = h->n_actions_full;
   W.d_pad = pl.d_pad;
-  W.d_main = p.nD / (pl.R + pl.S - 1) * (pl.R + pl.S - 1);
+  W.d_main = p.nD_win / (pl.R + pl.S - 1) * (pl.R + pl.S - 1);
   W.maxdir = P.maxdir;
-  W.n_demand = p.nD;
+  W.n_demand = p.nD_win;
   W.n_chunks = pl.n_chunks;
   W.chunk_blocks = pl.chunk_blocks;
   W.n_tiles = pl.n_tiles;
@@ -390,10 +388,10 @@ hipError_t launch_window(sdpgpu_handle* h, const DevParams& P, int period, const
         pl.chunk_blocks = chunk_actions / fine_r;
         pl.R = fine_r;
         pl.S = 1;
-        pl.d_pad = (p.nD + fine_r - 1) / fine_r * fine_r;
+        pl.d_pad = (p.nD_win + fine_r - 1) / fine_r * fine_r;
         pl.smem = (size_t)4 * (64 + chunk_actions + pl.d_pad + 1) * 16;
         W.d_pad = pl.d_pad;
-        W.d_main = p.nD / fine_r * fine_r;
+        W.d_main = p.nD_win / fine_r * fine_r;
         W.chunk_blocks = pl.chunk_blocks;
       }
       W.n_tiles = pl.n_tiles - count;

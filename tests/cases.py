@@ -64,10 +64,18 @@ def f1_wide(T=2):
 
 
 def f1_gapped(T=3):
-    """Non-unit-stride demand support (DiscreteDistribution style): forces the gather kernel."""
+    """Non-unit-stride demand support (DiscreteDistribution style): the window kernel lays it out on the unit-stride
+    grid with zero-probability steps in the gaps."""
     f = BackorderFunctor(fixedOrderingCost=10, variOrderingCost=1, holdingCost=1, penaltyCost=5, minInventory=-20,
                          maxInventory=30, maxOrderQuantity=12, iniInventory=0)
     return Workload("f1_gapped", f, OptDirection.MIN, discrete_pmf(T, [2, 5, 9], [0.25, 0.5, 0.25]))
+
+
+def f1_sparse_support(T=3):
+    """A support too sparse to pad (3 points over a range of 96): stays on the generic kernel."""
+    f = BackorderFunctor(fixedOrderingCost=10, variOrderingCost=1, holdingCost=1, penaltyCost=5, minInventory=-120,
+                         maxInventory=150, maxOrderQuantity=60, iniInventory=0)
+    return Workload("f1_sparse_support", f, OptDirection.MIN, discrete_pmf(T, [0, 40, 95], [0.25, 0.5, 0.25]))
 
 
 def f2_unclamped(T=3):
@@ -177,6 +185,6 @@ def f6_survival_gamma(T=3):
     return Workload("f6_survival_gamma", f, OptDirection.MAX, _pmf([3, 5, 4][:T], 9))
 
 
-ALL = [f1_small, f1_max, f1_gapped, f1_unclamped, f1_edge_single, f2_unclamped, f2_clamped, f2_pipeline, f3_tenths, f3_row, f3_testing, f3_dyadic, f3_min_gamma,
+ALL = [f1_small, f1_max, f1_gapped, f1_sparse_support, f1_unclamped, f1_edge_single, f2_unclamped, f2_clamped, f2_pipeline, f3_tenths, f3_row, f3_testing, f3_dyadic, f3_min_gamma,
        f4_overdraft, f5_cash_leadtime, f6_survival, f6_survival_gamma]
 TINY = [f1_small, f1_max, f1_gapped, f1_unclamped, f2_unclamped, f3_testing, f3_min_gamma, f4_overdraft]

@@ -385,7 +385,7 @@ def test_cfg2_full_horizon_properties(sia, oracle):
 
 def test_kernel_selection(sia):
     """The specialised kernels are the ones that run where they apply (kernel_used: 1 gather, 2 specialised)."""
-    expect = {cases.f1_small: 2, cases.f1_gapped: 1, cases.f1_unclamped: 2, cases.f1_edge_single: 2, cases.f2_clamped: 2,
+    expect = {cases.f1_small: 2, cases.f1_gapped: 2, cases.f1_sparse_support: 1, cases.f1_unclamped: 2, cases.f1_edge_single: 2, cases.f2_clamped: 2,
               cases.f2_unclamped: 2, cases.f2_pipeline: 2,
               cases.f3_tenths: 1,      # end-cash penalty: generic kernel
               cases.f3_row: 2,         # tenths, no penalty: cash row kernel
