@@ -196,8 +196,8 @@ struct alignas(16) RowEnt {
 };
 
 // FORMULA1: F3 with CashConstraintTesting.java's increment (no cash term); INTDIV: the quantiser divides by an
-// integer other than 1.  F3 with a non-zero end-cash penalty stays on the generic kernel (host: cash_row_eligible).
-template <int FAM, bool LAST, bool FORMULA1, bool INTDIV>
+// integer other than 1; PEN: F3 with a non-zero end-cash penalty rate (CashConstraint.java:115-118).
+template <int FAM, bool LAST, bool FORMULA1, bool INTDIV, bool PEN = false>
 __global__ __launch_bounds__(256) void cash_row_kernel(DevParams P, const double* __restrict__ v_next,
                                                        double* __restrict__ v_cur, int32_t* __restrict__ pol,
                                                        const double* __restrict__ pmf_d,
@@ -314,7 +314,10 @@ __global__ __launch_bounds__(256) void cash_row_kernel(DevParams P, const double
         } else {
           inc = e.u;
         }
-        // (end-cash penalty rate is zero here: `inc += 0 * endCash` changes nothing)
+        if constexpr (PEN) {
+          const double end_cash = s.cash + inc;
+          if (end_cash < 0) inc += P.pi * end_cash;
+        }  // (with a zero penalty rate `inc += 0 * endCash` changes nothing and is skipped)
         acc += pp.x * inc;
         if constexpr (!LAST) {
           const double ncash = s.cash + inc;  // CashConstraint.java:125

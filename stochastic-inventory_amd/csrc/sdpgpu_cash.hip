@@ -89,7 +89,6 @@ hipError_t launch_cash_shift(sdpgpu_handle* h, const DevParams& P, int period, c
 bool cash_row_eligible(const sdpgpu_handle* h, int period) {
   const sdpgpu_desc& d = h->d;
   if (h->custom || !has_cash(d.family) || !d.clamp_inventory || !h->use_cash_row) return false;
-  if (d.family == SDPGPU_FAMILY_CASH && d.penalty_cost != 0) return false;  // the end-cash penalty branch: generic kernel
   const PeriodInfo& p = h->per[period - 1];
   if (p.g.nc < 32) return false;                       // a wave is 64 consecutive cash points of one row
   if (p.S >= 2147483647LL) return false;               // 32-bit row offsets
@@ -97,11 +96,11 @@ bool cash_row_eligible(const sdpgpu_handle* h, int period) {
   return true;
 }
 
-template <int FAM, bool FORMULA1>
+template <int FAM, bool FORMULA1, bool PEN = false>
 hipError_t launch_cash_row_fam(const DevParams& P, bool last, bool intdiv, const double* v_next, double* v_cur,
                                int32_t* pol, const double* pmf_d, const double* pmf_p, int64_t lo, int64_t hi,
                                int64_t row0, int tiles_per_row, dim3 grid, size_t smem, hipStream_t st) {
-#define SDP_CR(LS, ID) hipLaunchKernelGGL((sdp::cash_row_kernel<FAM, LS, FORMULA1, ID>), grid, dim3(256), smem, st, P, v_next, v_cur, pol, pmf_d, pmf_p, lo, hi, row0, tiles_per_row)
+#define SDP_CR(LS, ID) hipLaunchKernelGGL((sdp::cash_row_kernel<FAM, LS, FORMULA1, ID, PEN>), grid, dim3(256), smem, st, P, v_next, v_cur, pol, pmf_d, pmf_p, lo, hi, row0, tiles_per_row)
   if (intdiv) {
     if (last) SDP_CR(true, true); else SDP_CR(false, true);
   } else {
@@ -126,6 +125,9 @@ hipError_t launch_cash_row(sdpgpu_handle* h, const DevParams& P, int period, con
 #define SDP_ROWARGS P, last, intdiv, v_next, v_cur, pol, pmf_d, pmf_p, lo, hi, row_lo, tiles_per_row, grid, smem, st
   switch (P.family) {
     case sdp::FAM_CASH:
+      if (P.pi != 0.0)
+        return P.cash_formula == 0 ? launch_cash_row_fam<sdp::FAM_CASH, false, true>(SDP_ROWARGS)
+                                   : launch_cash_row_fam<sdp::FAM_CASH, true, true>(SDP_ROWARGS);
       return P.cash_formula == 0 ? launch_cash_row_fam<sdp::FAM_CASH, false>(SDP_ROWARGS)
                                  : launch_cash_row_fam<sdp::FAM_CASH, true>(SDP_ROWARGS);
     case sdp::FAM_OVERDRAFT: return launch_cash_row_fam<sdp::FAM_OVERDRAFT, false>(SDP_ROWARGS);

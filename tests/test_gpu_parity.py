@@ -387,9 +387,9 @@ def test_kernel_selection(sia):
     """The specialised kernels are the ones that run where they apply (kernel_used: 1 gather, 2 specialised)."""
     expect = {cases.f1_small: 2, cases.f1_gapped: 2, cases.f1_sparse_support: 1, cases.f1_unclamped: 2, cases.f1_edge_single: 2, cases.f2_clamped: 2,
               cases.f2_unclamped: 2, cases.f2_pipeline: 2,
-              cases.f3_tenths: 1,      # end-cash penalty: generic kernel
+              cases.f3_tenths: 2,      # tenths, end-cash penalty: cash row kernel
               cases.f3_row: 2,         # tenths, no penalty: cash row kernel
-              cases.f3_testing: 2, cases.f3_dyadic: 2, cases.f3_min_gamma: 1, cases.f4_overdraft: 2,
+              cases.f3_testing: 2, cases.f3_dyadic: 2, cases.f3_min_gamma: 2, cases.f4_overdraft: 2,
               cases.f5_cash_leadtime: 2, cases.f6_survival: 2, cases.f6_survival_gamma: 2}
     for make, kind in expect.items():
         w = make()
