@@ -60,12 +60,15 @@ WinPlan plan_window(const sdpgpu_handle* h, int period, int64_t lo, int64_t hi) 
       const size_t smem = (size_t)4 * span * 16;
       if (smem > 64 * 1024) continue;
       const int64_t tasks = n_tiles * nch;
-      const int64_t rounds = (tasks + 1023) / 1024;  // tasks the busiest SIMD runs, one after the other
-      // fp64 issue rate one SIMD sustains with w resident waves (tools/valu_probe): 0.76 / 0.86 / 0.94 / 0.97
-      const int64_t w = std::min<int64_t>(rounds, c.occupancy);
-      const double eff = w >= 8 ? 0.97 : (w >= 4 ? 0.94 : (w >= 3 ? 0.90 : (w >= 2 ? 0.86 : 0.76)));
+      const int64_t q = (tasks + 1023) / 1024;  // tasks of the busiest SIMD
+      // A SIMD holds at most `occupancy` of them at a time and, with priority by progress, resident waves finish
+      // together: q tasks run as groups of `occupancy` plus a remainder group, a group of w tasks at the fp64 issue
+      // rate w resident waves sustain (per-wave stamps: 0.6 alone, 0.85 two, 0.91 three, 0.94 four, 0.97 eight).
+      auto eff = [](int64_t w) { return w >= 8 ? 0.97 : (w >= 4 ? 0.94 : (w >= 3 ? 0.91 : (w >= 2 ? 0.85 : 0.60))); };
+      const int64_t full = q / c.occupancy, rest = q % c.occupancy;
+      const double task_units = full * c.occupancy / eff(c.occupancy) + (rest ? rest / eff(rest) : 0.0);
       const double staging = 400.0 + 4.0 * span;
-      const double cost = (double)rounds * (bpc * block_cost + staging) / eff;
+      const double cost = task_units * (bpc * block_cost + staging);
       if (best_cost < 0 || cost < best_cost * 0.999) {
         best_cost = cost;
         best.R = r;
