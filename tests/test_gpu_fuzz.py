@@ -2,6 +2,8 @@
 PMF support), each solved by the automatically selected kernel, by the generic kernel and by the CPU oracle.
 All three must agree bit for bit (values) and exactly (policy indices); the north-star tolerance (1e-9 relative)
 is implied.  Sizes are kept small so that the whole file takes seconds."""
+import os
+
 import numpy as np
 import pytest
 
@@ -108,6 +110,8 @@ def make_instance(family, seed):
 @pytest.mark.parametrize("family", [1, 2, 3, 4, 5, 6])
 def test_random_instances_bit_exact(sia, oracle, family):
     n = 16 if family == 5 else 40
+    if os.environ.get("SDP_FUZZ_N"):  # soak run: SDP_FUZZ_N=500 python -m pytest tests/test_gpu_fuzz.py -m gpu
+        n = int(os.environ["SDP_FUZZ_N"]) // (3 if family == 5 else 1)
     kernels_seen = set()
     for seed in range(n):
         w = make_instance(family, seed)

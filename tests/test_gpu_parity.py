@@ -203,9 +203,21 @@ def test_sharded_periods_single_process(sia, oracle, make, world):
     """world_size N slabs driven from one process: each rank computes its slab into its own copy of
     V_t, the test plays the all-gather by hand.  Covers slab bounds, padding and the policy slabs
     (for F2 the slabs cut through preQ rows; for F1 through window tiles)."""
-    import ctypes as C
+    _run_sharded(sia, oracle, make(), world)
+
+
+@pytest.mark.parametrize("family", [1, 2, 3])
+def test_sharded_random_instances(sia, oracle, family):
+    """Seeded random instances (tests/test_gpu_fuzz.py) cut into 2..5 slabs: ragged slabs, empty slabs, slabs
+    smaller than a tile, key rows and value rows, split and whole periods."""
+    import test_gpu_fuzz as tf
+    for seed in range(12):
+        w = tf.make_instance(family, 100 + seed)
+        _run_sharded(sia, oracle, w, 2 + seed % 4)
+
+
+def _run_sharded(sia, oracle, w, world):
     import torch
-    w = make()
     engs = []
     for r in range(world):
         d = w.desc()
