@@ -114,25 +114,28 @@ __device__ inline bool c_better(bool maxdir, double v2, int k2, double v, int k)
   return maxdir ? (v2 > v || (v2 == v && k2 < k)) : (v2 < v || (v2 == v && k2 < k));
 }
 
-// One period: 256 threads = 16 consecutive states x 16 action slots; a lane walks its actions and, per action,
+// One period: 256 threads = SX consecutive states x 256/SX action slots (SX = 64, 16 or 4: small grids get more
+// action slots per state so that the launch still fills the chip); a lane walks its actions and, per action,
 // the demand index serially in the reference's order (Recursion.java:138-144).  q* != nullptr: evaluate the
 // given state tuples instead of grid states (getExpectedValue on an off-grid state).
-extern "C" __global__ __launch_bounds__(256) void sdp_custom_period(
-    CParams P, const double* __restrict__ v_next, double* __restrict__ v_cur, int* __restrict__ pol,
+template <int SX>
+__device__ inline void custom_period_body(
+    const CParams& P, const double* __restrict__ v_next, double* __restrict__ v_cur, int* __restrict__ pol,
     const double* __restrict__ pmf_d, const double* __restrict__ pmf_p, sdp_i64 lo, sdp_i64 hi,
     const double* __restrict__ qx, const double* __restrict__ qcash, const double* __restrict__ qpreq,
     unsigned long long* __restrict__ cells, int* __restrict__ err) {
+  constexpr int AS = 256 / SX;  // action slots
   extern __shared__ __attribute__((aligned(16))) char smem[];
   double2* s_pmf = reinterpret_cast<double2*>(smem);
   double* s_val = reinterpret_cast<double*>(smem + (size_t)P.n_demand * 16);
-  int* s_k = reinterpret_cast<int*>(s_val + 4 * 16);
+  int* s_k = reinterpret_cast<int*>(s_val + 4 * SX);
   const int tid = threadIdx.x;
   for (int j = tid; j < P.n_demand; j += 256) s_pmf[j] = make_double2(pmf_d[j], pmf_p[j]);
   __syncthreads();
 
-  const int sx = tid & 15;
-  const int as = tid >> 4;
-  const sdp_i64 idx = lo + (sdp_i64)blockIdx.x * 16 + sx;
+  const int sx = tid % SX;
+  const int as = tid / SX;
+  const sdp_i64 idx = lo + (sdp_i64)blockIdx.x * SX + sx;
   const bool live = idx < hi;
   CState s;
   if (qx) {
@@ -159,7 +162,7 @@ extern "C" __global__ __launch_bounds__(256) void sdp_custom_period(
   double best = P.maxdir ? -1.7976931348623157e308 : 1.7976931348623157e308;
   int bestk = 0;
   bool bad = false;
-  for (int k = as; k < nA; k += 16) {
+  for (int k = as; k < nA; k += AS) {
     const double a = (double)k * P.step;
     double acc = 0.0;
     for (int j = 0; j < nD; ++j) {
@@ -188,8 +191,9 @@ extern "C" __global__ __launch_bounds__(256) void sdp_custom_period(
     }
   }
   if (bad) atomicOr(err, 1);
-  // the four action slots of a state that live in this wave (lanes sx, sx+16, sx+32, sx+48)
-  for (int off = 16; off < 64; off <<= 1) {
+  // the action slots of a state that live in this wave (lanes sx, sx + SX, ...)
+#pragma unroll
+  for (int off = SX; off < 64; off <<= 1) {
     double ov = __shfl_xor(best, off, 64);
     int ok = __shfl_xor(bestk, off, 64);
     if (c_better(P.maxdir, ov, ok, best, bestk)) {
@@ -199,17 +203,17 @@ extern "C" __global__ __launch_bounds__(256) void sdp_custom_period(
   }
   const int wave = tid >> 6;
   const int lane = tid & 63;
-  if (lane < 16) {
-    s_val[wave * 16 + lane] = best;
-    s_k[wave * 16 + lane] = bestk;
+  if (lane < SX) {
+    s_val[wave * SX + lane] = best;
+    s_k[wave * SX + lane] = bestk;
   }
   __syncthreads();
-  if (tid < 16) {
+  if (tid < SX) {
     double bv = s_val[tid];
     int bk = s_k[tid];
     for (int w = 1; w < 4; ++w) {
-      double ov = s_val[w * 16 + tid];
-      int ok = s_k[w * 16 + tid];
+      double ov = s_val[w * SX + tid];
+      int ok = s_k[w * SX + tid];
       if (c_better(P.maxdir, ov, ok, bv, bk)) {
         bv = ov;
         bk = ok;
@@ -219,12 +223,25 @@ extern "C" __global__ __launch_bounds__(256) void sdp_custom_period(
       v_cur[idx] = bv;
       pol[idx] = bk;
     }
-    // cells of this workgroup = sum over its states of nA * D (tid < 16 holds as == 0: nA of state sx)
+    // cells of this workgroup = sum over its states of nA * D (tid < SX holds as == 0: nA of state sx)
     unsigned long long c = live ? (unsigned long long)nA * (unsigned long long)nD : 0ull;
-    for (int off = 8; off > 0; off >>= 1) c += __shfl_down(c, off, 64);
+#pragma unroll
+    for (int off = SX / 2; off > 0; off >>= 1) c += __shfl_down(c, off, 64);
     if (tid == 0 && cells) atomicAdd(cells, c);
   }
 }
+
+#define SDP_CUSTOM_PERIOD(SX)                                                                                        \
+  extern "C" __global__ __launch_bounds__(256) void sdp_custom_period_##SX(                                          \
+      CParams P, const double* __restrict__ v_next, double* __restrict__ v_cur, int* __restrict__ pol,               \
+      const double* __restrict__ pmf_d, const double* __restrict__ pmf_p, sdp_i64 lo, sdp_i64 hi,                    \
+      const double* __restrict__ qx, const double* __restrict__ qcash, const double* __restrict__ qpreq,             \
+      unsigned long long* __restrict__ cells, int* __restrict__ err) {                                               \
+    custom_period_body<SX>(P, v_next, v_cur, pol, pmf_d, pmf_p, lo, hi, qx, qcash, qpreq, cells, err);               \
+  }
+SDP_CUSTOM_PERIOD(64)
+SDP_CUSTOM_PERIOD(16)
+SDP_CUSTOM_PERIOD(4)
 
 // Forward reachable set (Recursion.java:90's key set): successors of every marked state over all feasible
 // actions and all demands; bankrupt successors of the survival loop are not visited.

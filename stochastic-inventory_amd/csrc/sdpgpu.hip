@@ -186,7 +186,9 @@ int allocate(sdpgpu_handle* h) {
   HIP_TRY(h, hipEventCreate(&h->ev_solve1));
   if (h->custom) {
     HIP_TRY(h, hipModuleLoadData(&h->custom_mod, h->custom_code.data()));
-    HIP_TRY(h, hipModuleGetFunction(&h->custom_period, h->custom_mod, "sdp_custom_period"));
+    HIP_TRY(h, hipModuleGetFunction(&h->custom_period[0], h->custom_mod, "sdp_custom_period_64"));
+    HIP_TRY(h, hipModuleGetFunction(&h->custom_period[1], h->custom_mod, "sdp_custom_period_16"));
+    HIP_TRY(h, hipModuleGetFunction(&h->custom_period[2], h->custom_mod, "sdp_custom_period_4"));
     HIP_TRY(h, hipModuleGetFunction(&h->custom_reach, h->custom_mod, "sdp_custom_reach"));
     HIP_TRY(h, hipMalloc((void**)&h->d_custom_params, std::max<size_t>(h->custom_params.size(), 1) * sizeof(double)));
     if (!h->custom_params.empty())

@@ -49,10 +49,15 @@ hipError_t launch_custom_period(sdpgpu_handle* h, int period, const double* v_ne
   }
   int* err = h->d_custom_err;
   void* args[] = {&C, &v_next, &v_cur, &pol, &pd, &pp, &llo, &lhi, &qx, &qcash, &qpreq, &cells, &err};
-  const int64_t blocks = (hi - lo + 15) / 16;
+  // enough workgroups to fill 256 CUs several times over: fewer states (more action slots) per workgroup on small grids
+  const int64_t n = hi - lo;
+  const int variant = n >= 64 * 2048 ? 0 : (n >= 16 * 1024 ? 1 : 2);
+  const int sx = variant == 0 ? 64 : (variant == 1 ? 16 : 4);
+  const int64_t blocks = (n + sx - 1) / sx;
   if (!grid_ok(blocks)) return hipErrorInvalidValue;
-  const size_t smem = (size_t)p.nD * 16 + 4 * 16 * (sizeof(double) + sizeof(int));
-  return hipModuleLaunchKernel(h->custom_period, (unsigned)blocks, 1, 1, 256, 1, 1, (unsigned)smem, h->stream, args, nullptr);
+  const size_t smem = (size_t)p.nD * 16 + (size_t)4 * sx * (sizeof(double) + sizeof(int));
+  return hipModuleLaunchKernel(h->custom_period[variant], (unsigned)blocks, 1, 1, 256, 1, 1, (unsigned)smem, h->stream, args,
+                               nullptr);
 }
 
 hipError_t launch_custom_reach(sdpgpu_handle* h, int period, const uint8_t* mcur, uint8_t* mnext, int64_t n,

@@ -111,7 +111,8 @@ struct sdpgpu_handle {
   std::vector<char> custom_code;
   std::vector<double> custom_params;
   hipModule_t custom_mod = nullptr;
-  hipFunction_t custom_period = nullptr, custom_reach = nullptr;
+  hipFunction_t custom_period[3] = {nullptr, nullptr, nullptr};  // 64 / 16 / 4 states per workgroup
+  hipFunction_t custom_reach = nullptr;
   double* d_custom_params = nullptr;
   unsigned long long* d_custom_cells = nullptr;  // [T]
   int* d_custom_err = nullptr;
