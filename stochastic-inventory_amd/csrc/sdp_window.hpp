@@ -453,10 +453,13 @@ __global__ __launch_bounds__(256) void window_f2_kernel(RowParams W, const doubl
         ring_v[(S - s) % S][r] = FUTURE ? rows[r * span + s] : 0.0;
       }
     }
-    for (int jb = 0; jb < W.d_pad; jb += S) {
+    // (four demand steps per trip -- d_pad is a multiple of 4, S divides 4 -- so that the loop control and the
+    // LDS address updates are paid once per four steps)
+    for (int jb = 0; jb < W.d_pad; jb += 4) {
 #pragma unroll
-      for (int u = 0; u < S; ++u) {
-        const int j = jb + u;
+      for (int t = 0; t < 4; ++t) {
+        const int u = t % S;
+        const int j = jb + t;
         const double p = pmf_p[j];
         const double mj = s_m[base - j];
 #pragma unroll
