@@ -129,4 +129,5 @@ def test_random_instances_bit_exact(sia, oracle, family):
                     gv, gp = eng.values(period), eng.policy(period)
                     assert np.array_equal(gp, pol[period - 1]), f"{w.name} kernel {kernel} t={period}: policy"
                     assert np.array_equal(gv, V[period - 1]), f"{w.name} kernel {kernel} t={period}: values"
-    assert 2 in kernels_seen or family == 0  # the specialised kernels took part
+    if not any(os.environ.get(k) == "0" for k in ("SDPGPU_CASH_ROW", "SDPGPU_CASH_SHIFT")):
+        assert 2 in kernels_seen  # the specialised kernels took part
