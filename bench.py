@@ -41,6 +41,9 @@ def parse_args():
     ap.add_argument("--backend", default="nccl", help="nccl (RCCL, default) | gloo (debug: N ranks on one GPU, host-staged)")
     ap.add_argument("--split", action="store_true", help="rehearsal: force the interior/boundary split of every period")
     ap.add_argument("--no-overlap", action="store_true", help="blocking all-gather between periods (no compute overlap)")
+    ap.add_argument("--schedule", default="auto",
+                    help="N > 1 exchange schedule: auto (time the candidates before the warm-up, keep the fastest) | overlap | "
+                         "blocking | blockedK (K periods per exchange on widened slabs, e.g. blocked4)")
     ap.add_argument("--check", action="store_true", help="compare the sharded result with a single-rank sweep (rank 0)")
     ap.add_argument("--cpu-seconds", type=float, default=15.0, help="target CPU time of the oracle sample")
     return ap.parse_args()
@@ -171,7 +174,6 @@ def main():
     backend = GpuSlabBackend(desc, w.pmf, w.overhead(), device=dev)
     solver = ShardedSolver(backend, stage_through_host=(args.backend == "gloo"))
     solver.force_split = args.split
-    overlap = not args.no_overlap
     eng = backend.engine
     T = w.T
 
@@ -180,36 +182,59 @@ def main():
             dist.barrier()
         torch.cuda.synchronize(dev)
 
+    # ---- exchange schedule (N > 1) ------------------------------------------------------------------------
+    # overlap:  all-gather of V_{t+1} beside the interior tiles of period t, boundary tiles after it
+    # blocking: kernel, all-gather, kernel, ...
+    # blockedK: K periods per exchange on slabs widened by the dependency footprint (redundant work, a K-th of the waits)
+    # Which one wins depends on how this node's all-gather latency compares with a period's compute (30 us at the
+    # configs[1] slab), so `auto` times every candidate (untimed, before the warm-up) and keeps the fastest; every
+    # rank takes the same decision (max over ranks of each timing).
+    def make_runner(name):
+        if name == "overlap":
+            return lambda: solver.solve(overlap=True)
+        if name == "blocking":
+            return lambda: solver.solve(overlap=False)
+        k = int(name[len("blocked"):])
+        return lambda: solver.solve_blocked(k)
+
+    sched_name = args.schedule
+    if args.no_overlap:
+        sched_name = "blocking"
+    if world == 1 or args.split:
+        sched_name = "overlap" if not args.no_overlap else "blocking"
+    blocked_ok = world > 1 and not args.split and solver.prepare_blocked(8)  # sizes the scratch rows for K <= 8
+    if sched_name.startswith("blocked") and not blocked_ok:
+        raise SystemExit("this workload has no bounded dependency footprint: no blocked schedule")
     schedule = "single rank"
-    if world > 1:
-        schedule = "blocking all-gather" if args.no_overlap else "all-gather overlapped with the interior tiles"
-    if world > 1 and not args.no_overlap and not args.split and (args.backend == "nccl" or os.environ.get("SDP_BENCH_CALIBRATE")):
-        # Which schedule is faster depends on how the all-gather latency of THIS node compares with a period's
-        # compute (30 us at the configs[1] slab): the overlapped one pays two cross-stream waits per period, the
-        # blocking one pays the collective's latency.  Measure both (untimed, before the warm-up) and keep the
-        # faster; every rank takes the same decision (max over ranks of each timing).
-        timing = []
-        for mode in (True, False):
-            solver.solve(overlap=mode)
+    if world > 1 and sched_name == "auto":
+        candidates = ["overlap", "blocking"] + (["blocked2", "blocked4", "blocked8"] if blocked_ok else [])
+        if not (args.backend == "nccl" or os.environ.get("SDP_BENCH_CALIBRATE")):
+            candidates = ["overlap"]
+        timing = {}
+        for name in candidates:
+            run_c = make_runner(name)
+            run_c()
             barrier()
             t0c = time.perf_counter()
-            solver.solve(overlap=mode)
-            solver.solve(overlap=mode)
+            run_c()
+            run_c()
             barrier()
             tc = torch.tensor([time.perf_counter() - t0c], dtype=torch.float64, device=dev)
             dist.all_reduce(tc, op=dist.ReduceOp.MAX)
-            timing.append(float(tc.item()))
-        overlap = timing[0] <= timing[1]
-        schedule = ("all-gather overlapped with the interior tiles" if overlap else "blocking all-gather") + \
-                   f" (calibrated: {timing[0] / 2 * 1e3:.3f} ms overlapped vs {timing[1] / 2 * 1e3:.3f} ms blocking per sweep)"
+            timing[name] = float(tc.item()) / 2
+        sched_name = min(timing, key=timing.get)
+        schedule = sched_name + " (calibrated, ms per sweep: " + ", ".join(f"{k} {v * 1e3:.3f}" for k, v in timing.items()) + ")"
+    elif world > 1:
+        schedule = sched_name
+    run_sweep = make_runner(sched_name)
     for _ in range(args.warmup):
-        solver.solve(overlap=overlap)
+        run_sweep()
     barrier()
     ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]
     t0 = time.perf_counter()
     for k in range(args.steps):
         ev[k][0].record()
-        solver.solve(overlap=overlap)
+        run_sweep()
         ev[k][1].record()
     barrier()
     elapsed = time.perf_counter() - t0
@@ -230,7 +255,7 @@ def main():
 
     # per-kernel event times in a separate, un-timed pass (cross-check for the rocprofv3 summary)
     eng.set_profiling(True)
-    solver.solve(overlap=overlap)
+    run_sweep()
     torch.cuda.synchronize(dev)
     per_kernel = [eng.period_ms(p) for p in range(1, T + 1)]
     eng.set_profiling(False)

@@ -285,6 +285,16 @@ int sdpgpu_run_period(sdpgpu_handle* h, int32_t period);
 #define SDPGPU_PART_INTERIOR 1
 #define SDPGPU_PART_BOUNDARY 2
 int sdpgpu_run_period_part(sdpgpu_handle* h, int32_t period, int32_t part);
+/* Fewer exchanges on small slabs: the backorder family on the window kernel reads a BOUNDED neighbourhood of
+ * V_{period+1} -- state i needs [i - left, i + right] (sdpgpu_footprint; SDPGPU_ERR_UNSUPPORTED when the family has
+ * no such bound).  A sharded caller can therefore run K periods between two exchanges by computing period t on its
+ * slab widened by the footprints of the periods still to come in the block (sdpgpu_run_period_range; the widening is
+ * redundant work that reproduces the neighbours' values bit for bit), and all-gather only to publish the rows.
+ * sdpgpu_set_halo (before the first run) announces the largest widening so that the scratch rows are sized for
+ * it.  Values are written for the whole range, policy indices only for this rank's own slab. */
+int sdpgpu_footprint(const sdpgpu_handle* h, int32_t period, int64_t* left, int64_t* right);
+int sdpgpu_set_halo(sdpgpu_handle* h, int64_t halo);
+int sdpgpu_run_period_range(sdpgpu_handle* h, int32_t period, int64_t lo, int64_t hi);
 /* Device address of the V_period table (padded row, fp64) -- for the in-place all-gather. */
 void* sdpgpu_values_device_ptr(sdpgpu_handle* h, int32_t period);
 /* Use caller-owned device memory for the value tables: `bytes` >= sdpgpu_values_bytes(h). */

@@ -161,6 +161,9 @@ EXPORTS = {
     "sdpgpu_solve": (C.c_int, [_P, C.c_int32]),
     "sdpgpu_run_period": (C.c_int, [_P, C.c_int32]),
     "sdpgpu_run_period_part": (C.c_int, [_P, C.c_int32, C.c_int32]),
+    "sdpgpu_footprint": (C.c_int, [_P, C.c_int32, _LP, _LP]),
+    "sdpgpu_set_halo": (C.c_int, [_P, C.c_int64]),
+    "sdpgpu_run_period_range": (C.c_int, [_P, C.c_int32, C.c_int64, C.c_int64]),
     "sdpgpu_values_device_ptr": (_P, [_P, C.c_int32]),
     "sdpgpu_values_bytes": (C.c_size_t, [_P]),
     "sdpgpu_attach_values": (C.c_int, [_P, _P, C.c_size_t]),

@@ -47,6 +47,7 @@ struct WinParams {
   int32_t maxdir;         // OptDirection.MAX
   int32_t pad0;
   int64_t partial_stride; // elements between chunk rows of the partial tables
+  int64_t pol_lo, pol_hi; // states whose action index may be stored (all of them when the rows are chunk rows)
 };
 
 // Order-preserving map double -> uint64 (and back): lets a 64-bit atomic min/max reduce fp64 values
@@ -279,7 +280,7 @@ __global__ __launch_bounds__(256) void window_f1_kernel(WinParams W, const doubl
     if (idx < hi) {
       const int64_t o = (int64_t)chunk * W.partial_stride + idx;
       out_val[o] = best[u];
-      out_idx[o] = bestk[u];
+      if (idx >= W.pol_lo && idx < W.pol_hi) out_idx[o] = bestk[u];
       if (W.n_chunks > 1) {
         if (MAXDIR)
           atomicMax(k_cur + idx, f64_key(best[u]));

@@ -281,7 +281,10 @@ void count_cells(sdpgpu_handle* h, int period) {
 
 // part: SDPGPU_PART_ALL, or the two halves a sharded caller overlaps with the all-gather of V_{t+1}:
 // INTERIOR = the states whose cells read only THIS rank's slab of V_{t+1}, BOUNDARY = the rest.
-int run_period_impl(sdpgpu_handle* h, int period, int part = SDPGPU_PART_ALL) {
+// range_lo/range_hi >= 0: sdpgpu_run_period_range -- the states [range_lo, range_hi) instead of this rank's slab
+// (F1 window kernel only: the one family whose dependency footprint is bounded).
+int run_period_impl(sdpgpu_handle* h, int period, int part = SDPGPU_PART_ALL, int64_t range_lo = -1,
+                    int64_t range_hi = -1) {
   int rc = allocate(h);
   if (rc) return rc;
   if (period < 1 || period > h->T) return fail(h, SDPGPU_ERR_ARG, "period %d out of 1..%d", period, h->T);
@@ -302,6 +305,16 @@ int run_period_impl(sdpgpu_handle* h, int period, int part = SDPGPU_PART_ALL) {
       HIP_TRY(h, hipEventCreate(&p.ev1));
     }
     HIP_TRY(h, hipEventRecord(p.ev0, h->stream));
+  }
+  const bool ranged = range_lo >= 0;
+  if (ranged) {
+    const bool f1_window = !h->custom && h->d.family == SDPGPU_FAMILY_BACKORDER &&
+                           (h->d.kernel == SDPGPU_KERNEL_AUTO || h->d.kernel == SDPGPU_KERNEL_WINDOW) &&
+                           window_eligible(h, period);
+    if (!f1_window) return fail(h, SDPGPU_ERR_UNSUPPORTED, "run_period_range: only the backorder family on the window kernel has a bounded footprint");
+    if (range_lo > range_hi || range_hi > p.S || range_lo < p.lo - h->halo || range_hi > p.hi + h->halo)
+      return fail(h, SDPGPU_ERR_ARG, "run_period_range: [%lld, %lld) leaves the slab [%lld, %lld) widened by the halo %lld",
+                  (long long)range_lo, (long long)range_hi, (long long)p.lo, (long long)p.hi, (long long)h->halo);
   }
   if (h->custom) {
     if (part == SDPGPU_PART_INTERIOR) return SDPGPU_OK;  // no bounded footprint is known for user lambdas
@@ -354,7 +367,8 @@ int run_period_impl(sdpgpu_handle* h, int period, int part = SDPGPU_PART_ALL) {
   }
   hipError_t e;
   if (use_window) {
-    e = launch_window(h, P, period, v_next, v_cur, pol, pd, h->d_pmf + p.pmf_win_off, p.lo, p.hi, h->stream, part);
+    e = launch_window(h, P, period, v_next, v_cur, pol, pd, h->d_pmf + p.pmf_win_off, ranged ? range_lo : p.lo,
+                      ranged ? range_hi : p.hi, h->stream, part);
     p.kernel_used = SDPGPU_KERNEL_WINDOW;
   } else if (h->d.kernel != SDPGPU_KERNEL_GATHER && h->use_cash_shift && cash_shift_eligible(h, period)) {
     e = flush_pending(h);
@@ -715,6 +729,56 @@ int sdpgpu_run_period(sdpgpu_handle* h, int32_t period) {
   } catch (...) {
     return fail(h, SDPGPU_ERR_ARG, "unknown exception");
   }
+}
+
+int sdpgpu_run_period_range(sdpgpu_handle* h, int32_t period, int64_t lo, int64_t hi) {
+  if (!h) return SDPGPU_ERR_ARG;
+  h->err.clear();
+  if (lo < 0 || hi < lo) return fail(h, SDPGPU_ERR_ARG, "run_period_range: bad range");
+  try {
+    int rc = run_period_impl(h, period, SDPGPU_PART_ALL, lo, hi);
+    if (rc == SDPGPU_OK) count_cells(h, period);  // (cells of the rank's own slab: the widening is redundant work)
+    return rc;
+  } catch (const std::exception& e) {
+    return fail(h, SDPGPU_ERR_ARG, "exception: %s", e.what());
+  } catch (...) {
+    return fail(h, SDPGPU_ERR_ARG, "unknown exception");
+  }
+}
+
+int sdpgpu_set_halo(sdpgpu_handle* h, int64_t halo) {
+  if (!h) return SDPGPU_ERR_ARG;
+  h->err.clear();
+  if (halo < 0) return fail(h, SDPGPU_ERR_ARG, "set_halo: negative halo");
+  if (h->d_chunk_val || h->allocated) return fail(h, SDPGPU_ERR_STATE, "set_halo must precede the first run");
+  h->halo = halo;
+  return SDPGPU_OK;
+}
+
+int sdpgpu_footprint(const sdpgpu_handle* hc, int32_t period, int64_t* left, int64_t* right) {
+  sdpgpu_handle* h = const_cast<sdpgpu_handle*>(hc);
+  if (!h) return SDPGPU_ERR_ARG;
+  h->err.clear();
+  if (period < 1 || period > h->T) return fail(h, SDPGPU_ERR_ARG, "footprint: period %d", period);
+  int rc = layout(h);
+  if (rc) return rc;
+  // (clamped grids only: with per-period boxes the slabs of consecutive periods are different index ranges and a
+  // widened slab is not simply "the same slab plus a margin")
+  if (h->custom || h->d.family != SDPGPU_FAMILY_BACKORDER || !h->d.clamp_inventory || h->d.kernel == SDPGPU_KERNEL_GATHER ||
+      h->d.kernel == SDPGPU_KERNEL_SEPARABLE || !window_eligible(h, period))
+    return fail(h, SDPGPU_ERR_UNSUPPORTED, "footprint: unbounded (only the backorder family on the window kernel reads a bounded neighbourhood)");
+  int64_t l = 0, r = 0;
+  if (period < h->T) {
+    // state i of period t reads V_{t+1}[i + idx_off - (D - 1) ... i + idx_off + A - 1] (then clamped to the grid)
+    const PeriodInfo& p = h->per[period - 1];
+    const double lev0 = p.g.x_lo - h->pmf_d[period - 1][0];
+    const int64_t idx_off = (int64_t)((lev0 - h->per[period].g.x_lo) / h->d.step);
+    l = std::max<int64_t>(0, (int64_t)p.nD_win - 1 - idx_off);
+    r = std::max<int64_t>(0, (int64_t)h->n_actions_full - 1 + idx_off);
+  }
+  if (left) *left = l;
+  if (right) *right = r;
+  return SDPGPU_OK;
 }
 
 int sdpgpu_run_period_part(sdpgpu_handle* h, int32_t period, int32_t part) {

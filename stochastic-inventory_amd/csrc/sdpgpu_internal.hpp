@@ -116,6 +116,9 @@ struct sdpgpu_handle {
   double* d_custom_params = nullptr;
   unsigned long long* d_custom_cells = nullptr;  // [T]
   int* d_custom_err = nullptr;
+  // sdpgpu_set_halo: a sharded caller may run a period on its slab widened by up to `halo` states on either side
+  // (sdpgpu_run_period_range); the chunk-row arenas are sized for that
+  int64_t halo = 0;
   std::string err;
   int device = -1;
 };
@@ -209,6 +212,9 @@ hipError_t flush_pending(sdpgpu_handle* h);
 bool window_interior_tiles(const sdpgpu_handle* h, int period, int64_t lo, int64_t hi, int* first, int* count);
 hipError_t launch_separable(sdpgpu_handle* h, const DevParams& P, int period, const double* v_next, double* v_cur,
                             int32_t* pol, const double* pd, const double* pp, bool* too_big);
+// geometry of a period's chunk rows: element stride between chunks and the state index of element 0
+inline int64_t chunk_row_cap(const sdpgpu_handle* h, const PeriodInfo& p) { return (p.hi - p.lo) + 2 * h->halo; }
+inline int64_t chunk_row_lo(const sdpgpu_handle* h, const PeriodInfo& p) { return p.lo - h->halo; }
 hipError_t launch_window(sdpgpu_handle* h, const DevParams& P, int period, const double* v_next, double* v_cur,
                          int32_t* pol, const double* pmf_d, const double* pmf_p, int64_t lo, int64_t hi, hipStream_t st,
                          int part);

@@ -121,11 +121,11 @@ hipError_t flush_pending(sdpgpu_handle* h) {
     const PeriodInfo& p = h->per[t];
     sdp::FinalizeJob J{};
     J.keys = h->d_keys + (size_t)t * h->key_stride;
-    J.part_val = h->d_chunk_val + h->chunk_off[t] - p.lo;
-    J.part_idx = h->d_chunk_idx + h->chunk_off[t] - p.lo;
+    J.part_val = h->d_chunk_val + h->chunk_off[t] - chunk_row_lo(h, p);
+    J.part_idx = h->d_chunk_idx + h->chunk_off[t] - chunk_row_lo(h, p);
     J.v_out = h->d_values + p.v_off;
     J.pol_out = h->d_policy + p.pol_off - p.lo;
-    J.stride = p.hi - p.lo;
+    J.stride = chunk_row_cap(h, p);
     J.lo = p.lo;
     J.hi = p.hi;
     // V_t is decoded over the whole row (after the all-gather every rank holds all keys), the policy
@@ -325,7 +325,7 @@ hipError_t launch_window(sdpgpu_handle* h, const DevParams& P, int period, const
         const PeriodInfo& q = h->per[t];
         h->chunk_off[t] = total;
         if (window_eligible(h, t + 1))
-          total += (size_t)plan_window(h, t + 1, q.lo, q.hi).n_chunks * (size_t)std::max<int64_t>(q.hi - q.lo, 0);
+          total += (size_t)plan_window(h, t + 1, q.lo, q.hi).n_chunks * (size_t)std::max<int64_t>(chunk_row_cap(h, q), 0);
       }
       e = hipMalloc((void**)&h->d_chunk_val, std::max<size_t>(total, 1) * sizeof(double));
       if (e == hipSuccess) e = hipMalloc((void**)&h->d_chunk_idx, std::max<size_t>(total, 1) * sizeof(int32_t));
@@ -407,12 +407,16 @@ hipError_t launch_window(sdpgpu_handle* h, const DevParams& P, int period, const
   }
   double* out_val = v_cur;
   int32_t* out_idx = pol;
+  // one task per tile: the action index goes straight into the policy slab, which holds this rank's states only
+  // (a widened range, sdpgpu_run_period_range, also computes neighbours' states: their values, not their policy)
+  W.pol_lo = chunked ? INT64_MIN : p.lo;
+  W.pol_hi = chunked ? INT64_MAX : p.hi;
   unsigned long long* k_cur = nullptr;
   const unsigned long long* k_next = keyed_in ? h->d_keys + (size_t)period * h->key_stride : nullptr;
   if (chunked) {
-    W.partial_stride = hi - lo;
-    out_val = h->d_chunk_val + h->chunk_off[period - 1] - lo;  // the kernel indexes rows by flat state index
-    out_idx = h->d_chunk_idx + h->chunk_off[period - 1] - lo;
+    W.partial_stride = chunk_row_cap(h, p);
+    out_val = h->d_chunk_val + h->chunk_off[period - 1] - chunk_row_lo(h, p);  // the kernel indexes rows by flat state index
+    out_idx = h->d_chunk_idx + h->chunk_off[period - 1] - chunk_row_lo(h, p);
     k_cur = h->d_keys + (size_t)(period - 1) * h->key_stride;
   }
   if (W.n_tasks > 0 && !grid_ok((W.n_tasks + 3) / 4)) return hipErrorInvalidValue;

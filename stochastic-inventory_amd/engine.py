@@ -147,6 +147,21 @@ class SdpEngine:
         """Enqueue the deferred read-out of every period run so far (no host wait)."""
         self._check(self._lib.sdpgpu_finalize(self._h))
 
+    def footprint(self, period: int):
+        """(left, right): state i of `period` reads V_{period+1}[i - left .. i + right]; None if unbounded."""
+        l, r = C.c_int64(), C.c_int64()
+        rc = self._lib.sdpgpu_footprint(self._h, period, C.byref(l), C.byref(r))
+        if rc == 4:
+            return None
+        self._check(rc)
+        return l.value, r.value
+
+    def set_halo(self, halo: int):
+        self._check(self._lib.sdpgpu_set_halo(self._h, int(halo)))
+
+    def run_period_range(self, period: int, lo: int, hi: int):
+        self._check(self._lib.sdpgpu_run_period_range(self._h, period, int(lo), int(hi)))
+
     def run_period_part(self, period: int, part: int):
         self._check(self._lib.sdpgpu_run_period_part(self._h, period, part))
 

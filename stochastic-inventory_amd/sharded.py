@@ -49,6 +49,21 @@ class SlabBackend:
         if part == 2:
             self.run_period(period)
 
+    # -- fewer exchanges (ShardedSolver.solve_blocked) -- optional ----------------------------------------
+    def footprint(self, period: int):
+        """(left, right): state i of `period` reads V_{period+1}[i - left .. i + right]; None = unbounded."""
+        return None
+
+    def num_states(self, period: int) -> int:
+        raise NotImplementedError
+
+    def set_halo(self, halo: int) -> None:
+        pass
+
+    def run_period_range(self, period: int, lo: int, hi: int) -> None:
+        """Compute the states [lo, hi) of `period` (a widened slab) into table(period)."""
+        raise NotImplementedError
+
 
 class GpuSlabBackend(SlabBackend):
     """SdpEngine on one GPU with its value arena held in a torch tensor (so RCCL can address it)."""
@@ -95,6 +110,18 @@ class GpuSlabBackend(SlabBackend):
 
     def run_period_part(self, period: int, part: int) -> None:
         self.engine.run_period_part(period, part)
+
+    def footprint(self, period: int):
+        return self.engine.footprint(period)
+
+    def num_states(self, period: int) -> int:
+        return self.engine.num_states(period)
+
+    def set_halo(self, halo: int) -> None:
+        self.engine.set_halo(halo)
+
+    def run_period_range(self, period: int, lo: int, hi: int) -> None:
+        self.engine.run_period_range(period, lo, hi)
 
     def close(self):
         self.engine.close()
@@ -156,6 +183,70 @@ class ShardedSolver:
         if in_flight is not None and in_flight is not True:
             in_flight.wait()
         self.backend.finalize()  # the sweep is done when every policy row exists
+
+    # -- K periods per exchange ---------------------------------------------------------------------------
+    def plan_blocks(self, K: int, first_period: int = 1):
+        """Blocks of at most K periods (descending) and, per period, how far the slab must be widened so that the
+        last period of its block comes out right on the slab itself: period t of a block [t_lo .. t_hi] needs
+        sum(left(tau)), sum(right(tau)) over tau = t_lo .. t-1.  None when some period has no bounded footprint."""
+        T = self.backend.T
+        fp = {}
+        for t in range(first_period, T + 1):
+            f = self.backend.footprint(t)
+            if f is None:
+                return None
+            fp[t] = f
+        blocks, halo = [], 0
+        t_hi = T
+        while t_hi >= first_period:
+            t_lo = max(first_period, t_hi - K + 1)
+            ext = {}
+            for t in range(t_lo, t_hi + 1):
+                ext[t] = (sum(fp[u][0] for u in range(t_lo, t)), sum(fp[u][1] for u in range(t_lo, t)))
+                halo = max(halo, *ext[t])
+            blocks.append((t_hi, t_lo, ext))
+            t_hi = t_lo - 1
+        return blocks, halo
+
+    def prepare_blocked(self, K: int, first_period: int = 1) -> bool:
+        """Call once, before the first run: sizes the backend's scratch for the widened slabs of solve_blocked(K)."""
+        plan = self.plan_blocks(K, first_period)
+        if plan is None:
+            return False
+        self.backend.set_halo(plan[1])
+        return True
+
+    def solve_blocked(self, K: int, first_period: int = 1) -> None:
+        """The compute stream waits for an exchange only once per K periods.  Inside a block every period is
+        computed on the slab widened by the footprints of the periods still to come (redundant work that
+        reproduces the neighbours' values bit for bit); its row is published by an all-gather that nobody waits
+        for until the block ends -- the collective overwrites the widened part with identical bytes."""
+        plan = self.plan_blocks(K, first_period)
+        if plan is None:
+            raise RuntimeError("solve_blocked needs a bounded dependency footprint in every period")
+        blocks, _ = plan
+        pending = []
+        boundary = None
+        for t_hi, t_lo, ext in blocks:
+            if boundary is not None:
+                boundary.wait()  # the full row of period t_hi + 1
+            for period in range(t_hi, t_lo - 1, -1):
+                _, lo, hi = self.backend.slab(period)
+                S = self.backend.num_states(period)
+                left, right = ext[period]
+                a, b = max(0, lo - left), min(S, hi + right)
+                if hi > lo:
+                    self.backend.run_period_range(period, a, b)
+                else:  # an empty slab still keeps its bookkeeping in step with the other ranks
+                    self.backend.run_period_range(period, min(lo, S), min(lo, S))
+                work = self.exchange(period, async_op=True) if period > first_period else None
+                if work is not None:
+                    pending.append(work)
+                if period == t_lo:
+                    boundary = work
+        for work in pending:
+            work.wait()
+        self.backend.finalize()
 
     def gather_policy(self, period: int, local: torch.Tensor) -> Optional[List[torch.Tensor]]:
         """Collect the per-rank policy slabs on rank 0 (host-side read-out, not on the hot path)."""

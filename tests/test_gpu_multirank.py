@@ -15,9 +15,12 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 @pytest.mark.parametrize("extra", [["--periods", "6"], ["--workload", "cfg5", "--states", "100000", "--periods", "3"],
                                    ["--periods", "6", "--split"],
                                    ["--workload", "cfg5", "--states", "100000", "--periods", "3", "--split"],
-                                   ["--periods", "6", "CALIBRATE"]],
+                                   ["--periods", "6", "CALIBRATE"],
+                                   ["--periods", "7", "--schedule", "blocked3"],
+                                   ["--workload", "cfg5", "--states", "100000", "--periods", "4", "--schedule", "blocked2"]],
                          ids=["cfg2_small_slabs_key_rows", "f1_large_slabs", "cfg2_interior_boundary_split",
-                              "f1_large_interior_boundary_split", "cfg2_schedule_calibration"])
+                              "f1_large_interior_boundary_split", "cfg2_schedule_calibration",
+                              "cfg2_three_periods_per_exchange", "f1_large_two_periods_per_exchange"])
 def test_two_ranks_match_single_rank(extra):
     env = dict(os.environ)
     if "CALIBRATE" in extra:  # the N > 1 schedule calibration bench.py runs under RCCL, rehearsed over gloo

@@ -16,7 +16,7 @@ sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "tests"))
 
 
-def _worker(rank, world, port, case_name, out_dir):
+def _worker(rank, world, port, case_name, out_dir, blocked_k=0):
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
@@ -56,9 +56,56 @@ def _worker(rank, world, port, case_name, out_dir):
             self.tables[period][lo:hi] = torch.from_numpy(v[lo:hi])
             self.policy[period] = pol[lo:hi].copy()
 
+        # -- the widened-slab interface of solve_blocked --
+        def footprint(self, period):
+            return geom.footprint(period)
+
+        def num_states(self, period):
+            return geom.num_states(period)
+
+        def set_halo(self, halo):
+            self.halo = halo
+
+        def run_period_range(self, period, a, b):
+            pad, lo, hi = geom.slab(period)
+            assert lo - self.halo <= a <= b <= hi + self.halo or a == b
+            S = geom.num_states(period)
+            v_next = self.tables[period + 1][:geom.num_states(period + 1)].numpy() if period < w.T else None
+            v = np.full(S, np.nan)
+            pol = np.zeros(S, dtype=np.int32)
+            if b > a:
+                P.period(period, v_next, a, b, 1, v, pol)  # a NaN it reads (an un-gathered slab) poisons the result
+                assert not np.isnan(v[a:b]).any(), "the widened slab read a part of V_{t+1} that was never valid here"
+                self.tables[period][a:b] = torch.from_numpy(v[a:b])
+            self.policy[period] = pol[lo:hi].copy()
+
+    class LateWork:
+        """An exchange that happens as late as the schedule allows: at wait()."""
+
+        def __init__(self, fn):
+            self.fn, self.done = fn, False
+
+        def wait(self):
+            if not self.done:
+                self.fn()
+                self.done = True
+
+    class LateSolver(ShardedSolver):
+        """Worst case for solve_blocked: every all-gather completes only when somebody waits for it, so a period
+        that read a row before its block boundary was waited for would read NaNs."""
+
+        def exchange(self, period, async_op=False):
+            if not async_op:
+                return super().exchange(period)
+            return LateWork(lambda: ShardedSolver.exchange(self, period))
+
     be = OracleSlab()
-    solver = ShardedSolver(be)
-    solver.solve()
+    solver = LateSolver(be) if blocked_k else ShardedSolver(be)
+    if blocked_k:
+        assert solver.prepare_blocked(blocked_k)
+        solver.solve_blocked(blocked_k)
+    else:
+        solver.solve()
     # V_1 is not exchanged by solve(); gather it here only to compare the whole table
     solver.exchange(1)
     np.savez(os.path.join(out_dir, f"rank{rank}.npz"),
@@ -80,4 +127,22 @@ def test_sharded_solver_gloo(tmp_path, oracle, world, case_name):
         S = len(V[p - 1])
         for r in range(world):
             assert np.array_equal(ranks[r][f"v{p}"][:S], V[p - 1]), (p, r)  # every rank holds the full table
+        assert np.array_equal(np.concatenate([ranks[r][f"p{p}"] for r in range(world)]), pol[p - 1])
+
+
+@pytest.mark.parametrize("world,case_name,k", [(2, "f1_small", 2), (3, "f1_small", 3), (3, "f1_clsp_main", 2),
+                                               (4, "f1_clsp_main", 4), (2, "f1_gapped", 3)])
+def test_blocked_schedule_gloo(tmp_path, oracle, world, case_name, k):
+    """K periods per exchange (ShardedSolver.solve_blocked): every period of a block runs on a widened slab, the
+    all-gathers only publish rows.  Same tables as the oracle's single sweep on every rank."""
+    import cases
+    port = 29500 + (os.getpid() % 2000) + 10 * world + k
+    mp.spawn(_worker, args=(world, port, case_name, str(tmp_path), k), nprocs=world, join=True)
+    w = getattr(cases, case_name)()
+    V, pol, _ = oracle.Problem(w.desc(), w.pmf, w.overhead()).solve()
+    ranks = [np.load(os.path.join(str(tmp_path), f"rank{r}.npz")) for r in range(world)]
+    for p in range(1, w.T + 1):
+        S = len(V[p - 1])
+        for r in range(world):
+            assert np.array_equal(ranks[r][f"v{p}"][:S], V[p - 1]), (p, r)
         assert np.array_equal(np.concatenate([ranks[r][f"p{p}"] for r in range(world)]), pol[p - 1])
