@@ -102,6 +102,24 @@ class GpuSlabBackend(SlabBackend):
                 raise RuntimeError("exchange row is not inside an arena this backend owns")
         return self._views[period]
 
+    def table_block(self, p_lo: int, p_hi: int) -> Optional[torch.Tensor]:
+        """The exchange rows of the consecutive periods p_lo..p_hi as ONE strided [rows, padded] view, when they
+        lie in one arena at a constant distance (they do: the arenas are [period][padded row])."""
+        rows = [self.table(p) for p in range(p_lo, p_hi + 1)]
+        if len(rows) < 2:
+            return rows[0].unsqueeze(0)
+        pad = rows[0].numel()
+        step = (rows[1].data_ptr() - rows[0].data_ptr()) // 8
+        if step < pad or any(r.numel() != pad or r.dtype != rows[0].dtype for r in rows) or \
+                any(rows[i + 1].data_ptr() - rows[i].data_ptr() != step * 8 for i in range(len(rows) - 1)):
+            return None
+        for arena in (self.arena, self.key_arena):
+            if arena is not None and arena.dtype == rows[0].dtype and \
+                    arena.data_ptr() <= rows[0].data_ptr() and rows[-1].data_ptr() + pad * 8 <= arena.data_ptr() + arena.numel() * 8:
+                base = (rows[0].data_ptr() - arena.data_ptr()) // 8
+                return arena.as_strided((len(rows), pad), (step, 1), base)
+        return None
+
     def run_period(self, period: int) -> None:
         self.engine.run_period(period)
 
@@ -216,36 +234,74 @@ class ShardedSolver:
         self.backend.set_halo(plan[1])
         return True
 
+    def exchange_many(self, p_lo: int, p_hi: int):
+        """Publish the rows of the consecutive periods p_lo..p_hi with ONE collective (a sweep of 30 us periods is
+        otherwise bound by the host cost of issuing one collective per period).  Returns a completion callable:
+        it makes the current stream wait for the collective and scatters the result into the rows."""
+        if p_hi < p_lo:
+            return None
+        block = self.backend.table_block(p_lo, p_hi) if hasattr(self.backend, "table_block") else None
+        if self.world == 1 and not self.force_exchange:
+            return None
+        if block is None or self.stage_through_host or block.shape[0] == 1:
+            works = [self.exchange(p, async_op=True) for p in range(p_hi, p_lo - 1, -1)]
+            return lambda: [wk.wait() for wk in works if wk is not None]
+        rows, pad = block.shape
+        n = pad // self.world
+        self.gathered_bytes += rows * pad * 8
+        inp = block[:, self.rank * n: (self.rank + 1) * n].contiguous()
+        out = torch.empty((self.world, rows, n), dtype=block.dtype, device=block.device)
+        work = dist.all_gather_into_tensor(out, inp, group=self.group, async_op=True)
+
+        def complete():
+            work.wait()
+            block.view(rows, self.world, n).copy_(out.permute(1, 0, 2))
+        return complete
+
+    def _blocked_program(self, K: int, first_period: int):
+        key = (K, first_period)
+        if getattr(self, "_programs", None) is None:
+            self._programs = {}
+        if key not in self._programs:
+            plan = self.plan_blocks(K, first_period)
+            if plan is None:
+                raise RuntimeError("solve_blocked needs a bounded dependency footprint in every period")
+            prog = []
+            for t_hi, t_lo, ext in plan[0]:
+                runs = []
+                for period in range(t_hi, t_lo - 1, -1):
+                    _, lo, hi = self.backend.slab(period)
+                    S = self.backend.num_states(period)
+                    left, right = ext[period]
+                    if hi > lo:
+                        runs.append((period, max(0, lo - left), min(S, hi + right)))
+                    else:  # an empty slab still keeps its bookkeeping in step with the other ranks
+                        runs.append((period, min(lo, S), min(lo, S)))
+                prog.append((t_hi, t_lo, runs))
+            self._programs[key] = prog
+        return self._programs[key]
+
     def solve_blocked(self, K: int, first_period: int = 1) -> None:
         """The compute stream waits for an exchange only once per K periods.  Inside a block every period is
         computed on the slab widened by the footprints of the periods still to come (redundant work that
-        reproduces the neighbours' values bit for bit); its row is published by an all-gather that nobody waits
-        for until the block ends -- the collective overwrites the widened part with identical bytes."""
-        plan = self.plan_blocks(K, first_period)
-        if plan is None:
-            raise RuntimeError("solve_blocked needs a bounded dependency footprint in every period")
-        blocks, _ = plan
+        reproduces the neighbours' values bit for bit).  Per block two collectives publish the rows: the block's
+        last row in place (the next block waits for that one), the others batched (nobody waits until the sweep
+        ends) -- a collective overwrites the widened part with identical bytes."""
         pending = []
         boundary = None
-        for t_hi, t_lo, ext in blocks:
+        for t_hi, t_lo, runs in self._blocked_program(K, first_period):
             if boundary is not None:
                 boundary.wait()  # the full row of period t_hi + 1
-            for period in range(t_hi, t_lo - 1, -1):
-                _, lo, hi = self.backend.slab(period)
-                S = self.backend.num_states(period)
-                left, right = ext[period]
-                a, b = max(0, lo - left), min(S, hi + right)
-                if hi > lo:
-                    self.backend.run_period_range(period, a, b)
-                else:  # an empty slab still keeps its bookkeeping in step with the other ranks
-                    self.backend.run_period_range(period, min(lo, S), min(lo, S))
-                work = self.exchange(period, async_op=True) if period > first_period else None
-                if work is not None:
-                    pending.append(work)
-                if period == t_lo:
-                    boundary = work
-        for work in pending:
-            work.wait()
+            for period, a, b in runs:
+                self.backend.run_period_range(period, a, b)
+            boundary = self.exchange(t_lo, async_op=True) if t_lo > first_period else None
+            done = self.exchange_many(max(t_lo + 1, first_period + 1), t_hi)
+            if done is not None:
+                pending.append(done)
+        if boundary is not None:
+            boundary.wait()
+        for done in pending:
+            done()
         self.backend.finalize()
 
     def gather_policy(self, period: int, local: torch.Tensor) -> Optional[List[torch.Tensor]]:

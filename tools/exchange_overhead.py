@@ -17,6 +17,9 @@ stream = torch.cuda.Stream()
 with torch.cuda.stream(stream):
     be = GpuSlabBackend(w.desc(), w.pmf)
     s = ShardedSolver(be)
+    s.force_exchange = True
+    s.prepare_blocked(8)
+    s.force_exchange = False
 
     def timed(fn, reps=20):
         fn(); torch.cuda.synchronize()
@@ -33,6 +36,20 @@ with torch.cuda.stream(stream):
     print(f"forced all-gather, blocking           {eager_block:.3f} ms  = {eager_block / w.T * 1e3:.1f} us/period", flush=True)
     eager = timed(lambda: s.solve(overlap=True))
     print(f"forced all-gather, async + split      {eager:.3f} ms  = {eager / w.T * 1e3:.1f} us/period", flush=True)
+    if s.plan_blocks(8) is not None:
+        for k in (1, 2, 4, 8):
+            tk = timed(lambda: s.solve_blocked(k))
+            print(f"forced all-gather, {k} period(s)/wait    {tk:.3f} ms  = {tk / w.T * 1e3:.1f} us/period", flush=True)
+    if s.plan_blocks(8) is not None:  # the batched publication path really ran: same tables as a plain sweep?
+        import numpy as np
+        s.solve_blocked(4)
+        torch.cuda.synchronize()
+        ref = GpuSlabBackend(w.desc(), w.pmf)
+        ref.engine.solve()
+        same = all(np.array_equal(be.engine.values(t), ref.engine.values(t)) and
+                   np.array_equal(be.engine.policy(t), ref.engine.policy(t)) for t in (1, 2, 3, 17, w.T))
+        print("blocked schedule with batched publication == plain sweep:", same, flush=True)
+        ref.close()
     if "--graph" in sys.argv:
         g = torch.cuda.CUDAGraph()
         torch.cuda.synchronize()
