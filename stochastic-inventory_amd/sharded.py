@@ -250,12 +250,12 @@ class ShardedSolver:
         n = pad // self.world
         self.gathered_bytes += rows * pad * 8
         inp = block[:, self.rank * n: (self.rank + 1) * n].contiguous()
-        out = torch.empty((self.world, rows, n), dtype=block.dtype, device=block.device)
+        out = torch.empty((self.world * rows, n), dtype=block.dtype, device=block.device)  # rank-major concatenation
         work = dist.all_gather_into_tensor(out, inp, group=self.group, async_op=True)
 
         def complete():
             work.wait()
-            block.view(rows, self.world, n).copy_(out.permute(1, 0, 2))
+            block.view(rows, self.world, n).copy_(out.view(self.world, rows, n).permute(1, 0, 2))
         return complete
 
     def _blocked_program(self, K: int, first_period: int):

@@ -35,8 +35,17 @@ def _worker(rank, world, port, case_name, out_dir, blocked_k=0):
         T = w.T
 
         def __init__(self):
-            self.tables = {p: torch.full((geom.slab(p)[0],), float("nan"), dtype=torch.float64) for p in range(1, w.T + 1)}
+            pads = [geom.slab(p)[0] for p in range(1, w.T + 1)]
+            if blocked_k and len(set(pads)) == 1:  # one arena [period][padded row], like the GPU backend
+                self.arena = torch.full((w.T, pads[0]), float("nan"), dtype=torch.float64)
+                self.tables = {p: self.arena[p - 1] for p in range(1, w.T + 1)}
+            else:
+                self.arena = None
+                self.tables = {p: torch.full((pads[p - 1],), float("nan"), dtype=torch.float64) for p in range(1, w.T + 1)}
             self.policy = {}
+
+        def table_block(self, p_lo, p_hi):
+            return None if self.arena is None else self.arena[p_lo - 1: p_hi]
 
         def slab(self, period):
             return geom.slab(period)
@@ -98,6 +107,16 @@ def _worker(rank, world, port, case_name, out_dir, blocked_k=0):
             if not async_op:
                 return super().exchange(period)
             return LateWork(lambda: ShardedSolver.exchange(self, period))
+
+        def exchange_many(self, p_lo, p_hi):  # the batched publication, also as late as possible
+            if p_hi < p_lo:
+                return None
+
+            def late():
+                done = ShardedSolver.exchange_many(self, p_lo, p_hi)
+                if done is not None:
+                    done()
+            return late
 
     be = OracleSlab()
     solver = LateSolver(be) if blocked_k else ShardedSolver(be)
