@@ -97,7 +97,14 @@ typedef enum sdpgpu_family {
    * lambdas of cashSurvival.java:98-143: orders limited by cash / variCost, no penalty term.  The value is
    * P(final cash >= 0 and no negative cash on the way) under the best policy, MAX only; a successor with
    * negative cash contributes 0 and is not visited. */
-  SDPGPU_FAMILY_SURVIVAL = 6
+  SDPGPU_FAMILY_SURVIVAL = 6,
+  /* state (staff number). workforce.StaffRecursion.getExpectedValue (StaffRecursion.java:81-118) with the lambdas of
+   * WorkforcePlanning.java:72-101 (clamp_inventory 1) / WorkforceTesting.java:80-107 (clamp_inventory 0): the pmf of
+   * a period depends on the hire-up-to level y = staff + hires (sdpgpu_set_level_pmf, not sdpgpu_set_pmf).  MIN only.
+   * Descriptor fields: min/max_inventory = minX/maxX (>= 0), ini_inventory = iniStaffNum, max_order_quantity =
+   * maxHireNum, step 1, fixed_order_cost = fixCost, unit_order_cost = unitVariCost, holding_cost = salary,
+   * penalty_cost = unitPenalty; minStaffNum[t] goes through sdpgpu_set_overhead (an integer). */
+  SDPGPU_FAMILY_STAFF = 7
 } sdpgpu_family;
 
 /* OptDirection, Recursion.java:44-47 / CashRecursion.java:34-37. */
@@ -242,7 +249,14 @@ const char* sdpgpu_last_error(const sdpgpu_handle* h);
 /* pmf[t] for t = 0..T-1 (period t+1): n pairs, demand[j] ascending as in GetPmf.java:119. */
 int sdpgpu_set_pmf(sdpgpu_handle* h, int32_t t, const double* demand, const double* prob, int32_t n);
 
-/* Optional per-period overhead cost (CashOverdraft.java:38-39 keeps an array). */
+/* STAFF family: the turnover pmf of period t+1 per hire-up-to level, pmfs[t] of StaffRecursion.java:23,92-95.
+ * prob[y * row_stride + j] = pmfs[t][y][j][1] for j < row_len[y] (the realisation pmfs[t][y][j][0] is j itself,
+ * WorkforcePlanning.java:57-68); row_len NULL means y + 1 entries per row; a level beyond the table uses its last
+ * row.  1 <= row_len[y] <= min(y + 1, row_stride): a realisation never exceeds the staff it applies to. */
+int sdpgpu_set_level_pmf(sdpgpu_handle* h, int32_t t, const double* prob, const int32_t* row_len, int32_t n_rows,
+                         int32_t row_stride);
+
+/* Optional per-period overhead cost (CashOverdraft.java:38-39 keeps an array).  STAFF family: minStaffNum[t]. */
 int sdpgpu_set_overhead(sdpgpu_handle* h, int32_t t, double overhead_cost);
 
 /* Launch kernels on a caller-owned hipStream_t (NULL = the legacy default stream).  Without this

@@ -6,20 +6,22 @@ The directory name carries a hyphen (it is fixed by the build contract); import 
 """
 from . import _abi
 from ._abi import (FAMILY_BACKORDER, FAMILY_CASH, FAMILY_CASH_LEADTIME, FAMILY_LEADTIME, FAMILY_OVERDRAFT,
-                   FAMILY_SURVIVAL,                   KERNEL_AUTO, KERNEL_GATHER, KERNEL_WINDOW, SdpgpuDesc, SdpgpuError, SdpgpuStats, desc_defaults)
+                   FAMILY_STAFF, FAMILY_SURVIVAL, KERNEL_AUTO, KERNEL_GATHER, KERNEL_WINDOW, SdpgpuDesc, SdpgpuError, SdpgpuStats, desc_defaults)
 from .engine import SdpEngine
 from .functors import (BackorderFunctor, CashFunctor, CashLeadtimeFunctor, CustomFunctor, LeadtimeFunctor, OverdraftFunctor,
                        SurvivalFunctor, java_round)
 from .multiitem import MultiLeadResult, multilead_solve
-from .pmf import DiscreteDistribution, GetPmf, NormalDist, PoissonDist, UniformIntDist
+from .pmf import BinomialDist, DiscreteDistribution, GetPmf, NormalDist, PoissonDist, UniformIntDist, staff_level_pmf
 from .recursion import CLSP, CashLeadtimeRecursion, CashRecursion, LeadtimeRecursion, Recursion, RiskRecursion
 from .simulation import RiskSimulation, Sampling, Simulation
+from .workforce import StaffFunctor, StaffRecursion, StaffState
 from .states import CashLeadtimeState, CashState, LeadtimeState, OptDirection, RiskState, State
 
 __all__ = [
     "SdpEngine", "SdpgpuDesc", "SdpgpuError", "SdpgpuStats", "desc_defaults",
     "BackorderFunctor", "LeadtimeFunctor", "CashFunctor", "OverdraftFunctor", "CashLeadtimeFunctor", "SurvivalFunctor", "CustomFunctor",
     "Recursion", "CLSP", "LeadtimeRecursion", "CashRecursion", "CashLeadtimeRecursion", "RiskRecursion",
+    "StaffRecursion", "StaffFunctor", "StaffState", "BinomialDist", "staff_level_pmf",
     "multilead_solve", "MultiLeadResult",
     "GetPmf", "PoissonDist", "NormalDist", "UniformIntDist", "DiscreteDistribution", "Simulation", "RiskSimulation", "Sampling",
     "State", "LeadtimeState", "CashState", "CashLeadtimeState", "RiskState", "OptDirection", "java_round",

@@ -20,6 +20,7 @@ FAMILY_CASH = 3
 FAMILY_OVERDRAFT = 4
 FAMILY_CASH_LEADTIME = 5
 FAMILY_SURVIVAL = 6
+FAMILY_STAFF = 7
 
 MIN = 0
 MAX = 1
@@ -148,6 +149,7 @@ EXPORTS = {
     "sdpgpu_destroy": (None, [_P]),
     "sdpgpu_last_error": (C.c_char_p, [_P]),
     "sdpgpu_set_pmf": (C.c_int, [_P, C.c_int32, _DP, _DP, C.c_int32]),
+    "sdpgpu_set_level_pmf": (C.c_int, [_P, C.c_int32, _DP, _IP, C.c_int32, C.c_int32]),
     "sdpgpu_set_overhead": (C.c_int, [_P, C.c_int32, C.c_double]),
     "sdpgpu_set_stream": (C.c_int, [_P, _P]),
     "sdpgpu_set_profiling": (C.c_int, [_P, C.c_int32]),

@@ -30,7 +30,7 @@ HIPCC_FLAGS = [
 
 def sources():
     return [os.path.join(CSRC, f) for f in ("sdpgpu.hip", "sdpgpu_generic.hip", "sdpgpu_window.hip", "sdpgpu_cash.hip",
-                                            "sdpgpu_sparse.hip")]
+                                            "sdpgpu_staff.hip", "sdpgpu_sparse.hip")]
 
 
 def deps():
@@ -66,7 +66,7 @@ def build(force: bool = False, extra_flags=(), verbose: bool = True) -> str:
         subprocess.run(cmd, check=True)
         return obj
 
-    with ThreadPoolExecutor(max_workers=min(5, os.cpu_count() or 1)) as ex:
+    with ThreadPoolExecutor(max_workers=min(6, os.cpu_count() or 1)) as ex:
         objs = list(ex.map(compile_one, sources()))
     cmd = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", OUT, *objs, "-lhiprtc"]
     if verbose:

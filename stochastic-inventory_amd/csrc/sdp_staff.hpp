@@ -1,0 +1,105 @@
+// sdp_staff.hpp -- period kernel of the STAFF family: workforce.StaffRecursion.getExpectedValue
+// (StaffRecursion.java:81-118) with the lambdas of WorkforcePlanning.java:84-101 / WorkforceTesting.java:91-107.
+//
+// What sets this family apart: the pmf is chosen by the hire-up-to level y = x + a (pmfs[t][min(y, rows-1)],
+// :92-95), so there is no per-period demand tile to stage -- every (state, action) pair walks its own row, of its
+// own length.  Layout: the table is stored TRANSPOSED, pT[j * rows + y], so that the 64 lanes of a wave -- 64
+// consecutive staff numbers x, one action a, hence 64 consecutive levels y -- read one 512-byte line per
+// realisation j; V_{t+1}[x + a - j] is likewise 64 consecutive doubles.  A level beyond the table clamps to the last
+// row: those lanes read one address (a broadcast).
+//
+// One wave = 64 states x one group of consecutive actions; per (lane, action) the realisations are summed SERIALLY
+// in the reference's order (:97-107), lanes with a shorter row simply drop out of the loop (exec mask).  The group's
+// strict-compare arg-min (ascending action) goes to a partial row; combine_staff_kernel scans the groups in
+// ascending order with the same strict compare, which is the reference's single scan (:110-113).
+//
+// Roofline: 8 B (V gather) + 8 B (probability) algorithmic per cell, both cache-resident (the table of a period is
+// rows^2 * 8 B = 3-8 MB, V is kilobytes); the limiter is fp64/int VALU issue (~11 instructions per cell).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace sdp {
+
+struct StaffParams {
+  double K, v, salary, pen;  // fixCost, unitVariCost, salary, unitPenalty
+  int32_t min_staff;         // minStaffNum[t]
+  int32_t n_actions;         // maxHireNum + 1
+  int32_t n_rows;            // pmfs[t].length
+  int32_t clamp, min_x, max_x;
+  int32_t x_lo;       // staff number of state index 0 (this period)
+  int32_t next_x_lo;  // ... of the next period
+  int32_t n_groups, group_actions;
+  int64_t part_stride;  // elements between the partial rows of two groups
+};
+
+template <bool FUTURE>
+__global__ __launch_bounds__(64) void staff_period_kernel(StaffParams P, const double* __restrict__ pT,
+                                                          const int32_t* __restrict__ row_len,
+                                                          const double* __restrict__ v_next,
+                                                          double* __restrict__ out_val, int32_t* __restrict__ out_idx,
+                                                          int64_t lo, int64_t hi) {
+  const int64_t tile = blockIdx.x / P.n_groups;
+  const int group = (int)(blockIdx.x - tile * P.n_groups);
+  const int64_t idx = lo + tile * 64 + threadIdx.x;
+  if (idx >= hi) return;
+  const int x = P.x_lo + (int)idx;
+  const int a_end = min(P.n_actions, (group + 1) * P.group_actions);
+  double best = 1.7976931348623157e308;  // Double.MAX_VALUE (:89)
+  int bestk = 0;                         // bestHireQty = 0 (:87)
+  for (int a = group * P.group_actions; a < a_end; ++a) {
+    const int y = x + a;
+    const int row = y >= P.n_rows - 1 ? P.n_rows - 1 : y;  // :93-94
+    const int nj = row_len[row];
+    const double fixHire = a > 0 ? P.K : 0.0;
+    const double variHire = P.v * (double)a;
+    const double fv = fixHire + variHire;  // first add of totalCosts, the same for every realisation
+    const double* prow = pT + row;
+    double acc = 0.0;
+    for (int j = 0; j < nj; ++j) {
+      const int n = y - j;  // nextStaffNum
+      const double salaryCost = P.salary * (double)n;
+      const double penalty = n > P.min_staff ? 0.0 : P.pen * (double)(P.min_staff - n);
+      const double imm = fv + salaryCost + penalty;
+      const double p = prow[(size_t)j * (size_t)P.n_rows];
+      acc += p * imm;
+      if constexpr (FUTURE) {
+        int nn = n;
+        if (P.clamp) {
+          nn = nn > P.max_x ? P.max_x : nn;
+          nn = nn < P.min_x ? P.min_x : nn;
+        }
+        acc += p * v_next[nn - P.next_x_lo];
+      }
+    }
+    if (acc < best) {
+      best = acc;
+      bestk = a;
+    }
+  }
+  const int64_t at = (int64_t)group * P.part_stride + idx;
+  out_val[at] = best;
+  out_idx[at] = bestk;
+}
+
+// groups in ascending action order, strict compare: the first best wins (StaffRecursion.java:110-113)
+__global__ __launch_bounds__(256) void combine_staff_kernel(const double* __restrict__ part_val,
+                                                            const int32_t* __restrict__ part_idx, int n_groups,
+                                                            int64_t part_stride, double* __restrict__ v_cur,
+                                                            int32_t* __restrict__ pol, int64_t lo, int64_t hi) {
+  const int64_t idx = lo + (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (idx >= hi) return;
+  double best = 1.7976931348623157e308;
+  int bestk = 0;
+  for (int g = 0; g < n_groups; ++g) {
+    const double v = part_val[(int64_t)g * part_stride + idx];
+    if (v < best) {
+      best = v;
+      bestk = part_idx[(int64_t)g * part_stride + idx];
+    }
+  }
+  v_cur[idx] = best;
+  pol[idx] = bestk;
+}
+
+}  // namespace sdp

@@ -27,7 +27,7 @@ int fail(sdpgpu_handle* h, int code, const char* fmt, ...) {
 
 int validate(const sdpgpu_desc& d) {
   if (d.abi_version != SDPGPU_ABI_VERSION) return fail(nullptr, SDPGPU_ERR_ARG, "abi_version %d != %d", d.abi_version, SDPGPU_ABI_VERSION);
-  if (d.family < 1 || d.family > 6) return fail(nullptr, SDPGPU_ERR_ARG, "unknown family %d", d.family);
+  if (d.family < 1 || d.family > 7) return fail(nullptr, SDPGPU_ERR_ARG, "unknown family %d", d.family);
   if (d.direction != SDPGPU_MIN && d.direction != SDPGPU_MAX) return fail(nullptr, SDPGPU_ERR_ARG, "bad direction %d", d.direction);
   if (d.periods < 1 || d.periods > 4096) return fail(nullptr, SDPGPU_ERR_ARG, "periods %d out of range", d.periods);
   if (!is_pow2_int(d.step)) return fail(nullptr, SDPGPU_ERR_UNSUPPORTED, "step %g: only power-of-two integer step sizes are supported (every in-scope driver uses 1)", d.step);
@@ -37,7 +37,7 @@ int validate(const sdpgpu_desc& d) {
     if (!(d.max_inventory >= d.min_inventory)) return fail(nullptr, SDPGPU_ERR_ARG, "max_inventory < min_inventory");
     if (std::fmod(d.min_inventory, d.step) != 0 || std::fmod(d.max_inventory, d.step) != 0) return fail(nullptr, SDPGPU_ERR_ARG, "inventory bounds must be multiples of step");
   } else {
-    if (d.family != SDPGPU_FAMILY_BACKORDER && d.family != SDPGPU_FAMILY_LEADTIME) return fail(nullptr, SDPGPU_ERR_UNSUPPORTED, "clamp_inventory = 0 only for the backorder / lead-time families");
+    if (d.family != SDPGPU_FAMILY_BACKORDER && d.family != SDPGPU_FAMILY_LEADTIME && d.family != SDPGPU_FAMILY_STAFF) return fail(nullptr, SDPGPU_ERR_UNSUPPORTED, "clamp_inventory = 0 only for the backorder / lead-time / staff families");
     if (std::fmod(d.ini_inventory, d.step) != 0) return fail(nullptr, SDPGPU_ERR_ARG, "ini_inventory must be a multiple of step");
   }
   if (has_cash(d.family)) {
@@ -51,6 +51,13 @@ int validate(const sdpgpu_desc& d) {
   if (d.lead_time == 2) {
     if (d.family != SDPGPU_FAMILY_LEADTIME) return fail(nullptr, SDPGPU_ERR_UNSUPPORTED, "lead_time 2 exists for the LEADTIME family only");
     if (!d.clamp_inventory) return fail(nullptr, SDPGPU_ERR_UNSUPPORTED, "lead_time 2 needs clamp_inventory = 1");
+  }
+  if (d.family == SDPGPU_FAMILY_STAFF) {
+    if (d.direction != SDPGPU_MIN) return fail(nullptr, SDPGPU_ERR_ARG, "StaffRecursion is MIN only (StaffRecursion.java:89,110)");
+    if (d.step != 1) return fail(nullptr, SDPGPU_ERR_UNSUPPORTED, "the staff family counts heads: step must be 1");
+    if (d.max_order_quantity != std::floor(d.max_order_quantity)) return fail(nullptr, SDPGPU_ERR_ARG, "maxHireNum must be an integer");
+    if (d.clamp_inventory ? (d.min_inventory < 0 || d.max_inventory > 1e9) : (d.ini_inventory < 0 || d.ini_inventory > 1e9)) return fail(nullptr, SDPGPU_ERR_ARG, "staff numbers must lie in 0 .. 1e9");
+    if (d.clamp_inventory && (d.ini_inventory < d.min_inventory || d.ini_inventory > d.max_inventory || d.ini_inventory != std::floor(d.ini_inventory))) return fail(nullptr, SDPGPU_ERR_ARG, "iniStaffNum must be an integer inside [minX, maxX]");
   }
   if ((d.family == SDPGPU_FAMILY_LEADTIME) && d.direction != SDPGPU_MIN) return fail(nullptr, SDPGPU_ERR_ARG, "LeadtimeRecursion is MIN only (LeadtimeRecursion.java:52,66)");
   if ((d.family == SDPGPU_FAMILY_SURVIVAL) && d.direction != SDPGPU_MAX) return fail(nullptr, SDPGPU_ERR_ARG, "getSurvProb maximises (RiskRecursion.java:70,101)");
@@ -68,8 +75,9 @@ int32_t full_action_count(const sdpgpu_desc& d) {
 int layout(sdpgpu_handle* h) {
   if (h->laid_out) return SDPGPU_OK;
   const sdpgpu_desc& d = h->d;
+  const bool staff = d.family == SDPGPU_FAMILY_STAFF;
   for (int t = 0; t < h->T; ++t)
-    if (!h->pmf_set[t]) return fail(h, SDPGPU_ERR_STATE, "pmf of period %d not set", t + 1);
+    if (!h->pmf_set[t]) return fail(h, SDPGPU_ERR_STATE, staff ? "level pmf of period %d not set (sdpgpu_set_level_pmf)" : "pmf of period %d not set", t + 1);
   int64_t nc = 1, k_lo = 0, nq = 1;
   if (has_cash(d.family)) {
     k_lo = cash_key_of_bound(d, d.min_cash);
@@ -101,7 +109,7 @@ int layout(sdpgpu_handle* h) {
     p.nD = (int32_t)h->pmf_d[t].size();
     p.pmf_off = pmf_off;
     pmf_off += 2 * (size_t)p.nD + kPmfPad;  // probabilities are followed by kPmfPad zeros (window kernel)
-    {
+    if (!staff) {
       const std::vector<double>& dv = h->pmf_d[t];
       const double span = (dv.back() - dv.front()) / d.step;  // demands are multiples of step (set_pmf)
       const int64_t dense = (int64_t)span + 1;
@@ -121,7 +129,13 @@ int layout(sdpgpu_handle* h) {
     if (d.store_all_values) v_off += (size_t)p.S_pad;
     s_pad_max = std::max(s_pad_max, p.S_pad);
     if (!p.overhead_set) p.overhead = d.overhead_cost;
-    if (!d.clamp_inventory) {
+    if (staff) {
+      if (p.overhead != std::floor(p.overhead) || std::fabs(p.overhead) > 1e9) return fail(h, SDPGPU_ERR_ARG, "minStaffNum of period %d (sdpgpu_set_overhead) must be an integer", t + 1);
+      if (!d.clamp_inventory) {  // successors x + a - j with 0 <= j <= min(x + a, longest row - 1): never below 0
+        lo = std::max(0.0, lo - (double)(h->lvl_maxj[t] - 1));
+        hi = hi + (double)(h->n_actions_full - 1);
+      }
+    } else if (!d.clamp_inventory) {
       double dmin = h->pmf_d[t][0], dmax = dmin;
       for (double v : h->pmf_d[t]) {
         dmin = std::min(dmin, v);
@@ -184,6 +198,10 @@ int allocate(sdpgpu_handle* h) {
   HIP_TRY(h, hipMemcpy(h->d_pmf, host.data(), pmf_elems * sizeof(double), hipMemcpyHostToDevice));
   HIP_TRY(h, hipEventCreate(&h->ev_solve0));
   HIP_TRY(h, hipEventCreate(&h->ev_solve1));
+  if (h->d.family == SDPGPU_FAMILY_STAFF) {
+    rc = staff_upload(h);
+    if (rc) return rc;
+  }
   if (h->custom) {
     HIP_TRY(h, hipModuleLoadData(&h->custom_mod, h->custom_code.data()));
     HIP_TRY(h, hipModuleGetFunction(&h->custom_period[0], h->custom_mod, "sdp_custom_period_64"));
@@ -256,6 +274,7 @@ void count_cells(sdpgpu_handle* h, int period) {
   int64_t nD = p.nD;
   auto range_cells = [&](int64_t lo, int64_t hi) -> int64_t {
     if (hi <= lo) return 0;
+    if (d.family == SDPGPU_FAMILY_STAFF) return staff_cells(h, period, lo, hi);
     if (d.family != SDPGPU_FAMILY_CASH && d.family != SDPGPU_FAMILY_SURVIVAL) {
       int64_t nA = h->n_actions_full;
       if (d.family == SDPGPU_FAMILY_CASH_LEADTIME && d.zero_order_last_period && period == h->T) nA = 1;
@@ -315,6 +334,22 @@ int run_period_impl(sdpgpu_handle* h, int period, int part = SDPGPU_PART_ALL, in
     if (range_lo > range_hi || range_hi > p.S || range_lo < p.lo - h->halo || range_hi > p.hi + h->halo)
       return fail(h, SDPGPU_ERR_ARG, "run_period_range: [%lld, %lld) leaves the slab [%lld, %lld) widened by the halo %lld",
                   (long long)range_lo, (long long)range_hi, (long long)p.lo, (long long)p.hi, (long long)h->halo);
+  }
+  if (h->d.family == SDPGPU_FAMILY_STAFF) {
+    if (part == SDPGPU_PART_INTERIOR) return SDPGPU_OK;  // the footprint spans the whole table (turnover up to all staff)
+    hipError_t es = launch_staff(h, period, v_next, v_cur, pol, p.lo, p.hi, h->stream);
+    if (es != hipSuccess) return fail(h, SDPGPU_ERR_DEVICE, "period %d staff kernel: %s", period, hipGetErrorString(es));
+    p.kernel_used = SDPGPU_KERNEL_GATHER;
+    if (h->profiling) {
+      HIP_TRY(h, hipEventRecord(p.ev1, h->stream));
+      p.timed = true;
+    } else {
+      p.timed = false;
+    }
+    h->period_done[period - 1] = 1;
+    h->policy_done[period - 1] = 1;
+    if (!h->d.store_all_values && period + 2 <= h->T) h->period_done[period + 1] = 0;
+    return SDPGPU_OK;
   }
   if (h->custom) {
     if (part == SDPGPU_PART_INTERIOR) return SDPGPU_OK;  // no bounded footprint is known for user lambdas
@@ -465,6 +500,10 @@ int sdpgpu_create(const sdpgpu_desc* desc, sdpgpu_handle** out) {
     h->pmf_d.resize((size_t)h->T);
     h->pmf_p.resize((size_t)h->T);
     h->pmf_set.assign((size_t)h->T, 0);
+    h->lvl_p.resize((size_t)h->T);
+    h->lvl_len.resize((size_t)h->T);
+    h->lvl_rows.assign((size_t)h->T, 0);
+    h->lvl_maxj.assign((size_t)h->T, 0);
     h->period_done.assign((size_t)h->T, 0);
     h->policy_done.assign((size_t)h->T, 0);
     h->pending_chunks.assign((size_t)h->T + 1, 0);
@@ -489,6 +528,7 @@ int sdpgpu_create_custom(const sdpgpu_desc* desc, const char* functor_source, co
   if (!desc || !out || !functor_source || n_params < 0 || n_params > 256 || (n_params > 0 && !params))
     return fail(nullptr, SDPGPU_ERR_ARG, "null argument, or more than 256 user parameters");
   *out = nullptr;
+  if (desc->family == SDPGPU_FAMILY_STAFF) return fail(nullptr, SDPGPU_ERR_UNSUPPORTED, "a user functor takes one pmf per period; the staff family's level-dependent pmf is a built-in shape");
   if (desc->lead_time == 2) return fail(nullptr, SDPGPU_ERR_UNSUPPORTED, "a user functor has one pipeline quantity at most (lead_time 2 is a built-in shape)");
   if (desc->kernel != SDPGPU_KERNEL_AUTO && desc->kernel != SDPGPU_KERNEL_GATHER) return fail(nullptr, SDPGPU_ERR_UNSUPPORTED, "a user functor runs on the generic kernel only");
   // compile: prelude + the user's three device functions + the engine kernels, strict fp64 (no FMA)
@@ -525,7 +565,7 @@ int sdpgpu_create_custom(const sdpgpu_desc* desc, const char* functor_source, co
 
 void sdpgpu_destroy(sdpgpu_handle* h) {
   if (!h) return;
-  if (h->allocated || h->d_policy || h->d_pmf) {
+  if (h->allocated || h->d_policy || h->d_pmf || !h->staff_owned.empty()) {
     if (h->device >= 0) (void)hipSetDevice(h->device);
     if (h->stream) (void)hipStreamSynchronize(h->stream);
   }
@@ -547,6 +587,9 @@ void sdpgpu_destroy(sdpgpu_handle* h) {
   if (h->d_chunk_val) (void)hipFree(h->d_chunk_val);
   if (h->d_chunk_idx) (void)hipFree(h->d_chunk_idx);
   if (h->d_jobs) (void)hipFree(h->d_jobs);
+  for (void* q : h->staff_owned) (void)hipFree(q);
+  if (h->d_staff_val) (void)hipFree(h->d_staff_val);
+  if (h->d_staff_idx) (void)hipFree(h->d_staff_idx);
   if (h->d_custom_params) (void)hipFree(h->d_custom_params);
   if (h->d_custom_cells) (void)hipFree(h->d_custom_cells);
   if (h->d_custom_err) (void)hipFree(h->d_custom_err);
@@ -562,6 +605,7 @@ int sdpgpu_set_pmf(sdpgpu_handle* h, int32_t t, const double* demand, const doub
   h->err.clear();
   if (t < 0 || t >= h->T || !demand || !prob || n < 1) return fail(h, SDPGPU_ERR_ARG, "set_pmf: bad argument (t=%d n=%d)", t, n);
   if (h->allocated) return fail(h, SDPGPU_ERR_STATE, "pmf is frozen once the device tables exist");
+  if (h->d.family == SDPGPU_FAMILY_STAFF) return fail(h, SDPGPU_ERR_ARG, "the staff family takes its pmf per hire-up-to level: sdpgpu_set_level_pmf");
   for (int32_t j = 0; j < n; ++j) {
     if (std::fmod(demand[j], h->d.step) != 0) return fail(h, SDPGPU_ERR_ARG, "demand %g of period %d is not a multiple of step", demand[j], t + 1);
     if (j && !(demand[j] > demand[j - 1])) return fail(h, SDPGPU_ERR_ARG, "demands of period %d must be strictly ascending", t + 1);
@@ -569,6 +613,38 @@ int sdpgpu_set_pmf(sdpgpu_handle* h, int32_t t, const double* demand, const doub
   try {
     h->pmf_d[t].assign(demand, demand + n);
     h->pmf_p[t].assign(prob, prob + n);
+  } catch (...) {
+    return fail(h, SDPGPU_ERR_ARG, "out of host memory");
+  }
+  h->pmf_set[t] = 1;
+  h->laid_out = false;
+  return SDPGPU_OK;
+}
+
+int sdpgpu_set_level_pmf(sdpgpu_handle* h, int32_t t, const double* prob, const int32_t* row_len, int32_t n_rows,
+                         int32_t row_stride) {
+  if (!h) return SDPGPU_ERR_ARG;
+  h->err.clear();
+  if (h->d.family != SDPGPU_FAMILY_STAFF) return fail(h, SDPGPU_ERR_ARG, "set_level_pmf: only the staff family has a level-dependent pmf");
+  if (t < 0 || t >= h->T || !prob || n_rows < 1 || row_stride < 1) return fail(h, SDPGPU_ERR_ARG, "set_level_pmf: bad argument (t=%d rows=%d stride=%d)", t, n_rows, row_stride);
+  if (h->allocated) return fail(h, SDPGPU_ERR_STATE, "pmf is frozen once the device tables exist");
+  try {
+    std::vector<int32_t> len((size_t)n_rows);
+    int32_t maxj = 1;
+    for (int32_t y = 0; y < n_rows; ++y) {
+      const int32_t n = row_len ? row_len[y] : y + 1;
+      if (n < 1 || n > y + 1 || n > row_stride) return fail(h, SDPGPU_ERR_ARG, "set_level_pmf: row %d of period %d has %d entries (1 .. min(y + 1, row_stride) allowed)", y, t + 1, n);
+      len[(size_t)y] = n;
+      maxj = std::max(maxj, n);
+    }
+    if ((size_t)n_rows * (size_t)maxj > ((size_t)1 << 31)) return fail(h, SDPGPU_ERR_UNSUPPORTED, "set_level_pmf: table of %d x %d entries is too large", n_rows, maxj);
+    std::vector<double> tp((size_t)n_rows * (size_t)maxj, 0.0);
+    for (int32_t y = 0; y < n_rows; ++y)
+      for (int32_t j = 0; j < len[(size_t)y]; ++j) tp[(size_t)j * (size_t)n_rows + (size_t)y] = prob[(size_t)y * (size_t)row_stride + (size_t)j];
+    h->lvl_p[(size_t)t].swap(tp);
+    h->lvl_len[(size_t)t].swap(len);
+    h->lvl_rows[(size_t)t] = n_rows;
+    h->lvl_maxj[(size_t)t] = maxj;
   } catch (...) {
     return fail(h, SDPGPU_ERR_ARG, "out of host memory");
   }
@@ -911,6 +987,7 @@ int sdpgpu_eval_states2(sdpgpu_handle* h, int32_t period, int64_t n, const doubl
   if (!h) return SDPGPU_ERR_ARG;
   h->err.clear();
   if (period < 1 || period > h->T || n < 0 || !x || !out_value || !out_action_index) return fail(h, SDPGPU_ERR_ARG, "eval_states: bad argument");
+  if (h->d.family == SDPGPU_FAMILY_STAFF) return fail(h, SDPGPU_ERR_UNSUPPORTED, "eval_states: every staff number the recursion can visit lies on the grid; read the tables");
   if (has_cash(h->d.family) && !cash) return fail(h, SDPGPU_ERR_ARG, "eval_states: cash array required");
   if (has_preq(h->d.family) && !preq) return fail(h, SDPGPU_ERR_ARG, "eval_states: preq array required");
   int rc = allocate(h);
@@ -960,6 +1037,17 @@ int sdpgpu_reachable(sdpgpu_handle* h, int32_t period, uint8_t* out, int64_t n) 
   if (!h) return SDPGPU_ERR_ARG;
   h->err.clear();
   if (period < 1 || period > h->T || !out) return fail(h, SDPGPU_ERR_ARG, "reachable: bad argument");
+  if (h->d.family == SDPGPU_FAMILY_STAFF) {  // an interval per period: host arithmetic (sdpgpu_staff.hip)
+    int rl = layout(h);
+    if (rl) return rl;
+    const PeriodInfo& ps = h->per[period - 1];
+    if (n < 0 || n > ps.S) return fail(h, SDPGPU_ERR_ARG, "reachable: n=%lld > %lld states", (long long)n, (long long)ps.S);
+    std::vector<int64_t> rlo, rhi;
+    staff_reach_intervals(h, &rlo, &rhi);
+    const int64_t x0 = (int64_t)ps.g.x_lo;
+    for (int64_t i = 0; i < n; ++i) out[i] = (x0 + i >= rlo[(size_t)period - 1] && x0 + i <= rhi[(size_t)period - 1]) ? 1 : 0;
+    return SDPGPU_OK;
+  }
   int rc = compute_reachable(h);
   if (rc) return rc;
   const PeriodInfo& p = h->per[period - 1];
@@ -975,6 +1063,7 @@ int sdpgpu_simulate(sdpgpu_handle* h, int64_t n_paths, const double* demand, con
   if (n_paths < 0 || !demand || !discount || !out_sum || !out_valid) return fail(h, SDPGPU_ERR_ARG, "simulate: bad argument");
   if (h->d.world_size != 1) return fail(h, SDPGPU_ERR_STATE, "simulate needs the whole policy on one GPU (world_size 1)");
   if (h->custom) return fail(h, SDPGPU_ERR_UNSUPPORTED, "simulate: a user functor's lambdas live on the host; roll the policy tables forward there");
+  if (h->d.family == SDPGPU_FAMILY_STAFF) return fail(h, SDPGPU_ERR_UNSUPPORTED, "simulate: the workforce drivers simulate an (s, S) rule with binomial draws (SimulatesS.java), not the table policy along demand paths");
   if (!h->allocated) return fail(h, SDPGPU_ERR_STATE, "simulate: nothing has been solved");
   for (int t = 0; t < h->T; ++t)
     if (!h->policy_done[t]) return fail(h, SDPGPU_ERR_STATE, "simulate: period %d has not been computed", t + 1);

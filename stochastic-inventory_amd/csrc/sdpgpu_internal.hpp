@@ -5,6 +5,7 @@
 //   sdpgpu_generic.hip  generic per-cell kernel (every family), reachable set, rollout, user-defined functors
 //   sdpgpu_window.hip   F1 window kernel (plan, chunk/key bookkeeping, finalize) and F2 row-window kernel
 //   sdpgpu_cash.hip     F3 uniform-shift kernel and the cash row kernel (F3-F6)
+//   sdpgpu_staff.hip    STAFF family (workforce.StaffRecursion): level-dependent pmf tables, its period kernel
 //   sdpgpu_sparse.hip   reachable-set engine of the two-product lead-time family (own entry point)
 #pragma once
 #include "../../include/sdpgpu.h"
@@ -119,6 +120,16 @@ struct sdpgpu_handle {
   // sdpgpu_set_halo: a sharded caller may run a period on its slab widened by up to `halo` states on either side
   // (sdpgpu_run_period_range); the chunk-row arenas are sized for that
   int64_t halo = 0;
+  // STAFF family (sdpgpu_set_level_pmf): per period the table transposed, lvl_p[t][j * rows + y], and its row lengths
+  std::vector<std::vector<double>> lvl_p;
+  std::vector<std::vector<int32_t>> lvl_len;
+  std::vector<int32_t> lvl_rows, lvl_maxj;
+  std::vector<double*> d_lvl_p;
+  std::vector<int32_t*> d_lvl_len;
+  std::vector<void*> staff_owned;   // the distinct device tables (periods given the same table share one)
+  double* d_staff_val = nullptr;    // partial arg-min rows [group][slab]
+  int32_t* d_staff_idx = nullptr;
+  size_t staff_part_elems = 0;
   std::string err;
   int device = -1;
 };
@@ -196,6 +207,13 @@ int compute_reachable(sdpgpu_handle* h);
 hipError_t launch_simulate(sdpgpu_handle* h, const sdp::SimPeriod* d_per, const double* d_dem, const double* d_disc,
                            int64_t n_paths, int64_t idx0, double ini_x, double ini_cash, double ini_preq,
                            double ini_preq2, int first_k, double* d_sum, uint8_t* d_valid);
+
+// ---- sdpgpu_staff.hip -----------------------------------------------------------------------------------
+int staff_upload(sdpgpu_handle* h);
+hipError_t launch_staff(sdpgpu_handle* h, int period, const double* v_next, double* v_cur, int32_t* pol, int64_t lo,
+                        int64_t hi, hipStream_t st);
+int64_t staff_cells(const sdpgpu_handle* h, int period, int64_t lo, int64_t hi);
+void staff_reach_intervals(const sdpgpu_handle* h, std::vector<int64_t>* lo_out, std::vector<int64_t>* hi_out);
 
 // ---- sdpgpu_cash.hip ---------------------------------------------------------------------------------------
 bool cash_shift_eligible(const sdpgpu_handle* h, int period);

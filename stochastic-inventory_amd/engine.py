@@ -36,14 +36,28 @@ class SdpEngine:
     """One backward-recursion problem on one GPU (or one rank's state slab of it)."""
 
     def __init__(self, desc: SdpgpuDesc, pmf, overhead: Optional[Sequence[float]] = None,
-                 custom_source: Optional[str] = None, custom_params: Optional[Sequence[float]] = None):
+                 custom_source: Optional[str] = None, custom_params: Optional[Sequence[float]] = None,
+                 level_pmf=None, level_row_len=None):
         """custom_source: HIP device text of the three lambdas (see sdpgpu_create_custom in include/sdpgpu.h),
-        custom_params: the doubles they read through `c.params`."""
+        custom_params: the doubles they read through `c.params`.
+        level_pmf (STAFF family, instead of pmf): array (T, rows, stride), level_pmf[t, y, j] = P(turnover j | level y);
+        level_row_len: entries per row (default y + 1).  `overhead` then carries minStaffNum[t]."""
         self._lib = _abi.load()
         self._h = C.c_void_p()
         self.desc = desc
-        tiles = split_pmf(pmf)
-        if len(tiles) != desc.periods:
+        staff = desc.family == _abi.FAMILY_STAFF
+        if staff:
+            if level_pmf is None:
+                raise ValueError("the STAFF family needs level_pmf")
+            level_pmf = np.ascontiguousarray(level_pmf, dtype=np.float64)
+            if level_pmf.ndim != 3 or level_pmf.shape[0] != desc.periods:
+                raise ValueError("level_pmf must have shape (periods, rows, stride)")
+            if level_row_len is not None:
+                level_row_len = np.ascontiguousarray(level_row_len, dtype=np.int32)
+                if level_row_len.shape != (level_pmf.shape[1],):
+                    raise ValueError("level_row_len must have one entry per row")
+        tiles = [] if staff else split_pmf(pmf)
+        if not staff and len(tiles) != desc.periods:
             raise ValueError(f"pmf has {len(tiles)} periods, descriptor says {desc.periods}")
         if custom_source is None:
             rc = self._lib.sdpgpu_create(C.byref(desc), C.byref(self._h))
@@ -56,6 +70,11 @@ class SdpEngine:
         try:
             for t, (d, p) in enumerate(tiles):
                 self._check(self._lib.sdpgpu_set_pmf(self._h, t, _dp(d), _dp(p), len(d)))
+            if staff:
+                for t in range(desc.periods):
+                    self._check(self._lib.sdpgpu_set_level_pmf(
+                        self._h, t, _dp(level_pmf[t]), None if level_row_len is None else _ip(level_row_len),
+                        level_pmf.shape[1], level_pmf.shape[2]))
             if overhead is not None:
                 for t, oh in enumerate(overhead):
                     self._check(self._lib.sdpgpu_set_overhead(self._h, t, float(oh)))

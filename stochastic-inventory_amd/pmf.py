@@ -117,6 +117,37 @@ class UniformIntDist(Distribution):
         return 0.5 * (self.i + self.j)
 
 
+class BinomialDist(Distribution):
+    """umontreal.ssj.probdist.BinomialDist(n, p): `prob(j)` is all the workforce drivers call
+    (WorkforcePlanning.java:61-66).  scipy's pmf stands in for SSJ's (parity unpinned at this boundary)."""
+
+    is_discrete_int = True
+
+    def __init__(self, n: int, p: float):
+        self.n, self.p = int(n), float(p)
+
+    def prob(self, j: int) -> float:
+        return float(stats.binom.pmf(j, self.n, self.p))
+
+    def cdf(self, x: float) -> float:
+        return float(stats.binom.cdf(math.floor(x), self.n, self.p))
+
+    def inverseF(self, u: float) -> float:
+        return float(stats.binom.ppf(u, self.n, self.p))
+
+
+def staff_level_pmf(turnoverRate: Sequence[float], xLength: int) -> np.ndarray:
+    """The table the workforce drivers build (WorkforcePlanning.java:52-69, WorkforceTesting.java:66-82):
+    out[t, i, j] = Binomial(i, turnoverRate[t]).prob(j) for j <= i, row 0 = {0: 1}; shape (T, xLength, xLength)."""
+    out = np.zeros((len(turnoverRate), xLength, xLength))
+    j = np.arange(xLength)
+    for t, rate in enumerate(turnoverRate):
+        out[t, 0, 0] = 1.0
+        for i in range(1, xLength):
+            out[t, i, : i + 1] = stats.binom.pmf(j[: i + 1], i, rate)
+    return out
+
+
 class DiscreteDistribution(Distribution):
     """umontreal.ssj.probdist.DiscreteDistribution(values, prob, n): values sorted ascending."""
 

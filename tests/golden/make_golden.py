@@ -17,7 +17,8 @@ sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "tests"))
 
 import cases  # noqa: E402
-from oracle import sdpref  # noqa: E402
+import staff_cases  # noqa: E402
+from oracle import sdpref, staffref  # noqa: E402
 
 
 def main():
@@ -31,6 +32,15 @@ def main():
             out[f"p{t + 1}"] = pol[t].astype(np.int16)
         np.savez_compressed(os.path.join(HERE, f"tables_{w.name}.npz"), **out)
         print(w.name, cells, sum(len(v) for v in V))
+    for make in staff_cases.ALL:  # STAFF family (oracle/staffref.c); the table is stored too: it comes from scipy
+        c = make()
+        V, pol, cells = c.oracle_problem(staffref).solve()
+        out = {"cells": np.int64(cells), "table": c.table}
+        for t in range(c.T):
+            out[f"v{t + 1}"] = V[t]
+            out[f"p{t + 1}"] = pol[t]
+        np.savez_compressed(os.path.join(HERE, f"{c.name}.npz"), **out)
+        print(c.name, cells, sum(len(v) for v in V))
 
 
 if __name__ == "__main__":

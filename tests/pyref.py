@@ -78,3 +78,38 @@ def surv_recursion(functor, pmf, ini_state, gamma=1.0):
 
     root = get_surv_prob(ini_state)
     return root, cache_values, cache_actions
+
+
+def staff_recursion(functor, table, row_len, T):
+    """workforce.StaffRecursion.getExpectedValue (StaffRecursion.java:81-118) as literal memoised Python over the
+    functor's host lambdas.  table[t][y][j]: probability of turnover j at hire-up-to level y.
+    -> (root value, {(period, staff): (value, action)})"""
+    sys.setrecursionlimit(100000)
+    from stochastic_inventory_amd.workforce import StaffState
+    cache = {}
+    n_rows = len(table[0])
+
+    def value(s):
+        key = (s.period, s.iniStaffNum)
+        if key in cache:
+            return cache[key][0]
+        t = s.period - 1
+        bestHireQty, val = 0, 1.7976931348623157e308
+        for orderQty in functor.feasibleActions(s):
+            hireUpTo = s.iniStaffNum + orderQty
+            if hireUpTo >= n_rows - 1:
+                hireUpTo = n_rows - 1
+            n = int(row_len[hireUpTo]) if row_len is not None else hireUpTo + 1
+            thisQValue = 0.0
+            for demand in range(n):
+                p = float(table[t][hireUpTo][demand])
+                thisQValue += p * functor.immediateValue(s, orderQty, demand)
+                if s.period < T:
+                    thisQValue += p * value(functor.stateTransition(s, orderQty, demand))
+            if thisQValue < val:
+                val, bestHireQty = thisQValue, orderQty
+        cache[key] = (val, bestHireQty)
+        return val
+
+    root = value(StaffState(1, functor.iniStaffNum))
+    return root, cache

@@ -1,0 +1,147 @@
+"""GPU parity of the STAFF family (workforce.StaffRecursion on the HIP engine) against oracle/staffref.c: every
+period's value table and policy bit for bit, the mirror class, slabs, and the full WorkforcePlanning.main size."""
+import os
+import sys
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+
+import staff_cases  # noqa: E402
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def staffref():
+    from oracle import staffref as m
+    m.build()
+    return m
+
+
+def _engine(sia, c, rank=0, world=1):
+    d = c.functor.to_desc(c.T)
+    d.rank, d.world_size = rank, world
+    return sia.SdpEngine(d, None, [float(m) for m in c.functor.minStaffNum], level_pmf=c.table,
+                         level_row_len=c.row_len)
+
+
+@pytest.mark.parametrize("make", staff_cases.ALL, ids=lambda m: m.__name__)
+def test_tables_match_oracle(sia, staffref, make):
+    c = make()
+    P = c.oracle_problem(staffref)
+    V, pol, cells = P.solve()
+    with _engine(sia, c) as eng:
+        eng.solve(sync=True)
+        for period in range(1, c.T + 1):
+            assert eng.grid(period)[:2] == (float(P.x_lo[period - 1]), int(P.nx[period - 1]))
+            assert np.array_equal(eng.values(period), V[period - 1]), period
+            assert np.array_equal(eng.policy(period), pol[period - 1]), period
+        st = eng.stats()
+        assert st.cells_evaluated == cells == st.cells_all_ranks
+
+
+def test_mirror_class_reads_like_the_reference_driver(sia, staffref):
+    """WorkforcePlanning.java:104-112: construct, getExpectedValue(initialState), getAction, getOptTable."""
+    c = staff_cases.staff_testing_small()
+    f = c.functor
+    P = c.oracle_problem(staffref)
+    V, pol, _ = P.solve()
+    # the reference's own pmf shape: double[T][xLength][i + 1][2]
+    pmf = [[[[j, c.table[t, i, j]] for j in range(i + 1)] for i in range(c.table.shape[1])] for t in range(c.T)]
+    recursion = sia.StaffRecursion(f.feasibleActions, f.stateTransition, f.immediateValue, pmf, c.T, functor=f)
+    initialState = sia.StaffState(1, f.iniStaffNum)
+    opt = recursion.getExpectedValue(initialState)
+    assert opt == V[0][0] and recursion.getAction(initialState) == pol[0][0]
+    table = recursion.getOptTable()
+    width = int(P.x_lo[-1] + P.nx[-1])
+    _, _, val, act, seen, _ = P.memo(width)
+    want = [(t + 1, x, act[t, x]) for t in range(c.T) for x in np.nonzero(seen[t])[0]]
+    assert [tuple(r) for r in table.tolist()] == [(float(a), float(b), float(q)) for a, b, q in want]
+    with pytest.raises(KeyError):
+        recursion.getExpectedValue(sia.StaffState(1, 5))  # period 1 holds the initial staff number only
+    with pytest.raises(NotImplementedError):
+        recursion.getExpectedValue(initialState, 3)
+    recursion.close()
+
+
+def test_reachable_interval_clamped(sia, staffref):
+    c = staff_cases.staff_rates()
+    P = c.oracle_problem(staffref)
+    _, _, _, _, seen, _ = P.memo(int(P.x_lo[-1] + P.nx[-1]))
+    with _engine(sia, c) as eng:
+        for period in range(1, c.T + 1):
+            assert np.array_equal(eng.reachable(period).astype(bool), seen[period - 1][: int(P.nx[period - 1])]), period
+
+
+@pytest.mark.parametrize("make,world", [(staff_cases.staff_planning_small, 2), (staff_cases.staff_testing_small, 3),
+                                        (staff_cases.staff_wide_actions, 4)], ids=lambda v: getattr(v, "__name__", str(v)))
+def test_slabs(sia, staffref, make, world):
+    """world_size N slabs from one process, the all-gather played by hand (as tests/test_gpu_parity.py does)."""
+    import torch
+    c = make()
+    V, pol, _ = c.oracle_problem(staffref).solve()
+    engs = [_engine(sia, c, r, world) for r in range(world)]
+    bufs = []
+    for e in engs:
+        t = torch.zeros(e.values_bytes() // 8, dtype=torch.float64, device="cuda")
+        e.attach_values(t.data_ptr(), t.numel() * 8)
+        e.set_stream(torch.cuda.current_stream().cuda_stream)
+        bufs.append(t)
+    for period in range(c.T, 0, -1):
+        rows = []
+        for r, e in enumerate(engs):
+            e.run_period(period)
+            pad, _, _ = e.slab(period)
+            base = (e.exchange_ptr(period) - bufs[r].data_ptr()) // 8
+            rows.append(bufs[r][base: base + pad])
+        torch.cuda.synchronize()
+        full = torch.zeros_like(rows[0])
+        for r, e in enumerate(engs):
+            _, lo, hi = e.slab(period)
+            full[lo:hi] = rows[r][lo:hi]
+        for r in range(world):
+            rows[r].copy_(full)
+    torch.cuda.synchronize()
+    for period in range(1, c.T + 1):
+        for e in engs:
+            assert np.array_equal(e.values(period), V[period - 1])
+        assert np.array_equal(np.concatenate([e.policy(period) for e in engs]), pol[period - 1])
+    assert sum(e.stats().cells_evaluated for e in engs) == engs[0].stats().cells_all_ranks
+    for e in engs:
+        e.close()
+
+
+def test_workforce_planning_main_size(sia, staffref):
+    """WorkforcePlanning.java:33-50 at full size: T = 3, staff 0..600, hires 0..500, Binomial(y, 0.5) turnover --
+    5.4e8 cells, every table bit for bit."""
+    from stochastic_inventory_amd.pmf import staff_level_pmf
+    f = sia.StaffFunctor(fixCost=100, unitVariCost=10, salary=20, unitPenalty=80, minStaffNum=[40, 40, 40], maxHireNum=500,
+                         minX=0, maxX=600, clampStaff=True, iniStaffNum=0)
+    c = staff_cases.StaffCase("workforce_planning_main", f, staff_level_pmf([0.5, 0.5, 0.5], 601))
+    V, pol, cells = c.oracle_problem(staffref).solve(nthreads=16)
+    with _engine(sia, c) as eng:
+        eng.solve(sync=True)
+        for period in range(1, 4):
+            assert np.array_equal(eng.values(period), V[period - 1]) and np.array_equal(eng.policy(period), pol[period - 1])
+        assert eng.stats().cells_evaluated == cells
+
+
+def test_misuse_is_reported(sia):
+    c = staff_cases.staff_planning_small()
+    d = c.functor.to_desc(c.T)
+    with pytest.raises(ValueError):
+        sia.SdpEngine(d, None, [8.0] * c.T)  # no level table
+    with pytest.raises(sia.SdpgpuError):
+        sia.SdpEngine(d, None, [8.0] * c.T, level_pmf=c.table, level_row_len=np.arange(31, dtype=np.int32) + 2)  # j > y
+    with pytest.raises(sia.SdpgpuError):
+        eng = sia.SdpEngine(d, None, [8.5] * c.T, level_pmf=c.table)  # minStaffNum is an int[]
+        eng.solve(sync=True)
+    with _engine(sia, c) as eng:
+        eng.solve(sync=True)
+        with pytest.raises(sia.SdpgpuError):
+            eng.eval_states(1, [3.0], [0.0], [0.0])
+        assert eng.footprint(1) is None
