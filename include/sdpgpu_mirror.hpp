@@ -19,6 +19,7 @@
 // use.  Errors of the C ABI become std::runtime_error carrying sdpgpu_last_error().
 #pragma once
 
+#include <algorithm>
 #include <array>
 #include <cmath>
 #include <functional>
@@ -35,6 +36,10 @@ enum class OptDirection { MIN, MAX };  // Recursion.java:44-47, CashRecursion.ja
 
 /** double[][][] pmf: pmf[t][j] = {demand, probability} (Recursion.java:38). */
 using Pmf = std::vector<std::vector<std::array<double, 2>>>;
+
+/** double[][][][] pmfs of workforce.StaffRecursion: pmfs[t][y][j] = {j, P(turnover j | hire-up-to level y)}
+ *  (StaffRecursion.java:23, WorkforcePlanning.java:52-69). */
+using LevelPmf = std::vector<std::vector<std::vector<std::array<double, 2>>>>;
 
 template <class S, class A, class R, class S2>
 using StateTransitionFunction = std::function<S2(const S&, A, R)>;
@@ -95,6 +100,17 @@ class CashLeadtimeState : public CashState {
 };
 
 }  // namespace cash
+
+namespace workforce {
+
+class StaffState {  // StaffState.java:4-35
+ public:
+  StaffState(int period, int iniStaffNum) : period(period), iniStaffNum(iniStaffNum) {}
+  bool operator==(const StaffState& o) const { return period == o.period && iniStaffNum == o.iniStaffNum; }
+  int period, iniStaffNum;
+};
+
+}  // namespace workforce
 
 namespace gpu {
 
@@ -238,6 +254,33 @@ class Engine {
         check(sdpgpu_set_pmf(h_, t, d.data(), p.data(), (int32_t)d.size()));
       }
       for (size_t t = 0; t < overhead.size(); ++t) check(sdpgpu_set_overhead(h_, (int32_t)t, overhead[t]));
+    } catch (...) {
+      sdpgpu_destroy(h_);
+      throw;
+    }
+  }
+  /** STAFF family: the level-dependent table instead of one pmf per period; minStaffNum[t] rides on set_overhead. */
+  Engine(sdpgpu_desc desc, const LevelPmf& pmfs, const std::vector<int>& minStaffNum) : T_((int)pmfs.size()) {
+    desc.periods = T_;
+    if (sdpgpu_create(&desc, &h_) != 0) throw std::runtime_error(sdpgpu_last_error(nullptr));
+    try {
+      for (int t = 0; t < T_; ++t) {
+        const int32_t rows = (int32_t)pmfs[t].size();
+        int32_t stride = 1;
+        std::vector<int32_t> len;
+        for (const auto& row : pmfs[t]) {
+          len.push_back((int32_t)row.size());
+          stride = std::max(stride, (int32_t)row.size());
+        }
+        std::vector<double> prob((size_t)rows * (size_t)stride, 0.0);
+        for (int32_t y = 0; y < rows; ++y)
+          for (size_t j = 0; j < pmfs[t][y].size(); ++j) {
+            if (pmfs[t][y][j][0] != (double)j) throw std::invalid_argument("pmfs[t][y][j][0] must be j");
+            prob[(size_t)y * (size_t)stride + j] = pmfs[t][y][j][1];
+          }
+        check(sdpgpu_set_level_pmf(h_, t, prob.data(), len.data(), rows, stride));
+        check(sdpgpu_set_overhead(h_, t, (double)minStaffNum.at((size_t)t)));
+      }
     } catch (...) {
       sdpgpu_destroy(h_);
       throw;
@@ -560,6 +603,81 @@ class CashLeadtimeRecursion {
     return d;
   }
   double step_;
+  Engine engine_;
+};
+
+// ---- workforce.StaffRecursion (StaffRecursion.java:42-118, 237-254): MIN only ---------------------------
+struct StaffFunctor {  // WorkforcePlanning.java:72-101 (clampStaff) / WorkforceTesting.java:80-107 (no clamp)
+  double fixCost = 0, unitVariCost = 0, salary = 0, unitPenalty = 0;
+  std::vector<int> minStaffNum;
+  int maxHireNum = 0, minX = 0, maxX = 0, iniStaffNum = 0;
+  bool clampStaff = true;
+  void fill(sdpgpu_desc& d) const {
+    d.family = SDPGPU_FAMILY_STAFF;
+    d.step = 1;
+    d.min_inventory = minX;
+    d.max_inventory = maxX;
+    d.clamp_inventory = clampStaff ? 1 : 0;
+    d.ini_inventory = iniStaffNum;
+    d.max_order_quantity = maxHireNum;
+    d.fixed_order_cost = fixCost;
+    d.unit_order_cost = unitVariCost;
+    d.holding_cost = salary;
+    d.penalty_cost = unitPenalty;
+  }
+};
+
+class StaffRecursion {
+ public:
+  using State = workforce::StaffState;
+  using Trans = StateTransitionFunction<State, int, int, State>;
+  using Imm = ImmediateValueFunction<State, int, int, double>;
+  using Actions = std::function<std::vector<int>(const State&)>;
+
+  StaffRecursion(Actions getFeasibleAction, Trans stateTransition, Imm immediateValue, const LevelPmf& pmf, int T,
+                 const StaffFunctor& functor)
+      : getFeasibleAction(std::move(getFeasibleAction)), stateTransition(std::move(stateTransition)),
+        immediateValue(std::move(immediateValue)), engine_(desc_of(functor), pmf, functor.minStaffNum) {
+    if (T != (int)pmf.size()) throw std::invalid_argument("T != pmf.length");
+  }
+
+  Trans getStateTransitionFunction() const { return stateTransition; }
+  Imm getImmediateValueFunction() const { return immediateValue; }
+
+  double getExpectedValue(const State& s) { return at(s).first; }
+  int getAction(const State& s) { return at(s).second; }
+  /** rows {period, iniStaffNum, action} of the visited states (StaffRecursion.java:245-254). */
+  std::vector<std::array<double, 3>> getOptTable() {
+    std::vector<std::array<double, 3>> rows;
+    for (int period = 1; period <= engine_.periods(); ++period) {
+      const auto mask = engine_.reachable(period);
+      const auto& pol = engine_.policy(period);
+      double x_lo;
+      int64_t nx, nc, nq;
+      engine_.check(sdpgpu_grid(engine_.handle(), period, &x_lo, &nx, &nc, &nq));
+      for (size_t i = 0; i < mask.size(); ++i)
+        if (mask[i]) rows.push_back({(double)period, x_lo + (double)i, (double)pol[i]});
+    }
+    return rows;
+  }
+  Engine& engine() { return engine_; }
+
+  Actions getFeasibleAction;
+  Trans stateTransition;
+  Imm immediateValue;
+
+ private:
+  std::pair<double, int> at(const State& s) {
+    engine_.solve();
+    if (sdpgpu_state_index(engine_.handle(), s.period, (double)s.iniStaffNum, 0, 0) < 0)
+      throw std::out_of_range("staff number outside what the recursion can reach");  // the reference would NPE
+    return engine_.lookup(s.period, (double)s.iniStaffNum, 0, 0);
+  }
+  static sdpgpu_desc desc_of(const StaffFunctor& f) {
+    sdpgpu_desc d = make_desc(OptDirection::MIN);
+    f.fill(d);
+    return d;
+  }
   Engine engine_;
 };
 

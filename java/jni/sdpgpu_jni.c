@@ -80,6 +80,20 @@ JNIEXPORT void JNICALL Java_sdp_gpu_SdpGpu_setPmf(JNIEnv* env, jclass cls, jlong
   CHECK(env, h, rc);
 }
 
+JNIEXPORT void JNICALL Java_sdp_gpu_SdpGpu_setLevelPmf(JNIEnv* env, jclass cls, jlong h, jint t, jdoubleArray prob,
+                                                        jintArray rowLen, jint nRows, jint rowStride) {
+  if ((jlong)(*env)->GetArrayLength(env, prob) < (jlong)nRows * rowStride || (*env)->GetArrayLength(env, rowLen) < nRows) {
+    throw_state(env, "setLevelPmf: arrays shorter than nRows * rowStride / nRows");
+    return;
+  }
+  jdouble* p = (*env)->GetPrimitiveArrayCritical(env, prob, NULL);
+  jint* len = (*env)->GetPrimitiveArrayCritical(env, rowLen, NULL);
+  int rc = sdpgpu_set_level_pmf(H(h), t, p, (const int32_t*)len, nRows, rowStride); /* copies */
+  (*env)->ReleasePrimitiveArrayCritical(env, rowLen, len, JNI_ABORT);
+  (*env)->ReleasePrimitiveArrayCritical(env, prob, p, JNI_ABORT);
+  CHECK(env, h, rc);
+}
+
 JNIEXPORT void JNICALL Java_sdp_gpu_SdpGpu_setOverhead(JNIEnv* env, jclass cls, jlong h, jint t, jdouble oh) {
   CHECK(env, h, sdpgpu_set_overhead(H(h), t, oh));
 }

@@ -23,7 +23,7 @@ public final class SdpGpu {
 
 	/** Families: the closed-form lambda families of the in-scope drivers (sdpgpu_family). */
 	public static final int FAMILY_BACKORDER = 1, FAMILY_LEADTIME = 2, FAMILY_CASH = 3, FAMILY_OVERDRAFT = 4,
-			FAMILY_CASH_LEADTIME = 5, FAMILY_SURVIVAL = 6;
+			FAMILY_CASH_LEADTIME = 5, FAMILY_SURVIVAL = 6, FAMILY_STAFF = 7;
 	public static final int MIN = 0, MAX = 1;
 
 	/**
@@ -43,6 +43,11 @@ public final class SdpGpu {
 	public static native void destroy(long handle);
 
 	public static native void setPmf(long handle, int t, double[] demand, double[] prob);
+
+	/**
+	 * sdpgpu_set_level_pmf (STAFF family): prob[y * rowStride + j] = pmfs[t][y][j][1], rowLen[y] = pmfs[t][y].length.
+	 */
+	public static native void setLevelPmf(long handle, int t, double[] prob, int[] rowLen, int nRows, int rowStride);
 
 	public static native void setOverhead(long handle, int t, double overheadCost);
 

@@ -340,11 +340,83 @@ static int overdraft_limit(const Pmf& pmf, const char* source_path) {
   return 0;
 }
 
+// workforce.WorkforcePlanning.main (src/workforce/WorkforcePlanning.java:32-118) on a smaller staff range; the
+// binomial table comes from the file (rows of i + 1 probabilities per period), SSJ is not available here.
+static int workforce_planning(const char* path) {
+  using workforce::StaffState;
+  std::ifstream in(path);
+  int T, xLength;
+  in >> T >> xLength;
+  LevelPmf pmf((size_t)T);
+  for (int t = 0; t < T; t++) {
+    pmf[t].resize((size_t)xLength);
+    for (int i = 0; i < xLength; i++) {
+      pmf[t][i].resize((size_t)i + 1);
+      for (int j = 0; j < i + 1; j++) {
+        pmf[t][i][j][0] = j;
+        in >> pmf[t][i][j][1];
+      }
+    }
+  }
+  int iniStaffNum = 0;
+  double fixCost = 100, unitVariCost = 10, salary = 20, unitPenalty = 80;
+  std::vector<int> minStaffNum((size_t)T, 12);
+  int maxHireNum = 40, stepSize = 1, minX = 0, maxX = xLength - 1;
+
+  auto getFeasibleAction = [=](const StaffState&) {
+    std::vector<int> feasibleActions((size_t)(maxHireNum / stepSize) + 1);
+    int index = 0;
+    for (int i = 0; i <= maxHireNum; i = i + stepSize) feasibleActions[(size_t)index++] = i;
+    return feasibleActions;
+  };
+  auto stateTransition = [=](const StaffState& state, int action, int randomDemand) {
+    int nextStaffNum = state.iniStaffNum + action - randomDemand;
+    nextStaffNum = nextStaffNum > maxX ? maxX : nextStaffNum;
+    nextStaffNum = nextStaffNum < minX ? minX : nextStaffNum;
+    return StaffState(state.period + 1, nextStaffNum);
+  };
+  auto immediateValue = [=](const StaffState& state, int action, int randomDemand) {
+    double fixHireCost = action > 0 ? fixCost : 0;
+    double variHireCost = unitVariCost * action;
+    int nextStaffNum = state.iniStaffNum + action - randomDemand;
+    double salaryCost = salary * nextStaffNum;
+    int t = state.period - 1;
+    double penaltyCost = nextStaffNum > minStaffNum[(size_t)t] ? 0 : unitPenalty * (minStaffNum[(size_t)t] - nextStaffNum);
+    double totalCosts = fixHireCost + variHireCost + salaryCost + penaltyCost;
+    return totalCosts;
+  };
+
+  gpu::StaffFunctor functor;
+  functor.fixCost = fixCost;
+  functor.unitVariCost = unitVariCost;
+  functor.salary = salary;
+  functor.unitPenalty = unitPenalty;
+  functor.minStaffNum = minStaffNum;
+  functor.maxHireNum = maxHireNum;
+  functor.minX = minX;
+  functor.maxX = maxX;
+  functor.iniStaffNum = iniStaffNum;
+  gpu::StaffRecursion recursion(getFeasibleAction, stateTransition, immediateValue, pmf, T, functor);
+  int period = 1;
+  StaffState initialState(period, iniStaffNum);
+  double opt = recursion.getExpectedValue(initialState);
+  std::printf("final optimal expected cost is: %.17g\n", opt);
+  int optQ = recursion.getAction(initialState);
+  std::printf("optimal hiring number in the first priod is : %d\n", optQ);
+  auto optTable = recursion.getOptTable();
+  std::printf("visited states: %zu\n", optTable.size());
+  // the lambdas handed in are the ones the device family restates: spot-check one cell on the host
+  StaffState s2 = recursion.getStateTransitionFunction()(initialState, optQ, 3);
+  std::printf("V_2 after the first decision and 3 leavers: %.17g\n", recursion.getExpectedValue(s2));
+  return 0;
+}
+
 int main(int argc, char** argv) {
   if (argc < 3) return 1;
   try {
-    const Pmf pmf = read_pmf(argv[2]);
     const std::string which = argv[1];
+    if (which == "workforce") return workforce_planning(argv[2]);
+    const Pmf pmf = read_pmf(argv[2]);
     if (which == "clsp") return clsp(pmf);
     if (which == "leadtime") return leadtime(pmf);
     if (which == "cash") return cash_constraint(pmf);

@@ -127,3 +127,27 @@ def test_overdraft_limit_main_with_user_lambdas(exe, tmp_path, sia, oracle):
     assert _last_number(lines[1]) == m["action"]
     by = {(int(p), x, c): v for p, x, c, v in zip(m["period"], m["x"], m["cash"], m["values"])}
     assert _last_number(lines[2]) in [v for (p, x, c), v in by.items() if p == 2]
+
+
+def test_workforce_planning_main(exe, tmp_path, sia):
+    """WorkforcePlanning.main's lambdas on a smaller staff range (0..60, hires 0..40, three periods, turnover 0.5):
+    optimal cost, first hire, visited states and one successor's value against oracle/staffref.c."""
+    from oracle import staffref
+    from stochastic_inventory_amd.pmf import staff_level_pmf
+    T, rows = 3, 61
+    table = staff_level_pmf([0.5] * T, rows)
+    path = tmp_path / "workforce.tbl"
+    with open(path, "w") as f:
+        f.write(f"{T} {rows}\n")
+        for t in range(T):
+            for i in range(rows):
+                f.write(" ".join(repr(float(p)) for p in table[t, i, : i + 1]) + "\n")
+    lines = subprocess.run([exe, "workforce", str(path)], check=True, capture_output=True, text=True).stdout.strip().splitlines()
+    P = staffref.Problem(T=T, min_x=0, max_x=rows - 1, clamp=True, ini_x=0, max_hire=40, fix_cost=100, unit_vari_cost=10,
+                         salary=20, unit_penalty=80, min_staff=[12] * T, prob=table)
+    V, pol, _ = P.solve()
+    root, act, val, acts, seen, _ = P.memo(rows)
+    assert _last_number(lines[0]) == V[0][0] == root
+    assert int(lines[1].split()[-1]) == pol[0][0] == act
+    assert int(lines[2].split()[-1]) == int(seen.sum())
+    assert _last_number(lines[3]) == V[1][pol[0][0] - 3]
