@@ -98,6 +98,7 @@ struct sdpgpu_handle {
   std::vector<int> pending_chunks;       // >0: period's final rows not written yet (value = n_chunks)
   int n_pending = 0;
   sdp::FinalizeJob* d_jobs = nullptr;
+  std::vector<unsigned char> jobs_host;  // upload source of d_jobs: T FinalizeJobs at a fixed address (flush_pending)
   bool fuse_combine = true;
   bool use_cash_shift = true;
   bool use_cash_row = true;   // SDPGPU_CASH_ROW=0 turns the cash row kernel off (generic kernel instead)

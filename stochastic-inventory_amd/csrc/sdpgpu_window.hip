@@ -114,7 +114,11 @@ hipError_t launch_combine(const double* pv, const int32_t* pi, int n_chunks, int
 // Turn every pending period's keys + chunk rows into its final V_t / policy rows: one launch.
 hipError_t flush_pending(sdpgpu_handle* h) {
   if (h->n_pending == 0) return hipSuccess;
-  std::vector<sdp::FinalizeJob> jobs;
+  // The job list lives in the handle, at a fixed address: a caller that captures a sweep in a HIP graph records this
+  // upload as a memcpy node FROM that address, and every sweep writes the same list there.
+  if (h->jobs_host.size() < (size_t)h->T * sizeof(sdp::FinalizeJob)) h->jobs_host.resize((size_t)h->T * sizeof(sdp::FinalizeJob));
+  sdp::FinalizeJob* jobs = reinterpret_cast<sdp::FinalizeJob*>(h->jobs_host.data());
+  size_t n_jobs = 0;
   int64_t total = 0;
   for (int t = 0; t < h->T; ++t) {
     if (h->pending_chunks[t] <= 0) continue;
@@ -135,20 +139,19 @@ hipError_t flush_pending(sdpgpu_handle* h) {
     J.first = total;
     J.n_chunks = h->pending_chunks[t];
     total += J.vhi - J.vlo;
-    jobs.push_back(J);
+    jobs[n_jobs++] = J;
     h->pending_chunks[t] = 0;
   }
   h->n_pending = 0;
-  if (jobs.empty() || total == 0) return hipSuccess;
+  if (n_jobs == 0 || total == 0) return hipSuccess;
   if (!h->d_jobs) {
     hipError_t e = hipMalloc((void**)&h->d_jobs, (size_t)h->T * sizeof(sdp::FinalizeJob));
     if (e != hipSuccess) return e;
   }
-  // pageable source: HIP stages the bytes before hipMemcpyAsync returns, so `jobs` may go out of scope
-  hipError_t e = hipMemcpyAsync(h->d_jobs, jobs.data(), jobs.size() * sizeof(sdp::FinalizeJob), hipMemcpyHostToDevice, h->stream);
+  hipError_t e = hipMemcpyAsync(h->d_jobs, jobs, n_jobs * sizeof(sdp::FinalizeJob), hipMemcpyHostToDevice, h->stream);
   if (e != hipSuccess) return e;
   hipLaunchKernelGGL(sdp::finalize_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, h->stream, h->d_jobs,
-                     (int)jobs.size(), total);
+                     (int)n_jobs, total);
   return hipGetLastError();
 }
 
