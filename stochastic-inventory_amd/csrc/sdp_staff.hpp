@@ -13,13 +13,24 @@
 // strict-compare arg-min (ascending action) goes to a partial row; combine_staff_kernel scans the groups in
 // ascending order with the same strict compare, which is the reference's single scan (:110-113).
 //
+// Register block: the cells (a, j) and (a + 1, j + 1) of one state leave the same staff n = x + a - j behind, so the
+// salary cost, the penalty, the clamp and the V_{t+1}[n] read are the same for both -- only the probability and the
+// action's own hiring cost differ.  A lane therefore walks R consecutive actions along that anti-diagonal (step k:
+// action r is at j = k - (R-1-r)), forming the n-dependent operands once per step and spending, per cell, the
+// reference's two adds of totalCosts, two multiplies and two accumulator adds: hoisting an operation whose operands
+// are identical does not change its result.  Off the ends of a row the table holds zeros (kStaffPadJ padded rows on
+// either side of j = 0 .. maxj-1): a zero-probability step adds +0.0 twice, which leaves the accumulator as it is.
+//
 // Roofline: 8 B (V gather) + 8 B (probability) algorithmic per cell, both cache-resident (the table of a period is
-// rows^2 * 8 B = 3-8 MB, V is kilobytes); the limiter is fp64/int VALU issue (~11 instructions per cell).
+// rows^2 * 8 B = 3-8 MB, V is kilobytes); the limiter is fp64/int VALU issue: 6 fp64 operations per cell plus ~10
+// per step shared by R cells.
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
 namespace sdp {
+
+constexpr int kStaffPadJ = 8;  // zero rows before j = 0 and after j = maxj - 1 of the transposed table (>= R - 1)
 
 struct StaffParams {
   double K, v, salary, pen;  // fixCost, unitVariCost, salary, unitPenalty
@@ -29,6 +40,7 @@ struct StaffParams {
   int32_t clamp, min_x, max_x;
   int32_t x_lo;       // staff number of state index 0 (this period)
   int32_t next_x_lo;  // ... of the next period
+  int32_t nn_lo, nn_hi;  // bounds of the next staff number: [minX, maxX] when clamped, else the next period's box
   int32_t n_groups, group_actions;
   int64_t part_stride;  // elements between the partial rows of two groups
 };
@@ -76,6 +88,71 @@ __global__ __launch_bounds__(64) void staff_period_kernel(StaffParams P, const d
       best = acc;
       bestk = a;
     }
+  }
+  const int64_t at = (int64_t)group * P.part_stride + idx;
+  out_val[at] = best;
+  out_idx[at] = bestk;
+}
+
+// The register-blocked form described at the top (pT0 = address of the j = 0 row inside the padded table).
+template <int R, bool FUTURE>
+__global__ __launch_bounds__(64) void staff_block_kernel(StaffParams P, const double* __restrict__ pT0,
+                                                         const int32_t* __restrict__ row_len,
+                                                         const double* __restrict__ v_next,
+                                                         double* __restrict__ out_val, int32_t* __restrict__ out_idx,
+                                                         int64_t lo, int64_t hi) {
+  static_assert(R - 1 <= kStaffPadJ, "table padding");
+  const int64_t tile = blockIdx.x / P.n_groups;
+  const int group = (int)(blockIdx.x - tile * P.n_groups);
+  const int64_t idx = lo + tile * 64 + threadIdx.x;
+  if (idx >= hi) return;
+  const int x = P.x_lo + (int)idx;
+  const int a_end = min(P.n_actions, (group + 1) * P.group_actions);
+  double best = 1.7976931348623157e308;
+  int bestk = 0;
+  for (int a0 = group * P.group_actions; a0 < a_end; a0 += R) {
+    double fv[R], acc[R];
+    int64_t poff[R];  // p of action r at step k: pT0[k * rows + poff[r]]
+    int kmax = 0;
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+      const int a = a0 + r;
+      const int y = x + a;
+      const int row = y >= P.n_rows - 1 ? P.n_rows - 1 : y;
+      const int nj = a < P.n_actions ? row_len[row] : 0;
+      kmax = max(kmax, nj > 0 ? nj + (R - 1 - r) : 0);
+      const double fixHire = a > 0 ? P.K : 0.0;
+      const double variHire = P.v * (double)a;
+      fv[r] = fixHire + variHire;
+      acc[r] = 0.0;
+      poff[r] = (int64_t)row - (int64_t)(R - 1 - r) * P.n_rows;
+    }
+    const int ytop = x + a0 + R - 1;
+    for (int k = 0; k < kmax; ++k) {
+      const int n = ytop - k;  // nextStaffNum of every cell of this step (>= 0 while any of them is inside its row)
+      const double salaryCost = P.salary * (double)n;
+      const double penalty = n > P.min_staff ? 0.0 : P.pen * (double)(P.min_staff - n);
+      double vn = 0.0;
+      if constexpr (FUTURE) {
+        int nn = n > P.nn_hi ? P.nn_hi : n;
+        nn = nn < P.nn_lo ? P.nn_lo : nn;
+        vn = v_next[nn - P.next_x_lo];
+      }
+      const double* pk = pT0 + (int64_t)k * P.n_rows;
+#pragma unroll
+      for (int r = 0; r < R; ++r) {
+        const double p = pk[poff[r]];
+        const double imm = fv[r] + salaryCost + penalty;
+        acc[r] += p * imm;
+        if constexpr (FUTURE) acc[r] += p * vn;
+      }
+    }
+#pragma unroll
+    for (int r = 0; r < R; ++r)
+      if (a0 + r < P.n_actions && acc[r] < best) {
+        best = acc[r];
+        bestk = a0 + r;
+      }
   }
   const int64_t at = (int64_t)group * P.part_stride + idx;
   out_val[at] = best;

@@ -5,7 +5,8 @@
 
 namespace sdpgpu_detail {
 
-// Transposed device copy of one period's table: pT[j * rows + y], zero beyond a row's length.
+// Transposed device copy of one period's table: pT[j * rows + y], zero beyond a row's length and in kStaffPadJ rows
+// before j = 0 and after j = maxj - 1 (the register-blocked kernel steps off both ends); d_lvl_p[t] is the j = 0 row.
 int staff_upload(sdpgpu_handle* h) {
   h->d_lvl_p.assign((size_t)h->T, nullptr);
   h->d_lvl_len.assign((size_t)h->T, nullptr);
@@ -20,10 +21,14 @@ int staff_upload(sdpgpu_handle* h) {
       continue;
     }
     const size_t rows = (size_t)h->lvl_rows[t], maxj = (size_t)h->lvl_maxj[t];
-    HIP_TRY(h, hipMalloc((void**)&h->d_lvl_p[t], rows * maxj * sizeof(double)));
+    const size_t pad = (size_t)sdp::kStaffPadJ * rows;
+    double* base = nullptr;
+    HIP_TRY(h, hipMalloc((void**)&base, (rows * maxj + 2 * pad) * sizeof(double)));
+    h->staff_owned.push_back(base);
     HIP_TRY(h, hipMalloc((void**)&h->d_lvl_len[t], rows * sizeof(int32_t)));
-    h->staff_owned.push_back(h->d_lvl_p[t]);
     h->staff_owned.push_back(h->d_lvl_len[t]);
+    HIP_TRY(h, hipMemset(base, 0, (rows * maxj + 2 * pad) * sizeof(double)));
+    h->d_lvl_p[t] = base + pad;
     HIP_TRY(h, hipMemcpy(h->d_lvl_p[t], h->lvl_p[t].data(), rows * maxj * sizeof(double), hipMemcpyHostToDevice));
     HIP_TRY(h, hipMemcpy(h->d_lvl_len[t], h->lvl_len[t].data(), rows * sizeof(int32_t), hipMemcpyHostToDevice));
   }
@@ -32,12 +37,21 @@ int staff_upload(sdpgpu_handle* h) {
 
 // action groups per state tile: enough waves to fill 1024 SIMDs a few times over, few enough to keep the partial
 // rows small
+static int staff_block() {  // register block of staff_block_kernel (SDPGPU_STAFF_R = 4 | 8)
+  static const int r = [] {
+    const char* e = std::getenv("SDPGPU_STAFF_R");
+    return e && std::atoi(e) == 8 ? 8 : 4;
+  }();
+  return r;
+}
+
 static void staff_groups(const sdpgpu_handle* h, int64_t states, int* n_groups, int* group_actions) {
   const int64_t tiles = std::max<int64_t>(1, (states + 63) / 64);
   const int nA = h->n_actions_full;
   int64_t want = std::max<int64_t>(1, 16384 / tiles);
   want = std::min<int64_t>(want, nA);
-  const int ga = (int)((nA + want - 1) / want);
+  const int R = staff_block();  // groups hold whole register blocks
+  const int ga = (int)(((nA + want - 1) / want + R - 1) / R * R);
   *group_actions = ga;
   *n_groups = (nA + ga - 1) / ga;
 }
@@ -60,6 +74,13 @@ hipError_t launch_staff(sdpgpu_handle* h, int period, const double* v_next, doub
   S.max_x = (int32_t)d.max_inventory;
   S.x_lo = (int32_t)p.g.x_lo;
   S.next_x_lo = period < h->T ? (int32_t)h->per[period].g.x_lo : 0;
+  if (d.clamp_inventory) {
+    S.nn_lo = S.min_x;
+    S.nn_hi = S.max_x;
+  } else {  // (never binding for a cell inside its row; keeps the reads of zero-probability steps inside the table)
+    S.nn_lo = S.next_x_lo;
+    S.nn_hi = period < h->T ? S.next_x_lo + (int32_t)h->per[period].g.nx - 1 : 0;
+  }
   staff_groups(h, hi - lo, &S.n_groups, &S.group_actions);
   const int64_t tiles = (hi - lo + 63) / 64;
   const int64_t blocks = tiles * S.n_groups;
@@ -86,12 +107,28 @@ hipError_t launch_staff(sdpgpu_handle* h, int period, const double* v_next, doub
   }
   const double* pT = h->d_lvl_p[period - 1];
   const int32_t* len = h->d_lvl_len[period - 1];
-  if (period < h->T)
-    hipLaunchKernelGGL((sdp::staff_period_kernel<true>), dim3((unsigned)blocks), dim3(64), 0, st, S, pT, len, v_next,
+  static const bool plain = std::getenv("SDPGPU_STAFF_BLOCK") && std::atoi(std::getenv("SDPGPU_STAFF_BLOCK")) == 0;
+  if (plain) {  // one action at a time (kept as the cross-check of the register-blocked kernel)
+    if (period < h->T)
+      hipLaunchKernelGGL((sdp::staff_period_kernel<true>), dim3((unsigned)blocks), dim3(64), 0, st, S, pT, len, v_next,
+                         out_val, out_idx, lo, hi);
+    else
+      hipLaunchKernelGGL((sdp::staff_period_kernel<false>), dim3((unsigned)blocks), dim3(64), 0, st, S, pT, len, v_next,
+                         out_val, out_idx, lo, hi);
+  } else if (staff_block() == 8) {
+    if (period < h->T)
+      hipLaunchKernelGGL((sdp::staff_block_kernel<8, true>), dim3((unsigned)blocks), dim3(64), 0, st, S, pT, len, v_next,
+                         out_val, out_idx, lo, hi);
+    else
+      hipLaunchKernelGGL((sdp::staff_block_kernel<8, false>), dim3((unsigned)blocks), dim3(64), 0, st, S, pT, len, v_next,
+                         out_val, out_idx, lo, hi);
+  } else if (period < h->T) {
+    hipLaunchKernelGGL((sdp::staff_block_kernel<4, true>), dim3((unsigned)blocks), dim3(64), 0, st, S, pT, len, v_next,
                        out_val, out_idx, lo, hi);
-  else
-    hipLaunchKernelGGL((sdp::staff_period_kernel<false>), dim3((unsigned)blocks), dim3(64), 0, st, S, pT, len, v_next,
+  } else {
+    hipLaunchKernelGGL((sdp::staff_block_kernel<4, false>), dim3((unsigned)blocks), dim3(64), 0, st, S, pT, len, v_next,
                        out_val, out_idx, lo, hi);
+  }
   hipError_t e = hipGetLastError();
   if (e != hipSuccess || S.n_groups == 1) return e;
   hipLaunchKernelGGL(sdp::combine_staff_kernel, dim3((unsigned)((hi - lo + 255) / 256)), dim3(256), 0, st, out_val,
