@@ -145,3 +145,59 @@ def test_misuse_is_reported(sia):
         with pytest.raises(sia.SdpgpuError):
             eng.eval_states(1, [3.0], [0.0], [0.0])
         assert eng.footprint(1) is None
+
+
+def _random_case(seed):
+    rng = np.random.default_rng(seed)
+    T = int(rng.integers(1, 5))
+    clamp = bool(rng.integers(0, 2))
+    rows = int(rng.integers(2, 70))
+    max_hire = int(rng.integers(0, 40))
+    rates = rng.uniform(0.05, 0.95, size=T)
+    table = staff_cases.staff_level_pmf(list(rates), rows)
+    row_len = None
+    if rng.integers(0, 3) == 0:  # truncated rows (renormalised), shorter than y + 1
+        cap = int(rng.integers(1, rows + 1))
+        row_len = np.minimum(np.arange(rows) + 1, cap).astype(np.int32)
+        t2 = np.zeros((T, rows, cap))
+        for y in range(rows):
+            n = row_len[y]
+            t2[:, y, :n] = table[:, y, :n] / table[:, y, :n].sum(axis=1, keepdims=True)
+        table = t2
+    if clamp:
+        min_x = int(rng.integers(0, 10))
+        max_x = min_x + int(rng.integers(0, 150))
+        ini = int(rng.integers(min_x, max_x + 1))
+    else:  # a start well above the longest row: the next period's box then begins above zero
+        min_x = max_x = 0
+        ini = int(rng.integers(0, 3 * rows))
+    f = staff_cases.StaffFunctor(fixCost=float(rng.integers(0, 200)), unitVariCost=float(rng.integers(0, 30)) / 4,
+                                 salary=float(rng.integers(0, 40)) / 2, unitPenalty=float(rng.integers(0, 300)),
+                                 minStaffNum=[int(v) for v in rng.integers(0, 60, size=T)], maxHireNum=max_hire,
+                                 minX=min_x, maxX=max_x, clampStaff=clamp, iniStaffNum=ini)
+    return staff_cases.StaffCase(f"staff_fuzz_{seed}", f, table, row_len)
+
+
+def test_random_instances(sia, staffref):
+    """Seeded random instances: clamped and not, truncated rows, tables shorter than the staff range, starts above the
+    longest row, zero hires, single periods; whole tables and cell counts, slabs on every third one."""
+    for seed in range(60):
+        c = _random_case(seed)
+        V, pol, cells = c.oracle_problem(staffref).solve()
+        world = 1 + (seed % 3 == 0) * (1 + seed % 4)
+        got_cells = 0
+        for rank in range(world):
+            with _engine(sia, c, rank, world) as eng:
+                if world == 1:
+                    eng.solve(sync=True)
+                    for period in range(1, c.T + 1):
+                        assert np.array_equal(eng.values(period), V[period - 1]), (seed, period)
+                        assert np.array_equal(eng.policy(period), pol[period - 1]), (seed, period)
+                else:  # a slab of the last period only (no exchange needed there)
+                    eng.run_period(c.T)
+                    _, lo, hi = eng.slab(c.T)
+                    assert np.array_equal(eng.values(c.T)[lo:hi], V[c.T - 1][lo:hi]), (seed, rank)
+                    assert np.array_equal(eng.policy(c.T), pol[c.T - 1][lo:hi]), (seed, rank)
+                got_cells += eng.stats().cells_evaluated
+        if world == 1:
+            assert got_cells == cells, seed
