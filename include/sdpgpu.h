@@ -392,6 +392,30 @@ typedef struct sdpgpu_multilead {
 int sdpgpu_multilead_solve(const sdpgpu_multilead* k, double* final_value, int32_t* q1, int32_t* q2,
                            int64_t* states_per_period, int64_t* cells, double* gpu_ms);
 const char* sdpgpu_multilead_last_error(void);
+
+/* sdp.cash.multiItem.CashRecursionMulti.getExpectedValue (CashRecursionMulti.java:82-116) over the lambdas of
+ * cash.multiItem.MultiItemCash (MultiItemCash.java:66-118): two products, cash-limited orders
+ * (variCost[0] * i + variCost[1] * j < cash + 0.1), no lead time, state (I1, I2, cash) truncated to ints by the
+ * transition, the `> val + 0.1` scan.  Runs on the same reachable-set engine as sdpgpu_multilead_solve.
+ * The joint pmf of period t+1 is the list GetPmfMulti.getPmf(t) returns (rows {d1, d2, probability}):
+ * entries pmf_off[t] .. pmf_off[t+1]-1 of d1 / d2 / p. */
+typedef struct sdpgpu_multicash {
+  int32_t T;       /* horizon (TLength) */
+  int32_t q_bound; /* actions (i, j), i, j in [0, Qbound) */
+  double price[2], vari_cost[2], sal_price[2];
+  double ini_cash, ini_i1, ini_i2;
+  double min_inventory, max_inventory, min_cash, max_cash; /* min_cash >= 0 */
+  double discount;
+  const int32_t* pmf_off; /* T + 1 offsets */
+  const double* d1;
+  const double* d2;
+  const double* p;
+} sdpgpu_multicash;
+
+/* final_value = iniCash + V_1(iniState) (MultiItemCash.java:132); cells counts the offered actions only (the
+ * reference evaluates nothing else); errors through sdpgpu_multilead_last_error(). */
+int sdpgpu_multicash_solve(const sdpgpu_multicash* k, double* final_value, int32_t* q1, int32_t* q2,
+                           int64_t* states_per_period, int64_t* cells, double* gpu_ms);
 /* Kernel time of period t of the last solve (ms), needs sdpgpu_set_profiling(h, 1). */
 double sdpgpu_period_ms(sdpgpu_handle* h, int32_t period);
 

@@ -1102,3 +1102,124 @@ int sdpref_kat_multilead(const sdpref_multilead* k, double* final_value, int32_t
   free(m.tab);
   return 0;
 }
+
+/* ------------------------------------------------------------------------------------------
+ * sdp.cash.multiItem.CashRecursionMulti.getExpectedValue (CashRecursionMulti.java:82-116) over the lambdas of
+ * cash.multiItem.MultiItemCash (MultiItemCash.java:66-118): the literal memoised recursion.  Parity unpinned by
+ * the reference (its main has the solve commented out and records no output).
+ * ---------------------------------------------------------------------------------------- */
+typedef struct mcmemo {
+  const sdpref_multicash* k;
+  mlentry* tab;
+  int64_t cap, n, cells;
+  int64_t per_period[17];
+} mcmemo;
+
+/* MultiItemCash.java:79-99 */
+static double mc_imm(const sdpref_multicash* k, const mst_t* s, int32_t a1, int32_t a2, int32_t dm1, int32_t dm2) {
+  double action1 = a1, action2 = a2, demand1 = dm1, demand2 = dm2;
+  double endInventory1 = jmax(0, s->i1 + action1 - demand1);
+  double endInventory2 = jmax(0, s->i2 + action2 - demand2);
+  double revenue1 = k->price[0] * (s->i1 + action1 - endInventory1);
+  double revenue2 = k->price[1] * (s->i2 + action2 - endInventory2);
+  double revenue = revenue1 + revenue2;
+  double orderingCost1 = k->vari_cost[0] * action1;
+  double orderingCost2 = k->vari_cost[1] * action2;
+  double orderingCosts = orderingCost1 + orderingCost2;
+  double salValue = 0;
+  if (s->period == k->T) salValue = k->sal_price[0] * endInventory1 + k->sal_price[1] * endInventory2;
+  return revenue - orderingCosts + salValue;
+}
+
+/* MultiItemCash.java:103-118 (one-sided clamps and (int) casts as written there) */
+static void mc_trans(const sdpref_multicash* k, const mst_t* s, int32_t a1, int32_t a2, int32_t dm1, int32_t dm2,
+                     mst_t* out) {
+  double endInventory1 = s->i1 + (double)a1 - (double)dm1;
+  endInventory1 = jmax(0, endInventory1);
+  double endInventory2 = s->i2 + (double)a2 - (double)dm2;
+  endInventory2 = jmax(0, endInventory2);
+  double nextCash = s->cash + mc_imm(k, s, a1, a2, dm1, dm2);
+  nextCash = nextCash > k->max_cash ? k->max_cash : nextCash;
+  nextCash = nextCash < k->min_cash ? k->min_cash : nextCash;
+  endInventory1 = endInventory1 > k->max_inventory ? k->max_inventory : endInventory1;
+  endInventory2 = endInventory2 < k->min_inventory ? k->min_inventory : endInventory2;
+  nextCash = (double)jd2i(nextCash);
+  endInventory1 = (double)jd2i(endInventory1);
+  endInventory2 = (double)jd2i(endInventory2);
+  out->period = s->period + 1;
+  out->i1 = endInventory1;
+  out->i2 = endInventory2;
+  out->q1 = 0;
+  out->q2 = 0;
+  out->cash = nextCash;
+}
+
+static mlentry* mc_find(mcmemo* m, const mst_t* s) {
+  mlmemo view = {NULL, m->tab, m->cap, m->n, 0};
+  return ml_find(&view, s);
+}
+
+static double mc_value(mcmemo* m, const mst_t* s) {
+  mlentry* e = mc_find(m, s);
+  if (e->used) return e->value;
+  const sdpref_multicash* k = m->k;
+  const int32_t t = s->period - 1;
+  double val = -DBL_MAX;
+  int32_t b1 = 0, b2 = 0; /* new Actions(0, 0) */
+  for (int32_t ai = 0; ai < k->q_bound; ai++)
+    for (int32_t aj = 0; aj < k->q_bound; aj++) {
+      if (!(k->vari_cost[0] * ai + k->vari_cost[1] * aj < s->cash + 0.1)) continue; /* buildActionList, :66-76 */
+      double thisActionsValue = 0;
+      for (int32_t j = k->pmf_off[t]; j < k->pmf_off[t + 1]; j++) {
+        int32_t dm1 = jd2i(k->d1[j]), dm2 = jd2i(k->d2[j]); /* new Demands((int) .., (int) ..) */
+        thisActionsValue += k->p[j] * mc_imm(k, s, ai, aj, dm1, dm2);
+        if (s->period < k->T) {
+          mst_t ns;
+          mc_trans(k, s, ai, aj, dm1, dm2, &ns);
+          thisActionsValue += k->p[j] * k->discount * mc_value(m, &ns);
+        }
+        m->cells++;
+      }
+      if (thisActionsValue > val + 0.1) { /* CashRecursionMulti.java:108 */
+        val = thisActionsValue;
+        b1 = ai;
+        b2 = aj;
+      }
+    }
+  if ((m->n + 1) * 2 > m->cap) {
+    mlmemo view = {NULL, m->tab, m->cap, m->n, 0};
+    ml_grow(&view);
+    m->tab = view.tab;
+    m->cap = view.cap;
+  }
+  e = mc_find(m, s);
+  e->key = *s;
+  e->value = val;
+  e->a1 = b1;
+  e->a2 = b2;
+  e->used = 1;
+  m->n++;
+  m->per_period[s->period]++;
+  return val;
+}
+
+int sdpref_multicash_memo(const sdpref_multicash* k, double* final_value, int32_t* q1, int32_t* q2,
+                          int64_t* states_per_period, int64_t* cells) {
+  if (!k || k->T < 1 || k->T > 16 || !k->pmf_off || !k->d1 || !k->d2 || !k->p) return 1;
+  mcmemo m;
+  memset(&m, 0, sizeof m);
+  m.k = k;
+  m.cap = 1 << 14;
+  m.tab = (mlentry*)calloc((size_t)m.cap, sizeof(mlentry));
+  mst_t ini = {1, k->ini_i1, k->ini_i2, 0, 0, k->ini_cash}; /* MultiItemCash.java:130 */
+  double v = mc_value(&m, &ini);
+  mlentry* e = mc_find(&m, &ini);
+  if (final_value) *final_value = k->ini_cash + v; /* :132 */
+  if (q1) *q1 = e->a1;
+  if (q2) *q2 = e->a2;
+  if (states_per_period)
+    for (int32_t t = 0; t < k->T; t++) states_per_period[t] = m.per_period[t + 1];
+  if (cells) *cells = m.cells;
+  free(m.tab);
+  return 0;
+}

@@ -100,6 +100,12 @@ typedef struct sdpref_multilead {
 int sdpref_kat_multilead(const sdpref_multilead* k, double* final_value, int32_t* q1, int32_t* q2,
                          int64_t* states_visited, int64_t* cells);
 
+/* CashRecursionMulti.getExpectedValue (CashRecursionMulti.java:82-116) over the lambdas of MultiItemCash.java:66-118:
+ * literal memoised recursion.  Same fields as sdpgpu_multicash (include/sdpgpu.h). */
+typedef sdpgpu_multicash sdpref_multicash;
+int sdpref_multicash_memo(const sdpref_multicash* k, double* final_value, int32_t* q1, int32_t* q2,
+                          int64_t* states_per_period, int64_t* cells);
+
 /* User-defined lambdas: host-compiled versions of the three functions sdpgpu_create_custom takes (signatures in
  * sdpref.c).  Pass NULLs to return to the built-in families.  Not thread-safe: test harness use only. */
 void sdpref_register_custom(void* count_fn, void* imm_fn, void* trans_fn, const double* params);

@@ -239,6 +239,20 @@ def kat_multilead(**kw):
     return fv.value, q1.value, q2.value, ns.value, nc.value
 
 
+def multicash_memo(**kw):
+    """sdpref_multicash_memo (CashRecursionMulti over MultiItemCash's lambdas): returns
+    (final_value, q1, q2, states_per_period, cells).  Takes the arguments of stochastic_inventory_amd.multicash_solve."""
+    from stochastic_inventory_amd._abi import SdpgpuMulticash  # struct layout only
+    from stochastic_inventory_amd.multiitem import fill_multicash  # fills the struct from the reference's arrays
+    k = fill_multicash(SdpgpuMulticash(), **kw)
+    fv, q1, q2, nc = C.c_double(), C.c_int32(), C.c_int32(), C.c_int64()
+    states = (C.c_int64 * k.T)()
+    rc = lib().sdpref_multicash_memo(C.byref(k), C.byref(fv), C.byref(q1), C.byref(q2), states, C.byref(nc))
+    if rc:
+        raise RuntimeError(f"sdpref_multicash_memo failed: {rc}")
+    return fv.value, q1.value, q2.value, list(states), nc.value
+
+
 # ---------------------------------------------------------------------------------------------------------
 # User-defined lambdas: the SAME source text the product hands to hipRTC, compiled for the host with g++
 # (-ffp-contract=off) and registered with the oracle as function pointers.

@@ -136,6 +136,20 @@ class SdpgpuMultilead(C.Structure):
     ]
 
 
+class SdpgpuMulticash(C.Structure):
+    """struct sdpgpu_multicash (include/sdpgpu.h)."""
+
+    _fields_ = [
+        ("T", C.c_int32), ("q_bound", C.c_int32),
+        ("price", C.c_double * 2), ("vari_cost", C.c_double * 2), ("sal_price", C.c_double * 2),
+        ("ini_cash", C.c_double), ("ini_i1", C.c_double), ("ini_i2", C.c_double),
+        ("min_inventory", C.c_double), ("max_inventory", C.c_double), ("min_cash", C.c_double),
+        ("max_cash", C.c_double), ("discount", C.c_double),
+        ("pmf_off", C.POINTER(C.c_int32)), ("d1", C.POINTER(C.c_double)), ("d2", C.POINTER(C.c_double)),
+        ("p", C.POINTER(C.c_double)),
+    ]
+
+
 # every symbol include/sdpgpu.h declares: name -> (restype, argtypes)
 _P = C.c_void_p
 _DP = C.POINTER(C.c_double)
@@ -185,6 +199,7 @@ EXPORTS = {
     "sdpgpu_period_ms": (C.c_double, [_P, C.c_int32]),
     "sdpgpu_multilead_solve": (C.c_int, [C.POINTER(SdpgpuMultilead), _DP, _IP, _IP, _LP, _LP, _DP]),
     "sdpgpu_multilead_last_error": (C.c_char_p, []),
+    "sdpgpu_multicash_solve": (C.c_int, [C.POINTER(SdpgpuMulticash), _DP, _IP, _IP, _LP, _LP, _DP]),
 }
 
 _lib = None

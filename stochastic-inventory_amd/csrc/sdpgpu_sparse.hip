@@ -44,6 +44,7 @@ struct MLParams {
   int32_t nd;       // demand pairs, index = i1 * n2 + i2 (GetPmfMulti.java:157-172)
   int32_t is_last;  // period == T: salvage applies, no transition
   int32_t cash_int_cast;  // MultiProductLeadtime.java:219
+  int32_t model;          // 0: CashRecursionMultiLead + MultiProductLeadtime lambdas; 1: CashRecursionMulti + MultiItemCash
 };
 
 struct Tuple {
@@ -131,9 +132,59 @@ __device__ __forceinline__ bool tuple_eq(const Tuple& a, const Tuple& b) {
   return a.i1 == b.i1 && a.i2 == b.i2 && a.q1 == b.q1 && a.q2 == b.q2 && a.cash == b.cash;
 }
 
+// ---- model 1: sdp.cash.multiItem.CashRecursionMulti over the lambdas of cash.multiItem.MultiItemCash ----------
+// buildActionList (MultiItemCash.java:66-76): (i, j) is offered iff variCost[0] * i + variCost[1] * j < iniCash + 0.1
+__device__ __forceinline__ bool mc_feasible(const MLParams& P, const Tuple& s, int a1, int a2) {
+  return P.vari[0] * a1 + P.vari[1] * a2 < s.cash + 0.1;
+}
+
+// immediateValue (MultiItemCash.java:79-99)
+__device__ __forceinline__ double mc_immediate(const MLParams& P, const Tuple& s, int a1, int a2, double demand1,
+                                               double demand2) {
+  const double action1 = (double)a1, action2 = (double)a2;
+  const double endInventory1 = jmax(0.0, s.i1 + action1 - demand1);
+  const double endInventory2 = jmax(0.0, s.i2 + action2 - demand2);
+  const double revenue1 = P.price[0] * (s.i1 + action1 - endInventory1);
+  const double revenue2 = P.price[1] * (s.i2 + action2 - endInventory2);
+  const double revenue = revenue1 + revenue2;
+  const double orderingCost1 = P.vari[0] * action1;
+  const double orderingCost2 = P.vari[1] * action2;
+  const double orderingCosts = orderingCost1 + orderingCost2;
+  double salValue = 0;
+  if (P.is_last) salValue = P.sal[0] * endInventory1 + P.sal[1] * endInventory2;
+  return revenue - orderingCosts + salValue;
+}
+
+// stateTransition (MultiItemCash.java:103-118): upper clamp on product 1 only, lower clamp on product 2 only, (int) casts
+__device__ __forceinline__ Tuple mc_successor(const MLParams& P, const Tuple& s, int a1, int a2, double demand1,
+                                              double demand2) {
+  double endInventory1 = s.i1 + (double)a1 - demand1;
+  endInventory1 = jmax(0.0, endInventory1);
+  double endInventory2 = s.i2 + (double)a2 - demand2;
+  endInventory2 = jmax(0.0, endInventory2);
+  double nextCash = s.cash + mc_immediate(P, s, a1, a2, demand1, demand2);
+  nextCash = nextCash > P.max_cash ? P.max_cash : nextCash;
+  nextCash = nextCash < P.min_cash ? P.min_cash : nextCash;
+  endInventory1 = endInventory1 > P.max_inventory ? P.max_inventory : endInventory1;
+  endInventory2 = endInventory2 < P.min_inventory ? P.min_inventory : endInventory2;
+  Tuple n;
+  n.cash = (double)(int)nextCash;
+  n.i1 = (double)(int)endInventory1;
+  n.i2 = (double)(int)endInventory2;
+  n.q1 = 0.0;
+  n.q2 = 0.0;
+  return n;
+}
+
 // The successor of (state, action a, demand j).
 __device__ __forceinline__ Tuple successor(const MLParams& P, const Tuple& s, int a, const double2* dem, int j) {
   const int a1 = a / P.qb, a2 = a - a1 * P.qb;
+  if (P.model == 1) {
+    // an action the state is not offered has no successors of its own: it stands in for (0, 0), which is always
+    // offered (0 < cash + 0.1 with cash >= min_cash >= 0), so the candidate list gains nothing new
+    const bool ok = mc_feasible(P, s, a1, a2);
+    return mc_successor(P, s, ok ? a1 : 0, ok ? a2 : 0, dem[j].x, dem[j].y);
+  }
   const double oc = P.vari[0] * (double)a1 + P.vari[1] * (double)a2;
   const double before = s.cash - oc - P.overhead;
   const double bi = before - ml_interest(P, before);
@@ -213,7 +264,8 @@ __global__ __launch_bounds__(256) void backward_kernel(MLParams P, const Tuple* 
                                                        int64_t n_states,
                                                        const double2* __restrict__ dem, const double* __restrict__ prob,
                                                        const double* __restrict__ v_next, const int* __restrict__ uid,
-                                                       double* __restrict__ v_out, int* __restrict__ act_out) {
+                                                       double* __restrict__ v_out, int* __restrict__ act_out,
+                                                       unsigned long long* __restrict__ cell_count) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int NA = P.qb * P.qb;
   double* s_q = reinterpret_cast<double*>(smem);                       // Q(s, a)
@@ -228,7 +280,24 @@ __global__ __launch_bounds__(256) void backward_kernel(MLParams P, const Tuple* 
     s_p[j] = prob[j];
   }
   __syncthreads();
-  for (int a = tid; a < NA; a += 256) {
+  unsigned long long offered = 0;
+  for (int a = tid; a < NA && P.model == 1; a += 256) {
+    const int a1 = a / P.qb, a2 = a - a1 * P.qb;
+    if (!mc_feasible(P, st, a1, a2)) {
+      s_q[a] = -1.7976931348623157e308;  // never passes `> val + 0.1`: as if it were not in the list
+      continue;
+    }
+    ++offered;
+    double acc = 0.0;  // thisActionsValue, CashRecursionMulti.java:97-105
+    for (int j = 0; j < P.nd; ++j) {
+      const double p = s_p[j];
+      acc += p * mc_immediate(P, st, a1, a2, dem[j].x, dem[j].y);
+      if (!P.is_last) acc += p * P.discount * v_next[uid[((int64_t)s * NA + a) * P.nd + j]];
+    }
+    s_q[a] = acc;
+  }
+  if (P.model == 1 && offered && cell_count) atomicAdd(cell_count, offered * (unsigned long long)P.nd);
+  for (int a = tid; a < NA && P.model == 0; a += 256) {
     const int a1 = a / P.qb, a2 = a - a1 * P.qb;
     const double oc = P.vari[0] * (double)a1 + P.vari[1] * (double)a2;
     const double before = st.cash - oc - P.overhead;
@@ -276,45 +345,29 @@ __global__ __launch_bounds__(256) void backward_kernel(MLParams P, const Tuple* 
     }                                                                                    \
   } while (0)
 
-}  // namespace
+struct SparseProblem {
+  int T = 0;
+  MLParams P{};
+  double overhead[16] = {0};
+  Tuple ini{};
+  std::vector<int> off;  // demand pairs of period t+1: [off[t], off[t+1])
+  std::vector<double2> dem;
+  std::vector<double> prob;
+};
 
-extern "C" {
-
-const char* sdpgpu_multilead_last_error(void) { return g_ml_error.c_str(); }
-
-int sdpgpu_multilead_solve(const sdpgpu_multilead* k, double* final_value, int32_t* q1, int32_t* q2,
-                           int64_t* states_per_period, int64_t* cells, double* gpu_ms) {
-  g_ml_error.clear();
-  if (!k || k->T < 1 || k->T > 16 || k->n1 < 1 || k->n1 > 16 || k->n2 < 1 || k->n2 > 16 || k->q_bound < 1 ||
-      k->q_bound > 256) {
-    g_ml_error = "multilead: bad descriptor";
-    return SDPGPU_ERR_ARG;
-  }
+int sparse_solve(const SparseProblem& sp, double* final_value, int32_t* q1, int32_t* q2, int64_t* states_per_period,
+                 int64_t* cells, double* gpu_ms) {
   int ndev = 0;
   if (hipGetDeviceCount(&ndev) != hipSuccess || ndev < 1) {
     g_ml_error = "no HIP device available; this library has no CPU path";
     return SDPGPU_ERR_DEVICE;
   }
-  const int T = k->T, nd = k->n1 * k->n2, NA = k->q_bound * k->q_bound;
-  std::vector<double2> h_dem((size_t)nd);
-  std::vector<double> h_prob((size_t)nd);
-  for (int i = 0; i < k->n1; ++i)
-    for (int j = 0; j < k->n2; ++j) {
-      // `new Demands((int) dAndP[j][0], (int) dAndP[j][1])`, CashRecursionMultiLead.java:74
-      h_dem[(size_t)i * k->n2 + j] = make_double2((double)(int)k->v1[i], (double)(int)k->v2[j]);
-      h_prob[(size_t)i * k->n2 + j] = k->p1[i] * k->p2[j];
-    }
-  MLParams P{};
-  for (int i = 0; i < 2; ++i) {
-    P.price[i] = k->price[i];
-    P.vari[i] = k->vari_cost[i];
-    P.sal[i] = k->sal_value[i];
-  }
-  P.r0 = k->r0; P.r1 = k->r1; P.r2 = k->r2; P.limit = k->limit; P.interest_free = k->interest_free;
-  P.min_inventory = k->min_inventory; P.max_inventory = k->max_inventory;
-  P.min_cash = k->min_cash; P.max_cash = k->max_cash; P.discount = k->discount;
-  P.qb = k->q_bound; P.nd = nd;
-  P.cash_int_cast = k->cash_int_cast;
+  const int T = sp.T, NA = sp.P.qb * sp.P.qb;
+  const int nd_all = sp.off[(size_t)T];
+  const std::vector<double2>& h_dem = sp.dem;
+  const std::vector<double>& h_prob = sp.prob;
+  MLParams P = sp.P;
+  const Tuple ini = sp.ini;
 
   std::vector<Tuple*> d_states((size_t)T, nullptr);
   std::vector<int*> d_uid((size_t)T, nullptr);
@@ -327,30 +380,35 @@ int sdpgpu_multilead_solve(const sdpgpu_multilead* k, double* final_value, int32
   void* d_tmp = nullptr;
   double *d_vcur = nullptr, *d_vnext = nullptr;
   int* d_act = nullptr;
+  unsigned long long* d_cells = nullptr;
   hipEvent_t ev0 = nullptr, ev1 = nullptr;
   int64_t total_cells = 0;
   int rc = SDPGPU_ERR_DEVICE;
   {
     ML_TRY(hipEventCreate(&ev0));
     ML_TRY(hipEventCreate(&ev1));
-    ML_TRY(hipMalloc((void**)&d_dem, (size_t)nd * sizeof(double2)));
-    ML_TRY(hipMalloc((void**)&d_prob, (size_t)nd * sizeof(double)));
-    ML_TRY(hipMemcpy(d_dem, h_dem.data(), (size_t)nd * sizeof(double2), hipMemcpyHostToDevice));
-    ML_TRY(hipMemcpy(d_prob, h_prob.data(), (size_t)nd * sizeof(double), hipMemcpyHostToDevice));
-    Tuple ini{k->ini_i1, k->ini_i2, 0.0, 0.0, k->ini_cash};  // MultiProductLeadtime.java:232
+    ML_TRY(hipMalloc((void**)&d_dem, (size_t)nd_all * sizeof(double2)));
+    ML_TRY(hipMalloc((void**)&d_prob, (size_t)nd_all * sizeof(double)));
+    ML_TRY(hipMemcpy(d_dem, h_dem.data(), (size_t)nd_all * sizeof(double2), hipMemcpyHostToDevice));
+    ML_TRY(hipMemcpy(d_prob, h_prob.data(), (size_t)nd_all * sizeof(double), hipMemcpyHostToDevice));
+    ML_TRY(hipMalloc((void**)&d_cells, 8));
+    ML_TRY(hipMemset(d_cells, 0, 8));
     ML_TRY(hipMalloc((void**)&d_states[0], sizeof(Tuple)));
     ML_TRY(hipMemcpy(d_states[0], &ini, sizeof(Tuple), hipMemcpyHostToDevice));
     n_states[0] = 1;
     ML_TRY(hipEventRecord(ev0, 0));
     // ---- forward ----
     for (int t = 0; t + 1 < T; ++t) {
+      const int nd = sp.off[(size_t)t + 1] - sp.off[(size_t)t];
+      const double2* dem_t = d_dem + sp.off[(size_t)t];
+      P.nd = nd;
       const int64_t nc = n_states[t] * NA * nd;
       if (nc >= 2000000000LL) {
         g_ml_error = "multilead: the reachable set outgrows 32-bit candidate indices (the reference's own comment calls such instances unsolvable)";
         rc = SDPGPU_ERR_UNSUPPORTED;
         goto fail;
       }
-      P.overhead = k->overhead[t];
+      P.overhead = sp.overhead[t];
       P.is_last = 0;
       ML_TRY(hipMalloc((void**)&d_hash, (size_t)nc * 8));
       ML_TRY(hipMalloc((void**)&d_hash2, (size_t)nc * 8));
@@ -360,7 +418,7 @@ int sdpgpu_multilead_solve(const sdpgpu_multilead* k, double* final_value, int32
       ML_TRY(hipMalloc((void**)&d_rank, (size_t)nc * 4));
       ML_TRY(hipMalloc((void**)&d_uid[t], (size_t)nc * 4));
       const unsigned gsa = (unsigned)((n_states[t] * NA + 255) / 256);
-      hipLaunchKernelGGL(expand_kernel, dim3(gsa), dim3(256), 0, 0, P, d_states[t], n_states[t], d_dem, d_hash, d_order);
+      hipLaunchKernelGGL(expand_kernel, dim3(gsa), dim3(256), 0, 0, P, d_states[t], n_states[t], dem_t, d_hash, d_order);
       ML_TRY(hipGetLastError());
       size_t tmp_bytes = 0;
       ML_TRY(hipcub::DeviceRadixSort::SortPairs(nullptr, tmp_bytes, d_hash, d_hash2, d_order, d_order2, (int)nc));
@@ -369,7 +427,7 @@ int sdpgpu_multilead_solve(const sdpgpu_multilead* k, double* final_value, int32
       ML_TRY(hipFree(d_tmp));
       d_tmp = nullptr;
       const unsigned gc = (unsigned)((nc + 255) / 256);
-      hipLaunchKernelGGL(mark_heads_kernel, dim3(gc), dim3(256), 0, 0, P, d_states[t], d_dem, d_order2, nc, d_head);
+      hipLaunchKernelGGL(mark_heads_kernel, dim3(gc), dim3(256), 0, 0, P, d_states[t], dem_t, d_order2, nc, d_head);
       ML_TRY(hipGetLastError());
       ML_TRY(hipcub::DeviceScan::InclusiveSum(nullptr, tmp_bytes, d_head, d_rank, (int)nc));
       ML_TRY(hipMalloc(&d_tmp, tmp_bytes));
@@ -380,7 +438,7 @@ int sdpgpu_multilead_solve(const sdpgpu_multilead* k, double* final_value, int32
       ML_TRY(hipMemcpy(&n_next, d_rank + (nc - 1), 4, hipMemcpyDeviceToHost));
       n_states[t + 1] = n_next;
       ML_TRY(hipMalloc((void**)&d_states[t + 1], (size_t)n_next * sizeof(Tuple)));
-      hipLaunchKernelGGL(scatter_kernel, dim3(gc), dim3(256), 0, 0, P, d_states[t], d_dem, d_order2, d_head, d_rank, nc,
+      hipLaunchKernelGGL(scatter_kernel, dim3(gc), dim3(256), 0, 0, P, d_states[t], dem_t, d_order2, d_head, d_rank, nc,
                          d_states[t + 1], d_uid[t]);
       ML_TRY(hipGetLastError());
       ML_TRY(hipDeviceSynchronize());
@@ -392,7 +450,9 @@ int sdpgpu_multilead_solve(const sdpgpu_multilead* k, double* final_value, int32
     }
     // ---- backward ----
     for (int t = T - 1; t >= 0; --t) {
-      P.overhead = k->overhead[t];
+      const int nd = sp.off[(size_t)t + 1] - sp.off[(size_t)t];
+      P.nd = nd;
+      P.overhead = sp.overhead[t];
       P.is_last = (t == T - 1);
       ML_TRY(hipMalloc((void**)&d_vcur, (size_t)n_states[t] * 8));
       if (d_act) (void)hipFree(d_act);
@@ -403,10 +463,10 @@ int sdpgpu_multilead_solve(const sdpgpu_multilead* k, double* final_value, int32
       for (int64_t first = 0; first < n_states[t]; first += (int64_t)1 << 22) {
         const int64_t nb = std::min<int64_t>((int64_t)1 << 22, n_states[t] - first);
         hipLaunchKernelGGL(backward_kernel, dim3((unsigned)nb), dim3(256), smem, 0, P, d_states[t], first, n_states[t],
-                           d_dem, d_prob, d_vnext, d_uid[t], d_vcur, d_act);
+                           d_dem + sp.off[(size_t)t], d_prob + sp.off[(size_t)t], d_vnext, d_uid[t], d_vcur, d_act, d_cells);
         ML_TRY(hipGetLastError());
       }
-      total_cells += n_states[t] * (int64_t)NA * nd;
+      if (P.model == 0) total_cells += n_states[t] * (int64_t)NA * nd;
       if (d_vnext) (void)hipFree(d_vnext);
       d_vnext = d_vcur;
       d_vcur = nullptr;
@@ -417,9 +477,14 @@ int sdpgpu_multilead_solve(const sdpgpu_multilead* k, double* final_value, int32
     int act = 0;
     ML_TRY(hipMemcpy(&v, d_vnext, 8, hipMemcpyDeviceToHost));
     ML_TRY(hipMemcpy(&act, d_act, 4, hipMemcpyDeviceToHost));
-    if (final_value) *final_value = k->ini_cash + v;  // MultiProductLeadtime.java:234
-    if (q1) *q1 = act / k->q_bound;
-    if (q2) *q2 = act % k->q_bound;
+    if (P.model == 1) {  // only the actions a state is offered were evaluated: counted on the device
+      unsigned long long c = 0;
+      ML_TRY(hipMemcpy(&c, d_cells, 8, hipMemcpyDeviceToHost));
+      total_cells = (int64_t)c;
+    }
+    if (final_value) *final_value = ini.cash + v;  // MultiProductLeadtime.java:234 / MultiItemCash.java:132
+    if (q1) *q1 = act / P.qb;
+    if (q2) *q2 = act % P.qb;
     if (states_per_period)
       for (int t = 0; t < T; ++t) states_per_period[t] = n_states[t];
     if (cells) *cells = total_cells;
@@ -445,9 +510,93 @@ fail:
   if (d_vcur) (void)hipFree(d_vcur);
   if (d_vnext) (void)hipFree(d_vnext);
   if (d_act) (void)hipFree(d_act);
+  if (d_cells) (void)hipFree(d_cells);
   if (ev0) (void)hipEventDestroy(ev0);
   if (ev1) (void)hipEventDestroy(ev1);
   return rc;
+}
+
+}  // namespace
+
+extern "C" {
+
+const char* sdpgpu_multilead_last_error(void) { return g_ml_error.c_str(); }
+
+int sdpgpu_multilead_solve(const sdpgpu_multilead* k, double* final_value, int32_t* q1, int32_t* q2,
+                           int64_t* states_per_period, int64_t* cells, double* gpu_ms) {
+  g_ml_error.clear();
+  if (!k || k->T < 1 || k->T > 16 || k->n1 < 1 || k->n1 > 16 || k->n2 < 1 || k->n2 > 16 || k->q_bound < 1 ||
+      k->q_bound > 256) {
+    g_ml_error = "multilead: bad descriptor";
+    return SDPGPU_ERR_ARG;
+  }
+  SparseProblem sp;
+  sp.T = k->T;
+  const int nd = k->n1 * k->n2;
+  for (int t = 0; t <= k->T; ++t) sp.off.push_back(t * nd);
+  for (int t = 0; t < k->T; ++t)  // the same product list every period (GetPmfMulti.java:157-172)
+    for (int i = 0; i < k->n1; ++i)
+      for (int j = 0; j < k->n2; ++j) {
+        // `new Demands((int) dAndP[j][0], (int) dAndP[j][1])`, CashRecursionMultiLead.java:74
+        sp.dem.push_back(make_double2((double)(int)k->v1[i], (double)(int)k->v2[j]));
+        sp.prob.push_back(k->p1[i] * k->p2[j]);
+      }
+  MLParams& P = sp.P;
+  for (int i = 0; i < 2; ++i) {
+    P.price[i] = k->price[i];
+    P.vari[i] = k->vari_cost[i];
+    P.sal[i] = k->sal_value[i];
+  }
+  P.r0 = k->r0; P.r1 = k->r1; P.r2 = k->r2; P.limit = k->limit; P.interest_free = k->interest_free;
+  P.min_inventory = k->min_inventory; P.max_inventory = k->max_inventory;
+  P.min_cash = k->min_cash; P.max_cash = k->max_cash; P.discount = k->discount;
+  P.qb = k->q_bound;
+  P.cash_int_cast = k->cash_int_cast;
+  P.model = 0;
+  for (int t = 0; t < k->T; ++t) sp.overhead[t] = k->overhead[t];
+  sp.ini = Tuple{k->ini_i1, k->ini_i2, 0.0, 0.0, k->ini_cash};  // MultiProductLeadtime.java:232
+  return sparse_solve(sp, final_value, q1, q2, states_per_period, cells, gpu_ms);
+}
+
+int sdpgpu_multicash_solve(const sdpgpu_multicash* k, double* final_value, int32_t* q1, int32_t* q2,
+                           int64_t* states_per_period, int64_t* cells, double* gpu_ms) {
+  g_ml_error.clear();
+  if (!k || k->T < 1 || k->T > 16 || k->q_bound < 1 || k->q_bound > 256 || !k->pmf_off || !k->d1 || !k->d2 || !k->p) {
+    g_ml_error = "multicash: bad descriptor";
+    return SDPGPU_ERR_ARG;
+  }
+  if (k->min_cash < 0 || k->ini_cash < 0) {
+    // (0, 0) must always be on offer (0 < cash + 0.1): the candidate lists lean on it
+    g_ml_error = "multicash: negative cash is not supported (MultiItemCash.java:51 has minCashState = 0)";
+    return SDPGPU_ERR_UNSUPPORTED;
+  }
+  SparseProblem sp;
+  sp.T = k->T;
+  for (int t = 0; t <= k->T; ++t) {
+    if (k->pmf_off[t] < 0 || (t && k->pmf_off[t] <= k->pmf_off[t - 1]) || k->pmf_off[t] - (t ? k->pmf_off[t - 1] : 0) > 4096) {
+      g_ml_error = "multicash: pmf_off must ascend, with 1..4096 demand pairs per period";
+      return SDPGPU_ERR_ARG;
+    }
+    sp.off.push_back(k->pmf_off[t] - k->pmf_off[0]);
+  }
+  for (int32_t j = k->pmf_off[0]; j < k->pmf_off[k->T]; ++j) {
+    // `new Demands((int) dAndP[j][0], (int) dAndP[j][1])`, CashRecursionMulti.java:96
+    sp.dem.push_back(make_double2((double)(int)k->d1[j], (double)(int)k->d2[j]));
+    sp.prob.push_back(k->p[j]);
+  }
+  MLParams& P = sp.P;
+  for (int i = 0; i < 2; ++i) {
+    P.price[i] = k->price[i];
+    P.vari[i] = k->vari_cost[i];
+    P.sal[i] = k->sal_price[i];
+  }
+  P.min_inventory = k->min_inventory; P.max_inventory = k->max_inventory;
+  P.min_cash = k->min_cash; P.max_cash = k->max_cash; P.discount = k->discount;
+  P.qb = k->q_bound;
+  P.cash_int_cast = 1;
+  P.model = 1;
+  sp.ini = Tuple{k->ini_i1, k->ini_i2, 0.0, 0.0, k->ini_cash};  // MultiItemCash.java:130
+  return sparse_solve(sp, final_value, q1, q2, states_per_period, cells, gpu_ms);
 }
 
 }  // extern "C"

@@ -12,7 +12,9 @@ from dataclasses import dataclass, field
 from typing import List, Sequence
 
 from . import _abi
-from ._abi import SdpgpuError, SdpgpuMultilead
+import numpy as np
+
+from ._abi import SdpgpuError, SdpgpuMulticash, SdpgpuMultilead
 
 
 @dataclass
@@ -55,6 +57,45 @@ def multilead_solve(**kw) -> MultiLeadResult:
     states = (C.c_int64 * k.T)()
     cells, ms = C.c_int64(), C.c_double()
     rc = lib.sdpgpu_multilead_solve(C.byref(k), C.byref(fv), C.byref(q1), C.byref(q2), states, C.byref(cells),
+                                    C.byref(ms))
+    if rc:
+        raise SdpgpuError(rc, lib.sdpgpu_multilead_last_error().decode())
+    return MultiLeadResult(fv.value, q1.value, q2.value, list(states), cells.value, ms.value)
+
+
+def fill_multicash(k, *, T, q_bound, price, vari_cost, sal_price, ini_cash, ini_i1, ini_i2, min_inventory, max_inventory,
+                   min_cash, max_cash, discount, pmf):
+    """pmf[t] = rows {d1, d2, probability}: what GetPmfMulti.getPmf(t) returns (GetPmfMulti.java:41-69).  The
+    arrays the struct points to are kept alive on `k._keep`."""
+    k.T, k.q_bound = T, q_bound
+    for name, val in (("price", price), ("vari_cost", vari_cost), ("sal_price", sal_price)):
+        getattr(k, name)[0], getattr(k, name)[1] = val
+    for name, val in (("ini_cash", ini_cash), ("ini_i1", ini_i1), ("ini_i2", ini_i2), ("min_inventory", min_inventory),
+                      ("max_inventory", max_inventory), ("min_cash", min_cash), ("max_cash", max_cash),
+                      ("discount", discount)):
+        setattr(k, name, float(val))
+    if len(pmf) != T:
+        raise ValueError(f"pmf has {len(pmf)} periods, T = {T}")
+    tiles = [np.asarray(t, dtype=np.float64).reshape(-1, 3) for t in pmf]
+    off = np.concatenate([[0], np.cumsum([len(t) for t in tiles])]).astype(np.int32)
+    allp = np.concatenate(tiles, axis=0)
+    d1, d2, p = (np.ascontiguousarray(allp[:, c]) for c in range(3))
+    k._keep = (off, d1, d2, p)
+    k.pmf_off = off.ctypes.data_as(C.POINTER(C.c_int32))
+    k.d1, k.d2, k.p = (a.ctypes.data_as(C.POINTER(C.c_double)) for a in (d1, d2, p))
+    return k
+
+
+def multicash_solve(**kw) -> MultiLeadResult:
+    """`sdp.cash.multiItem.CashRecursionMulti` as `cash.multiItem.MultiItemCash.main` sets it up
+    (MultiItemCash.java:66-132; the lambdas are fixed in form, so the mirror takes their parameters):
+    one call = `iniCash + recursion.getExpectedValue(iniState)` + `getAction(iniState)`."""
+    lib = _abi.load()
+    k = fill_multicash(SdpgpuMulticash(), **kw)
+    fv, q1, q2 = C.c_double(), C.c_int32(), C.c_int32()
+    states = (C.c_int64 * k.T)()
+    cells, ms = C.c_int64(), C.c_double()
+    rc = lib.sdpgpu_multicash_solve(C.byref(k), C.byref(fv), C.byref(q1), C.byref(q2), states, C.byref(cells),
                                     C.byref(ms))
     if rc:
         raise SdpgpuError(rc, lib.sdpgpu_multilead_last_error().decode())

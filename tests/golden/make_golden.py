@@ -16,7 +16,10 @@ ROOT = os.path.dirname(os.path.dirname(HERE))
 sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "tests"))
 
+import json  # noqa: E402
+
 import cases  # noqa: E402
+import multicash_cases  # noqa: E402
 import staff_cases  # noqa: E402
 from oracle import sdpref, staffref  # noqa: E402
 
@@ -41,6 +44,15 @@ def main():
             out[f"p{t + 1}"] = pol[t]
         np.savez_compressed(os.path.join(HERE, f"{c.name}.npz"), **out)
         print(c.name, cells, sum(len(v) for v in V))
+    # CashRecursionMulti over MultiItemCash.main's parameters (oracle: literal recursion, ~2 minutes single-threaded);
+    # the joint pmf is stored too: it comes from scipy
+    if "--multicash" in sys.argv or not os.path.exists(os.path.join(HERE, "multicash_main.json")):
+        kw = multicash_cases.main_instance()
+        fv, q1, q2, states, cells = sdpref.multicash_memo(**kw)
+        rec = {"final_value": fv, "q1": q1, "q2": q2, "states_per_period": states, "cells": cells,
+               "pmf": [t.tolist() for t in kw["pmf"]]}
+        json.dump(rec, open(os.path.join(HERE, "multicash_main.json"), "w"))
+        print("multicash_main", fv, q1, q2, states, cells)
 
 
 if __name__ == "__main__":

@@ -113,3 +113,63 @@ def staff_recursion(functor, table, row_len, T):
 
     root = value(StaffState(1, functor.iniStaffNum))
     return root, cache
+
+
+def multicash_recursion(*, T, q_bound, price, vari_cost, sal_price, ini_cash, ini_i1, ini_i2, min_inventory,
+                        max_inventory, min_cash, max_cash, discount, pmf):
+    """sdp.cash.multiItem.CashRecursionMulti.getExpectedValue (CashRecursionMulti.java:82-116) over the lambdas of
+    cash.multiItem.MultiItemCash (MultiItemCash.java:66-118) as literal memoised Python.
+    -> (iniCash + value, Q1, Q2, number of states visited)"""
+    sys.setrecursionlimit(100000)
+
+    def java_int(x):
+        return float(int(x))  # (int) truncates toward zero; the values here stay far inside int range
+
+    def immediate(period, i1, i2, cash, a1, a2, dm1, dm2):
+        action1, action2, demand1, demand2 = float(a1), float(a2), float(dm1), float(dm2)
+        endInventory1 = max(0.0, i1 + action1 - demand1)
+        endInventory2 = max(0.0, i2 + action2 - demand2)
+        revenue1 = price[0] * (i1 + action1 - endInventory1)
+        revenue2 = price[1] * (i2 + action2 - endInventory2)
+        revenue = revenue1 + revenue2
+        orderingCosts = vari_cost[0] * action1 + vari_cost[1] * action2
+        salValue = 0.0
+        if period == T:
+            salValue = sal_price[0] * endInventory1 + sal_price[1] * endInventory2
+        return revenue - orderingCosts + salValue
+
+    def transition(period, i1, i2, cash, a1, a2, dm1, dm2):
+        endInventory1 = max(0.0, i1 + float(a1) - float(dm1))
+        endInventory2 = max(0.0, i2 + float(a2) - float(dm2))
+        nextCash = cash + immediate(period, i1, i2, cash, a1, a2, dm1, dm2)
+        nextCash = max_cash if nextCash > max_cash else nextCash
+        nextCash = min_cash if nextCash < min_cash else nextCash
+        endInventory1 = max_inventory if endInventory1 > max_inventory else endInventory1
+        endInventory2 = min_inventory if endInventory2 < min_inventory else endInventory2
+        return (period + 1, java_int(endInventory1), java_int(endInventory2), java_int(nextCash))
+
+    cache = {}
+
+    def value(s):
+        if s in cache:
+            return cache[s][0]
+        period, i1, i2, cash = s
+        val, best = -1.7976931348623157e308, (0, 0)
+        for a1 in range(q_bound):
+            for a2 in range(q_bound):
+                if not (vari_cost[0] * a1 + vari_cost[1] * a2 < cash + 0.1):
+                    continue
+                q = 0.0
+                for d1, d2, p in pmf[period - 1]:
+                    dm1, dm2 = int(d1), int(d2)
+                    q += p * immediate(period, i1, i2, cash, a1, a2, dm1, dm2)
+                    if period < T:
+                        q += p * discount * value(transition(period, i1, i2, cash, a1, a2, dm1, dm2))
+                if q > val + 0.1:
+                    val, best = q, (a1, a2)
+        cache[s] = (val, best)
+        return val
+
+    root = (1, float(ini_i1), float(ini_i2), float(ini_cash))
+    v = value(root)
+    return ini_cash + v, cache[root][1][0], cache[root][1][1], len(cache)
