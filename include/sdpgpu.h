@@ -416,6 +416,14 @@ typedef struct sdpgpu_multicash {
  * reference evaluates nothing else); errors through sdpgpu_multilead_last_error(). */
 int sdpgpu_multicash_solve(const sdpgpu_multicash* k, double* final_value, int32_t* q1, int32_t* q2,
                            int64_t* states_per_period, int64_t* cells, double* gpu_ms);
+
+/* sdp.cash.multiItem.CashRecursionMultiXR.getExpectedValue (CashRecursionMultiXR.java:60-96) over the lambdas of
+ * cash.multiItem.MultiItemCashXR (MultiItemCashXR.java:92-148): state (x1, x2, R) with R = cash + variCost . x, actions
+ * = order-up-to levels (y1, y2) in [(int) x, (int) x + Qbound), no cash limit on them, demands kept as doubles.  Same
+ * descriptor as sdpgpu_multicash_solve (ini_cash is the R of the period-1 state, MultiItemCashXR.java:158) plus
+ * depositeRate; final_value = iniCash + V_1(iniState) (:160), (y1, y2) = getAction(iniState). */
+int sdpgpu_multixr_solve(const sdpgpu_multicash* k, double deposit_rate, double* final_value, int32_t* y1, int32_t* y2,
+                         int64_t* states_per_period, int64_t* cells, double* gpu_ms);
 /* Kernel time of period t of the last solve (ms), needs sdpgpu_set_profiling(h, 1). */
 double sdpgpu_period_ms(sdpgpu_handle* h, int32_t period);
 

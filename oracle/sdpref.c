@@ -1223,3 +1223,129 @@ int sdpref_multicash_memo(const sdpref_multicash* k, double* final_value, int32_
   free(m.tab);
   return 0;
 }
+
+/* ------------------------------------------------------------------------------------------
+ * sdp.cash.multiItem.CashRecursionMultiXR.getExpectedValue (CashRecursionMultiXR.java:60-96) over the lambdas of
+ * cash.multiItem.MultiItemCashXR (MultiItemCashXR.java:92-148): state (x1, x2, R), R kept in mst_t.cash; actions are
+ * order-up-to levels.  Parity unpinned (the reference records no output of it).
+ * ---------------------------------------------------------------------------------------- */
+typedef struct xrmemo {
+  const sdpref_multicash* k;
+  double deposit_rate;
+  mlentry* tab;
+  int64_t cap, n, cells;
+  int64_t per_period[17];
+} xrmemo;
+
+/* MultiItemCashXR.java:108-128 */
+static double xr_imm(const xrmemo* m, const mst_t* s, double action1, double action2, double demand1, double demand2) {
+  const sdpref_multicash* k = m->k;
+  double endInventory1 = jmax(0, action1 - demand1);
+  double endInventory2 = jmax(0, action2 - demand2);
+  double revenue1 = k->price[0] * (action1 - endInventory1);
+  double revenue2 = k->price[1] * (action2 - endInventory2);
+  double revenue = revenue1 + revenue2;
+  double initialCash = s->cash - k->vari_cost[0] * s->i1 - k->vari_cost[1] * s->i2;
+  double orderingCostY1 = k->vari_cost[0] * action1;
+  double orderingCostY2 = k->vari_cost[1] * action2;
+  double orderingCostsY = orderingCostY1 + orderingCostY2;
+  double salValue = 0;
+  if (s->period == k->T) salValue = k->sal_price[0] * endInventory1 + k->sal_price[1] * endInventory2;
+  return revenue + (1 - m->deposit_rate) * (s->cash - orderingCostsY) + salValue - initialCash;
+}
+
+/* MultiItemCashXR.java:132-148 */
+static void xr_trans(const xrmemo* m, const mst_t* s, double action1, double action2, double demand1, double demand2,
+                     mst_t* out) {
+  const sdpref_multicash* k = m->k;
+  double endInventory1 = action1 - demand1;
+  endInventory1 = jmax(0, endInventory1);
+  double endInventory2 = action2 - demand2;
+  endInventory2 = jmax(0, endInventory2);
+  double initialCash = s->cash - k->vari_cost[0] * s->i1 - k->vari_cost[1] * s->i2;
+  double nextCash = initialCash + xr_imm(m, s, action1, action2, demand1, demand2);
+  nextCash = nextCash > k->max_cash ? k->max_cash : nextCash;
+  nextCash = nextCash < k->min_cash ? k->min_cash : nextCash;
+  endInventory1 = endInventory1 > k->max_inventory ? k->max_inventory : endInventory1;
+  endInventory2 = endInventory2 < k->min_inventory ? k->min_inventory : endInventory2;
+  nextCash = (double)jd2i(nextCash);
+  endInventory1 = (double)jd2i(endInventory1);
+  endInventory2 = (double)jd2i(endInventory2);
+  double nextR = jd2i(nextCash) + k->vari_cost[0] * endInventory1 + k->vari_cost[1] * endInventory2;
+  out->period = s->period + 1;
+  out->i1 = endInventory1;
+  out->i2 = endInventory2;
+  out->q1 = 0;
+  out->q2 = 0;
+  out->cash = nextR;
+}
+
+static mlentry* xr_find(xrmemo* m, const mst_t* s) {
+  mlmemo view = {NULL, m->tab, m->cap, m->n, 0};
+  return ml_find(&view, s);
+}
+
+static double xr_value(xrmemo* m, const mst_t* s) {
+  mlentry* e = xr_find(m, s);
+  if (e->used) return e->value;
+  const sdpref_multicash* k = m->k;
+  const int32_t t = s->period - 1;
+  double val = -DBL_MAX;
+  int32_t b1 = 0, b2 = 0; /* bestYs = {0, 0} */
+  int32_t miny1 = jd2i(s->i1), miny2 = jd2i(s->i2);
+  for (int32_t yi = miny1; yi < miny1 + k->q_bound; yi++)
+    for (int32_t yj = miny2; yj < miny2 + k->q_bound; yj++) { /* buildActionList, :92-105 */
+      double thisActionsValue = 0;
+      for (int32_t j = k->pmf_off[t]; j < k->pmf_off[t + 1]; j++) {
+        thisActionsValue += k->p[j] * xr_imm(m, s, yi, yj, k->d1[j], k->d2[j]);
+        if (s->period < k->T) {
+          mst_t ns;
+          xr_trans(m, s, yi, yj, k->d1[j], k->d2[j], &ns);
+          thisActionsValue += k->p[j] * k->discount * xr_value(m, &ns);
+        }
+        m->cells++;
+      }
+      if (thisActionsValue > val + 0.1) { /* CashRecursionMultiXR.java:89 */
+        val = thisActionsValue;
+        b1 = yi;
+        b2 = yj;
+      }
+    }
+  if ((m->n + 1) * 2 > m->cap) {
+    mlmemo view = {NULL, m->tab, m->cap, m->n, 0};
+    ml_grow(&view);
+    m->tab = view.tab;
+    m->cap = view.cap;
+  }
+  e = xr_find(m, s);
+  e->key = *s;
+  e->value = val;
+  e->a1 = b1;
+  e->a2 = b2;
+  e->used = 1;
+  m->n++;
+  m->per_period[s->period]++;
+  return val;
+}
+
+int sdpref_multixr_memo(const sdpref_multicash* k, double deposit_rate, double* final_value, int32_t* y1, int32_t* y2,
+                        int64_t* states_per_period, int64_t* cells) {
+  if (!k || k->T < 1 || k->T > 16 || !k->pmf_off || !k->d1 || !k->d2 || !k->p) return 1;
+  xrmemo m;
+  memset(&m, 0, sizeof m);
+  m.k = k;
+  m.deposit_rate = deposit_rate;
+  m.cap = 1 << 14;
+  m.tab = (mlentry*)calloc((size_t)m.cap, sizeof(mlentry));
+  mst_t ini = {1, k->ini_i1, k->ini_i2, 0, 0, k->ini_cash}; /* MultiItemCashXR.java:158: iniCash handed over as R */
+  double v = xr_value(&m, &ini);
+  mlentry* e = xr_find(&m, &ini);
+  if (final_value) *final_value = k->ini_cash + v; /* :160 */
+  if (y1) *y1 = e->a1;
+  if (y2) *y2 = e->a2;
+  if (states_per_period)
+    for (int32_t t = 0; t < k->T; t++) states_per_period[t] = m.per_period[t + 1];
+  if (cells) *cells = m.cells;
+  free(m.tab);
+  return 0;
+}

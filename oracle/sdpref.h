@@ -106,6 +106,10 @@ typedef sdpgpu_multicash sdpref_multicash;
 int sdpref_multicash_memo(const sdpref_multicash* k, double* final_value, int32_t* q1, int32_t* q2,
                           int64_t* states_per_period, int64_t* cells);
 
+/* CashRecursionMultiXR.getExpectedValue (CashRecursionMultiXR.java:60-96) over MultiItemCashXR.java:92-148. */
+int sdpref_multixr_memo(const sdpref_multicash* k, double deposit_rate, double* final_value, int32_t* y1, int32_t* y2,
+                        int64_t* states_per_period, int64_t* cells);
+
 /* User-defined lambdas: host-compiled versions of the three functions sdpgpu_create_custom takes (signatures in
  * sdpref.c).  Pass NULLs to return to the built-in families.  Not thread-safe: test harness use only. */
 void sdpref_register_custom(void* count_fn, void* imm_fn, void* trans_fn, const double* params);

@@ -200,6 +200,7 @@ EXPORTS = {
     "sdpgpu_multilead_solve": (C.c_int, [C.POINTER(SdpgpuMultilead), _DP, _IP, _IP, _LP, _LP, _DP]),
     "sdpgpu_multilead_last_error": (C.c_char_p, []),
     "sdpgpu_multicash_solve": (C.c_int, [C.POINTER(SdpgpuMulticash), _DP, _IP, _IP, _LP, _LP, _DP]),
+    "sdpgpu_multixr_solve": (C.c_int, [C.POINTER(SdpgpuMulticash), C.c_double, _DP, _IP, _IP, _LP, _LP, _DP]),
 }
 
 _lib = None

@@ -44,7 +44,9 @@ struct MLParams {
   int32_t nd;       // demand pairs, index = i1 * n2 + i2 (GetPmfMulti.java:157-172)
   int32_t is_last;  // period == T: salvage applies, no transition
   int32_t cash_int_cast;  // MultiProductLeadtime.java:219
-  int32_t model;          // 0: CashRecursionMultiLead + MultiProductLeadtime lambdas; 1: CashRecursionMulti + MultiItemCash
+  int32_t model;          // 0: CashRecursionMultiLead + MultiProductLeadtime lambdas; 1: CashRecursionMulti + MultiItemCash;
+                          // 2: CashRecursionMultiXR + MultiItemCashXR (state (x1, x2, R), actions = order-up-to levels)
+  double one_minus_deposit;  // model 2: 1 - depositeRate
 };
 
 struct Tuple {
@@ -176,6 +178,51 @@ __device__ __forceinline__ Tuple mc_successor(const MLParams& P, const Tuple& s,
   return n;
 }
 
+// ---- model 2: sdp.cash.multiItem.CashRecursionMultiXR over the lambdas of cash.multiItem.MultiItemCashXR ------
+// The state is (x1, x2, R) with R = cash + variCost . x (kept in Tuple::cash); an action is a pair of order-up-to
+// levels (y1, y2) = ((int) x1 + i, (int) x2 + j), i, j in [0, Qbound) (MultiItemCashXR.java:92-105).
+// immediateValue (MultiItemCashXR.java:108-128)
+__device__ __forceinline__ double xr_immediate(const MLParams& P, const Tuple& s, double action1, double action2,
+                                               double demand1, double demand2) {
+  const double endInventory1 = jmax(0.0, action1 - demand1);
+  const double endInventory2 = jmax(0.0, action2 - demand2);
+  const double revenue1 = P.price[0] * (action1 - endInventory1);
+  const double revenue2 = P.price[1] * (action2 - endInventory2);
+  const double revenue = revenue1 + revenue2;
+  const double initialCash = s.cash - P.vari[0] * s.i1 - P.vari[1] * s.i2;
+  const double orderingCostY1 = P.vari[0] * action1;
+  const double orderingCostY2 = P.vari[1] * action2;
+  const double orderingCostsY = orderingCostY1 + orderingCostY2;
+  double salValue = 0;
+  if (P.is_last) salValue = P.sal[0] * endInventory1 + P.sal[1] * endInventory2;
+  return revenue + P.one_minus_deposit * (s.cash - orderingCostsY) + salValue - initialCash;
+}
+
+// stateTransition (MultiItemCashXR.java:132-148)
+__device__ __forceinline__ Tuple xr_successor(const MLParams& P, const Tuple& s, double action1, double action2,
+                                              double demand1, double demand2) {
+  double endInventory1 = action1 - demand1;
+  endInventory1 = jmax(0.0, endInventory1);
+  double endInventory2 = action2 - demand2;
+  endInventory2 = jmax(0.0, endInventory2);
+  const double initialCash = s.cash - P.vari[0] * s.i1 - P.vari[1] * s.i2;
+  double nextCash = initialCash + xr_immediate(P, s, action1, action2, demand1, demand2);
+  nextCash = nextCash > P.max_cash ? P.max_cash : nextCash;
+  nextCash = nextCash < P.min_cash ? P.min_cash : nextCash;
+  endInventory1 = endInventory1 > P.max_inventory ? P.max_inventory : endInventory1;
+  endInventory2 = endInventory2 < P.min_inventory ? P.min_inventory : endInventory2;
+  nextCash = (double)(int)nextCash;
+  endInventory1 = (double)(int)endInventory1;
+  endInventory2 = (double)(int)endInventory2;
+  Tuple n;
+  n.i1 = endInventory1;
+  n.i2 = endInventory2;
+  n.q1 = 0.0;
+  n.q2 = 0.0;
+  n.cash = (double)(int)nextCash + P.vari[0] * endInventory1 + P.vari[1] * endInventory2;  // nextR
+  return n;
+}
+
 // The successor of (state, action a, demand j).
 __device__ __forceinline__ Tuple successor(const MLParams& P, const Tuple& s, int a, const double2* dem, int j) {
   const int a1 = a / P.qb, a2 = a - a1 * P.qb;
@@ -185,6 +232,8 @@ __device__ __forceinline__ Tuple successor(const MLParams& P, const Tuple& s, in
     const bool ok = mc_feasible(P, s, a1, a2);
     return mc_successor(P, s, ok ? a1 : 0, ok ? a2 : 0, dem[j].x, dem[j].y);
   }
+  if (P.model == 2)
+    return xr_successor(P, s, (double)((int)s.i1 + a1), (double)((int)s.i2 + a2), dem[j].x, dem[j].y);
   const double oc = P.vari[0] * (double)a1 + P.vari[1] * (double)a2;
   const double before = s.cash - oc - P.overhead;
   const double bi = before - ml_interest(P, before);
@@ -297,6 +346,17 @@ __global__ __launch_bounds__(256) void backward_kernel(MLParams P, const Tuple* 
     s_q[a] = acc;
   }
   if (P.model == 1 && offered && cell_count) atomicAdd(cell_count, offered * (unsigned long long)P.nd);
+  for (int a = tid; a < NA && P.model == 2; a += 256) {
+    const int a1 = a / P.qb, a2 = a - a1 * P.qb;
+    const double y1 = (double)((int)st.i1 + a1), y2 = (double)((int)st.i2 + a2);
+    double acc = 0.0;  // thisActionsValue, CashRecursionMultiXR.java:76-86
+    for (int j = 0; j < P.nd; ++j) {
+      const double p = s_p[j];
+      acc += p * xr_immediate(P, st, y1, y2, dem[j].x, dem[j].y);
+      if (!P.is_last) acc += p * P.discount * v_next[uid[((int64_t)s * NA + a) * P.nd + j]];
+    }
+    s_q[a] = acc;
+  }
   for (int a = tid; a < NA && P.model == 0; a += 256) {
     const int a1 = a / P.qb, a2 = a - a1 * P.qb;
     const double oc = P.vari[0] * (double)a1 + P.vari[1] * (double)a2;
@@ -466,7 +526,7 @@ int sparse_solve(const SparseProblem& sp, double* final_value, int32_t* q1, int3
                            d_dem + sp.off[(size_t)t], d_prob + sp.off[(size_t)t], d_vnext, d_uid[t], d_vcur, d_act, d_cells);
         ML_TRY(hipGetLastError());
       }
-      if (P.model == 0) total_cells += n_states[t] * (int64_t)NA * nd;
+      if (P.model != 1) total_cells += n_states[t] * (int64_t)NA * nd;
       if (d_vnext) (void)hipFree(d_vnext);
       d_vnext = d_vcur;
       d_vcur = nullptr;
@@ -558,14 +618,14 @@ int sdpgpu_multilead_solve(const sdpgpu_multilead* k, double* final_value, int32
   return sparse_solve(sp, final_value, q1, q2, states_per_period, cells, gpu_ms);
 }
 
-int sdpgpu_multicash_solve(const sdpgpu_multicash* k, double* final_value, int32_t* q1, int32_t* q2,
-                           int64_t* states_per_period, int64_t* cells, double* gpu_ms) {
+static int multicash_common(const sdpgpu_multicash* k, int model, double deposit_rate, double* final_value, int32_t* q1,
+                            int32_t* q2, int64_t* states_per_period, int64_t* cells, double* gpu_ms) {
   g_ml_error.clear();
   if (!k || k->T < 1 || k->T > 16 || k->q_bound < 1 || k->q_bound > 256 || !k->pmf_off || !k->d1 || !k->d2 || !k->p) {
     g_ml_error = "multicash: bad descriptor";
     return SDPGPU_ERR_ARG;
   }
-  if (k->min_cash < 0 || k->ini_cash < 0) {
+  if (model == 1 && (k->min_cash < 0 || k->ini_cash < 0)) {
     // (0, 0) must always be on offer (0 < cash + 0.1): the candidate lists lean on it
     g_ml_error = "multicash: negative cash is not supported (MultiItemCash.java:51 has minCashState = 0)";
     return SDPGPU_ERR_UNSUPPORTED;
@@ -580,8 +640,12 @@ int sdpgpu_multicash_solve(const sdpgpu_multicash* k, double* final_value, int32
     sp.off.push_back(k->pmf_off[t] - k->pmf_off[0]);
   }
   for (int32_t j = k->pmf_off[0]; j < k->pmf_off[k->T]; ++j) {
-    // `new Demands((int) dAndP[j][0], (int) dAndP[j][1])`, CashRecursionMulti.java:96
-    sp.dem.push_back(make_double2((double)(int)k->d1[j], (double)(int)k->d2[j]));
+    // `new Demands((int) dAndP[j][0], (int) dAndP[j][1])`, CashRecursionMulti.java:96; CashRecursionMultiXR keeps
+    // the doubles (`new double[] {dAndP[j][0], dAndP[j][1]}`, CashRecursionMultiXR.java:79)
+    if (model == 1)
+      sp.dem.push_back(make_double2((double)(int)k->d1[j], (double)(int)k->d2[j]));
+    else
+      sp.dem.push_back(make_double2(k->d1[j], k->d2[j]));
     sp.prob.push_back(k->p[j]);
   }
   MLParams& P = sp.P;
@@ -594,9 +658,27 @@ int sdpgpu_multicash_solve(const sdpgpu_multicash* k, double* final_value, int32
   P.min_cash = k->min_cash; P.max_cash = k->max_cash; P.discount = k->discount;
   P.qb = k->q_bound;
   P.cash_int_cast = 1;
-  P.model = 1;
-  sp.ini = Tuple{k->ini_i1, k->ini_i2, 0.0, 0.0, k->ini_cash};  // MultiItemCash.java:130
-  return sparse_solve(sp, final_value, q1, q2, states_per_period, cells, gpu_ms);
+  P.model = model;
+  P.one_minus_deposit = 1 - deposit_rate;
+  // MultiItemCash.java:130; MultiItemCashXR.java:158 hands iniCash over as R
+  sp.ini = Tuple{k->ini_i1, k->ini_i2, 0.0, 0.0, k->ini_cash};
+  int a1 = 0, a2 = 0;
+  const int rc = sparse_solve(sp, final_value, &a1, &a2, states_per_period, cells, gpu_ms);
+  if (rc == SDPGPU_OK) {  // model 2 answers with the order-up-to levels themselves (getAction(iniState)[0], [1])
+    if (q1) *q1 = model == 2 ? (int)k->ini_i1 + a1 : a1;
+    if (q2) *q2 = model == 2 ? (int)k->ini_i2 + a2 : a2;
+  }
+  return rc;
+}
+
+int sdpgpu_multicash_solve(const sdpgpu_multicash* k, double* final_value, int32_t* q1, int32_t* q2,
+                           int64_t* states_per_period, int64_t* cells, double* gpu_ms) {
+  return multicash_common(k, 1, 0.0, final_value, q1, q2, states_per_period, cells, gpu_ms);
+}
+
+int sdpgpu_multixr_solve(const sdpgpu_multicash* k, double deposit_rate, double* final_value, int32_t* y1, int32_t* y2,
+                         int64_t* states_per_period, int64_t* cells, double* gpu_ms) {
+  return multicash_common(k, 2, deposit_rate, final_value, y1, y2, states_per_period, cells, gpu_ms);
 }
 
 }  // extern "C"

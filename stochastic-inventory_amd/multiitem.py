@@ -100,3 +100,19 @@ def multicash_solve(**kw) -> MultiLeadResult:
     if rc:
         raise SdpgpuError(rc, lib.sdpgpu_multilead_last_error().decode())
     return MultiLeadResult(fv.value, q1.value, q2.value, list(states), cells.value, ms.value)
+
+
+def multixr_solve(depositeRate: float = 0.0, **kw) -> MultiLeadResult:
+    """`sdp.cash.multiItem.CashRecursionMultiXR` as `cash.multiItem.MultiItemCashXR.main` sets it up
+    (MultiItemCashXR.java:92-164): state (x1, x2, R), actions = order-up-to levels; `ini_cash` is the R of the period-1
+    state.  firstAction / secondAction of the result are y1 / y2 (`recursion.getAction(iniState)[0]`, `[1]`)."""
+    lib = _abi.load()
+    k = fill_multicash(SdpgpuMulticash(), **kw)
+    fv, y1, y2 = C.c_double(), C.c_int32(), C.c_int32()
+    states = (C.c_int64 * k.T)()
+    cells, ms = C.c_int64(), C.c_double()
+    rc = lib.sdpgpu_multixr_solve(C.byref(k), C.c_double(depositeRate), C.byref(fv), C.byref(y1), C.byref(y2), states,
+                                  C.byref(cells), C.byref(ms))
+    if rc:
+        raise SdpgpuError(rc, lib.sdpgpu_multilead_last_error().decode())
+    return MultiLeadResult(fv.value, y1.value, y2.value, list(states), cells.value, ms.value)

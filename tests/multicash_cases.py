@@ -47,3 +47,31 @@ def random_instance(seed):
                 ini_cash=float(rng.integers(0, 40)), ini_i1=float(rng.integers(0, 4)), ini_i2=float(rng.integers(0, 4)),
                 min_inventory=0, max_inventory=float(rng.integers(3, 12)), min_cash=0, max_cash=float(rng.integers(30, 200)),
                 discount=float(rng.choice([1.0, 0.95])), pmf=pmf)
+
+
+def poisson_joint_pmf(means, q=0.99):
+    """GetPmfMulti.getPmf for two PoissonDists (GetPmfMulti.java:107-138)."""
+    lb = [int(stats.poisson.ppf(1 - q, m)) for m in means]
+    ub = [int(stats.poisson.ppf(q, m)) for m in means]
+    psum = (2 * q - 1) * (2 * q - 1)
+    return np.array([[float(lb[0] + i), float(lb[1] + j),
+                      float(stats.poisson.pmf(lb[0] + i, means[0]) * stats.poisson.pmf(lb[1] + j, means[1]) / psum)]
+                     for i in range(ub[0] - lb[0] + 1) for j in range(ub[1] - lb[1] + 1)])
+
+
+def xr_main_instance(q_bound=50, q=0.99):
+    """MultiItemCashXR.main as it stands (MultiItemCashXR.java:41-78): price {5, 10}, variCost {1, 2}, salvage half the
+    cost, Poisson demands with means {20, 10}, T = 2, Qbound 50, truncation quantile 0.99, iniCash 0, no deposit."""
+    pmf = [poisson_joint_pmf([20, 10], q) for _ in range(2)]
+    return dict(T=2, q_bound=q_bound, price=[5, 10], vari_cost=[1, 2], sal_price=[0.5, 1.0], ini_cash=0, ini_i1=0,
+                ini_i2=0, min_inventory=0, max_inventory=200, min_cash=0, max_cash=10000, discount=1, pmf=pmf)
+
+
+def xr_random_instance(seed):
+    kw = random_instance(seed)
+    rng = np.random.default_rng(1000 + seed)
+    # R = cash + variCost . x of the period-1 state
+    kw["ini_cash"] = kw["ini_cash"] + kw["vari_cost"][0] * kw["ini_i1"] + kw["vari_cost"][1] * kw["ini_i2"]
+    if kw["T"] == 3:
+        kw["q_bound"] = min(kw["q_bound"], 4)
+    return float(rng.choice([0.0, 0.05])), kw

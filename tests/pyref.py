@@ -173,3 +173,60 @@ def multicash_recursion(*, T, q_bound, price, vari_cost, sal_price, ini_cash, in
     root = (1, float(ini_i1), float(ini_i2), float(ini_cash))
     v = value(root)
     return ini_cash + v, cache[root][1][0], cache[root][1][1], len(cache)
+
+
+def multixr_recursion(deposit_rate=0.0, *, T, q_bound, price, vari_cost, sal_price, ini_cash, ini_i1, ini_i2, min_inventory,
+                      max_inventory, min_cash, max_cash, discount, pmf):
+    """sdp.cash.multiItem.CashRecursionMultiXR.getExpectedValue (CashRecursionMultiXR.java:60-96) over the lambdas of
+    cash.multiItem.MultiItemCashXR (MultiItemCashXR.java:92-148) as literal memoised Python: state (period, x1, x2, R).
+    -> (iniCash + value, y1, y2, number of states visited)"""
+    sys.setrecursionlimit(100000)
+
+    def immediate(period, x1, x2, R, action1, action2, demand1, demand2):
+        endInventory1 = max(0.0, action1 - demand1)
+        endInventory2 = max(0.0, action2 - demand2)
+        revenue1 = price[0] * (action1 - endInventory1)
+        revenue2 = price[1] * (action2 - endInventory2)
+        revenue = revenue1 + revenue2
+        initialCash = R - vari_cost[0] * x1 - vari_cost[1] * x2
+        orderingCostsY = vari_cost[0] * action1 + vari_cost[1] * action2
+        salValue = 0.0
+        if period == T:
+            salValue = sal_price[0] * endInventory1 + sal_price[1] * endInventory2
+        return revenue + (1 - deposit_rate) * (R - orderingCostsY) + salValue - initialCash
+
+    def transition(period, x1, x2, R, action1, action2, demand1, demand2):
+        endInventory1 = max(0.0, action1 - demand1)
+        endInventory2 = max(0.0, action2 - demand2)
+        initialCash = R - vari_cost[0] * x1 - vari_cost[1] * x2
+        nextCash = initialCash + immediate(period, x1, x2, R, action1, action2, demand1, demand2)
+        nextCash = max_cash if nextCash > max_cash else nextCash
+        nextCash = min_cash if nextCash < min_cash else nextCash
+        endInventory1 = max_inventory if endInventory1 > max_inventory else endInventory1
+        endInventory2 = min_inventory if endInventory2 < min_inventory else endInventory2
+        nextCash, endInventory1, endInventory2 = float(int(nextCash)), float(int(endInventory1)), float(int(endInventory2))
+        nextR = int(nextCash) + vari_cost[0] * endInventory1 + vari_cost[1] * endInventory2
+        return (period + 1, endInventory1, endInventory2, nextR)
+
+    cache = {}
+
+    def value(s):
+        if s in cache:
+            return cache[s][0]
+        period, x1, x2, R = s
+        val, best = -1.7976931348623157e308, (0, 0)
+        for y1 in range(int(x1), int(x1) + q_bound):
+            for y2 in range(int(x2), int(x2) + q_bound):
+                q = 0.0
+                for d1, d2, p in pmf[period - 1]:
+                    q += p * immediate(period, x1, x2, R, float(y1), float(y2), d1, d2)
+                    if period < T:
+                        q += p * discount * value(transition(period, x1, x2, R, float(y1), float(y2), d1, d2))
+                if q > val + 0.1:
+                    val, best = q, (y1, y2)
+        cache[s] = (val, best)
+        return val
+
+    root = (1, float(ini_i1), float(ini_i2), float(ini_cash))
+    v = value(root)
+    return ini_cash + v, cache[root][1][0], cache[root][1][1], len(cache)

@@ -54,3 +54,33 @@ def test_misuse(sia):
     kw["min_cash"] = -5
     with pytest.raises(sia.SdpgpuError):
         sia.multicash_solve(**kw)
+
+
+@pytest.mark.parametrize("seed", range(24))
+def test_xr_random_instances_match_the_oracle(sia, oracle, seed):
+    dep, kw = multicash_cases.xr_random_instance(seed)
+    r = sia.multixr_solve(dep, **kw)
+    fv, y1, y2, states, cells = oracle.multixr_memo(dep, **kw)
+    assert r.finalValue == fv and (r.firstAction, r.secondAction) == (y1, y2)
+    assert r.statesPerPeriod == states and r.cells == cells
+
+
+def test_multi_item_cash_xr_main_smaller(sia, oracle):
+    """MultiItemCashXR.main's parameters on a smaller box (Qbound 30, demand supports cut at the 0.9 quantile: 8.9e8
+    cells; the full instance is 1.8e11 cells, half an hour for the oracle's single-threaded recursion)."""
+    kw = multicash_cases.xr_main_instance(q_bound=30, q=0.9)
+    r = sia.multixr_solve(0.0, **kw)
+    fv, y1, y2, states, cells = oracle.multixr_memo(0.0, **kw)
+    assert r.finalValue == fv and (r.firstAction, r.secondAction) == (y1, y2)
+    assert r.statesPerPeriod == states and r.cells == cells
+
+
+def test_multi_item_cash_xr_main_full_size_runs(sia):
+    """MultiItemCashXR.main as it stands: T = 2, Qbound 50, 352 demand pairs.  No oracle at this size (the same kernels
+    as the instances above): checks the bookkeeping only and prints what the driver would print."""
+    kw = multicash_cases.xr_main_instance()
+    r = sia.multixr_solve(0.0, **kw)
+    print(f"MultiItemCashXR.main: final optimal cash {r.finalValue!r}, y1 = {r.firstAction}, y2 = {r.secondAction}, "
+          f"states {r.statesPerPeriod}, {r.cells:.3g} cells in {r.gpu_ms:.1f} ms")
+    assert r.statesPerPeriod[0] == 1 and r.cells == sum(r.statesPerPeriod) * 2500 * len(kw["pmf"][0])
+    assert 0 <= r.firstAction < 50 and 0 <= r.secondAction < 50 and r.finalValue > 0

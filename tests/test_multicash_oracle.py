@@ -40,3 +40,24 @@ def test_tolerance_scan_keeps_the_earlier_action(oracle):
               min_inventory=0, max_inventory=10, min_cash=0, max_cash=100, discount=1, pmf=[[[1, 1, 1.0]]])
     fv, q1, q2, _, _ = oracle.multicash_memo(**kw)
     assert (q1, q2) == (0, 0) and fv == 2.0  # 0.04 and 0.08 never exceed 0 + 0.1
+
+
+@pytest.mark.parametrize("seed", range(12))
+def test_xr_oracle_equals_pure_python(oracle, seed):
+    dep, kw = multicash_cases.xr_random_instance(seed)
+    fv, y1, y2, states, cells = oracle.multixr_memo(dep, **kw)
+    pv, p1, p2, n = pyref.multixr_recursion(dep, **kw)
+    assert (fv, y1, y2) == (pv, p1, p2)
+    assert sum(states) == n and states[0] == 1 and cells > 0
+
+
+def test_xr_hand_computed_single_period(oracle):
+    """T = 1, x = (1, 0), R = 4 (cash 3 + 1 unit at cost 1), costs {1, 2}, prices {3, 5}, salvage {0.5, 1}, demand (2, 1)
+    for sure, Qbound 2: order-up-to levels y1 in {1, 2}, y2 in {0, 1}; initialCash = 3.
+      value(y) = revenue + (R - cost . y) + salvage - initialCash
+      (1,0): 3 + (4 - 1) + 0 - 3 = 3;  (1,1): 8 + (4 - 3) + 0 - 3 = 6;  (2,0): 6 + (4 - 2) + 0 - 3 = 5;
+      (2,1): 11 + (4 - 4) + 0 - 3 = 8.   Scan: 3, 6, (2,0) no, 8 -> y = (2, 1), final R + 8 = 12."""
+    kw = dict(T=1, q_bound=2, price=[3, 5], vari_cost=[1, 2], sal_price=[0.5, 1], ini_cash=4, ini_i1=1, ini_i2=0,
+              min_inventory=0, max_inventory=10, min_cash=0, max_cash=100, discount=1, pmf=[[[2, 1, 1.0]]])
+    fv, y1, y2, states, cells = oracle.multixr_memo(0.0, **kw)
+    assert (fv, y1, y2, states, cells) == (12.0, 2, 1, [1], 4)
