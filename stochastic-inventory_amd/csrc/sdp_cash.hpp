@@ -39,11 +39,25 @@ struct CashShiftParams {
   int32_t row0;           // first inventory row launched
 };
 
+// Per (action, demand) operands of the demand loop, in BYTES of V_{t+1} so that a cell's gather address is
+// `v_next + clamp(ic8 + off8, lo8, hi8)`: one integer add, one v_med3_i32 and a load with a scalar base and a
+// 32-bit offset (the launcher refuses tables of 4 GB and more).
 struct ShiftEntry {
-  double t1;      // p_j * inc
-  int32_t rowoff; // next inventory index * nc
-  int32_t delta;  // cash index shift
+  double t1;     // p_j * inc
+  int32_t off8;  // 8 * (next inventory index * nc + cash index shift)
+  int32_t lo8;   // 8 * next inventory index * nc: byte offset of the row's first cash point
 };
+struct ShiftEntry2 {
+  double pg;     // p_j * gamma
+  int32_t hi8;   // lo8 + 8 * (nc - 1): the row's last cash point
+  int32_t pad;
+};
+
+__device__ __forceinline__ int med3_i32(int x, int lo, int hi) {
+  int r;
+  asm("v_med3_i32 %0, %1, %2, %3" : "=v"(r) : "v"(x), "v"(lo), "v"(hi));
+  return r;
+}
 
 template <bool MAXDIR, bool LAST>
 __global__ __launch_bounds__(256) void cash_shift_kernel(CashShiftParams P, const double* __restrict__ v_next,
@@ -53,8 +67,10 @@ __global__ __launch_bounds__(256) void cash_shift_kernel(CashShiftParams P, cons
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int D = P.n_demand;
   double2* s_pmf = reinterpret_cast<double2*>(smem);                     // {d_j, p_j * gamma}
-  ShiftEntry* s_ent = reinterpret_cast<ShiftEntry*>(smem + (size_t)D * 16);  // [4 waves][D]
-  double* s_val = reinterpret_cast<double*>(smem + (size_t)D * 16 * 5);
+  const int DP = (D + 7) & ~7;  // the demand loop runs in blocks of eight; the padding entries add exact zeros
+  ShiftEntry* s_ent = reinterpret_cast<ShiftEntry*>(smem + (size_t)D * 16);  // [4 waves][DP]
+  ShiftEntry2* s_ent2 = reinterpret_cast<ShiftEntry2*>(smem + (size_t)D * 16 + (size_t)DP * 16 * 4);  // [4 waves][DP]
+  double* s_val = reinterpret_cast<double*>(smem + (size_t)D * 16 + (size_t)DP * 16 * 8);
   int* s_k = reinterpret_cast<int*>(s_val + 4 * 64);
 
   const int tid = threadIdx.x;
@@ -83,10 +99,17 @@ __global__ __launch_bounds__(256) void cash_shift_kernel(CashShiftParams P, cons
   }
   nA_max = __builtin_amdgcn_readfirstlane(nA_max);
 
-  ShiftEntry* ent = s_ent + (size_t)wave * D;
+  ShiftEntry* ent = s_ent + (size_t)wave * DP;
+  ShiftEntry2* ent2 = s_ent2 + (size_t)wave * DP;
+  if (lane < DP - D) {  // t1 = 0, p = 0, a valid address: acc += 0.0; acc += 0.0 * V[0]
+    ent[D + lane] = ShiftEntry{0.0, 0, 0};
+    ent2[D + lane] = ShiftEntry2{0.0, 0, 0};
+  }
+  const int ic8 = ic_c * 8;
+  const int nc18 = (P.nc - 1) * 8;
+  const char* vbase = reinterpret_cast<const char*>(v_next);
   double best = MAXDIR ? -1.7976931348623157e308 : 1.7976931348623157e308;
   int bestk = 0;
-  const int nc1 = P.nc - 1;
   for (int k = wave; k < nA_max; k += 4) {
     // ---- per-action setup: lanes walk the demand index, every operation below is exact ----
     const double a = (double)k * P.step;
@@ -102,14 +125,22 @@ __global__ __launch_bounds__(256) void cash_shift_kernel(CashShiftParams P, cons
       if constexpr (LAST) inc += P.salvage * pos;
       ShiftEntry e;
       e.t1 = pmf_p[j] * inc;
-      e.rowoff = 0;
-      e.delta = 0;
+      e.off8 = 0;
+      e.lo8 = 0;
       if constexpr (!LAST) {
         double ninv = jmax(0.0, level);
         ninv = ninv > P.max_inventory ? P.max_inventory : ninv;
         ninv = ninv < P.min_inventory ? P.min_inventory : ninv;
-        e.rowoff = (int)((ninv - P.next_x_lo) / P.step) * P.nc;
-        e.delta = (int)jround_d(inc * P.q);
+        const int rowoff = (int)((ninv - P.next_x_lo) / P.step) * P.nc;
+        // the shift is held to +-nc: anything beyond already clamps every cash point of the row to an end
+        int delta = (int)jmax(jmin(jround_d(inc * P.q), (double)P.nc), -(double)P.nc);
+        e.lo8 = rowoff * 8;
+        e.off8 = (rowoff + delta) * 8;
+        ShiftEntry2 e2;
+        e2.pg = dp.y;
+        e2.hi8 = e.lo8 + nc18;
+        e2.pad = 0;
+        ent2[j] = e2;
       }
       ent[j] = e;
     }
@@ -120,14 +151,15 @@ __global__ __launch_bounds__(256) void cash_shift_kernel(CashShiftParams P, cons
     if constexpr (LAST) {
       for (int j = 0; j < D; ++j) acc += ent[j].t1;
     } else {
-      for (int j = 0; j < D; ++j) {
-        const ShiftEntry e = ent[j];
-        const double pg = s_pmf[j].y;
-        int t = ic_c + e.delta;
-        t = t < 0 ? 0 : t;
-        t = t > nc1 ? nc1 : t;
-        acc += e.t1;
-        acc += pg * v_next[e.rowoff + t];
+      for (int jb = 0; jb < DP; jb += 8) {  // eight gathers in flight per wave
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+          const ShiftEntry e = ent[jb + u];
+          const ShiftEntry2 e2 = ent2[jb + u];
+          const int t8 = med3_i32(ic8 + e.off8, e.lo8, e2.hi8);  // 8 * (rowoff + clamp(ic + delta, 0, nc - 1))
+          acc += e.t1;
+          acc += e2.pg * *reinterpret_cast<const double*>(vbase + (uint32_t)t8);
+        }
       }
     }
     __builtin_amdgcn_wave_barrier();

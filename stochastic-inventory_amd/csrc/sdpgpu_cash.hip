@@ -39,7 +39,8 @@ bool cash_shift_eligible(const sdpgpu_handle* h, int period) {
   double incmax = (std::fabs(d.price) + std::fabs(d.holding_cost) + std::fabs(d.salvage_value)) * (ymax + dmax) +
                   std::fabs(d.fixed_order_cost) + std::fabs(d.unit_order_cost) * d.max_order_quantity * d.step + std::fabs(p.overhead);
   if (incmax * q > 1.0e9) return false;
-  if (p.S >= 2147483647LL || p.nD > 2000) return false;
+  // (byte offsets into V_{t+1} are formed and clamped in signed 32-bit arithmetic)
+  if ((p.S + 2 * p.g.nc) * 8 >= 2147483647LL || p.nD > 2000) return false;
   return true;
 }
 
@@ -73,7 +74,8 @@ hipError_t launch_cash_shift(sdpgpu_handle* h, const DevParams& P, int period, c
   C.row0 = (int32_t)row_lo;
   if (!grid_ok((row_hi - row_lo + 1) * (int64_t)C.tiles_per_row)) return hipErrorInvalidValue;
   dim3 grid((unsigned)((row_hi - row_lo + 1) * C.tiles_per_row));
-  size_t smem = (size_t)p.nD * 16 * 5 + 4 * 64 * (sizeof(double) + sizeof(int));
+  const size_t dp8 = ((size_t)p.nD + 7) & ~(size_t)7;
+  size_t smem = (size_t)p.nD * 16 + dp8 * 16 * 8 + 4 * 64 * (sizeof(double) + sizeof(int));
   const bool last = period == h->T;
 #define SDP_CS(MX, LS) hipLaunchKernelGGL((sdp::cash_shift_kernel<MX, LS>), grid, dim3(256), smem, st, C, v_next, v_cur, pol, pmf_d, pmf_p, lo, hi)
   if (P.maxdir) {

@@ -79,3 +79,19 @@ for label, kw, remark in (
     print(f"{label}: final cash {r.finalValue!r}, Q=({r.firstAction},{r.secondAction}), reachable states {r.statesPerPeriod}, "
           f"{r.cells:.3g} cells, GPU {r.gpu_ms:.0f} ms, wall {time.perf_counter() - t0:.2f} s   [reference comment: {remark}]",
           flush=True)
+
+# cash.multiItem.MultiItemCash (CashRecursionMulti; its solve is commented out in the reference) and
+# cash.multiItem.MultiItemCashXR (CashRecursionMultiXR; header comment: "2 periods running time is 0.5s")
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests"))
+import multicash_cases  # noqa: E402  (instance builders only: parameters as they stand in the two mains)
+for label, solve, kw, remark in (
+        ("MultiItemCash.main (T=2, Qbound 100)", sia.multicash_solve, multicash_cases.main_instance(), "solve commented out"),
+        ("MultiItemCashXR.main (T=2, Qbound 50)", lambda **k: sia.multixr_solve(0.0, **k), multicash_cases.xr_main_instance(),
+         "'2 periods running time is 0.5s', MultiItemCashXR.java:9")):
+    t0 = time.perf_counter()
+    r = solve(**kw)
+    print(f"{label}: final cash {r.finalValue!r}, actions ({r.firstAction},{r.secondAction}), reachable states {r.statesPerPeriod}, "
+          f"{r.cells:.3g} cells, GPU {r.gpu_ms:.0f} ms, wall {time.perf_counter() - t0:.2f} s   [reference comment: {remark}]",
+          flush=True)
+
+# workforce.WorkforcePlanning.main / one instance of WorkforceTesting.main (StaffRecursion): tools/workforce_drivers.py
