@@ -35,7 +35,7 @@ struct CashShiftParams {
   int32_t n_actions_cap;  // (int) maxOrderQuantity + 1
   double max_order_quantity;
   int32_t is_last;
-  int32_t tiles_per_row;  // ceil(nc / 64)
+  int32_t tiles_per_row;  // ceil(nc / (64 S))
   int32_t row0;           // first inventory row launched
 };
 
@@ -59,11 +59,22 @@ __device__ __forceinline__ int med3_i32(int x, int lo, int hi) {
   return r;
 }
 
-template <bool MAXDIR, bool LAST>
+// S = cash tiles per wave: lane l owns the points ic0 + 64 s + l, s < S (each gather stays one contiguous 512 B).
+// The per-(action, demand) operands are wave-uniform, read from LDS as broadcasts; an LDS broadcast still costs the
+// full 64-lane data path (32 B per step here), and at S = 1 that, not the gathers, is what bounds the loop
+// (four SIMDs x 16 clk per step = 4 cells/clk/CU).  S tiles share one read.
+// W = adjacent cash points per lane.  The gather unit (TA) is what bounds this loop: it is busy ~14 cycles per 64-lane
+// 8-byte gather (rocprofv3 TA_BUSY: 85 % of the kernel's cycles at W = 1).  With W = 2 a lane reads its two
+// neighbouring points with ONE 16-byte load -- the wave's 1 KB is contiguous -- and picks them apart again at the
+// clamped ends of the row: half the gather instructions per cell.
+typedef double dpair_u __attribute__((ext_vector_type(2), aligned(8)));
+
+template <bool MAXDIR, bool LAST, int S, int W>
 __global__ __launch_bounds__(256) void cash_shift_kernel(CashShiftParams P, const double* __restrict__ v_next,
                                                          double* __restrict__ v_cur, int32_t* __restrict__ pol,
                                                          const double* __restrict__ pmf_d,
                                                          const double* __restrict__ pmf_p, int64_t lo, int64_t hi) {
+  constexpr int TS = 64 * S * W;
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int D = P.n_demand;
   double2* s_pmf = reinterpret_cast<double2*>(smem);                     // {d_j, p_j * gamma}
@@ -71,7 +82,7 @@ __global__ __launch_bounds__(256) void cash_shift_kernel(CashShiftParams P, cons
   ShiftEntry* s_ent = reinterpret_cast<ShiftEntry*>(smem + (size_t)D * 16);  // [4 waves][DP]
   ShiftEntry2* s_ent2 = reinterpret_cast<ShiftEntry2*>(smem + (size_t)D * 16 + (size_t)DP * 16 * 4);  // [4 waves][DP]
   double* s_val = reinterpret_cast<double*>(smem + (size_t)D * 16 + (size_t)DP * 16 * 8);
-  int* s_k = reinterpret_cast<int*>(s_val + 4 * 64);
+  int* s_k = reinterpret_cast<int*>(s_val + 4 * TS);
 
   const int tid = threadIdx.x;
   const int lane = tid & 63;
@@ -80,18 +91,26 @@ __global__ __launch_bounds__(256) void cash_shift_kernel(CashShiftParams P, cons
   __syncthreads();
 
   const int row = P.row0 + blockIdx.x / P.tiles_per_row;
-  const int ic0 = (blockIdx.x % P.tiles_per_row) * 64;
-  const int ic = ic0 + lane;
-  const int64_t idx = (int64_t)row * P.nc + ic;
-  const bool live = ic < P.nc && idx >= lo && idx < hi;
+  const int ic0 = (blockIdx.x % P.tiles_per_row) * TS;
   const double x = P.x_lo + (double)row * P.step;
 
-  // feasible action count per lane (CashConstraint.java:96-99) and the tile's maximum (cash ascending)
-  const int ic_c = ic < P.nc ? ic : P.nc - 1;
-  const double cash = (double)(P.k_lo + ic_c) / P.q;  // exact: q is a power of two
-  double m = jmin(P.max_order_quantity, jmax(0.0, (cash - P.overhead - P.K) / P.v));
-  const int nA = ((m != m) ? 0 : (int)m) + 1;
-  int nA_max = nA;
+  // feasible action count per point (CashConstraint.java:96-99) and the wave's maximum
+  int ic8[S], nA[S][W];  // lane l of tile s owns the points ic0 + 64 W s + W l + w, w < W
+  int nA_max = 0;
+#pragma unroll
+  for (int s = 0; s < S; ++s) {
+    const int ic_first = ic0 + 64 * W * s + W * lane;
+    ic8[s] = (ic_first < P.nc ? ic_first : P.nc - 1) * 8;
+#pragma unroll
+    for (int w = 0; w < W; ++w) {
+      const int ic = ic_first + w;
+      const int ic_c = ic < P.nc ? ic : P.nc - 1;
+      const double cash = (double)(P.k_lo + ic_c) / P.q;  // exact: q is a power of two
+      double m = jmin(P.max_order_quantity, jmax(0.0, (cash - P.overhead - P.K) / P.v));
+      nA[s][w] = ((m != m) ? 0 : (int)m) + 1;
+      nA_max = nA[s][w] > nA_max ? nA[s][w] : nA_max;
+    }
+  }
 #pragma unroll
   for (int off = 32; off > 0; off >>= 1) {
     int o = __shfl_xor(nA_max, off, 64);
@@ -105,11 +124,17 @@ __global__ __launch_bounds__(256) void cash_shift_kernel(CashShiftParams P, cons
     ent[D + lane] = ShiftEntry{0.0, 0, 0};
     ent2[D + lane] = ShiftEntry2{0.0, 0, 0};
   }
-  const int ic8 = ic_c * 8;
   const int nc18 = (P.nc - 1) * 8;
   const char* vbase = reinterpret_cast<const char*>(v_next);
-  double best = MAXDIR ? -1.7976931348623157e308 : 1.7976931348623157e308;
-  int bestk = 0;
+  double best[S][W];
+  int bestk[S][W];
+#pragma unroll
+  for (int s = 0; s < S; ++s)
+#pragma unroll
+    for (int w = 0; w < W; ++w) {
+      best[s][w] = MAXDIR ? -1.7976931348623157e308 : 1.7976931348623157e308;
+      bestk[s][w] = 0;
+    }
   for (int k = wave; k < nA_max; k += 4) {
     // ---- per-action setup: lanes walk the demand index, every operation below is exact ----
     const double a = (double)k * P.step;
@@ -147,45 +172,86 @@ __global__ __launch_bounds__(256) void cash_shift_kernel(CashShiftParams P, cons
     __builtin_amdgcn_wave_barrier();
     __builtin_amdgcn_s_waitcnt(0xC07F);  // lgkmcnt(0): the wave's own LDS writes have landed
     // ---- the demand loop: serial in j, reference order (CashRecursion.java:113-122) ----
-    double acc = 0.0;
-    if constexpr (LAST) {
-      for (int j = 0; j < D; ++j) acc += ent[j].t1;
-    } else {
-      for (int jb = 0; jb < DP; jb += 8) {  // eight gathers in flight per wave
+    double acc[S][W];
 #pragma unroll
-        for (int u = 0; u < 8; ++u) {
+    for (int s = 0; s < S; ++s)
+#pragma unroll
+      for (int w = 0; w < W; ++w) acc[s][w] = 0.0;
+    if constexpr (LAST) {
+      for (int j = 0; j < D; ++j) {
+        const double t1 = ent[j].t1;
+#pragma unroll
+        for (int s = 0; s < S; ++s)
+#pragma unroll
+          for (int w = 0; w < W; ++w) acc[s][w] += t1;
+      }
+    } else {
+      constexpr int U = S == 1 ? 8 : (S == 2 ? 4 : 2);  // steps per trip: eight gathers in flight per wave
+      for (int jb = 0; jb < DP; jb += U) {
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
           const ShiftEntry e = ent[jb + u];
           const ShiftEntry2 e2 = ent2[jb + u];
-          const int t8 = med3_i32(ic8 + e.off8, e.lo8, e2.hi8);  // 8 * (rowoff + clamp(ic + delta, 0, nc - 1))
-          acc += e.t1;
-          acc += e2.pg * *reinterpret_cast<const double*>(vbase + (uint32_t)t8);
+#pragma unroll
+          for (int s = 0; s < S; ++s) {
+            const int i8 = ic8[s] + e.off8;  // 8 * (rowoff + ic + delta), before the clamp to the row
+            if constexpr (W == 1) {
+              const int t8 = med3_i32(i8, e.lo8, e2.hi8);  // 8 * (rowoff + clamp(ic + delta, 0, nc - 1))
+              acc[s][0] += e.t1;
+              acc[s][0] += e2.pg * *reinterpret_cast<const double*>(vbase + (uint32_t)t8);
+            } else {
+              // the pair {V[c], V[c + 1]}, c = clamp(ic + delta, 0, nc - 2); at the ends of the row both points of
+              // the lane may clamp to the same entry
+              const int c8 = med3_i32(i8, e.lo8, e2.hi8 - 8);
+              const dpair_u v = *reinterpret_cast<const dpair_u*>(vbase + (uint32_t)c8);
+              const double v0 = i8 > e2.hi8 - 8 ? v.y : v.x;  // ic + delta     >= nc - 1: the last entry
+              const double v1 = i8 < e.lo8 ? v.x : v.y;       // ic + delta + 1 <= 0:      the first entry
+              acc[s][0] += e.t1;
+              acc[s][0] += e2.pg * v0;
+              acc[s][1] += e.t1;
+              acc[s][1] += e2.pg * v1;
+            }
+          }
         }
       }
     }
     __builtin_amdgcn_wave_barrier();
-    if (k < nA && (MAXDIR ? (acc > best) : (acc < best))) {
-      best = acc;
-      bestk = k;
-    }
+#pragma unroll
+    for (int s = 0; s < S; ++s)
+#pragma unroll
+      for (int w = 0; w < W; ++w)
+        if (k < nA[s][w] && (MAXDIR ? (acc[s][w] > best[s][w]) : (acc[s][w] < best[s][w]))) {
+          best[s][w] = acc[s][w];
+          bestk[s][w] = k;
+        }
   }
 
-  s_val[wave * 64 + lane] = best;
-  s_k[wave * 64 + lane] = bestk;
-  __syncthreads();
-  if (tid < 64 && live) {
-    double bv = s_val[tid];
-    int bk = s_k[tid];
 #pragma unroll
-    for (int w = 1; w < 4; ++w) {
-      double ov = s_val[w * 64 + tid];
-      int ok = s_k[w * 64 + tid];
-      if (better<MAXDIR>(ov, ok, bv, bk)) {
-        bv = ov;
-        bk = ok;
-      }
+  for (int s = 0; s < S; ++s)
+#pragma unroll
+    for (int w = 0; w < W; ++w) {
+      s_val[wave * TS + 64 * W * s + W * lane + w] = best[s][w];
+      s_k[wave * TS + 64 * W * s + W * lane + w] = bestk[s][w];
     }
-    v_cur[idx] = bv;
-    pol[idx] = bk;
+  __syncthreads();
+  for (int q = tid; q < TS; q += 256) {
+    const int ic = ic0 + q;
+    const int64_t idx = (int64_t)row * P.nc + ic;
+    if (ic < P.nc && idx >= lo && idx < hi) {
+      double bv = s_val[q];
+      int bk = s_k[q];
+#pragma unroll
+      for (int w = 1; w < 4; ++w) {
+        double ov = s_val[w * TS + q];
+        int ok = s_k[w * TS + q];
+        if (better<MAXDIR>(ov, ok, bv, bk)) {
+          bv = ov;
+          bk = ok;
+        }
+      }
+      v_cur[idx] = bv;
+      pol[idx] = bk;
+    }
   }
 }
 

@@ -69,20 +69,48 @@ hipError_t launch_cash_shift(sdpgpu_handle* h, const DevParams& P, int period, c
   C.n_demand = p.nD;
   C.max_order_quantity = d.max_order_quantity;
   C.is_last = period == h->T;
-  C.tiles_per_row = (int32_t)((p.g.nc + 63) / 64);
+  // points per lane (W) and tiles per wave (S), see cash_shift_kernel.  W = 2 whenever the row has two points: the
+  // gather unit is the bound and a 16-byte gather serves two cells (configs[2]: 101 -> 64 ms per sweep).  With the
+  // gathers halved the LDS broadcasts of the operands show: S tiles share them (64 -> 57 ms at S = 2) where the grid
+  // is large enough to keep the chip full.
+  int W = p.g.nc >= 2 ? 2 : 1, S = 1;
+  const int64_t n_rows_launch = (hi - 1) / p.g.nc - lo / p.g.nc + 1;
+  for (int s_try : {4, 2})
+    if (S == 1 && n_rows_launch * ((p.g.nc + 128 * s_try - 1) / (128 * s_try)) >= 2048) S = s_try;
+  if (const char* e = std::getenv("SDPGPU_CASH_W")) W = std::atoi(e) == 1 ? 1 : W;
+  if (const char* e = std::getenv("SDPGPU_CASH_S")) {
+    const int v = std::atoi(e);
+    if (v == 1 || v == 2 || v == 4) S = v;
+  }
+  const int TSZ = 64 * S * W;
+  C.tiles_per_row = (int32_t)((p.g.nc + TSZ - 1) / TSZ);
   const int64_t row_lo = lo / p.g.nc, row_hi = (hi - 1) / p.g.nc;
   C.row0 = (int32_t)row_lo;
   if (!grid_ok((row_hi - row_lo + 1) * (int64_t)C.tiles_per_row)) return hipErrorInvalidValue;
   dim3 grid((unsigned)((row_hi - row_lo + 1) * C.tiles_per_row));
   const size_t dp8 = ((size_t)p.nD + 7) & ~(size_t)7;
-  size_t smem = (size_t)p.nD * 16 + dp8 * 16 * 8 + 4 * 64 * (sizeof(double) + sizeof(int));
+  size_t smem = (size_t)p.nD * 16 + dp8 * 16 * 8 + (size_t)4 * TSZ * (sizeof(double) + sizeof(int));
   const bool last = period == h->T;
-#define SDP_CS(MX, LS) hipLaunchKernelGGL((sdp::cash_shift_kernel<MX, LS>), grid, dim3(256), smem, st, C, v_next, v_cur, pol, pmf_d, pmf_p, lo, hi)
+#define SDP_CS(MX, LS, SS, WW) hipLaunchKernelGGL((sdp::cash_shift_kernel<MX, LS, SS, WW>), grid, dim3(256), smem, st, C, v_next, v_cur, pol, pmf_d, pmf_p, lo, hi)
+#define SDP_CS_S(MX, LS)      \
+  if (S == 4 && W == 2)       \
+    SDP_CS(MX, LS, 4, 2);     \
+  else if (S == 2 && W == 2)  \
+    SDP_CS(MX, LS, 2, 2);     \
+  else if (S == 4)            \
+    SDP_CS(MX, LS, 4, 1);     \
+  else if (S == 2)            \
+    SDP_CS(MX, LS, 2, 1);     \
+  else if (W == 2)            \
+    SDP_CS(MX, LS, 1, 2);     \
+  else                        \
+    SDP_CS(MX, LS, 1, 1)
   if (P.maxdir) {
-    if (last) SDP_CS(true, true); else SDP_CS(true, false);
+    if (last) { SDP_CS_S(true, true); } else { SDP_CS_S(true, false); }
   } else {
-    if (last) SDP_CS(false, true); else SDP_CS(false, false);
+    if (last) { SDP_CS_S(false, true); } else { SDP_CS_S(false, false); }
   }
+#undef SDP_CS_S
 #undef SDP_CS
   return hipGetLastError();
 }
