@@ -159,6 +159,103 @@ __global__ __launch_bounds__(64) void staff_block_kernel(StaffParams P, const do
   out_idx[at] = bestk;
 }
 
+// Two ADJACENT states per lane.  The gather unit (TA) spends ~14 cycles on a 64-lane 8-byte gather and barely more on
+// a 16-byte one, and at one probability gather per cell it is what bounds staff_block_kernel.  The states x and x + 1
+// sit at the levels y and y + 1, whose table entries are neighbours in the transposed table, and they leave n and
+// n + 1 behind, neighbours in V_{t+1}: one 16-byte gather serves both, picked apart where a clamp (the table's last
+// row, the staff range) folds the two onto one entry.
+typedef double staff_pair_u __attribute__((ext_vector_type(2), aligned(8)));
+
+template <int R, bool FUTURE>
+__global__ __launch_bounds__(64) void staff_pair_kernel(StaffParams P, const double* __restrict__ pT0,
+                                                        const int32_t* __restrict__ row_len,
+                                                        const double* __restrict__ v_next,
+                                                        double* __restrict__ out_val, int32_t* __restrict__ out_idx,
+                                                        int64_t lo, int64_t hi) {
+  static_assert(R - 1 <= kStaffPadJ, "table padding");
+  const int64_t tile = blockIdx.x / P.n_groups;
+  const int group = (int)(blockIdx.x - tile * P.n_groups);
+  const int64_t idx = lo + tile * 128 + 2 * threadIdx.x;  // this lane: states idx, idx + 1
+  if (idx >= hi) return;
+  const bool two = idx + 1 < hi;
+  const int x = P.x_lo + (int)idx;
+  const int a_end = min(P.n_actions, (group + 1) * P.group_actions);
+  const int last_row = P.n_rows - 1;
+  double best[2] = {1.7976931348623157e308, 1.7976931348623157e308};
+  int bestk[2] = {0, 0};
+  for (int a0 = group * P.group_actions; a0 < a_end; a0 += R) {
+    double fv[R], acc[2][R];
+    int64_t poff[R];  // {p(y), p(y + 1)} of action r at step k: the pair at pT0[k * rows + poff[r]]
+    bool fold[R];     // y >= last row: both levels use the last row (the pair's second entry)
+    int kmax = 0;
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+      const int a = a0 + r;
+      const int y = x + a;
+      const int row0 = y >= last_row ? last_row : y;
+      const int row1 = y + 1 >= last_row ? last_row : y + 1;
+      const int nj = a < P.n_actions ? max(row_len[row0], row_len[row1]) : 0;  // (zeros beyond the shorter row)
+      kmax = max(kmax, nj > 0 ? nj + (R - 1 - r) : 0);
+      const double fixHire = a > 0 ? P.K : 0.0;
+      const double variHire = P.v * (double)a;
+      fv[r] = fixHire + variHire;
+      acc[0][r] = 0.0;
+      acc[1][r] = 0.0;
+      fold[r] = y >= last_row;
+      const int c = y >= last_row ? last_row - 1 : y;  // rows >= 2 (the launcher checks)
+      poff[r] = (int64_t)c - (int64_t)(R - 1 - r) * P.n_rows;
+    }
+    const int ytop = x + a0 + R - 1;
+    for (int k = 0; k < kmax; ++k) {
+      const int n0 = ytop - k;  // nextStaffNum of state x at this step; state x + 1 leaves n0 + 1
+      const double sal0 = P.salary * (double)n0;
+      const double sal1 = P.salary * (double)(n0 + 1);
+      const double pen0 = n0 > P.min_staff ? 0.0 : P.pen * (double)(P.min_staff - n0);
+      const double pen1 = n0 + 1 > P.min_staff ? 0.0 : P.pen * (double)(P.min_staff - (n0 + 1));
+      double v0 = 0.0, v1 = 0.0;
+      if constexpr (FUTURE) {
+        // {V[c], V[c + 1]}, c = clamp(n0, lo, hi - 1): where the bounds fold both onto one entry, select it
+        int c = n0 > P.nn_hi - 1 ? P.nn_hi - 1 : n0;
+        c = c < P.nn_lo ? P.nn_lo : c;
+        const staff_pair_u v = *reinterpret_cast<const staff_pair_u*>(v_next + (c - P.next_x_lo));
+        v0 = n0 > P.nn_hi - 1 ? v.y : v.x;  // n0 >= hi: the last entry
+        v1 = n0 < P.nn_lo ? v.x : v.y;      // n0 + 1 <= lo: the first entry
+      }
+      const double* pk = pT0 + (int64_t)k * P.n_rows;
+#pragma unroll
+      for (int r = 0; r < R; ++r) {
+        const staff_pair_u p = *reinterpret_cast<const staff_pair_u*>(pk + poff[r]);
+        const double p0 = fold[r] ? p.y : p.x;
+        const double imm0 = fv[r] + sal0 + pen0;
+        acc[0][r] += p0 * imm0;
+        if constexpr (FUTURE) acc[0][r] += p0 * v0;
+        const double imm1 = fv[r] + sal1 + pen1;
+        acc[1][r] += p.y * imm1;
+        if constexpr (FUTURE) acc[1][r] += p.y * v1;
+      }
+    }
+#pragma unroll
+    for (int r = 0; r < R; ++r)
+      if (a0 + r < P.n_actions) {
+        if (acc[0][r] < best[0]) {
+          best[0] = acc[0][r];
+          bestk[0] = a0 + r;
+        }
+        if (acc[1][r] < best[1]) {
+          best[1] = acc[1][r];
+          bestk[1] = a0 + r;
+        }
+      }
+  }
+  const int64_t at = (int64_t)group * P.part_stride + idx;
+  out_val[at] = best[0];
+  out_idx[at] = bestk[0];
+  if (two) {
+    out_val[at + 1] = best[1];
+    out_idx[at + 1] = bestk[1];
+  }
+}
+
 // groups in ascending action order, strict compare: the first best wins (StaffRecursion.java:110-113)
 __global__ __launch_bounds__(256) void combine_staff_kernel(const double* __restrict__ part_val,
                                                             const int32_t* __restrict__ part_idx, int n_groups,

@@ -45,8 +45,8 @@ static int staff_block() {  // register block of staff_block_kernel (SDPGPU_STAF
   return r;
 }
 
-static void staff_groups(const sdpgpu_handle* h, int64_t states, int* n_groups, int* group_actions) {
-  const int64_t tiles = std::max<int64_t>(1, (states + 63) / 64);
+static void staff_groups(const sdpgpu_handle* h, int64_t states, int tile_states, int* n_groups, int* group_actions) {
+  const int64_t tiles = std::max<int64_t>(1, (states + tile_states - 1) / tile_states);
   const int nA = h->n_actions_full;
   int64_t want = std::max<int64_t>(1, 16384 / tiles);
   want = std::min<int64_t>(want, nA);
@@ -81,8 +81,16 @@ hipError_t launch_staff(sdpgpu_handle* h, int period, const double* v_next, doub
     S.nn_lo = S.next_x_lo;
     S.nn_hi = period < h->T ? S.next_x_lo + (int32_t)h->per[period].g.nx - 1 : 0;
   }
-  staff_groups(h, hi - lo, &S.n_groups, &S.group_actions);
-  const int64_t tiles = (hi - lo + 63) / 64;
+  // two adjacent states per lane (staff_pair_kernel) wherever the table and the next period's box have two entries
+  static const bool pair_off = std::getenv("SDPGPU_STAFF_PAIR") && std::atoi(std::getenv("SDPGPU_STAFF_PAIR")) == 0;
+  static const bool plain = std::getenv("SDPGPU_STAFF_BLOCK") && std::atoi(std::getenv("SDPGPU_STAFF_BLOCK")) == 0;
+  // (only where 128-state tiles x action blocks still make a few waves per SIMD: small staff ranges keep 64-state tiles)
+  const bool roomy = ((hi - lo + 127) / 128) * (int64_t)((h->n_actions_full + 3) / 4) >= 4096;
+  const bool pair = !pair_off && !plain && staff_block() == 4 && S.n_rows >= 2 && (period == h->T || S.nn_hi > S.nn_lo) &&
+                    (roomy || std::getenv("SDPGPU_STAFF_PAIR"));
+  const int tile_states = pair ? 128 : 64;
+  staff_groups(h, hi - lo, tile_states, &S.n_groups, &S.group_actions);
+  const int64_t tiles = (hi - lo + tile_states - 1) / tile_states;
   const int64_t blocks = tiles * S.n_groups;
   if (blocks * 64 >= 4294967296LL) return hipErrorInvalidValue;
   double* out_val = v_cur;
@@ -107,8 +115,14 @@ hipError_t launch_staff(sdpgpu_handle* h, int period, const double* v_next, doub
   }
   const double* pT = h->d_lvl_p[period - 1];
   const int32_t* len = h->d_lvl_len[period - 1];
-  static const bool plain = std::getenv("SDPGPU_STAFF_BLOCK") && std::atoi(std::getenv("SDPGPU_STAFF_BLOCK")) == 0;
-  if (plain) {  // one action at a time (kept as the cross-check of the register-blocked kernel)
+  if (pair) {
+    if (period < h->T)
+      hipLaunchKernelGGL((sdp::staff_pair_kernel<4, true>), dim3((unsigned)blocks), dim3(64), 0, st, S, pT, len, v_next,
+                         out_val, out_idx, lo, hi);
+    else
+      hipLaunchKernelGGL((sdp::staff_pair_kernel<4, false>), dim3((unsigned)blocks), dim3(64), 0, st, S, pT, len, v_next,
+                         out_val, out_idx, lo, hi);
+  } else if (plain) {  // one action at a time (kept as the cross-check of the register-blocked kernel)
     if (period < h->T)
       hipLaunchKernelGGL((sdp::staff_period_kernel<true>), dim3((unsigned)blocks), dim3(64), 0, st, S, pT, len, v_next,
                          out_val, out_idx, lo, hi);

@@ -201,3 +201,26 @@ def test_random_instances(sia, staffref):
                 got_cells += eng.stats().cells_evaluated
         if world == 1:
             assert got_cells == cells, seed
+
+
+def test_two_states_per_lane_kernel_on_every_case(sia, staffref, monkeypatch):
+    """staff_pair_kernel (two adjacent states per lane, 16-byte gathers) is chosen by itself only on large staff ranges;
+    forced here on every named case and on the random ones: the clamp folds at the table's last row and at both ends
+    of the staff range, odd slab ends, truncated rows."""
+    monkeypatch.setenv("SDPGPU_STAFF_PAIR", "1")
+    cases = [m() for m in staff_cases.ALL] + [_random_case(s) for s in range(100, 140)]
+    for c in cases:
+        V, pol, cells = c.oracle_problem(staffref).solve()
+        with _engine(sia, c) as eng:
+            eng.solve(sync=True)
+            for period in range(1, c.T + 1):
+                assert np.array_equal(eng.values(period), V[period - 1]), (c.name, period)
+                assert np.array_equal(eng.policy(period), pol[period - 1]), (c.name, period)
+    c = staff_cases.staff_wide_actions()
+    V, pol, _ = c.oracle_problem(staffref).solve()
+    for world in (2, 3):  # slabs with odd lengths: a lane's second state may belong to the next rank
+        for rank in range(world):
+            with _engine(sia, c, rank, world) as eng:
+                eng.run_period(c.T)
+                _, lo, hi = eng.slab(c.T)
+                assert np.array_equal(eng.values(c.T)[lo:hi], V[c.T - 1][lo:hi]) and np.array_equal(eng.policy(c.T), pol[c.T - 1][lo:hi])
