@@ -393,6 +393,28 @@ int sdpgpu_multilead_solve(const sdpgpu_multilead* k, double* final_value, int32
                            int64_t* states_per_period, int64_t* cells, double* gpu_ms);
 const char* sdpgpu_multilead_last_error(void);
 
+/* Read-out of the whole memo of the two-product solvers -- what getCacheActions() / getOptTable() iterate
+ * (CashRecursionMulti.java:140-168, CashRecursionMultiLead.java:92-101): register a table before a solve
+ * (sdpgpu_multi_set_table, per thread; NULL clears it) and the next sdpgpu_multi*_solve of that thread fills it with one
+ * row per visited state: period, the state tuple (q1 = q2 = 0 outside the lead-time family; `cash` holds R for the XR
+ * family), V(state), and the chosen action pair (order-up-to levels for the XR family).  `rows` receives the number of
+ * visited states; nothing is written when it exceeds `capacity` (call again with larger arrays).  Rows are grouped by
+ * period, in no particular order inside a period. */
+typedef struct sdpgpu_multi_table {
+  int64_t capacity;
+  int64_t rows;
+  int32_t* period;
+  double* i1;
+  double* i2;
+  double* q1;
+  double* q2;
+  double* cash;
+  double* value;
+  int32_t* a1;
+  int32_t* a2;
+} sdpgpu_multi_table;
+void sdpgpu_multi_set_table(sdpgpu_multi_table* table);
+
 /* sdp.cash.multiItem.CashRecursionMulti.getExpectedValue (CashRecursionMulti.java:82-116) over the lambdas of
  * cash.multiItem.MultiItemCash (MultiItemCash.java:66-118): two products, cash-limited orders
  * (variCost[0] * i + variCost[1] * j < cash + 0.1), no lead time, state (I1, I2, cash) truncated to ints by the

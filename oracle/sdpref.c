@@ -989,6 +989,30 @@ static void ml_grow(mlmemo* m) {
   free(old);
 }
 
+/* read-out of a finished memo (same row layout as the product's sdpgpu_multi_table) */
+static sdpgpu_multi_table* g_ref_table = NULL;
+void sdpref_multi_set_table(sdpgpu_multi_table* t) { g_ref_table = t; }
+static void dump_memo(const mlentry* tab, int64_t cap, int64_t n) {
+  sdpgpu_multi_table* t = g_ref_table;
+  if (!t) return;
+  t->rows = n;
+  if (n > t->capacity) return;
+  int64_t r = 0;
+  for (int64_t i = 0; i < cap; i++)
+    if (tab[i].used) {
+      t->period[r] = tab[i].key.period;
+      t->i1[r] = tab[i].key.i1;
+      t->i2[r] = tab[i].key.i2;
+      t->q1[r] = tab[i].key.q1;
+      t->q2[r] = tab[i].key.q2;
+      t->cash[r] = tab[i].key.cash;
+      t->value[r] = tab[i].value;
+      t->a1[r] = tab[i].a1;
+      t->a2[r] = tab[i].a2;
+      r++;
+    }
+}
+
 /* MultiProductLeadtime.java:162-199 */
 static double ml_imm(const sdpref_multilead* k, const mst_t* s, int32_t a1, int32_t a2, int32_t dm1, int32_t dm2) {
   double action1 = a1, action2 = a2, demand1 = dm1, demand2 = dm2;
@@ -1099,6 +1123,7 @@ int sdpref_kat_multilead(const sdpref_multilead* k, double* final_value, int32_t
   if (q2) *q2 = e->a2;
   if (states_visited) *states_visited = m.n;
   if (cells) *cells = m.cells;
+  dump_memo(m.tab, m.cap, m.n);
   free(m.tab);
   return 0;
 }
@@ -1220,6 +1245,7 @@ int sdpref_multicash_memo(const sdpref_multicash* k, double* final_value, int32_
   if (states_per_period)
     for (int32_t t = 0; t < k->T; t++) states_per_period[t] = m.per_period[t + 1];
   if (cells) *cells = m.cells;
+  dump_memo(m.tab, m.cap, m.n);
   free(m.tab);
   return 0;
 }
@@ -1346,6 +1372,7 @@ int sdpref_multixr_memo(const sdpref_multicash* k, double deposit_rate, double* 
   if (states_per_period)
     for (int32_t t = 0; t < k->T; t++) states_per_period[t] = m.per_period[t + 1];
   if (cells) *cells = m.cells;
+  dump_memo(m.tab, m.cap, m.n);
   free(m.tab);
   return 0;
 }

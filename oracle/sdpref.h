@@ -110,6 +110,10 @@ int sdpref_multicash_memo(const sdpref_multicash* k, double* final_value, int32_
 int sdpref_multixr_memo(const sdpref_multicash* k, double deposit_rate, double* final_value, int32_t* y1, int32_t* y2,
                         int64_t* states_per_period, int64_t* cells);
 
+/* Register a table (layout of sdpgpu_multi_table) that the next sdpref_kat_multilead / sdpref_multicash_memo /
+ * sdpref_multixr_memo call fills with its whole memo; NULL clears it. */
+void sdpref_multi_set_table(sdpgpu_multi_table* t);
+
 /* User-defined lambdas: host-compiled versions of the three functions sdpgpu_create_custom takes (signatures in
  * sdpref.c).  Pass NULLs to return to the built-in families.  Not thread-safe: test harness use only. */
 void sdpref_register_custom(void* count_fn, void* imm_fn, void* trans_fn, const double* params);

@@ -239,6 +239,22 @@ def kat_multilead(**kw):
     return fv.value, q1.value, q2.value, ns.value, nc.value
 
 
+def _with_table(run, n_rows_hint=1 << 16):
+    """Run a memo function with a read-out table registered; grows the table until every visited state fits."""
+    from stochastic_inventory_amd._abi import make_multi_table, multi_table_rows  # struct layout / row sorting only
+    cap = n_rows_hint
+    while True:
+        t, arrs = make_multi_table(cap)
+        lib().sdpref_multi_set_table(C.byref(t))
+        try:
+            out = run()
+        finally:
+            lib().sdpref_multi_set_table(None)
+        if t.rows <= cap:
+            return out, multi_table_rows(t, arrs)
+        cap = int(t.rows)
+
+
 def multicash_memo(**kw):
     """sdpref_multicash_memo (CashRecursionMulti over MultiItemCash's lambdas): returns
     (final_value, q1, q2, states_per_period, cells).  Takes the arguments of stochastic_inventory_amd.multicash_solve."""
@@ -326,3 +342,10 @@ class custom_functor:
 
     def __exit__(self, *exc):
         lib().sdpref_register_custom(None, None, None, None)
+
+
+def memo_table(kind, *args, **kw):
+    """(result tuple, sorted memo rows) of kat_multilead / multicash_memo / multixr_memo: every visited state with its
+    value and action, columns as stochastic_inventory_amd._abi.multi_table_rows."""
+    fn = {"multilead": kat_multilead, "multicash": multicash_memo, "multixr": multixr_memo}[kind]
+    return _with_table(lambda: fn(*args, **kw))

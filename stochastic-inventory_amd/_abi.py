@@ -150,6 +150,38 @@ class SdpgpuMulticash(C.Structure):
     ]
 
 
+class SdpgpuMultiTable(C.Structure):
+    """struct sdpgpu_multi_table (include/sdpgpu.h)."""
+
+    _fields_ = [("capacity", C.c_int64), ("rows", C.c_int64), ("period", C.POINTER(C.c_int32)),
+                ("i1", C.POINTER(C.c_double)), ("i2", C.POINTER(C.c_double)), ("q1", C.POINTER(C.c_double)),
+                ("q2", C.POINTER(C.c_double)), ("cash", C.POINTER(C.c_double)), ("value", C.POINTER(C.c_double)),
+                ("a1", C.POINTER(C.c_int32)), ("a2", C.POINTER(C.c_int32))]
+
+
+def make_multi_table(capacity: int):
+    """-> (struct, dict of numpy arrays it points to)."""
+    import numpy as np
+    arrs = {"period": np.zeros(capacity, np.int32), "a1": np.zeros(capacity, np.int32), "a2": np.zeros(capacity, np.int32)}
+    for n in ("i1", "i2", "q1", "q2", "cash", "value"):
+        arrs[n] = np.zeros(capacity)
+    t = SdpgpuMultiTable()
+    t.capacity, t.rows = capacity, 0
+    for n, a in arrs.items():
+        setattr(t, n, a.ctypes.data_as(C.POINTER(C.c_int32 if a.dtype == np.int32 else C.c_double)))
+    return t, arrs
+
+
+def multi_table_rows(t, arrs):
+    """The filled rows as an array sorted the way the reference's TreeMap orders its keys:
+    columns period, i1, i2, q1, q2, cash, value, a1, a2."""
+    import numpy as np
+    n = int(t.rows)
+    m = np.stack([arrs[c][:n].astype(np.float64) for c in ("period", "i1", "i2", "q1", "q2", "cash", "value", "a1", "a2")], axis=1)
+    order = np.lexsort((m[:, 5], m[:, 4], m[:, 3], m[:, 2], m[:, 1], m[:, 0]))
+    return m[order]
+
+
 # every symbol include/sdpgpu.h declares: name -> (restype, argtypes)
 _P = C.c_void_p
 _DP = C.POINTER(C.c_double)
@@ -199,6 +231,7 @@ EXPORTS = {
     "sdpgpu_period_ms": (C.c_double, [_P, C.c_int32]),
     "sdpgpu_multilead_solve": (C.c_int, [C.POINTER(SdpgpuMultilead), _DP, _IP, _IP, _LP, _LP, _DP]),
     "sdpgpu_multilead_last_error": (C.c_char_p, []),
+    "sdpgpu_multi_set_table": (None, [C.POINTER(SdpgpuMultiTable)]),
     "sdpgpu_multicash_solve": (C.c_int, [C.POINTER(SdpgpuMulticash), _DP, _IP, _IP, _LP, _LP, _DP]),
     "sdpgpu_multixr_solve": (C.c_int, [C.POINTER(SdpgpuMulticash), C.c_double, _DP, _IP, _IP, _LP, _LP, _DP]),
 }

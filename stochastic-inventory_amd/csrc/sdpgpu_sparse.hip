@@ -34,6 +34,7 @@
 namespace {
 
 thread_local std::string g_ml_error;
+thread_local sdpgpu_multi_table* g_ml_table = nullptr;  // read-out request for the next solve of this thread
 
 struct MLParams {
   double price[2], vari[2], sal[2];
@@ -444,6 +445,10 @@ int sparse_solve(const SparseProblem& sp, double* final_value, int32_t* q1, int3
   hipEvent_t ev0 = nullptr, ev1 = nullptr;
   int64_t total_cells = 0;
   int rc = SDPGPU_ERR_DEVICE;
+  bool table_rows_ok = false;
+  std::vector<int64_t> table_off((size_t)T, 0);
+  std::vector<Tuple> h_tuples;
+  std::vector<int> h_acts;
   {
     ML_TRY(hipEventCreate(&ev0));
     ML_TRY(hipEventCreate(&ev1));
@@ -508,6 +513,18 @@ int sparse_solve(const SparseProblem& sp, double* final_value, int32_t* q1, int3
       d_order = d_order2 = nullptr;
       d_head = d_rank = nullptr;
     }
+    // ---- read-out request (sdpgpu_multi_set_table): room for every state of every period? ----
+    if (g_ml_table) {
+      int64_t rows = 0;
+      for (int t = 0; t < T; ++t) {
+        table_off[(size_t)t] = rows;
+        rows += n_states[t];
+      }
+      g_ml_table->rows = rows;
+      table_rows_ok = rows <= g_ml_table->capacity && g_ml_table->period && g_ml_table->i1 && g_ml_table->i2 &&
+                      g_ml_table->q1 && g_ml_table->q2 && g_ml_table->cash && g_ml_table->value && g_ml_table->a1 &&
+                      g_ml_table->a2;
+    }
     // ---- backward ----
     for (int t = T - 1; t >= 0; --t) {
       const int nd = sp.off[(size_t)t + 1] - sp.off[(size_t)t];
@@ -527,6 +544,27 @@ int sparse_solve(const SparseProblem& sp, double* final_value, int32_t* q1, int3
         ML_TRY(hipGetLastError());
       }
       if (P.model != 1) total_cells += n_states[t] * (int64_t)NA * nd;
+      if (table_rows_ok) {  // the memo of this period: states, values, actions (hash order; sorted on the host below)
+        const size_t n = (size_t)n_states[t];
+        const size_t at = (size_t)table_off[(size_t)t];
+        h_tuples.resize(n);
+        h_acts.resize(n);
+        ML_TRY(hipMemcpy(h_tuples.data(), d_states[t], n * sizeof(Tuple), hipMemcpyDeviceToHost));
+        ML_TRY(hipMemcpy(g_ml_table->value + at, d_vcur, n * 8, hipMemcpyDeviceToHost));
+        ML_TRY(hipMemcpy(h_acts.data(), d_act, n * 4, hipMemcpyDeviceToHost));
+        for (size_t i = 0; i < n; ++i) {
+          const Tuple& u = h_tuples[i];
+          g_ml_table->period[at + i] = t + 1;
+          g_ml_table->i1[at + i] = u.i1;
+          g_ml_table->i2[at + i] = u.i2;
+          g_ml_table->q1[at + i] = u.q1;
+          g_ml_table->q2[at + i] = u.q2;
+          g_ml_table->cash[at + i] = u.cash;
+          const int a1 = h_acts[i] / P.qb, a2 = h_acts[i] % P.qb;
+          g_ml_table->a1[at + i] = P.model == 2 ? (int)u.i1 + a1 : a1;  // model 2 reports order-up-to levels
+          g_ml_table->a2[at + i] = P.model == 2 ? (int)u.i2 + a2 : a2;
+        }
+      }
       if (d_vnext) (void)hipFree(d_vnext);
       d_vnext = d_vcur;
       d_vcur = nullptr;
@@ -581,6 +619,8 @@ fail:
 extern "C" {
 
 const char* sdpgpu_multilead_last_error(void) { return g_ml_error.c_str(); }
+
+void sdpgpu_multi_set_table(sdpgpu_multi_table* table) { g_ml_table = table; }
 
 int sdpgpu_multilead_solve(const sdpgpu_multilead* k, double* final_value, int32_t* q1, int32_t* q2,
                            int64_t* states_per_period, int64_t* cells, double* gpu_ms) {

@@ -25,6 +25,9 @@ class MultiLeadResult:
     statesPerPeriod: List[int]
     cells: int
     gpu_ms: float
+    # rows {period, i1, i2, q1, q2, cash (R for the XR family), value, action 1, action 2} of every visited state in the
+    # order of the reference's TreeMap keys -- what getCacheActions() / getOptTable() iterate; None unless asked for
+    table: object = None
 
 
 def fill_multilead(k, *, T, q_bound, price, vari_cost, sal_value, ini_cash, ini_i1, ini_i2, r0, r1, r2, limit,
@@ -49,18 +52,38 @@ def fill_multilead(k, *, T, q_bound, price, vari_cost, sal_value, ini_cash, ini_
     return k
 
 
-def multilead_solve(**kw) -> MultiLeadResult:
-    """One call = `recursion.getExpectedValue(iniState)` + `getAction(iniState)` of MultiProductLeadtime.main."""
+def _run(call, T: int, want_table: bool) -> MultiLeadResult:
+    """call(fv, q1, q2, states, cells, ms) -> rc.  With want_table the solve is run a second time with a table large
+    enough for every visited state (the first run says how many there are)."""
+    lib = _abi.load()
+
+    def once():
+        fv, q1, q2 = C.c_double(), C.c_int32(), C.c_int32()
+        states = (C.c_int64 * T)()
+        cells, ms = C.c_int64(), C.c_double()
+        rc = call(C.byref(fv), C.byref(q1), C.byref(q2), states, C.byref(cells), C.byref(ms))
+        if rc:
+            raise SdpgpuError(rc, lib.sdpgpu_multilead_last_error().decode())
+        return MultiLeadResult(fv.value, q1.value, q2.value, list(states), cells.value, ms.value)
+
+    res = once()
+    if want_table:
+        t, arrs = _abi.make_multi_table(sum(res.statesPerPeriod))
+        lib.sdpgpu_multi_set_table(C.byref(t))
+        try:
+            res = once()
+        finally:
+            lib.sdpgpu_multi_set_table(None)
+        res.table = _abi.multi_table_rows(t, arrs)
+    return res
+
+
+def multilead_solve(table: bool = False, **kw) -> MultiLeadResult:
+    """One call = `recursion.getExpectedValue(iniState)` + `getAction(iniState)` of MultiProductLeadtime.main;
+    table=True also returns the whole memo (see MultiLeadResult.table)."""
     lib = _abi.load()
     k = fill_multilead(SdpgpuMultilead(), **kw)
-    fv, q1, q2 = C.c_double(), C.c_int32(), C.c_int32()
-    states = (C.c_int64 * k.T)()
-    cells, ms = C.c_int64(), C.c_double()
-    rc = lib.sdpgpu_multilead_solve(C.byref(k), C.byref(fv), C.byref(q1), C.byref(q2), states, C.byref(cells),
-                                    C.byref(ms))
-    if rc:
-        raise SdpgpuError(rc, lib.sdpgpu_multilead_last_error().decode())
-    return MultiLeadResult(fv.value, q1.value, q2.value, list(states), cells.value, ms.value)
+    return _run(lambda *out: lib.sdpgpu_multilead_solve(C.byref(k), *out), k.T, table)
 
 
 def fill_multicash(k, *, T, q_bound, price, vari_cost, sal_price, ini_cash, ini_i1, ini_i2, min_inventory, max_inventory,
@@ -86,33 +109,20 @@ def fill_multicash(k, *, T, q_bound, price, vari_cost, sal_price, ini_cash, ini_
     return k
 
 
-def multicash_solve(**kw) -> MultiLeadResult:
+def multicash_solve(table: bool = False, **kw) -> MultiLeadResult:
     """`sdp.cash.multiItem.CashRecursionMulti` as `cash.multiItem.MultiItemCash.main` sets it up
     (MultiItemCash.java:66-132; the lambdas are fixed in form, so the mirror takes their parameters):
-    one call = `iniCash + recursion.getExpectedValue(iniState)` + `getAction(iniState)`."""
+    one call = `iniCash + recursion.getExpectedValue(iniState)` + `getAction(iniState)`; table=True also returns the
+    rows `getOptTable` is built from."""
     lib = _abi.load()
     k = fill_multicash(SdpgpuMulticash(), **kw)
-    fv, q1, q2 = C.c_double(), C.c_int32(), C.c_int32()
-    states = (C.c_int64 * k.T)()
-    cells, ms = C.c_int64(), C.c_double()
-    rc = lib.sdpgpu_multicash_solve(C.byref(k), C.byref(fv), C.byref(q1), C.byref(q2), states, C.byref(cells),
-                                    C.byref(ms))
-    if rc:
-        raise SdpgpuError(rc, lib.sdpgpu_multilead_last_error().decode())
-    return MultiLeadResult(fv.value, q1.value, q2.value, list(states), cells.value, ms.value)
+    return _run(lambda *out: lib.sdpgpu_multicash_solve(C.byref(k), *out), k.T, table)
 
 
-def multixr_solve(depositeRate: float = 0.0, **kw) -> MultiLeadResult:
+def multixr_solve(depositeRate: float = 0.0, table: bool = False, **kw) -> MultiLeadResult:
     """`sdp.cash.multiItem.CashRecursionMultiXR` as `cash.multiItem.MultiItemCashXR.main` sets it up
     (MultiItemCashXR.java:92-164): state (x1, x2, R), actions = order-up-to levels; `ini_cash` is the R of the period-1
     state.  firstAction / secondAction of the result are y1 / y2 (`recursion.getAction(iniState)[0]`, `[1]`)."""
     lib = _abi.load()
     k = fill_multicash(SdpgpuMulticash(), **kw)
-    fv, y1, y2 = C.c_double(), C.c_int32(), C.c_int32()
-    states = (C.c_int64 * k.T)()
-    cells, ms = C.c_int64(), C.c_double()
-    rc = lib.sdpgpu_multixr_solve(C.byref(k), C.c_double(depositeRate), C.byref(fv), C.byref(y1), C.byref(y2), states,
-                                  C.byref(cells), C.byref(ms))
-    if rc:
-        raise SdpgpuError(rc, lib.sdpgpu_multilead_last_error().decode())
-    return MultiLeadResult(fv.value, y1.value, y2.value, list(states), cells.value, ms.value)
+    return _run(lambda *out: lib.sdpgpu_multixr_solve(C.byref(k), C.c_double(depositeRate), *out), k.T, table)

@@ -84,3 +84,19 @@ def test_multi_item_cash_xr_main_full_size_runs(sia):
           f"states {r.statesPerPeriod}, {r.cells:.3g} cells in {r.gpu_ms:.1f} ms")
     assert r.statesPerPeriod[0] == 1 and r.cells == sum(r.statesPerPeriod) * 2500 * len(kw["pmf"][0])
     assert 0 <= r.firstAction < 50 and 0 <= r.secondAction < 50 and r.finalValue > 0
+
+
+@pytest.mark.parametrize("kind,seed", [("multicash", s) for s in range(8)] + [("multixr", s) for s in range(8)])
+def test_whole_memo_matches_the_oracle(sia, oracle, kind, seed):
+    """Every visited state -- its tuple, V(state) and the chosen action pair, in the reference's key order (what
+    getCacheActions / getOptTable iterate) -- not only the root."""
+    if kind == "multicash":
+        kw = multicash_cases.random_instance(seed)
+        r = sia.multicash_solve(table=True, **kw)
+        (_, _, _, states, _), want = oracle.memo_table("multicash", **kw)
+    else:
+        dep, kw = multicash_cases.xr_random_instance(seed)
+        r = sia.multixr_solve(dep, table=True, **kw)
+        (_, _, _, states, _), want = oracle.memo_table("multixr", dep, **kw)
+    assert r.table.shape == want.shape == (sum(states), 9)
+    assert (r.table == want).all()

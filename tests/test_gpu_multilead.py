@@ -74,3 +74,15 @@ def test_random_instances_match_the_oracle(sia, oracle, seed):
     assert g.finalValue == fv
     assert (g.firstAction, g.secondAction) == (q1, q2)
     assert sum(g.statesPerPeriod) == states and g.cells == cells
+
+
+def test_kat1_whole_memo_matches_the_oracle(sia, oracle):
+    """All 2501 states the reference's recursion visits for KAT-1: tuple, value and action of each."""
+    from stochastic_inventory_amd.multiitem import multilead_solve
+    k = KATS["kat1"]
+    kw = {n: k[n] for n in KEYS}
+    r = multilead_solve(table=True, **kw)
+    _, want = oracle.memo_table("multilead", **kw)
+    assert r.table.shape == want.shape == (2501, 9)
+    assert (r.table == want).all()
+    assert r.table[0, 0] == 1 and r.table[0, 6] + k["ini_cash"] == k["expected_final_cash"]
