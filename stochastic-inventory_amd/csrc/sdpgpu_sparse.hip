@@ -135,6 +135,42 @@ __device__ __forceinline__ bool tuple_eq(const Tuple& a, const Tuple& b) {
   return a.i1 == b.i1 && a.i2 == b.i2 && a.q1 == b.q1 && a.q2 == b.q2 && a.cash == b.cash;
 }
 
+// ---- integer-lattice states (models 1 and 2) ---------------------------------------------------------------
+// After their (int) casts the successors of the two cash-constrained families live on an integer lattice
+// (i1, i2, cash-or-R) inside a box the parameters bound.  A period's state set is then a BITMAP over the box and the
+// id of a state is its rank among the set bits (exclusive prefix of the words' popcounts + the bits below it):
+// nothing per candidate is stored, so the horizon is not limited by states x actions x demand pairs the way the
+// sort-based path is.  The price: the backward pass recomputes the successor of every cell and reads two words to
+// rank it.
+struct Lattice {
+  long long n2, nc;  // idx = (i1 * n2 + i2) * nc + (c - c0)
+  long long c0;
+  long long bits;
+};
+
+__device__ __forceinline__ long long lattice_index(const Lattice& L, const Tuple& t) {
+  return ((long long)t.i1 * L.n2 + (long long)t.i2) * L.nc + ((long long)t.cash - L.c0);
+}
+
+__device__ __forceinline__ Tuple lattice_tuple(const Lattice& L, long long idx) {
+  Tuple t;
+  const long long c = idx % L.nc, r = idx / L.nc;
+  t.cash = (double)(c + L.c0);
+  t.i2 = (double)(r % L.n2);
+  t.i1 = (double)(r / L.n2);
+  t.q1 = 0.0;
+  t.q2 = 0.0;
+  return t;
+}
+
+// rank of a set bit: states of a period are numbered in lattice order
+// (word and prefix interleaved: one 8-byte gather ranks a state)
+__device__ __forceinline__ int lattice_rank(const uint2* __restrict__ rank_info, long long idx) {
+  const uint2 wp = rank_info[idx >> 5];
+  const unsigned int below = wp.x & ((1u << (idx & 31)) - 1u);
+  return (int)(wp.y + __popc(below));
+}
+
 // ---- model 1: sdp.cash.multiItem.CashRecursionMulti over the lambdas of cash.multiItem.MultiItemCash ----------
 // buildActionList (MultiItemCash.java:66-76): (i, j) is offered iff variCost[0] * i + variCost[1] * j < iniCash + 0.1
 __device__ __forceinline__ bool mc_feasible(const MLParams& P, const Tuple& s, int a1, int a2) {
@@ -309,13 +345,57 @@ __global__ __launch_bounds__(256) void scatter_kernel(MLParams P, const Tuple* _
   }
 }
 
+// ---- forward on the lattice: mark the successors of every (state, offered action, demand pair) ---------------
+__global__ __launch_bounds__(256) void lattice_mark_kernel(MLParams P, Lattice L, const Tuple* __restrict__ states,
+                                                           int64_t n_states, const double2* __restrict__ dem,
+                                                           unsigned int* __restrict__ words, int* __restrict__ oob) {
+  const int NA = P.qb * P.qb;
+  const int64_t g = (int64_t)blockIdx.x * 256 + threadIdx.x;  // (s, a)
+  if (g >= n_states * NA) return;
+  const int64_t s = g / NA;
+  const int a = (int)(g - s * NA);
+  const Tuple st = states[s];
+  if (P.model == 1 && !mc_feasible(P, st, a / P.qb, a % P.qb)) return;  // not offered: no successors
+  for (int j = 0; j < P.nd; ++j) {
+    const long long idx = lattice_index(L, successor(P, st, a, dem, j));
+    if (idx < 0 || idx >= L.bits) {
+      *oob = 1;  // the host's box was too small: reported, never silently dropped
+      continue;
+    }
+    const unsigned int bit = 1u << (idx & 31);
+    if (!(words[idx >> 5] & bit)) atomicOr(&words[idx >> 5], bit);  // (most candidates are already marked)
+  }
+}
+
+__global__ __launch_bounds__(256) void lattice_popc_kernel(const unsigned int* __restrict__ words, long long n_words,
+                                                           unsigned int* __restrict__ counts) {
+  const long long w = (long long)blockIdx.x * 256 + threadIdx.x;
+  if (w < n_words) counts[w] = (unsigned int)__popc(words[w]);
+}
+
+__global__ __launch_bounds__(256) void lattice_list_kernel(Lattice L, const unsigned int* __restrict__ words,
+                                                           const unsigned int* __restrict__ prefix, long long n_words,
+                                                           Tuple* __restrict__ states, uint2* __restrict__ rank_info) {
+  const long long w = (long long)blockIdx.x * 256 + threadIdx.x;
+  if (w >= n_words) return;
+  unsigned int bits = words[w];
+  unsigned int k = prefix[w];
+  rank_info[w] = make_uint2(bits, k);
+  while (bits) {
+    const int b = __ffs((int)bits) - 1;
+    bits &= bits - 1;
+    states[k++] = lattice_tuple(L, (w << 5) + b);
+  }
+}
+
 // ---- backward: one workgroup per state ------------------------------------------------------------
 __global__ __launch_bounds__(256) void backward_kernel(MLParams P, const Tuple* __restrict__ states, int64_t s_first,
                                                        int64_t n_states,
                                                        const double2* __restrict__ dem, const double* __restrict__ prob,
                                                        const double* __restrict__ v_next, const int* __restrict__ uid,
                                                        double* __restrict__ v_out, int* __restrict__ act_out,
-                                                       unsigned long long* __restrict__ cell_count) {
+                                                       unsigned long long* __restrict__ cell_count, Lattice L,
+                                                       const uint2* __restrict__ lat_rank) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int NA = P.qb * P.qb;
   double* s_q = reinterpret_cast<double*>(smem);                       // Q(s, a)
@@ -342,7 +422,11 @@ __global__ __launch_bounds__(256) void backward_kernel(MLParams P, const Tuple* 
     for (int j = 0; j < P.nd; ++j) {
       const double p = s_p[j];
       acc += p * mc_immediate(P, st, a1, a2, dem[j].x, dem[j].y);
-      if (!P.is_last) acc += p * P.discount * v_next[uid[((int64_t)s * NA + a) * P.nd + j]];
+      if (!P.is_last) {
+        const int id = lat_rank ? lattice_rank(lat_rank, lattice_index(L, mc_successor(P, st, a1, a2, dem[j].x, dem[j].y)))
+                                 : uid[((int64_t)s * NA + a) * P.nd + j];
+        acc += p * P.discount * v_next[id];
+      }
     }
     s_q[a] = acc;
   }
@@ -354,7 +438,11 @@ __global__ __launch_bounds__(256) void backward_kernel(MLParams P, const Tuple* 
     for (int j = 0; j < P.nd; ++j) {
       const double p = s_p[j];
       acc += p * xr_immediate(P, st, y1, y2, dem[j].x, dem[j].y);
-      if (!P.is_last) acc += p * P.discount * v_next[uid[((int64_t)s * NA + a) * P.nd + j]];
+      if (!P.is_last) {
+        const int id = lat_rank ? lattice_rank(lat_rank, lattice_index(L, xr_successor(P, st, y1, y2, dem[j].x, dem[j].y)))
+                                 : uid[((int64_t)s * NA + a) * P.nd + j];
+        acc += p * P.discount * v_next[id];
+      }
     }
     s_q[a] = acc;
   }
@@ -414,6 +502,8 @@ struct SparseProblem {
   std::vector<int> off;  // demand pairs of period t+1: [off[t], off[t+1])
   std::vector<double2> dem;
   std::vector<double> prob;
+  bool lattice_ok = false;  // models 1 / 2 with integer-lattice successors inside the box `lat`
+  Lattice lat{};
 };
 
 int sparse_solve(const SparseProblem& sp, double* final_value, int32_t* q1, int32_t* q2, int64_t* states_per_period,
@@ -432,6 +522,12 @@ int sparse_solve(const SparseProblem& sp, double* final_value, int32_t* q1, int3
 
   std::vector<Tuple*> d_states((size_t)T, nullptr);
   std::vector<int*> d_uid((size_t)T, nullptr);
+  // lattice path: bitmap and rank prefix of S_{t+1}, kept for the backward pass of period t
+  std::vector<uint2*> d_lat_rank((size_t)T, nullptr);
+  unsigned int *d_lat_words = nullptr, *d_lat_prefix = nullptr, *d_lat_counts = nullptr;
+  int* d_oob = nullptr;
+  const char* lat_env = std::getenv("SDPGPU_MULTI_LATTICE");
+  const bool lat_force = lat_env && std::atoi(lat_env) == 1, lat_never = lat_env && std::atoi(lat_env) == 0;
   std::vector<int64_t> n_states((size_t)T, 0);
   double2* d_dem = nullptr;
   double* d_prob = nullptr;
@@ -468,6 +564,67 @@ int sparse_solve(const SparseProblem& sp, double* final_value, int32_t* q1, int3
       const double2* dem_t = d_dem + sp.off[(size_t)t];
       P.nd = nd;
       const int64_t nc = n_states[t] * NA * nd;
+      if (sp.lattice_ok && !lat_never && (lat_force || nc >= 2000000000LL)) {
+        // ---- lattice path: no per-candidate storage ----
+        const Lattice L = sp.lat;
+        const long long n_words = (L.bits + 31) / 32;
+        P.overhead = sp.overhead[t];
+        P.is_last = 0;
+        ML_TRY(hipMalloc((void**)&d_lat_words, (size_t)n_words * 4));
+        ML_TRY(hipMemset(d_lat_words, 0, (size_t)n_words * 4));
+        ML_TRY(hipMalloc((void**)&d_lat_prefix, (size_t)n_words * 4));
+        ML_TRY(hipMalloc((void**)&d_lat_rank[t], (size_t)n_words * 8));
+        ML_TRY(hipMalloc((void**)&d_lat_counts, (size_t)n_words * 4));
+        if (!d_oob) {
+          ML_TRY(hipMalloc((void**)&d_oob, 4));
+          ML_TRY(hipMemset(d_oob, 0, 4));
+        }
+        // a dispatch carries at most 2^32 work-items: batches of states
+        const int64_t per_batch = std::max<int64_t>(1, ((int64_t)1 << 30) / NA);
+        for (int64_t first = 0; first < n_states[t]; first += per_batch) {
+          const int64_t ns = std::min<int64_t>(per_batch, n_states[t] - first);
+          hipLaunchKernelGGL(lattice_mark_kernel, dim3((unsigned)((ns * NA + 255) / 256)), dim3(256), 0, 0, P, L,
+                             d_states[t] + first, ns, dem_t, d_lat_words, d_oob);
+          ML_TRY(hipGetLastError());
+        }
+        const unsigned gw = (unsigned)((n_words + 255) / 256);
+        hipLaunchKernelGGL(lattice_popc_kernel, dim3(gw), dim3(256), 0, 0, d_lat_words, n_words, d_lat_counts);
+        ML_TRY(hipGetLastError());
+        size_t tmp_bytes = 0;
+        ML_TRY(hipcub::DeviceScan::ExclusiveSum(nullptr, tmp_bytes, d_lat_counts, d_lat_prefix, (int)n_words));
+        ML_TRY(hipMalloc(&d_tmp, tmp_bytes));
+        ML_TRY(hipcub::DeviceScan::ExclusiveSum(d_tmp, tmp_bytes, d_lat_counts, d_lat_prefix, (int)n_words));
+        ML_TRY(hipFree(d_tmp));
+        d_tmp = nullptr;
+        unsigned int last_prefix = 0, last_count = 0;
+        int oob = 0;
+        ML_TRY(hipMemcpy(&last_prefix, d_lat_prefix + (n_words - 1), 4, hipMemcpyDeviceToHost));
+        ML_TRY(hipMemcpy(&last_count, d_lat_counts + (n_words - 1), 4, hipMemcpyDeviceToHost));
+        ML_TRY(hipMemcpy(&oob, d_oob, 4, hipMemcpyDeviceToHost));
+        (void)hipFree(d_lat_counts);
+        d_lat_counts = nullptr;
+        if (oob) {
+          g_ml_error = "two-product solver: a successor left the state box computed from the parameters (negative demands?)";
+          rc = SDPGPU_ERR_UNSUPPORTED;
+          goto fail;
+        }
+        const int64_t n_next = (int64_t)last_prefix + last_count;
+        if (n_next >= 2000000000LL) {
+          g_ml_error = "two-product solver: more than 2e9 reachable states in one period";
+          rc = SDPGPU_ERR_UNSUPPORTED;
+          goto fail;
+        }
+        n_states[t + 1] = n_next;
+        ML_TRY(hipMalloc((void**)&d_states[t + 1], (size_t)std::max<int64_t>(n_next, 1) * sizeof(Tuple)));
+        hipLaunchKernelGGL(lattice_list_kernel, dim3(gw), dim3(256), 0, 0, L, d_lat_words, d_lat_prefix, n_words,
+                           d_states[t + 1], d_lat_rank[t]);
+        ML_TRY(hipGetLastError());
+        ML_TRY(hipDeviceSynchronize());
+        (void)hipFree(d_lat_words);
+        (void)hipFree(d_lat_prefix);
+        d_lat_words = d_lat_prefix = nullptr;
+        continue;
+      }
       if (nc >= 2000000000LL) {
         g_ml_error = "multilead: the reachable set outgrows 32-bit candidate indices (the reference's own comment calls such instances unsolvable)";
         rc = SDPGPU_ERR_UNSUPPORTED;
@@ -540,7 +697,8 @@ int sparse_solve(const SparseProblem& sp, double* final_value, int32_t* q1, int3
       for (int64_t first = 0; first < n_states[t]; first += (int64_t)1 << 22) {
         const int64_t nb = std::min<int64_t>((int64_t)1 << 22, n_states[t] - first);
         hipLaunchKernelGGL(backward_kernel, dim3((unsigned)nb), dim3(256), smem, 0, P, d_states[t], first, n_states[t],
-                           d_dem + sp.off[(size_t)t], d_prob + sp.off[(size_t)t], d_vnext, d_uid[t], d_vcur, d_act, d_cells);
+                           d_dem + sp.off[(size_t)t], d_prob + sp.off[(size_t)t], d_vnext, d_uid[t], d_vcur, d_act, d_cells,
+                           sp.lat, d_lat_rank[t]);
         ML_TRY(hipGetLastError());
       }
       if (P.model != 1) total_cells += n_states[t] * (int64_t)NA * nd;
@@ -596,6 +754,11 @@ int sparse_solve(const SparseProblem& sp, double* final_value, int32_t* q1, int3
 fail:
   for (Tuple* p : d_states) if (p) (void)hipFree(p);
   for (int* p : d_uid) if (p) (void)hipFree(p);
+  for (uint2* p : d_lat_rank) if (p) (void)hipFree(p);
+  if (d_lat_words) (void)hipFree(d_lat_words);
+  if (d_lat_prefix) (void)hipFree(d_lat_prefix);
+  if (d_lat_counts) (void)hipFree(d_lat_counts);
+  if (d_oob) (void)hipFree(d_oob);
   if (d_dem) (void)hipFree(d_dem);
   if (d_prob) (void)hipFree(d_prob);
   if (d_hash) (void)hipFree(d_hash);
@@ -700,6 +863,33 @@ static int multicash_common(const sdpgpu_multicash* k, int model, double deposit
   P.cash_int_cast = 1;
   P.model = model;
   P.one_minus_deposit = 1 - deposit_rate;
+  {
+    // The box the (int)-cast successors live in: i1 is clamped above by maxInventoryState, i2 can only grow by
+    // Qbound - 1 a period (it has no upper clamp, MultiItemCash.java:113), cash is clamped; the XR family's R adds
+    // variCost . x to the cash and is an integer when the unit costs are.
+    bool ok = true;
+    for (int32_t j = k->pmf_off[0]; j < k->pmf_off[k->T]; ++j) ok = ok && k->d1[j] >= 0 && k->d2[j] >= 0;
+    const double b1 = std::max(std::floor(std::fabs(k->ini_i1)), std::floor(std::fabs(k->max_inventory)));
+    const double b2 = std::max(std::floor(std::fabs(k->ini_i2)) + (double)(k->T - 1) * (k->q_bound - 1) + (double)k->q_bound,
+                               std::floor(std::fabs(k->min_inventory)));
+    double c_lo = std::floor(k->min_cash) - 1, c_hi = std::ceil(k->max_cash) + 1;
+    if (model == 2) {
+      ok = ok && k->vari_cost[0] >= 0 && k->vari_cost[1] >= 0 && k->vari_cost[0] == std::floor(k->vari_cost[0]) &&
+           k->vari_cost[1] == std::floor(k->vari_cost[1]);
+      c_hi += k->vari_cost[0] * b1 + k->vari_cost[1] * b2;
+    }
+    ok = ok && k->ini_i1 >= 0 && k->ini_i2 >= 0 && b1 < 1e6 && b2 < 1e6 && c_hi - c_lo < 1e9;
+    if (ok) {
+      Lattice L;
+      L.n2 = (long long)b2 + 1;
+      L.nc = (long long)(c_hi - c_lo) + 1;
+      L.c0 = (long long)c_lo;
+      const double bits = ((double)b1 + 1) * (double)L.n2 * (double)L.nc;
+      L.bits = bits < 6.0e10 ? (long long)bits : 0;  // <= 7.5 GB of bitmap; int32 word indices
+      sp.lat = L;
+      sp.lattice_ok = L.bits > 0;
+    }
+  }
   // MultiItemCash.java:130; MultiItemCashXR.java:158 hands iniCash over as R
   sp.ini = Tuple{k->ini_i1, k->ini_i2, 0.0, 0.0, k->ini_cash};
   int a1 = 0, a2 = 0;

@@ -100,3 +100,27 @@ def test_whole_memo_matches_the_oracle(sia, oracle, kind, seed):
         (_, _, _, states, _), want = oracle.memo_table("multixr", dep, **kw)
     assert r.table.shape == want.shape == (sum(states), 9)
     assert (r.table == want).all()
+
+
+@pytest.mark.parametrize("kind", ["multicash", "multixr"])
+def test_lattice_path_whole_memo(sia, oracle, kind, monkeypatch):
+    """The bitmap / rank path of the reachable-set engine (chosen by itself when states x actions x demand pairs
+    outgrow 32-bit candidate indices), forced on small instances: every visited state, value and action pair."""
+    monkeypatch.setenv("SDPGPU_MULTI_LATTICE", "1")
+    done = 0
+    for seed in range(24):
+        if kind == "multicash":
+            kw = multicash_cases.random_instance(seed)
+            r = sia.multicash_solve(table=True, **kw)
+            (fv, q1, q2, states, cells), want = oracle.memo_table("multicash", **kw)
+        else:
+            dep, kw = multicash_cases.xr_random_instance(seed)
+            if any(c != int(c) for c in kw["vari_cost"]):
+                kw["vari_cost"] = [float(int(c) + 1) for c in kw["vari_cost"]]  # R = cash + c . x must stay an integer
+            r = sia.multixr_solve(dep, table=True, **kw)
+            (fv, q1, q2, states, cells), want = oracle.memo_table("multixr", dep, **kw)
+        assert r.finalValue == fv and (r.firstAction, r.secondAction) == (q1, q2), seed
+        assert r.statesPerPeriod == states and r.cells == cells, seed
+        assert r.table.shape == want.shape and (r.table == want).all(), seed
+        done += 1
+    assert done == 24
