@@ -10,7 +10,8 @@ from ._abi import (FAMILY_BACKORDER, FAMILY_CASH, FAMILY_CASH_LEADTIME, FAMILY_L
 from .engine import SdpEngine
 from .functors import (BackorderFunctor, CashFunctor, CashLeadtimeFunctor, CustomFunctor, LeadtimeFunctor, OverdraftFunctor,
                        SurvivalFunctor, java_round)
-from .multiitem import MultiLeadResult, multicash_solve, multilead_solve, multixr_solve
+from .multiitem import (Actions, CashRecursionMulti, CashRecursionMultiLead, CashRecursionMultiXR, CashStateMulti,
+                        CashStateMultiLead, CashStateMultiXR, MultiLeadResult, multicash_solve, multilead_solve, multixr_solve)
 from .pmf import BinomialDist, DiscreteDistribution, GetPmf, NormalDist, PoissonDist, UniformIntDist, staff_level_pmf
 from .recursion import CLSP, CashLeadtimeRecursion, CashRecursion, LeadtimeRecursion, Recursion, RiskRecursion
 from .simulation import RiskSimulation, Sampling, Simulation
@@ -22,7 +23,8 @@ __all__ = [
     "BackorderFunctor", "LeadtimeFunctor", "CashFunctor", "OverdraftFunctor", "CashLeadtimeFunctor", "SurvivalFunctor", "CustomFunctor",
     "Recursion", "CLSP", "LeadtimeRecursion", "CashRecursion", "CashLeadtimeRecursion", "RiskRecursion",
     "StaffRecursion", "StaffFunctor", "StaffState", "BinomialDist", "staff_level_pmf",
-    "multilead_solve", "multicash_solve", "multixr_solve", "MultiLeadResult",
+    "multilead_solve", "multicash_solve", "multixr_solve", "MultiLeadResult", "Actions", "CashRecursionMulti",
+    "CashRecursionMultiLead", "CashRecursionMultiXR", "CashStateMulti", "CashStateMultiLead", "CashStateMultiXR",
     "GetPmf", "PoissonDist", "NormalDist", "UniformIntDist", "DiscreteDistribution", "Simulation", "RiskSimulation", "Sampling",
     "State", "LeadtimeState", "CashState", "CashLeadtimeState", "RiskState", "OptDirection", "java_round",
 ]

@@ -124,3 +124,46 @@ def test_lattice_path_whole_memo(sia, oracle, kind, monkeypatch):
         assert r.table.shape == want.shape and (r.table == want).all(), seed
         done += 1
     assert done == 24
+
+
+def test_mirror_classes_read_like_the_reference_mains(sia, oracle):
+    """MultiItemCash.main (:120-133) / MultiItemCashXR.main (:150-164) / MultiProductLeadtime.main (:225-239) through
+    the mirror classes: construct, getExpectedValue(iniState), getAction(iniState), getOptTable(variCost)."""
+    # --- CashRecursionMulti
+    kw = multicash_cases.random_instance(5)
+    functor = {k: v for k, v in kw.items() if k not in ("pmf", "ini_i1", "ini_i2", "ini_cash", "T", "discount")}
+    recursion = sia.CashRecursionMulti(kw["discount"], kw["pmf"], None, None, None, kw["T"], functor=functor)
+    iniState = sia.CashStateMulti(1, kw["ini_i1"], kw["ini_i2"], kw["ini_cash"])
+    finalValue = kw["ini_cash"] + recursion.getExpectedValue(iniState)
+    (fv, q1, q2, states, _), memo = oracle.memo_table("multicash", **kw)
+    assert finalValue == fv
+    assert (recursion.getAction(iniState).getFirstAction(), recursion.getAction(iniState).getSecondAction()) == (q1, q2)
+    table = recursion.getOptTable(kw["vari_cost"])
+    assert table.shape == (sum(states), 11)
+    assert (table[:, [0, 1, 2, 3, 7, 8]] == memo[:, [0, 1, 2, 5, 7, 8]]).all()
+    row = memo[len(memo) // 2]  # any visited state can be asked for afterwards
+    s = sia.CashStateMulti(int(row[0]), row[1], row[2], row[5])
+    assert recursion.getExpectedValue(s) == row[6]
+    with pytest.raises(KeyError):
+        recursion.getAction(sia.CashStateMulti(1, 77, 77, 77))
+    # --- CashRecursionMultiXR
+    dep, kw = multicash_cases.xr_random_instance(6)
+    functor = {k: v for k, v in kw.items() if k not in ("pmf", "ini_i1", "ini_i2", "ini_cash", "T", "discount")}
+    functor["depositeRate"] = dep
+    recursion = sia.CashRecursionMultiXR(kw["discount"], kw["pmf"], None, None, None, kw["T"], functor=functor)
+    iniState = sia.CashStateMultiXR(1, kw["ini_i1"], kw["ini_i2"], kw["ini_cash"])
+    (fv, y1, y2, states, _), memo = oracle.memo_table("multixr", dep, **kw)
+    assert kw["ini_cash"] + recursion.getExpectedValue(iniState) == fv
+    assert recursion.getAction(iniState) == [float(y1), float(y2)]
+    assert recursion.getOptTable(kw["vari_cost"]).shape == (sum(states), 11)
+    # --- CashRecursionMultiLead (KAT-1)
+    import json
+    k = json.load(open(os.path.join(ROOT, "tests", "golden", "kat_reference.json")))["kat1"]
+    functor = {n: k[n] for n in ("q_bound", "price", "vari_cost", "sal_value", "r0", "r1", "r2", "limit", "interest_free",
+                                 "min_inventory", "max_inventory", "min_cash", "max_cash", "overhead", "values", "probs")}
+    recursion = sia.CashRecursionMultiLead(k["discount"], None, None, None, None, k["T"], functor=functor)
+    iniState = sia.CashStateMultiLead(1, k["ini_i1"], k["ini_i2"], 0, 0, k["ini_cash"])
+    assert k["ini_cash"] + recursion.getExpectedValue(iniState) == k["expected_final_cash"]  # -17.800000000000008
+    a = recursion.getAction(iniState)
+    assert (a.getFirstAction(), a.getSecondAction()) == (k["expected_q1"], k["expected_q2"])
+    assert len(recursion.getCacheActions()) == 2501
