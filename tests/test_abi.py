@@ -49,6 +49,26 @@ def test_struct_layout_matches_the_header(sia, lib):
     assert d.abi_version == 2 and d.discount_factor == 1.0 and d.cash_round_div == 10.0 and d.world_size == 1
 
 
+def test_two_product_struct_layouts_match_the_header(sia):
+    """sdpgpu_multilead / sdpgpu_multicash / sdpgpu_multi_table: size and every field offset as gcc sees the header."""
+    import subprocess, tempfile
+    from stochastic_inventory_amd import _abi
+    pairs = [("sdpgpu_multilead", _abi.SdpgpuMultilead), ("sdpgpu_multicash", _abi.SdpgpuMulticash),
+             ("sdpgpu_multi_table", _abi.SdpgpuMultiTable)]
+    body = ""
+    for cname, cls in pairs:
+        body += f'printf("%zu", sizeof({cname}));' + "".join(f'printf(" %zu", offsetof({cname}, {f[0]}));' for f in cls._fields_) + 'printf("\\n");'
+    src = '#include <stdio.h>\n#include <stddef.h>\n#include "sdpgpu.h"\nint main(void){' + body + 'return 0;}'
+    with tempfile.TemporaryDirectory() as td:
+        open(os.path.join(td, "a.c"), "w").write(src)
+        subprocess.run(["gcc", "-I", os.path.join(ROOT, "include"), "-o", os.path.join(td, "a"), os.path.join(td, "a.c")], check=True)
+        lines = subprocess.run([os.path.join(td, "a")], capture_output=True, text=True, check=True).stdout.strip().splitlines()
+    for (cname, cls), line in zip(pairs, lines):
+        out = [int(v) for v in line.split()]
+        assert out[0] == C.sizeof(cls), cname
+        assert out[1:] == [getattr(cls, f[0]).offset for f in cls._fields_], cname
+
+
 def test_create_rejects_bad_descriptors(sia, lib):
     d = sia.desc_defaults()
     d.family = 9
