@@ -150,7 +150,7 @@ def test_sharded_solver_gloo(tmp_path, oracle, world, case_name):
 
 
 @pytest.mark.parametrize("world,case_name,k", [(2, "f1_small", 2), (3, "f1_small", 3), (3, "f1_clsp_main", 2),
-                                               (4, "f1_clsp_main", 4), (2, "f1_gapped", 3)])
+                                               (4, "f1_clsp_main", 4), (2, "f1_gapped", 3), (8, "f1_clsp_main", 3)])
 def test_blocked_schedule_gloo(tmp_path, oracle, world, case_name, k):
     """K periods per exchange (ShardedSolver.solve_blocked): every period of a block runs on a widened slab, the
     all-gathers only publish rows.  Same tables as the oracle's single sweep on every rank."""
