@@ -167,3 +167,21 @@ def test_mirror_classes_read_like_the_reference_mains(sia, oracle):
     a = recursion.getAction(iniState)
     assert (a.getFirstAction(), a.getSecondAction()) == (k["expected_q1"], k["expected_q2"])
     assert len(recursion.getCacheActions()) == 2501
+
+
+@pytest.mark.skipif(not os.environ.get("SDP_FUZZ_N"), reason="soak run: SDP_FUZZ_N=400 python -m pytest tests/test_gpu_multicash.py -m gpu -k soak")
+def test_soak_whole_memo_both_paths(sia, oracle, monkeypatch):
+    n = int(os.environ["SDP_FUZZ_N"])
+    for seed in range(1000, 1000 + n):
+        for path in ("0", "1"):
+            monkeypatch.setenv("SDPGPU_MULTI_LATTICE", path)
+            kw = multicash_cases.random_instance(seed)
+            r = sia.multicash_solve(table=True, **kw)
+            (fv, q1, q2, states, cells), want = oracle.memo_table("multicash", **kw)
+            assert r.finalValue == fv and r.statesPerPeriod == states and r.cells == cells and (r.table == want).all(), (seed, path)
+            dep, kw = multicash_cases.xr_random_instance(seed)
+            if path == "1":
+                kw["vari_cost"] = [float(int(c) + 1) for c in kw["vari_cost"]]
+            r = sia.multixr_solve(dep, table=True, **kw)
+            (fv, y1, y2, states, cells), want = oracle.memo_table("multixr", dep, **kw)
+            assert r.finalValue == fv and r.statesPerPeriod == states and r.cells == cells and (r.table == want).all(), (seed, path)

@@ -181,7 +181,7 @@ def _random_case(seed):
 def test_random_instances(sia, staffref):
     """Seeded random instances: clamped and not, truncated rows, tables shorter than the staff range, starts above the
     longest row, zero hires, single periods; whole tables and cell counts, slabs on every third one."""
-    for seed in range(60):
+    for seed in range(int(os.environ.get("SDP_FUZZ_N", "60"))):  # soak: SDP_FUZZ_N=3000
         c = _random_case(seed)
         V, pol, cells = c.oracle_problem(staffref).solve()
         world = 1 + (seed % 3 == 0) * (1 + seed % 4)
