@@ -1354,6 +1354,128 @@ static double xr_value(xrmemo* m, const mst_t* s) {
   return val;
 }
 
+/* T == 2 only: the period-2 states (no recursion below them) evaluated by several threads before the root is; the
+ * arithmetic and its order per state are xr_value's, only WHO computes a state changes.  Lets the full-size
+ * MultiItemCashXR.main (6.3e10 cells) be checked in about a minute. */
+typedef struct xr_par_job {
+  xrmemo* m;
+  mst_t* states;
+  double* val;
+  int32_t *b1, *b2;
+  int64_t lo, hi, cells;
+} xr_par_job;
+
+static void* xr_par_worker(void* arg) {
+  xr_par_job* j = (xr_par_job*)arg;
+  const sdpref_multicash* k = j->m->k;
+  for (int64_t i = j->lo; i < j->hi; i++) {
+    const mst_t* s = &j->states[i];
+    const int32_t t = s->period - 1;
+    double val = -DBL_MAX;
+    int32_t b1 = 0, b2 = 0;
+    int32_t miny1 = jd2i(s->i1), miny2 = jd2i(s->i2);
+    for (int32_t yi = miny1; yi < miny1 + k->q_bound; yi++)
+      for (int32_t yj = miny2; yj < miny2 + k->q_bound; yj++) {
+        double thisActionsValue = 0;
+        for (int32_t d = k->pmf_off[t]; d < k->pmf_off[t + 1]; d++) {
+          thisActionsValue += k->p[d] * xr_imm(j->m, s, yi, yj, k->d1[d], k->d2[d]);
+          j->cells++;
+        }
+        if (thisActionsValue > val + 0.1) {
+          val = thisActionsValue;
+          b1 = yi;
+          b2 = yj;
+        }
+      }
+    j->val[i] = val;
+    j->b1[i] = b1;
+    j->b2[i] = b2;
+  }
+  return NULL;
+}
+
+static int xr_prefill_last_period(xrmemo* m, const mst_t* ini, int32_t nthreads) {
+  const sdpref_multicash* k = m->k;
+  /* distinct successors of the root (period 2 == T) */
+  xrmemo seen;
+  memset(&seen, 0, sizeof seen);
+  seen.k = k;
+  seen.cap = 1 << 16;
+  seen.tab = (mlentry*)calloc((size_t)seen.cap, sizeof(mlentry));
+  int64_t n = 0, cap = 1 << 16;
+  mst_t* states = (mst_t*)malloc((size_t)cap * sizeof(mst_t));
+  int32_t miny1 = jd2i(ini->i1), miny2 = jd2i(ini->i2);
+  for (int32_t yi = miny1; yi < miny1 + k->q_bound; yi++)
+    for (int32_t yj = miny2; yj < miny2 + k->q_bound; yj++)
+      for (int32_t d = k->pmf_off[0]; d < k->pmf_off[1]; d++) {
+        mst_t ns;
+        xr_trans(m, ini, yi, yj, k->d1[d], k->d2[d], &ns);
+        mlentry* e = xr_find(&seen, &ns);
+        if (e->used) continue;
+        if ((seen.n + 1) * 2 > seen.cap) {
+          mlmemo view = {NULL, seen.tab, seen.cap, seen.n, 0};
+          ml_grow(&view);
+          seen.tab = view.tab;
+          seen.cap = view.cap;
+          e = xr_find(&seen, &ns);
+        }
+        e->key = ns;
+        e->used = 1;
+        seen.n++;
+        if (n == cap) {
+          cap *= 2;
+          states = (mst_t*)realloc(states, (size_t)cap * sizeof(mst_t));
+        }
+        states[n++] = ns;
+      }
+  free(seen.tab);
+  double* val = (double*)malloc((size_t)n * sizeof(double));
+  int32_t* b1 = (int32_t*)malloc((size_t)n * sizeof(int32_t));
+  int32_t* b2 = (int32_t*)malloc((size_t)n * sizeof(int32_t));
+  if (nthreads > 64) nthreads = 64;
+  pthread_t th[64];
+  xr_par_job jobs[64];
+  for (int32_t w = 0; w < nthreads; w++) {
+    jobs[w].m = m;
+    jobs[w].states = states;
+    jobs[w].val = val;
+    jobs[w].b1 = b1;
+    jobs[w].b2 = b2;
+    jobs[w].lo = n * w / nthreads;
+    jobs[w].hi = n * (w + 1) / nthreads;
+    jobs[w].cells = 0;
+    pthread_create(&th[w], NULL, xr_par_worker, &jobs[w]);
+  }
+  for (int32_t w = 0; w < nthreads; w++) {
+    pthread_join(th[w], NULL);
+    m->cells += jobs[w].cells;
+  }
+  for (int64_t i = 0; i < n; i++) { /* into the memo, as xr_value would have left them */
+    if ((m->n + 1) * 2 > m->cap) {
+      mlmemo view = {NULL, m->tab, m->cap, m->n, 0};
+      ml_grow(&view);
+      m->tab = view.tab;
+      m->cap = view.cap;
+    }
+    mlentry* e = xr_find(m, &states[i]);
+    e->key = states[i];
+    e->value = val[i];
+    e->a1 = b1[i];
+    e->a2 = b2[i];
+    e->used = 1;
+    m->n++;
+    m->per_period[states[i].period]++;
+  }
+  free(states);
+  free(val);
+  free(b1);
+  free(b2);
+  return 0;
+}
+
+static int32_t g_xr_threads = 1;
+void sdpref_multixr_set_threads(int32_t n) { g_xr_threads = n < 1 ? 1 : n; }
+
 int sdpref_multixr_memo(const sdpref_multicash* k, double deposit_rate, double* final_value, int32_t* y1, int32_t* y2,
                         int64_t* states_per_period, int64_t* cells) {
   if (!k || k->T < 1 || k->T > 16 || !k->pmf_off || !k->d1 || !k->d2 || !k->p) return 1;
@@ -1364,6 +1486,7 @@ int sdpref_multixr_memo(const sdpref_multicash* k, double deposit_rate, double* 
   m.cap = 1 << 14;
   m.tab = (mlentry*)calloc((size_t)m.cap, sizeof(mlentry));
   mst_t ini = {1, k->ini_i1, k->ini_i2, 0, 0, k->ini_cash}; /* MultiItemCashXR.java:158: iniCash handed over as R */
+  if (k->T == 2 && g_xr_threads > 1) xr_prefill_last_period(&m, &ini, g_xr_threads);
   double v = xr_value(&m, &ini);
   mlentry* e = xr_find(&m, &ini);
   if (final_value) *final_value = k->ini_cash + v; /* :160 */

@@ -114,6 +114,9 @@ int sdpref_multixr_memo(const sdpref_multicash* k, double deposit_rate, double* 
  * sdpref_multixr_memo call fills with its whole memo; NULL clears it. */
 void sdpref_multi_set_table(sdpgpu_multi_table* t);
 
+/* Threads sdpref_multixr_memo uses for the period-2 states of a T == 2 instance (default 1: the plain recursion). */
+void sdpref_multixr_set_threads(int32_t n);
+
 /* User-defined lambdas: host-compiled versions of the three functions sdpgpu_create_custom takes (signatures in
  * sdpref.c).  Pass NULLs to return to the built-in families.  Not thread-safe: test harness use only. */
 void sdpref_register_custom(void* count_fn, void* imm_fn, void* trans_fn, const double* params);

@@ -53,6 +53,17 @@ def main():
                "pmf": [t.tolist() for t in kw["pmf"]]}
         json.dump(rec, open(os.path.join(HERE, "multicash_main.json"), "w"))
         print("multicash_main", fv, q1, q2, states, cells)
+    # CashRecursionMultiXR over MultiItemCashXR.main's parameters: 6.3e10 cells; the oracle evaluates the period-2
+    # states on all cores (sdpref_multixr_set_threads), same arithmetic per state as its plain recursion
+    if "--multixr" in sys.argv or not os.path.exists(os.path.join(HERE, "multixr_main.json")):
+        kw = multicash_cases.xr_main_instance()
+        sdpref.lib().sdpref_multixr_set_threads(os.cpu_count() or 1)
+        fv, y1, y2, states, cells = sdpref.multixr_memo(0.0, **kw)
+        sdpref.lib().sdpref_multixr_set_threads(1)
+        rec = {"final_value": fv, "y1": y1, "y2": y2, "states_per_period": states, "cells": cells,
+               "pmf": [t.tolist() for t in kw["pmf"]]}
+        json.dump(rec, open(os.path.join(HERE, "multixr_main.json"), "w"))
+        print("multixr_main", fv, y1, y2, states, cells)
 
 
 if __name__ == "__main__":

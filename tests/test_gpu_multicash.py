@@ -75,15 +75,20 @@ def test_multi_item_cash_xr_main_smaller(sia, oracle):
     assert r.statesPerPeriod == states and r.cells == cells
 
 
-def test_multi_item_cash_xr_main_full_size_runs(sia):
-    """MultiItemCashXR.main as it stands: T = 2, Qbound 50, 352 demand pairs.  No oracle at this size (the same kernels
-    as the instances above): checks the bookkeeping only and prints what the driver would print."""
+def test_multi_item_cash_xr_main(sia):
+    """MultiItemCashXR.main as it stands (its solve is live in the reference): T = 2, Qbound 50, 352 demand pairs,
+    71767 period-2 states, 6.3e10 cells -- against the oracle's result committed in tests/golden/multixr_main.json
+    (six minutes on eight threads, tests/golden/make_golden.py)."""
+    import json
+    g = json.load(open(os.path.join(ROOT, "tests", "golden", "multixr_main.json")))
     kw = multicash_cases.xr_main_instance()
+    for t in range(kw["T"]):
+        assert kw["pmf"][t].tolist() == g["pmf"][t]  # the instance itself (scipy's Poisson pmf) has not drifted
     r = sia.multixr_solve(0.0, **kw)
     print(f"MultiItemCashXR.main: final optimal cash {r.finalValue!r}, y1 = {r.firstAction}, y2 = {r.secondAction}, "
           f"states {r.statesPerPeriod}, {r.cells:.3g} cells in {r.gpu_ms:.1f} ms")
-    assert r.statesPerPeriod[0] == 1 and r.cells == sum(r.statesPerPeriod) * 2500 * len(kw["pmf"][0])
-    assert 0 <= r.firstAction < 50 and 0 <= r.secondAction < 50 and r.finalValue > 0
+    assert r.finalValue == g["final_value"] and (r.firstAction, r.secondAction) == (g["y1"], g["y2"])
+    assert r.statesPerPeriod == g["states_per_period"] and r.cells == g["cells"]
 
 
 @pytest.mark.parametrize("kind,seed", [("multicash", s) for s in range(8)] + [("multixr", s) for s in range(8)])
