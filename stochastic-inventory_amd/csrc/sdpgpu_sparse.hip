@@ -356,6 +356,7 @@ __global__ __launch_bounds__(256) void lattice_mark_kernel(MLParams P, Lattice L
   const int a = (int)(g - s * NA);
   const Tuple st = states[s];
   if (P.model == 1 && !mc_feasible(P, st, a / P.qb, a % P.qb)) return;  // not offered: no successors
+#pragma unroll 4
   for (int j = 0; j < P.nd; ++j) {
     const long long idx = lattice_index(L, successor(P, st, a, dem, j));
     if (idx < 0 || idx >= L.bits) {
@@ -419,6 +420,7 @@ __global__ __launch_bounds__(256) void backward_kernel(MLParams P, const Tuple* 
     }
     ++offered;
     double acc = 0.0;  // thisActionsValue, CashRecursionMulti.java:97-105
+#pragma unroll 4
     for (int j = 0; j < P.nd; ++j) {
       const double p = s_p[j];
       acc += p * mc_immediate(P, st, a1, a2, dem[j].x, dem[j].y);
@@ -435,6 +437,7 @@ __global__ __launch_bounds__(256) void backward_kernel(MLParams P, const Tuple* 
     const int a1 = a / P.qb, a2 = a - a1 * P.qb;
     const double y1 = (double)((int)st.i1 + a1), y2 = (double)((int)st.i2 + a2);
     double acc = 0.0;  // thisActionsValue, CashRecursionMultiXR.java:76-86
+#pragma unroll 4
     for (int j = 0; j < P.nd; ++j) {
       const double p = s_p[j];
       acc += p * xr_immediate(P, st, y1, y2, dem[j].x, dem[j].y);
