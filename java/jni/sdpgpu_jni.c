@@ -160,3 +160,67 @@ JNIEXPORT void JNICALL Java_sdp_gpu_SdpGpu_reachable(JNIEnv* env, jclass cls, jl
   (*env)->ReleasePrimitiveArrayCritical(env, out, o, 0);
   CHECK(env, h, rc);
 }
+
+
+/* sdpgpu_multicash_solve / sdpgpu_multixr_solve + sdpgpu_multi_set_table: two calls, the first sizes the table */
+JNIEXPORT jobjectArray JNICALL Java_sdp_gpu_SdpGpu_multiSolve(JNIEnv* env, jclass cls, jint model, jint T, jint qBound,
+                                                              jdoubleArray scalars, jintArray pmfOff, jdoubleArray d1,
+                                                              jdoubleArray d2, jdoubleArray p) {
+  if ((*env)->GetArrayLength(env, scalars) < 15 || (*env)->GetArrayLength(env, pmfOff) < T + 1 || T < 1 || T > 16) {
+    throw_state(env, "multiSolve: bad arguments");
+    return NULL;
+  }
+  jdouble v[15];
+  (*env)->GetDoubleArrayRegion(env, scalars, 0, 15, v);
+  jint* off = (*env)->GetIntArrayElements(env, pmfOff, NULL);
+  jdouble* a1 = (*env)->GetDoubleArrayElements(env, d1, NULL);
+  jdouble* a2 = (*env)->GetDoubleArrayElements(env, d2, NULL);
+  jdouble* ap = (*env)->GetDoubleArrayElements(env, p, NULL);
+  sdpgpu_multicash k;
+  memset(&k, 0, sizeof k);
+  k.T = T; k.q_bound = qBound;
+  k.price[0] = v[0]; k.price[1] = v[1]; k.vari_cost[0] = v[2]; k.vari_cost[1] = v[3]; k.sal_price[0] = v[4]; k.sal_price[1] = v[5];
+  k.ini_cash = v[6]; k.ini_i1 = v[7]; k.ini_i2 = v[8]; k.min_inventory = v[9]; k.max_inventory = v[10];
+  k.min_cash = v[11]; k.max_cash = v[12]; k.discount = v[13];
+  k.pmf_off = (const int32_t*)off; k.d1 = a1; k.d2 = a2; k.p = ap;
+  double fv, ms;
+  int32_t q1, q2;
+  int64_t states[16], cells, rows = 0;
+  sdpgpu_multi_table tab;
+  memset(&tab, 0, sizeof tab);
+  jobjectArray out = NULL;
+  int rc = model == 2 ? sdpgpu_multixr_solve(&k, v[14], &fv, &q1, &q2, states, &cells, &ms)
+                      : sdpgpu_multicash_solve(&k, &fv, &q1, &q2, states, &cells, &ms);
+  if (rc == 0) {
+    for (int t = 0; t < T; t++) rows += states[t];
+    tab.capacity = rows;
+    tab.period = malloc(sizeof(int32_t) * (size_t)rows); tab.a1 = malloc(sizeof(int32_t) * (size_t)rows);
+    tab.a2 = malloc(sizeof(int32_t) * (size_t)rows); tab.i1 = malloc(sizeof(double) * (size_t)rows);
+    tab.i2 = malloc(sizeof(double) * (size_t)rows); tab.q1 = malloc(sizeof(double) * (size_t)rows);
+    tab.q2 = malloc(sizeof(double) * (size_t)rows); tab.cash = malloc(sizeof(double) * (size_t)rows);
+    tab.value = malloc(sizeof(double) * (size_t)rows);
+    sdpgpu_multi_set_table(&tab);
+    rc = model == 2 ? sdpgpu_multixr_solve(&k, v[14], &fv, &q1, &q2, states, &cells, &ms)
+                    : sdpgpu_multicash_solve(&k, &fv, &q1, &q2, states, &cells, &ms);
+    sdpgpu_multi_set_table(NULL);
+  }
+  (*env)->ReleaseDoubleArrayElements(env, p, ap, JNI_ABORT);
+  (*env)->ReleaseDoubleArrayElements(env, d2, a2, JNI_ABORT);
+  (*env)->ReleaseDoubleArrayElements(env, d1, a1, JNI_ABORT);
+  (*env)->ReleaseIntArrayElements(env, pmfOff, off, JNI_ABORT);
+  if (rc != 0) {
+    throw_state(env, sdpgpu_multilead_last_error());
+  } else {
+    jclass rowCls = (*env)->FindClass(env, "[D");
+    out = (*env)->NewObjectArray(env, (jsize)rows, rowCls, NULL);
+    for (int64_t i = 0; i < rows && out; i++) {
+      jdouble r[7] = {tab.period[i], tab.i1[i], tab.i2[i], tab.cash[i], tab.value[i], tab.a1[i], tab.a2[i]};
+      jdoubleArray row = (*env)->NewDoubleArray(env, 7);
+      (*env)->SetDoubleArrayRegion(env, row, 0, 7, r);
+      (*env)->SetObjectArrayElement(env, out, (jsize)i, row);
+      (*env)->DeleteLocalRef(env, row);
+    }
+  }
+  free(tab.period); free(tab.a1); free(tab.a2); free(tab.i1); free(tab.i2); free(tab.q1); free(tab.q2); free(tab.cash); free(tab.value);
+  return out;
+}

@@ -70,4 +70,15 @@ public final class SdpGpu {
 			double[] outValue, int[] outActionIndex);
 
 	public static native void reachable(long handle, int period, byte[] out);
+
+	/**
+	 * sdpgpu_multicash_solve (model 1, CashRecursionMulti over MultiItemCash's lambdas) / sdpgpu_multixr_solve (model 2,
+	 * CashRecursionMultiXR over MultiItemCashXR's lambdas) with the memo read-out (sdpgpu_multi_set_table).
+	 * scalars = {price0, price1, variCost0, variCost1, salPrice0, salPrice1, iniCashOrR, iniInventory1, iniInventory2,
+	 * minInventory, maxInventory, minCash, maxCash, discountFactor, depositeRate}; pmfOff has T + 1 offsets into
+	 * d1 / d2 / p (the rows of GetPmfMulti.getPmf(t)).  Returns rows {period, x1, x2, cashOrR, value, action1, action2}
+	 * of every visited state, the period-1 state first.
+	 */
+	public static native double[][] multiSolve(int model, int T, int qBound, double[] scalars, int[] pmfOff, double[] d1,
+			double[] d2, double[] p);
 }
