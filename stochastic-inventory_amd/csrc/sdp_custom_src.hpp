@@ -62,6 +62,16 @@ struct CParams {
 };
 static_assert(sizeof(CParams) == 168, "CParams layout is mirrored in sdp_custom_src.hpp");
 
+// The state shape, the loop variant and the direction are fixed when the handle is created, so sdpgpu_create_custom
+// passes them as -D constants and the branches on them fold away; without the defines they are read from P.
+#ifndef SDP_HAS_CASH
+#define SDP_HAS_CASH P.has_cash
+#define SDP_HAS_PREQ P.has_preq
+#define SDP_SURVIVAL P.survival
+#define SDP_MAXDIR P.maxdir
+#define SDP_CASH_INT_DIV P.cash_int_div
+#endif
+
 struct CState { double x, cash, preq; };
 
 __device__ inline void c_decode(const CParams& P, sdp_i64 idx, CState& s) {
@@ -71,8 +81,8 @@ __device__ inline void c_decode(const CParams& P, sdp_i64 idx, CState& s) {
   sdp_i64 iq = r / P.cur.nx;
   s.x = P.cur.x_lo + (double)ix * P.step;
   double k = (double)(P.cur.k_lo + ic);
-  s.cash = P.has_cash ? (P.cash_int_div ? k : k / P.round_div) : 0.0;
-  s.preq = P.has_preq ? (double)iq * P.step : 0.0;
+  s.cash = SDP_HAS_CASH ? (SDP_CASH_INT_DIV ? k : k / P.round_div) : 0.0;
+  s.preq = SDP_HAS_PREQ ? (double)iq * P.step : 0.0;
 }
 
 // Flat index of the state the user's transition returned, which must be a grid point of period + 1 (the Java
@@ -85,10 +95,10 @@ __device__ inline sdp_i64 c_next_index(const CParams& P, double nx, double ncash
   const int ix = (int)fx;
   bool ok = (double)ix == fx && ix >= 0 && ix < (int)P.next.nx;
   int ic = 0, iq = 0;
-  if (P.has_cash) {
+  if (SDP_HAS_CASH) {
     int k;
     double back;
-    if (P.cash_int_div) {
+    if (SDP_CASH_INT_DIV) {
       k = (int)ncash;
       back = (double)k;
     } else {
@@ -98,7 +108,7 @@ __device__ inline sdp_i64 c_next_index(const CParams& P, double nx, double ncash
     ic = k - (int)P.next.k_lo;
     ok = ok && back == ncash && ic >= 0 && ic < (int)P.next.nc;
   }
-  if (P.has_preq) {
+  if (SDP_HAS_PREQ) {
     const double fq = npreq * P.inv_step;
     iq = (int)fq;
     ok = ok && (double)iq == fq && iq >= 0 && iq < (int)P.next.nq;
@@ -118,7 +128,7 @@ __device__ inline bool c_better(bool maxdir, double v2, int k2, double v, int k)
 // action slots per state so that the launch still fills the chip); a lane walks its actions and, per action,
 // the demand index serially in the reference's order (Recursion.java:138-144).  q* != nullptr: evaluate the
 // given state tuples instead of grid states (getExpectedValue on an off-grid state).
-template <int SX>
+template <int SX, bool LAST>
 __device__ inline void custom_period_body(
     const CParams& P, const double* __restrict__ v_next, double* __restrict__ v_cur, int* __restrict__ pol,
     const double* __restrict__ pmf_d, const double* __restrict__ pmf_p, sdp_i64 lo, sdp_i64 hi,
@@ -159,7 +169,7 @@ __device__ inline void custom_period_body(
   const int nA = live ? sdp_feasible_count(U, s.x, s.cash, s.preq) : 0;
   const int nD = P.n_demand;
 
-  double best = P.maxdir ? -1.7976931348623157e308 : 1.7976931348623157e308;
+  double best = SDP_MAXDIR ? -1.7976931348623157e308 : 1.7976931348623157e308;
   int bestk = 0;
   bool bad = false;
   for (int k = as; k < nA; k += AS) {
@@ -168,8 +178,8 @@ __device__ inline void custom_period_body(
     for (int j = 0; j < nD; ++j) {
       const double2 dp = s_pmf[j];
       const double imm = sdp_immediate(U, s.x, s.cash, s.preq, a, dp.x);
-      if (P.survival) {  // RiskRecursion.java:78-98
-        if (P.is_last) {
+      if (SDP_SURVIVAL) {  // RiskRecursion.java:78-98
+        if (LAST) {
           acc += dp.y * ((s.cash + imm) >= 0 ? 1.0 : 0.0);
         } else {
           double nx, nc, nq;
@@ -178,14 +188,14 @@ __device__ inline void custom_period_body(
         }
       } else {
         acc += dp.y * imm;
-        if (!P.is_last) {
+        if (!LAST) {
           double nx, nc, nq;
           sdp_transition(U, s.x, s.cash, s.preq, a, dp.x, nx, nc, nq);
           acc += (dp.y * P.gamma) * v_next[c_next_index(P, nx, nc, nq, bad)];
         }
       }
     }
-    if (P.maxdir ? (acc > best) : (acc < best)) {
+    if (SDP_MAXDIR ? (acc > best) : (acc < best)) {
       best = acc;
       bestk = k;
     }
@@ -196,7 +206,7 @@ __device__ inline void custom_period_body(
   for (int off = SX; off < 64; off <<= 1) {
     double ov = __shfl_xor(best, off, 64);
     int ok = __shfl_xor(bestk, off, 64);
-    if (c_better(P.maxdir, ov, ok, best, bestk)) {
+    if (c_better(SDP_MAXDIR, ov, ok, best, bestk)) {
       best = ov;
       bestk = ok;
     }
@@ -214,7 +224,7 @@ __device__ inline void custom_period_body(
     for (int w = 1; w < 4; ++w) {
       double ov = s_val[w * SX + tid];
       int ok = s_k[w * SX + tid];
-      if (c_better(P.maxdir, ov, ok, bv, bk)) {
+      if (c_better(SDP_MAXDIR, ov, ok, bv, bk)) {
         bv = ov;
         bk = ok;
       }
@@ -237,7 +247,10 @@ __device__ inline void custom_period_body(
       const double* __restrict__ pmf_d, const double* __restrict__ pmf_p, sdp_i64 lo, sdp_i64 hi,                    \
       const double* __restrict__ qx, const double* __restrict__ qcash, const double* __restrict__ qpreq,             \
       unsigned long long* __restrict__ cells, int* __restrict__ err) {                                               \
-    custom_period_body<SX>(P, v_next, v_cur, pol, pmf_d, pmf_p, lo, hi, qx, qcash, qpreq, cells, err);               \
+    if (P.is_last)                                                                                                   \
+      custom_period_body<SX, true>(P, v_next, v_cur, pol, pmf_d, pmf_p, lo, hi, qx, qcash, qpreq, cells, err);       \
+    else                                                                                                             \
+      custom_period_body<SX, false>(P, v_next, v_cur, pol, pmf_d, pmf_p, lo, hi, qx, qcash, qpreq, cells, err);      \
   }
 SDP_CUSTOM_PERIOD(64)
 SDP_CUSTOM_PERIOD(16)
@@ -280,7 +293,7 @@ extern "C" __global__ __launch_bounds__(256) void sdp_custom_reach(
     for (int j = 0; j < P.n_demand; ++j) {
       double nx, nc, nq;
       sdp_transition(U, s.x, s.cash, s.preq, a, pmf_d[j], nx, nc, nq);
-      if (P.survival && nc < 0) continue;
+      if (SDP_SURVIVAL && nc < 0) continue;
       mask_next[c_next_index(P, nx, nc, nq, bad)] = 1;
     }
   }

@@ -537,8 +537,17 @@ int sdpgpu_create_custom(const sdpgpu_desc* desc, const char* functor_source, co
   if (hiprtcCreateProgram(&prog, src.c_str(), "sdp_custom.hip", 0, nullptr, nullptr) != HIPRTC_SUCCESS)
     return fail(nullptr, SDPGPU_ERR_DEVICE, "hiprtcCreateProgram failed");
   const std::string np_def = "-DSDP_NP=" + std::to_string(std::max(1, (int)n_params));
-  const char* opts[] = {"--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fno-fast-math", np_def.c_str()};
-  hiprtcResult cr = hiprtcCompileProgram(prog, 6, opts);
+  // the state shape, loop variant and direction of this handle as compile-time constants (sdp_custom_src.hpp)
+  const std::string shape_defs[5] = {
+      std::string("-DSDP_HAS_CASH=") + (has_cash(desc->family) ? "1" : "0"),
+      std::string("-DSDP_HAS_PREQ=") + (has_preq(desc->family) ? "1" : "0"),
+      std::string("-DSDP_SURVIVAL=") + (desc->family == SDPGPU_FAMILY_SURVIVAL ? "1" : "0"),
+      std::string("-DSDP_MAXDIR=") + (desc->direction == SDPGPU_MAX ? "1" : "0"),
+      std::string("-DSDP_CASH_INT_DIV=") + (desc->cash_round_int_div ? "1" : "0")};
+  const char* opts[] = {"--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fno-fast-math", np_def.c_str(),
+                        shape_defs[0].c_str(), shape_defs[1].c_str(), shape_defs[2].c_str(), shape_defs[3].c_str(),
+                        shape_defs[4].c_str()};
+  hiprtcResult cr = hiprtcCompileProgram(prog, 11, opts);
   if (cr != HIPRTC_SUCCESS) {
     size_t n = 0;
     (void)hiprtcGetProgramLogSize(prog, &n);
