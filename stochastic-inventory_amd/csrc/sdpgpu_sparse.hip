@@ -142,22 +142,31 @@ __device__ __forceinline__ bool tuple_eq(const Tuple& a, const Tuple& b) {
 // nothing per candidate is stored, so the horizon is not limited by states x actions x demand pairs the way the
 // sort-based path is.  The price: the backward pass recomputes the successor of every cell and reads two words to
 // rank it.
+// Axis order (i1, R, i2) with R = cash + variCost . x and i2 fastest: as long as a product does not stock out, the R
+// a (state, demand pair) leads to does not depend on the order quantities (revenue - cost of the units sold), and
+// neighbouring second-product quantities lead to neighbouring i2 -- so the 64 lanes of a wave (consecutive second
+// actions) rank and read a handful of words instead of 64 lines.  (XR family: the state's third field IS R, skew 0;
+// MultiItemCash family: R is formed from the cash with the integer unit costs, or stays the cash when they are not.)
 struct Lattice {
-  long long n2, nc;  // idx = (i1 * n2 + i2) * nc + (c - c0)
-  long long c0;
+  long long n2, nr;  // idx = (i1 * nr + (R - r0)) * n2 + i2
+  long long r0;
+  long long skew1, skew2;  // R = cash-field + skew1 * i1 + skew2 * i2
   long long bits;
 };
 
 __device__ __forceinline__ long long lattice_index(const Lattice& L, const Tuple& t) {
-  return ((long long)t.i1 * L.n2 + (long long)t.i2) * L.nc + ((long long)t.cash - L.c0);
+  const long long i1 = (long long)t.i1, i2 = (long long)t.i2;
+  const long long r = (long long)t.cash + L.skew1 * i1 + L.skew2 * i2;
+  return (i1 * L.nr + (r - L.r0)) * L.n2 + i2;
 }
 
 __device__ __forceinline__ Tuple lattice_tuple(const Lattice& L, long long idx) {
   Tuple t;
-  const long long c = idx % L.nc, r = idx / L.nc;
-  t.cash = (double)(c + L.c0);
-  t.i2 = (double)(r % L.n2);
-  t.i1 = (double)(r / L.n2);
+  const long long i2 = idx % L.n2, q = idx / L.n2;
+  const long long r = q % L.nr + L.r0, i1 = q / L.nr;
+  t.cash = (double)(r - L.skew1 * i1 - L.skew2 * i2);
+  t.i2 = (double)i2;
+  t.i1 = (double)i1;
   t.q1 = 0.0;
   t.q2 = 0.0;
   return t;
@@ -876,18 +885,19 @@ static int multicash_common(const sdpgpu_multicash* k, int model, double deposit
     const double b2 = std::max(std::floor(std::fabs(k->ini_i2)) + (double)(k->T - 1) * (k->q_bound - 1) + (double)k->q_bound,
                                std::floor(std::fabs(k->min_inventory)));
     double c_lo = std::floor(k->min_cash) - 1, c_hi = std::ceil(k->max_cash) + 1;
-    if (model == 2) {
-      ok = ok && k->vari_cost[0] >= 0 && k->vari_cost[1] >= 0 && k->vari_cost[0] == std::floor(k->vari_cost[0]) &&
-           k->vari_cost[1] == std::floor(k->vari_cost[1]);
-      c_hi += k->vari_cost[0] * b1 + k->vari_cost[1] * b2;
-    }
+    const bool int_costs = k->vari_cost[0] >= 0 && k->vari_cost[1] >= 0 && k->vari_cost[0] == std::floor(k->vari_cost[0]) &&
+                           k->vari_cost[1] == std::floor(k->vari_cost[1]) && k->vari_cost[0] < 1e6 && k->vari_cost[1] < 1e6;
+    if (model == 2) ok = ok && int_costs;  // (its R is an integer only then)
+    if (int_costs) c_hi += k->vari_cost[0] * b1 + k->vari_cost[1] * b2;  // the range of R = cash + variCost . x
     ok = ok && k->ini_i1 >= 0 && k->ini_i2 >= 0 && b1 < 1e6 && b2 < 1e6 && c_hi - c_lo < 1e9;
     if (ok) {
       Lattice L;
       L.n2 = (long long)b2 + 1;
-      L.nc = (long long)(c_hi - c_lo) + 1;
-      L.c0 = (long long)c_lo;
-      const double bits = ((double)b1 + 1) * (double)L.n2 * (double)L.nc;
+      L.nr = (long long)(c_hi - c_lo) + 1;
+      L.r0 = (long long)c_lo;
+      L.skew1 = (model == 1 && int_costs) ? (long long)k->vari_cost[0] : 0;
+      L.skew2 = (model == 1 && int_costs) ? (long long)k->vari_cost[1] : 0;
+      const double bits = ((double)b1 + 1) * (double)L.n2 * (double)L.nr;
       L.bits = bits < 6.0e10 ? (long long)bits : 0;  // <= 7.5 GB of bitmap; int32 word indices
       sp.lat = L;
       sp.lattice_ok = L.bits > 0;
