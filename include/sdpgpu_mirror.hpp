@@ -26,6 +26,7 @@
 #include <map>
 #include <stdexcept>
 #include <string>
+#include <tuple>
 #include <vector>
 
 #include "sdpgpu.h"
@@ -680,6 +681,118 @@ class StaffRecursion {
   }
   Engine engine_;
 };
+
+// ---- sdp.cash.multiItem.CashRecursionMulti / CashRecursionMultiXR (two products, cash-constrained) -------------
+// CashRecursionMulti.java:39-57,82-116 over the lambdas of MultiItemCash.java:66-118 (model 1) and
+// CashRecursionMultiXR.java:39-57,60-96 over those of MultiItemCashXR.java:92-148 (model 2).  The lambdas are fixed
+// in form, so the functor carries their parameters; the joint pmf of period t is the list GetPmfMulti.getPmf(t)
+// returns: rows {d1, d2, probability}.
+struct MultiItemFunctor {
+  int Qbound = 0;
+  std::array<double, 2> price{}, variCost{}, salPrice{};
+  double minInventoryState = 0, maxInventoryState = 0, minCashState = 0, maxCashState = 0, depositeRate = 0;
+};
+using MultiPmf = std::vector<std::vector<std::array<double, 3>>>;
+
+namespace multiItem {
+struct CashStateMulti {  // CashStateMulti.java:14-70; for the XR class `iniCash` holds R (CashStateMultiXR.java:21-73)
+  int period;
+  double iniInventory1, iniInventory2, iniCash;
+  bool operator<(const CashStateMulti& o) const {
+    return std::tie(period, iniInventory1, iniInventory2, iniCash) < std::tie(o.period, o.iniInventory1, o.iniInventory2, o.iniCash);
+  }
+};
+}  // namespace multiItem
+
+template <int MODEL>
+class CashRecursionMultiBase {
+ public:
+  using State = multiItem::CashStateMulti;
+  CashRecursionMultiBase(double discountFactor, MultiPmf pmf, int TLength, MultiItemFunctor functor)
+      : discount_(discountFactor), pmf_(std::move(pmf)), T_(TLength), f_(functor) {}
+
+  /** The first call (a period-1 state) solves and reads the whole memo back; later calls answer from it. */
+  double getExpectedValue(const State& s) { return find(s)[0]; }
+  /** Actions (Q1, Q2) for CashRecursionMulti, order-up-to levels (y1, y2) for CashRecursionMultiXR. */
+  std::array<int, 2> getAction(const State& s) {
+    const auto& e = find(s);
+    return {(int)e[1], (int)e[2]};
+  }
+  const std::map<State, std::array<double, 3>>& getCacheActions() const { return memo_; }  // key order = the reference's
+
+ private:
+  const std::array<double, 3>& find(const State& s) {
+    if (memo_.empty()) solve(s);
+    auto it = memo_.find(s);
+    if (it == memo_.end()) throw std::out_of_range("state was not visited from the initial state");
+    return it->second;
+  }
+  void solve(const State& ini) {
+    if (ini.period != 1) throw std::invalid_argument("the first query fixes the initial (period-1) state");
+    std::vector<int32_t> off{0};
+    std::vector<double> d1, d2, p;
+    for (const auto& tile : pmf_) {
+      for (const auto& r : tile) {
+        d1.push_back(r[0]);
+        d2.push_back(r[1]);
+        p.push_back(r[2]);
+      }
+      off.push_back((int32_t)d1.size());
+    }
+    sdpgpu_multicash k{};
+    k.T = T_;
+    k.q_bound = f_.Qbound;
+    for (int i = 0; i < 2; ++i) {
+      k.price[i] = f_.price[i];
+      k.vari_cost[i] = f_.variCost[i];
+      k.sal_price[i] = f_.salPrice[i];
+    }
+    k.ini_cash = ini.iniCash;
+    k.ini_i1 = ini.iniInventory1;
+    k.ini_i2 = ini.iniInventory2;
+    k.min_inventory = f_.minInventoryState;
+    k.max_inventory = f_.maxInventoryState;
+    k.min_cash = f_.minCashState;
+    k.max_cash = f_.maxCashState;
+    k.discount = discount_;
+    k.pmf_off = off.data();
+    k.d1 = d1.data();
+    k.d2 = d2.data();
+    k.p = p.data();
+    auto run = [&](int64_t* states) {
+      double fv, ms;
+      int32_t a1, a2;
+      int64_t cells;
+      const int rc = MODEL == 2 ? sdpgpu_multixr_solve(&k, f_.depositeRate, &fv, &a1, &a2, states, &cells, &ms)
+                                : sdpgpu_multicash_solve(&k, &fv, &a1, &a2, states, &cells, &ms);
+      if (rc != 0) throw std::runtime_error(sdpgpu_multilead_last_error());
+    };
+    std::vector<int64_t> states((size_t)T_);
+    run(states.data());
+    int64_t rows = 0;
+    for (int64_t n : states) rows += n;
+    std::vector<int32_t> period((size_t)rows), a1((size_t)rows), a2((size_t)rows);
+    std::vector<double> i1((size_t)rows), i2((size_t)rows), q1((size_t)rows), q2((size_t)rows), cash((size_t)rows), value((size_t)rows);
+    sdpgpu_multi_table tab{rows, 0, period.data(), i1.data(), i2.data(), q1.data(), q2.data(), cash.data(), value.data(), a1.data(), a2.data()};
+    sdpgpu_multi_set_table(&tab);
+    try {
+      run(states.data());
+    } catch (...) {
+      sdpgpu_multi_set_table(nullptr);
+      throw;
+    }
+    sdpgpu_multi_set_table(nullptr);
+    for (int64_t r = 0; r < tab.rows; ++r)
+      memo_[State{period[(size_t)r], i1[(size_t)r], i2[(size_t)r], cash[(size_t)r]}] = {value[(size_t)r], (double)a1[(size_t)r], (double)a2[(size_t)r]};
+  }
+  double discount_;
+  MultiPmf pmf_;
+  int T_;
+  MultiItemFunctor f_;
+  std::map<State, std::array<double, 3>> memo_;
+};
+using CashRecursionMulti = CashRecursionMultiBase<1>;
+using CashRecursionMultiXR = CashRecursionMultiBase<2>;
 
 }  // namespace gpu
 }  // namespace sdp

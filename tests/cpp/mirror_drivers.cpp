@@ -411,11 +411,49 @@ static int workforce_planning(const char* path) {
   return 0;
 }
 
+// cash.multiItem.MultiItemCashXR.main (src/cash/multiItem/MultiItemCashXR.java:41-164) on a smaller box: the joint
+// pmf comes from the file (T, then per period n and n rows {d1, d2, p}); SSJ is not available here.
+static int multi_item_cash_xr(const char* path) {
+  std::ifstream in(path);
+  int T;
+  in >> T;
+  gpu::MultiPmf pmf((size_t)T);
+  for (int t = 0; t < T; t++) {
+    int n;
+    in >> n;
+    pmf[t].resize((size_t)n);
+    for (auto& r : pmf[t]) in >> r[0] >> r[1] >> r[2];
+  }
+  double iniCash = 0;
+  int iniInventory1 = 0, iniInventory2 = 0;
+  gpu::MultiItemFunctor functor;
+  functor.Qbound = 20;
+  functor.price = {5, 10};
+  functor.variCost = {1, 2};
+  functor.salPrice = {0.5, 1.0};
+  functor.minInventoryState = 0;
+  functor.maxInventoryState = 200;
+  functor.minCashState = 0;
+  functor.maxCashState = 10000;
+  functor.depositeRate = 0;
+  double discountFactor = 1;
+  gpu::CashRecursionMultiXR recursion(discountFactor, pmf, T, functor);
+  int period = 1;
+  gpu::CashRecursionMultiXR::State iniState{period, (double)iniInventory1, (double)iniInventory2, iniCash};
+  double finalValue = iniCash + recursion.getExpectedValue(iniState);
+  std::printf("final optimal cash  is %.17g\n", finalValue);
+  auto y = recursion.getAction(iniState);
+  std::printf("optimal order quantity in the first priod is :  y1 = %d, y2 = %d\n", y[0], y[1]);
+  std::printf("visited states: %zu\n", recursion.getCacheActions().size());
+  return 0;
+}
+
 int main(int argc, char** argv) {
   if (argc < 3) return 1;
   try {
     const std::string which = argv[1];
     if (which == "workforce") return workforce_planning(argv[2]);
+    if (which == "multixr") return multi_item_cash_xr(argv[2]);
     const Pmf pmf = read_pmf(argv[2]);
     if (which == "clsp") return clsp(pmf);
     if (which == "leadtime") return leadtime(pmf);

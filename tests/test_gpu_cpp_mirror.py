@@ -151,3 +151,24 @@ def test_workforce_planning_main(exe, tmp_path, sia):
     assert int(lines[1].split()[-1]) == pol[0][0] == act
     assert int(lines[2].split()[-1]) == int(seen.sum())
     assert _last_number(lines[3]) == V[1][pol[0][0] - 3]
+
+
+def test_multi_item_cash_xr_main(exe, tmp_path, sia, oracle):
+    """MultiItemCashXR.main's parameters with Qbound 20 and demand supports cut at the 0.9 quantile, through the C++
+    mirror class: final cash, order-up-to levels and the number of visited states against the oracle's recursion."""
+    import sys
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import multicash_cases
+    kw = multicash_cases.xr_main_instance(q_bound=20, q=0.9)
+    path = tmp_path / "multixr.pmf"
+    with open(path, "w") as f:
+        f.write(f"{kw['T']}\n")
+        for tile in kw["pmf"]:
+            f.write(f"{len(tile)}\n")
+            for d1, d2, p in tile:
+                f.write(f"{float(d1)!r} {float(d2)!r} {float(p)!r}\n")
+    lines = subprocess.run([exe, "multixr", str(path)], check=True, capture_output=True, text=True).stdout.strip().splitlines()
+    fv, y1, y2, states, _ = oracle.multixr_memo(0.0, **kw)
+    assert _last_number(lines[0]) == fv
+    assert lines[1].endswith(f"y1 = {y1}, y2 = {y2}")
+    assert int(lines[2].split()[-1]) == sum(states)
