@@ -420,14 +420,38 @@ __global__ __launch_bounds__(256) void backward_kernel(MLParams P, const Tuple* 
     s_p[j] = prob[j];
   }
   __syncthreads();
-  unsigned long long offered = 0;
-  for (int a = tid; a < NA && P.model == 1; a += 256) {
-    const int a1 = a / P.qb, a2 = a - a1 * P.qb;
-    if (!mc_feasible(P, st, a1, a2)) {
-      s_q[a] = -1.7976931348623157e308;  // never passes `> val + 0.1`: as if it were not in the list
-      continue;
+  // Model 1: the state is offered only the pairs with variCost . (i, j) < cash + 0.1 -- for each i a prefix of the
+  // j's (the test is monotone in j).  The lanes walk that list itself, in the reference's order (i outer, j inner),
+  // not the Qbound x Qbound box: s_off[i] = number of offered pairs before row i, Q values stored compactly.
+  int* s_off = reinterpret_cast<int*>(s_p + P.nd);
+  int n_offered = NA;
+  if (P.model == 1) {
+    if (tid < P.qb) {
+      int n2 = 0;
+      while (n2 < P.qb && mc_feasible(P, st, tid, n2)) ++n2;
+      s_off[tid + 1] = n2;
     }
-    ++offered;
+    __syncthreads();
+    if (tid == 0) {
+      s_off[0] = 0;
+      for (int i = 0; i < P.qb; ++i) s_off[i + 1] += s_off[i];
+    }
+    __syncthreads();
+    n_offered = s_off[P.qb];
+  }
+  auto offered_pair = [&](int k, int& a1, int& a2) {  // k-th offered pair: the last row with s_off[row] <= k
+    int lo_r = 0, hi_r = P.qb - 1;
+    while (lo_r < hi_r) {
+      const int mid = (lo_r + hi_r + 1) >> 1;
+      if (s_off[mid] <= k) lo_r = mid; else hi_r = mid - 1;
+    }
+    a1 = lo_r;
+    a2 = k - s_off[lo_r];
+  };
+  for (int k = tid; k < n_offered && P.model == 1; k += 256) {
+    int a1, a2;
+    offered_pair(k, a1, a2);
+    const int a = a1 * P.qb + a2;
     double acc = 0.0;  // thisActionsValue, CashRecursionMulti.java:97-105
 #pragma unroll 4
     for (int j = 0; j < P.nd; ++j) {
@@ -439,9 +463,9 @@ __global__ __launch_bounds__(256) void backward_kernel(MLParams P, const Tuple* 
         acc += p * P.discount * v_next[id];
       }
     }
-    s_q[a] = acc;
+    s_q[k] = acc;
   }
-  if (P.model == 1 && offered && cell_count) atomicAdd(cell_count, offered * (unsigned long long)P.nd);
+  if (P.model == 1 && tid == 0 && cell_count) atomicAdd(cell_count, (unsigned long long)n_offered * (unsigned long long)P.nd);
   for (int a = tid; a < NA && P.model == 2; a += 256) {
     const int a1 = a / P.qb, a2 = a - a1 * P.qb;
     const double y1 = (double)((int)st.i1 + a1), y2 = (double)((int)st.i2 + a2);
@@ -477,12 +501,12 @@ __global__ __launch_bounds__(256) void backward_kernel(MLParams P, const Tuple* 
   if (tid < 64) {
     double val = -1.7976931348623157e308;
     int best = 0;  // new Actions(0, 0)
-    for (int base = 0; base < NA; base += 64) {
+    for (int base = 0; base < n_offered; base += 64) {  // (n_offered == NA outside model 1)
       const int a = base + tid;
-      const double q = a < NA ? s_q[a] : -1.7976931348623157e308;
+      const double q = a < n_offered ? s_q[a] : -1.7976931348623157e308;
       int from = 0;
       while (true) {
-        const unsigned long long m = __ballot(a < NA && tid >= from && q > val + 0.1);
+        const unsigned long long m = __ballot(a < n_offered && tid >= from && q > val + 0.1);
         if (!m) break;
         const int first = __ffsll((long long)m) - 1;
         val = __shfl(q, first, 64);
@@ -491,6 +515,11 @@ __global__ __launch_bounds__(256) void backward_kernel(MLParams P, const Tuple* 
       }
     }
     if (tid == 0) {
+      if (P.model == 1) {  // position in the offered list -> (i, j)
+        int a1, a2;
+        offered_pair(best, a1, a2);
+        best = a1 * P.qb + a2;
+      }
       v_out[s] = val;
       act_out[s] = best;
     }
@@ -704,7 +733,7 @@ int sparse_solve(const SparseProblem& sp, double* final_value, int32_t* q1, int3
       if (d_act) (void)hipFree(d_act);
       d_act = nullptr;
       ML_TRY(hipMalloc((void**)&d_act, (size_t)n_states[t] * 4));
-      const size_t smem = (size_t)NA * 8 + (size_t)nd * (sizeof(DemandTerms) + 8);
+      const size_t smem = (size_t)NA * 8 + (size_t)nd * (sizeof(DemandTerms) + 8) + (size_t)(P.qb + 1) * 4;
       // a dispatch carries at most 2^32 work-items: batches of 4M workgroups (2^30 lanes)
       for (int64_t first = 0; first < n_states[t]; first += (int64_t)1 << 22) {
         const int64_t nb = std::min<int64_t>((int64_t)1 << 22, n_states[t] - first);
@@ -839,6 +868,10 @@ static int multicash_common(const sdpgpu_multicash* k, int model, double deposit
   if (!k || k->T < 1 || k->T > 16 || k->q_bound < 1 || k->q_bound > 256 || !k->pmf_off || !k->d1 || !k->d2 || !k->p) {
     g_ml_error = "multicash: bad descriptor";
     return SDPGPU_ERR_ARG;
+  }
+  if (model == 1 && (k->vari_cost[0] < 0 || k->vari_cost[1] < 0)) {
+    g_ml_error = "multicash: negative unit costs are not supported (the offered actions of a row must form a prefix)";
+    return SDPGPU_ERR_UNSUPPORTED;
   }
   if (model == 1 && (k->min_cash < 0 || k->ini_cash < 0)) {
     // (0, 0) must always be on offer (0 < cash + 0.1): the candidate lists lean on it
