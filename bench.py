@@ -388,6 +388,9 @@ def main():
             "hbm_measured_GBps": (traffic / (avg_launch_ms * 1e-3) / 1e9) if (traffic and avg_launch_ms > 0) else None,
             "fp64_TFLOPs_at_reference_op_count": out["value"] * flops_per_cell / 1e12,
             "reference_fp64_ops_per_cell": flops_per_cell,
+            # what a period must move at the very least: read V_{t+1} once, write V_t and the policy (20 B per state)
+            "compulsory_bytes_per_launch": 20.0 * states_step_rank / T,
+            "compulsory_GBps": (20.0 * states_step_rank / T / (avg_launch_ms * 1e-3) / 1e9) if avg_launch_ms > 0 else None,
             "note": "the reference's formulas spend 14 (F1/F2) / 25 (F3) fp64 operations per cell; the kernels execute fewer "
                     "(identical operations are formed once), see valu_roofline",
         }
