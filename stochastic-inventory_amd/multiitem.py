@@ -8,8 +8,8 @@ for (the comment block at MultiProductLeadtime.java:30-50).
 from __future__ import annotations
 
 import ctypes as C
-from dataclasses import dataclass, field
-from typing import List, Sequence
+from dataclasses import dataclass
+from typing import List
 
 from . import _abi
 import numpy as np
