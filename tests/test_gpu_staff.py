@@ -224,3 +224,19 @@ def test_two_states_per_lane_kernel_on_every_case(sia, staffref, monkeypatch):
                 eng.run_period(c.T)
                 _, lo, hi = eng.slab(c.T)
                 assert np.array_equal(eng.values(c.T)[lo:hi], V[c.T - 1][lo:hi]) and np.array_equal(eng.policy(c.T), pol[c.T - 1][lo:hi])
+
+
+def test_ping_pong_tables(sia, staffref):
+    """store_all_values = 0: two value rows reused period after period; V_1 (and the policy of every period) must not
+    care."""
+    c = staff_cases.staff_testing_small()
+    V, pol, _ = c.oracle_problem(staffref).solve()
+    d = c.functor.to_desc(c.T)
+    d.store_all_values = 0
+    with sia.SdpEngine(d, None, [float(m) for m in c.functor.minStaffNum], level_pmf=c.table) as eng:
+        eng.solve(sync=True)
+        assert np.array_equal(eng.values(1), V[0])
+        for period in range(1, c.T + 1):
+            assert np.array_equal(eng.policy(period), pol[period - 1])
+        with pytest.raises(sia.SdpgpuError):
+            eng.values(c.T)  # overwritten long ago
