@@ -31,6 +31,8 @@
  *                            CashLeadtimeRecursion.java:48-79): fills the value and
  *                            action maps.  Here: dense backward sweep t = T..1.
  *   sdpgpu_run_period        one level of that recursion (all states of period t).
+ *   sdpgpu_solve_sharded /   the same first call with the state axis cut over the GPUs of a node (one rank per
+ *   sdpgpu_solve_multi       process, or all devices from one process): still ONE call per rank / per JVM.
  *   sdpgpu_values            `cacheValues` lookups (Recursion.java:36,90).
  *   sdpgpu_policy            `cacheActions` lookups / getAction / getCacheActions
  *                            (Recursion.java:35,160,165-171).
@@ -67,7 +69,7 @@ extern "C" {
 #pragma GCC visibility push(default) /* the library is built with -fvisibility=hidden: only this header is exported */
 #endif
 
-#define SDPGPU_ABI_VERSION 2
+#define SDPGPU_ABI_VERSION 3
 
 /* status codes */
 #define SDPGPU_OK 0
@@ -330,6 +332,48 @@ int sdpgpu_attach_keys(sdpgpu_handle* h, void* device_ptr, size_t bytes);
 int sdpgpu_finalize(sdpgpu_handle* h);
 /* sdpgpu_finalize, then block until everything queued on the handle's stream has finished. */
 int sdpgpu_synchronize(sdpgpu_handle* h);
+
+/* ---- multi-GPU: the state axis sharded over the GPUs of one node ------------------------------------------
+ * The reference's contract is "one call solves everything" (`getExpectedValue(initialState)`,
+ * Recursion.java:89); with the state axis cut into world_size slabs that call becomes a sweep of per-slab period
+ * kernels with ONE all-gather of V_t between periods (RCCL over xGMI, in place in the row the next period reads,
+ * issued by this library -- no Python or torch in the data path).  Two ways to drive it:
+ *
+ *  (1) one process (or thread) per GPU:  every rank creates its handle with desc.rank / desc.world_size /
+ *      desc.device, ONE rank calls sdpgpu_comm_unique_id and hands the 128 bytes to the others by whatever channel
+ *      the host has (a file, a socket, MPI, torch.distributed's store), every rank calls sdpgpu_comm_init (collective:
+ *      ncclCommInitRank), then sdpgpu_solve_sharded.
+ *  (2) one process that owns all the GPUs (a JVM calling through JNI): one handle per device, all in this process,
+ *      and ONE call sdpgpu_solve_multi(handles, n, ...) -- the library builds the communicators itself
+ *      (ncclCommInitAll), drives every device from the calling thread and groups the per-period all-gathers.
+ *      Handles that SHARE a device (a rehearsal of N ranks on one GPU) exchange their slabs by device-to-device
+ *      copies instead, since RCCL refuses two ranks on one device; the slab arithmetic and results are the same.
+ *
+ * RCCL is loaded on first use (dlopen of librccl.so.1): a single-GPU caller never pays for it.  RCCL failures come
+ * back as SDPGPU_ERR_DEVICE with ncclGetErrorString's text.  Policy tables stay sharded (sdpgpu_policy reads this
+ * rank's slab); after the sweep every rank holds every full V_t with t >= 2, and V_1 complete only on its own slab
+ * unless `gather_first` is set. */
+#define SDPGPU_UNIQUE_ID_BYTES 128
+int sdpgpu_comm_unique_id(void* out_id /* SDPGPU_UNIQUE_ID_BYTES */);
+/* Collective over the `world` ranks; rank / world must equal the handle's desc.rank / desc.world_size.  world = 1 is
+ * allowed (a one-rank communicator: the collective path with nobody to talk to -- used by the tests). */
+int sdpgpu_comm_init(sdpgpu_handle* h, const void* unique_id, int32_t rank, int32_t world);
+int sdpgpu_comm_destroy(sdpgpu_handle* h);
+/* The all-gather of the row of `period` alone (sdpgpu_exchange_ptr), enqueued on the handle's stream behind the
+ * period's kernel -- for a caller that steps the periods itself with sdpgpu_run_period. */
+int sdpgpu_exchange(sdpgpu_handle* h, int32_t period);
+/* Whole backward sweep t = T..1 of this rank's slab with the exchanges in between; every rank calls it.
+ * flags: SDPGPU_SHARDED_SYNC        wait for the stream before returning (else asynchronous, like sdpgpu_solve)
+ *        SDPGPU_SHARDED_OVERLAP     run the all-gather of V_{t+1} on a second stream beside the INTERIOR part of
+ *                                   period t (families with a bounded footprint; otherwise same as blocking)
+ *        SDPGPU_SHARDED_GATHER_FIRST  also all-gather V_1 (needed only if every rank wants the whole V_1) */
+#define SDPGPU_SHARDED_SYNC 1
+#define SDPGPU_SHARDED_OVERLAP 2
+#define SDPGPU_SHARDED_GATHER_FIRST 4
+int sdpgpu_solve_sharded(sdpgpu_handle* h, int32_t flags);
+/* Way (2): handles[r] is the handle of rank r (desc.rank = r, desc.world_size = n, any devices).  The communicators
+ * are created at the first call and kept in the handles.  Errors are reported on handles[0]. */
+int sdpgpu_solve_multi(sdpgpu_handle** handles, int32_t n, int32_t flags);
 
 /* ---- results ----------------------------------------------------------------------------- */
 /* Copy V_period[0..n) to host (n <= num_states). */

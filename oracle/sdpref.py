@@ -149,7 +149,10 @@ class Problem:
                 "cash": arrs[1][:k], "preq": arrs[2][:k], "preq2": arrs[3][:k], "values": arrs[4][:k],
                 "actions": arrs[5][:k]}
 
-    def eval_states(self, period: int, v_next, x, cash=None, preq=None, preq2=None):
+    def eval_states(self, period: int, v_next, x, cash=None, preq=None, preq2=None, nthreads: int = 1):
+        """States of `period` against a given V_{period+1}: (values, action indices).  nthreads > 1 cuts the list into
+        runs evaluated by as many host threads (the C function is re-entrant and ctypes releases the GIL); every state
+        is still evaluated by the same scalar code."""
         x = np.ascontiguousarray(x, dtype=np.float64)
         n = len(x)
         ca = None if cash is None else np.ascontiguousarray(cash, dtype=np.float64)
@@ -158,10 +161,22 @@ class Problem:
         vn = None if v_next is None else np.ascontiguousarray(v_next, dtype=np.float64)
         val = np.zeros(n, dtype=np.float64)
         act = np.zeros(n, dtype=np.int32)
-        rc = lib().sdpref_eval_states(*self._args(), period, _dp(vn), C.c_int64(n), _dp(x), _dp(ca), _dp(pq),
-                                      _dp(pq2), _dp(val), act.ctypes.data_as(_IP))
-        if rc:
-            raise RuntimeError(f"sdpref_eval_states failed: {rc}")
+
+        def run(a, b):
+            sl = lambda arr: None if arr is None else arr[a:b]  # noqa: E731
+            return lib().sdpref_eval_states(*self._args(), period, _dp(vn), C.c_int64(b - a), _dp(x[a:b]), _dp(sl(ca)),
+                                            _dp(sl(pq)), _dp(sl(pq2)), _dp(val[a:b]), act[a:b].ctypes.data_as(_IP))
+
+        nthreads = max(1, min(int(nthreads), n))
+        if nthreads == 1:
+            rcs = [run(0, n)]
+        else:
+            from concurrent.futures import ThreadPoolExecutor
+            cuts = [n * i // nthreads for i in range(nthreads + 1)]
+            with ThreadPoolExecutor(max_workers=nthreads) as ex:
+                rcs = list(ex.map(lambda ab: run(*ab), zip(cuts[:-1], cuts[1:])))
+        if any(rcs):
+            raise RuntimeError(f"sdpref_eval_states failed: {[r for r in rcs if r]}")
         return val, act
 
     def reachable(self):

@@ -12,7 +12,7 @@ import os
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libsdpgpu.so")
 
-SDPGPU_ABI_VERSION = 2
+SDPGPU_ABI_VERSION = 3
 
 FAMILY_BACKORDER = 1
 FAMILY_LEADTIME = 2
@@ -29,6 +29,11 @@ KERNEL_AUTO = 0
 KERNEL_GATHER = 1
 KERNEL_WINDOW = 2
 KERNEL_SEPARABLE = 3  # opt-in, F1 only: reassociated sum, values to 1e-9, arg-opt may differ on near-ties
+
+SHARDED_SYNC = 1
+SHARDED_OVERLAP = 2
+SHARDED_GATHER_FIRST = 4
+UNIQUE_ID_BYTES = 128
 
 PART_ALL = 0
 PART_INTERIOR = 1
@@ -212,6 +217,12 @@ EXPORTS = {
     "sdpgpu_footprint": (C.c_int, [_P, C.c_int32, _LP, _LP]),
     "sdpgpu_set_halo": (C.c_int, [_P, C.c_int64]),
     "sdpgpu_run_period_range": (C.c_int, [_P, C.c_int32, C.c_int64, C.c_int64]),
+    "sdpgpu_comm_unique_id": (C.c_int, [_P]),
+    "sdpgpu_comm_init": (C.c_int, [_P, _P, C.c_int32, C.c_int32]),
+    "sdpgpu_comm_destroy": (C.c_int, [_P]),
+    "sdpgpu_exchange": (C.c_int, [_P, C.c_int32]),
+    "sdpgpu_solve_sharded": (C.c_int, [_P, C.c_int32]),
+    "sdpgpu_solve_multi": (C.c_int, [C.POINTER(_P), C.c_int32, C.c_int32]),
     "sdpgpu_values_device_ptr": (_P, [_P, C.c_int32]),
     "sdpgpu_values_bytes": (C.c_size_t, [_P]),
     "sdpgpu_attach_values": (C.c_int, [_P, _P, C.c_size_t]),
@@ -270,6 +281,25 @@ def _share_hip_runtime_with_torch():
             C.CDLL(cand, mode=C.RTLD_GLOBAL)
         except OSError:
             pass  # fall back to the system runtime
+
+
+def share_rccl_with_torch():
+    """One RCCL per process, the same way: libsdpgpu.so opens `librccl.so.1` on first use of a communicator
+    (sdpgpu_comm.hip) and takes a copy the process already holds.  When PyTorch is installed its bundled copy (same
+    SONAME, built against the HIP runtime loaded above) is loaded first so that both agree."""
+    import importlib.util
+    try:
+        spec = importlib.util.find_spec("torch")
+    except (ImportError, ValueError):
+        spec = None
+    if spec is None or not spec.origin:
+        return
+    cand = os.path.join(os.path.dirname(spec.origin), "lib", "librccl.so")
+    if os.path.exists(cand):
+        try:
+            C.CDLL(cand, mode=C.RTLD_GLOBAL)
+        except OSError:
+            pass  # the system RCCL then
 
 
 def load():

@@ -302,8 +302,7 @@ void count_cells(sdpgpu_handle* h, int period) {
 // INTERIOR = the states whose cells read only THIS rank's slab of V_{t+1}, BOUNDARY = the rest.
 // range_lo/range_hi >= 0: sdpgpu_run_period_range -- the states [range_lo, range_hi) instead of this rank's slab
 // (F1 window kernel only: the one family whose dependency footprint is bounded).
-int run_period_impl(sdpgpu_handle* h, int period, int part = SDPGPU_PART_ALL, int64_t range_lo = -1,
-                    int64_t range_hi = -1) {
+int run_period_impl(sdpgpu_handle* h, int period, int part, int64_t range_lo, int64_t range_hi) {
   int rc = allocate(h);
   if (rc) return rc;
   if (period < 1 || period > h->T) return fail(h, SDPGPU_ERR_ARG, "period %d out of 1..%d", period, h->T);
@@ -603,6 +602,7 @@ void sdpgpu_destroy(sdpgpu_handle* h) {
   if (h->d_custom_cells) (void)hipFree(h->d_custom_cells);
   if (h->d_custom_err) (void)hipFree(h->d_custom_err);
   if (h->custom_mod) (void)hipModuleUnload(h->custom_mod);
+  comm_release(h);
   if (h->stream && h->own_stream) (void)hipStreamDestroy(h->stream);
   delete h;
 }

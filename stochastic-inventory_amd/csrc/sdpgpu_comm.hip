@@ -1,0 +1,396 @@
+// sdpgpu_comm.hip -- the multi-GPU half of the C ABI: the state axis of a period is cut into world_size contiguous
+// slabs (layout(), sdpgpu.hip), each rank computes its slab reading the FULL V_{t+1}, and ONE all-gather per period
+// rebuilds V_t on every rank, in place in the row the next period reads.  The reference's
+// contract is one call that solves everything (Recursion.java:89 `getExpectedValue(initialState)`): here that call is
+// sdpgpu_solve_sharded (one rank per process / thread) or sdpgpu_solve_multi (one process that owns all devices).
+//
+// RCCL is not linked: librccl.so.1 is opened on first use, so a single-GPU caller never loads it.  xGMI is
+// point-to-point (7 links per GPU); the message is S/world * 8 B per rank per period (1 MB at the 1e6-state grid,
+// 100 MB at 1e8 states) against milliseconds to seconds of compute, so one ring/direct all-gather per period on the
+// compute stream is the whole protocol; the overlapped schedule (second stream, interior tiles first) exists for the
+// families with a bounded footprint and small slabs.
+#include "sdpgpu_internal.hpp"
+
+#include <dlfcn.h>
+#include <rccl/rccl.h>
+
+#include <mutex>
+
+using namespace sdpgpu_detail;
+
+namespace {
+
+struct RcclApi {
+  void* lib = nullptr;
+  decltype(&ncclGetUniqueId) GetUniqueId = nullptr;
+  decltype(&ncclCommInitRank) CommInitRank = nullptr;
+  decltype(&ncclCommInitAll) CommInitAll = nullptr;
+  decltype(&ncclCommDestroy) CommDestroy = nullptr;
+  decltype(&ncclAllGather) AllGather = nullptr;
+  decltype(&ncclGroupStart) GroupStart = nullptr;
+  decltype(&ncclGroupEnd) GroupEnd = nullptr;
+  decltype(&ncclGetErrorString) GetErrorString = nullptr;
+  std::string err;
+};
+
+RcclApi g_rccl;
+std::once_flag g_rccl_once;
+
+// nullptr + message when the library or one of its symbols is missing
+RcclApi* rccl() {
+  std::call_once(g_rccl_once, [] {
+    static_assert(SDPGPU_UNIQUE_ID_BYTES == NCCL_UNIQUE_ID_BYTES, "unique id size");
+    const char* names[] = {"librccl.so.1", "librccl.so"};
+    for (const char* n : names) {
+      g_rccl.lib = dlopen(n, RTLD_NOW | RTLD_GLOBAL | RTLD_NOLOAD);  // a copy the process already holds (e.g. PyTorch's)
+      if (g_rccl.lib) break;
+    }
+    for (int i = 0; !g_rccl.lib && i < 2; ++i) g_rccl.lib = dlopen(names[i], RTLD_NOW | RTLD_GLOBAL);
+    if (!g_rccl.lib) {
+      const char* e = dlerror();
+      g_rccl.err = std::string("cannot load librccl.so.1: ") + (e ? e : "?");
+      return;
+    }
+    bool ok = true;
+    auto sym = [&](const char* name) {
+      void* p = dlsym(g_rccl.lib, name);
+      if (!p) {
+        ok = false;
+        g_rccl.err = std::string("librccl lacks ") + name;
+      }
+      return p;
+    };
+    g_rccl.GetUniqueId = (decltype(g_rccl.GetUniqueId))sym("ncclGetUniqueId");
+    g_rccl.CommInitRank = (decltype(g_rccl.CommInitRank))sym("ncclCommInitRank");
+    g_rccl.CommInitAll = (decltype(g_rccl.CommInitAll))sym("ncclCommInitAll");
+    g_rccl.CommDestroy = (decltype(g_rccl.CommDestroy))sym("ncclCommDestroy");
+    g_rccl.AllGather = (decltype(g_rccl.AllGather))sym("ncclAllGather");
+    g_rccl.GroupStart = (decltype(g_rccl.GroupStart))sym("ncclGroupStart");
+    g_rccl.GroupEnd = (decltype(g_rccl.GroupEnd))sym("ncclGroupEnd");
+    g_rccl.GetErrorString = (decltype(g_rccl.GetErrorString))sym("ncclGetErrorString");
+    if (!ok) g_rccl.lib = nullptr;
+  });
+  return g_rccl.lib ? &g_rccl : nullptr;
+}
+
+#define NCCL_TRY(h, api, expr)                                                                             \
+  do {                                                                                                     \
+    ncclResult_t r_ = (expr);                                                                              \
+    if (r_ != ncclSuccess) return fail(h, SDPGPU_ERR_DEVICE, "%s: %s", #expr, (api)->GetErrorString(r_)); \
+  } while (0)
+
+// the row of `period` that travels, as sdpgpu_exchange_ptr reports it: 8-byte elements, S_pad of them
+void* exchange_row(sdpgpu_handle* h, int period) {
+  if (h->pending_chunks[period - 1] > 0) return h->d_keys + (size_t)(period - 1) * h->key_stride;
+  return h->d_values + h->per[period - 1].v_off;
+}
+
+int ensure_comm_stream(sdpgpu_handle* h) {
+  if (h->comm_stream) return SDPGPU_OK;
+  HIP_TRY(h, hipStreamCreateWithFlags(&h->comm_stream, hipStreamNonBlocking));
+  HIP_TRY(h, hipEventCreateWithFlags(&h->ev_comp, hipEventDisableTiming));
+  HIP_TRY(h, hipEventCreateWithFlags(&h->ev_comm, hipEventDisableTiming));
+  return SDPGPU_OK;
+}
+
+// all-gather of this rank's slab of the row of `period`, in place, on stream `st`
+int enqueue_allgather(sdpgpu_handle* h, RcclApi* api, int period, hipStream_t st) {
+  const PeriodInfo& p = h->per[period - 1];
+  const size_t n = (size_t)(p.S_pad / h->d.world_size);
+  if (n == 0) return SDPGPU_OK;
+  char* row = (char*)exchange_row(h, period);
+  // bytes travel untouched (an all-gather does no arithmetic): the keys and the fp64 values are both sent as u64
+  NCCL_TRY(h, api, api->AllGather(row + (size_t)h->d.rank * n * 8, row, n, ncclUint64, (ncclComm_t)h->comm, st));
+  return SDPGPU_OK;
+}
+
+// One rank's sweep.  `exchange(period, overlapped)` enqueues the collective for the row of `period`.
+template <class Exchange>
+int sweep_rank(sdpgpu_handle* h, int flags, Exchange&& exchange) {
+  int rc = allocate(h);
+  if (rc) return rc;
+  rc = ensure_device(h);
+  if (rc) return rc;
+  const bool overlap = (flags & SDPGPU_SHARDED_OVERLAP) != 0;
+  const int last = (flags & SDPGPU_SHARDED_GATHER_FIRST) ? 1 : 2;  // lowest period whose row is exchanged
+  if (overlap) {
+    rc = ensure_comm_stream(h);
+    if (rc) return rc;
+  }
+  std::fill(h->period_done.begin(), h->period_done.end(), 0);
+  HIP_TRY(h, hipEventRecord(h->ev_solve0, h->stream));
+  bool in_flight = false;  // the exchange of period + 1 is running on the second stream
+  for (int period = h->T; period >= 1; --period) {
+    if (in_flight) {
+      // interior tiles read only this rank's slab of V_{period+1}: they run beside the all-gather
+      rc = run_period_impl(h, period, SDPGPU_PART_INTERIOR);
+      if (rc) return rc;
+      HIP_TRY(h, hipStreamWaitEvent(h->stream, h->ev_comm, 0));
+      rc = run_period_impl(h, period, SDPGPU_PART_BOUNDARY);
+      in_flight = false;
+    } else {
+      rc = run_period_impl(h, period);
+    }
+    if (rc) return rc;
+    count_cells(h, period);
+    if (period >= last) {
+      if (overlap && period > 1) {
+        HIP_TRY(h, hipEventRecord(h->ev_comp, h->stream));
+        HIP_TRY(h, hipStreamWaitEvent(h->comm_stream, h->ev_comp, 0));
+        rc = exchange(period, true);
+        if (rc) return rc;
+        HIP_TRY(h, hipEventRecord(h->ev_comm, h->comm_stream));
+        in_flight = true;
+      } else {
+        rc = exchange(period, false);
+        if (rc) return rc;
+      }
+    }
+  }
+  if (in_flight) HIP_TRY(h, hipStreamWaitEvent(h->stream, h->ev_comm, 0));
+  rc = flush_api(h);  // deferred read-out: every V_t row (decoded over the whole row) and this rank's policy rows
+  if (rc) return rc;
+  HIP_TRY(h, hipEventRecord(h->ev_solve1, h->stream));
+  h->solve_timed = true;
+  if (flags & SDPGPU_SHARDED_SYNC) HIP_TRY(h, hipStreamSynchronize(h->stream));
+  return SDPGPU_OK;
+}
+
+}  // namespace
+
+namespace sdpgpu_detail {
+
+void comm_release(sdpgpu_handle* h) {
+  if (h->comm) {
+    if (RcclApi* api = rccl()) (void)api->CommDestroy((ncclComm_t)h->comm);
+    h->comm = nullptr;
+  }
+  if (h->ev_comp) (void)hipEventDestroy(h->ev_comp);
+  if (h->ev_comm) (void)hipEventDestroy(h->ev_comm);
+  if (h->comm_stream) (void)hipStreamDestroy(h->comm_stream);
+  h->ev_comp = h->ev_comm = nullptr;
+  h->comm_stream = nullptr;
+  // the siblings of a multi-handle solve must not touch this handle any more
+  for (sdpgpu_handle* s : h->siblings)
+    if (s && s != h) s->siblings.clear();
+  h->siblings.clear();
+}
+
+}  // namespace sdpgpu_detail
+
+extern "C" {
+
+int sdpgpu_comm_unique_id(void* out_id) {
+  g_create_error.clear();
+  if (!out_id) return fail(nullptr, SDPGPU_ERR_ARG, "comm_unique_id: null buffer");
+  RcclApi* api = rccl();
+  if (!api) return fail(nullptr, SDPGPU_ERR_DEVICE, "%s", g_rccl.err.c_str());
+  ncclUniqueId id;
+  NCCL_TRY(nullptr, api, api->GetUniqueId(&id));
+  std::memcpy(out_id, &id, sizeof id);
+  return SDPGPU_OK;
+}
+
+int sdpgpu_comm_init(sdpgpu_handle* h, const void* unique_id, int32_t rank, int32_t world) {
+  if (!h) return SDPGPU_ERR_ARG;
+  h->err.clear();
+  if (!unique_id) return fail(h, SDPGPU_ERR_ARG, "comm_init: null unique id");
+  if (rank != h->d.rank || world != h->d.world_size)
+    return fail(h, SDPGPU_ERR_ARG, "comm_init: rank %d of %d, but the handle was created as rank %d of %d", rank, world, h->d.rank, h->d.world_size);
+  if (h->comm) return fail(h, SDPGPU_ERR_STATE, "comm_init: the handle already has a communicator");
+  try {
+    RcclApi* api = rccl();
+    if (!api) return fail(h, SDPGPU_ERR_DEVICE, "%s", g_rccl.err.c_str());
+    int rc = allocate(h);  // needs the device: no CPU path
+    if (rc) return rc;
+    rc = ensure_device(h);
+    if (rc) return rc;
+    if (h->device < 0) HIP_TRY(h, hipGetDevice(&h->device));  // the communicator is bound to a device: pin the handle to it
+    ncclUniqueId id;
+    std::memcpy(&id, unique_id, sizeof id);
+    ncclComm_t comm = nullptr;
+    NCCL_TRY(h, api, api->CommInitRank(&comm, world, id, rank));
+    h->comm = comm;
+    h->multi_copy = false;
+    return SDPGPU_OK;
+  } catch (const std::exception& e) {
+    return fail(h, SDPGPU_ERR_ARG, "exception: %s", e.what());
+  } catch (...) {
+    return fail(h, SDPGPU_ERR_ARG, "unknown exception");
+  }
+}
+
+int sdpgpu_comm_destroy(sdpgpu_handle* h) {
+  if (!h) return SDPGPU_ERR_ARG;
+  h->err.clear();
+  if (h->allocated) {
+    int rc = ensure_device(h);
+    if (rc) return rc;
+    HIP_TRY(h, hipStreamSynchronize(h->stream));
+    if (h->comm_stream) HIP_TRY(h, hipStreamSynchronize(h->comm_stream));
+  }
+  comm_release(h);
+  return SDPGPU_OK;
+}
+
+int sdpgpu_exchange(sdpgpu_handle* h, int32_t period) {
+  if (!h) return SDPGPU_ERR_ARG;
+  h->err.clear();
+  if (period < 1 || period > h->T) return fail(h, SDPGPU_ERR_ARG, "exchange: period %d out of 1..%d", period, h->T);
+  if (!h->comm) return fail(h, SDPGPU_ERR_STATE, "exchange: no communicator (sdpgpu_comm_init first)");
+  if (!h->allocated || !h->period_done[period - 1]) return fail(h, SDPGPU_ERR_STATE, "exchange: period %d has not been run", period);
+  try {
+    RcclApi* api = rccl();
+    if (!api) return fail(h, SDPGPU_ERR_DEVICE, "%s", g_rccl.err.c_str());
+    int rc = ensure_device(h);
+    if (rc) return rc;
+    return enqueue_allgather(h, api, period, h->stream);
+  } catch (...) {
+    return fail(h, SDPGPU_ERR_ARG, "unknown exception");
+  }
+}
+
+int sdpgpu_solve_sharded(sdpgpu_handle* h, int32_t flags) {
+  if (!h) return SDPGPU_ERR_ARG;
+  h->err.clear();
+  if (!h->comm) return fail(h, SDPGPU_ERR_STATE, "solve_sharded: no communicator (sdpgpu_comm_init first)");
+  try {
+    RcclApi* api = rccl();
+    if (!api) return fail(h, SDPGPU_ERR_DEVICE, "%s", g_rccl.err.c_str());
+    return sweep_rank(h, flags, [&](int period, bool overlapped) {
+      return enqueue_allgather(h, api, period, overlapped ? h->comm_stream : h->stream);
+    });
+  } catch (const std::exception& e) {
+    return fail(h, SDPGPU_ERR_ARG, "exception: %s", e.what());
+  } catch (...) {
+    return fail(h, SDPGPU_ERR_ARG, "unknown exception");
+  }
+}
+
+// One host thread drives every rank: per period the kernels of all ranks are enqueued first (each on its own
+// device and stream), then the exchange of that period for all ranks -- one RCCL group, or device-to-device copies
+// when ranks share a device.  Streams are asynchronous, so the devices run concurrently.
+int sdpgpu_solve_multi(sdpgpu_handle** hs, int32_t n, int32_t flags) {
+  if (!hs || n < 1 || !hs[0]) return SDPGPU_ERR_ARG;
+  sdpgpu_handle* h0 = hs[0];
+  h0->err.clear();
+  try {
+    for (int r = 0; r < n; ++r) {
+      if (!hs[r]) return fail(h0, SDPGPU_ERR_ARG, "solve_multi: handle %d is null", r);
+      if (hs[r]->d.rank != r || hs[r]->d.world_size != n)
+        return fail(h0, SDPGPU_ERR_ARG, "solve_multi: handle %d was created as rank %d of %d (want rank %d of %d)", r, hs[r]->d.rank, hs[r]->d.world_size, r, n);
+      if (hs[r]->T != h0->T) return fail(h0, SDPGPU_ERR_ARG, "solve_multi: handles describe different horizons");
+      for (int q = 0; q < r; ++q)
+        if (hs[q] == hs[r]) return fail(h0, SDPGPU_ERR_ARG, "solve_multi: handle %d given twice", r);
+    }
+    // devices: distinct -> RCCL (ncclCommInitAll), shared -> copies
+    std::vector<int> dev((size_t)n);
+    bool distinct = true;
+    for (int r = 0; r < n; ++r) {
+      sdpgpu_handle* h = hs[r];
+      int rc = allocate(h);
+      if (rc) return h == h0 ? rc : fail(h0, rc, "rank %d: %s", r, h->err.c_str());
+      rc = ensure_device(h);
+      if (rc) return h == h0 ? rc : fail(h0, rc, "rank %d: %s", r, h->err.c_str());
+      if (h->device < 0) HIP_TRY(h0, hipGetDevice(&h->device));
+      dev[(size_t)r] = h->device;
+      for (int q = 0; q < r; ++q) distinct = distinct && dev[(size_t)q] != dev[(size_t)r];
+    }
+    const char* force = std::getenv("SDPGPU_MULTI_EXCHANGE");  // "copy": device-to-device copies even on distinct devices
+    const bool want_copy = !distinct || (force && std::strcmp(force, "copy") == 0);
+    bool same_group = true;
+    for (int r = 0; r < n; ++r) same_group = same_group && hs[r]->siblings.size() == (size_t)n && std::equal(hs, hs + n, hs[r]->siblings.begin());
+    RcclApi* api = nullptr;
+    if (!want_copy) {
+      api = rccl();
+      if (!api) return fail(h0, SDPGPU_ERR_DEVICE, "%s", g_rccl.err.c_str());
+    }
+    if (!same_group || hs[0]->multi_copy != want_copy || (!want_copy && !hs[0]->comm)) {
+      for (int r = 0; r < n; ++r) {
+        if (hs[r]->comm && api) (void)api->CommDestroy((ncclComm_t)hs[r]->comm);
+        hs[r]->comm = nullptr;
+      }
+      if (!want_copy) {
+        std::vector<ncclComm_t> comms((size_t)n, nullptr);
+        NCCL_TRY(h0, api, api->CommInitAll(comms.data(), n, dev.data()));
+        for (int r = 0; r < n; ++r) hs[r]->comm = comms[(size_t)r];
+      }
+      for (int r = 0; r < n; ++r) {
+        hs[r]->siblings.assign(hs, hs + n);
+        hs[r]->multi_copy = want_copy;
+      }
+    }
+    if (want_copy)
+      for (int r = 0; r < n; ++r) {
+        int rc = ensure_device(hs[r]);
+        if (!rc) rc = ensure_comm_stream(hs[r]);  // (for its events)
+        if (rc) return hs[r] == h0 ? rc : fail(h0, rc, "rank %d: %s", r, hs[r]->err.c_str());
+      }
+    const int last = (flags & SDPGPU_SHARDED_GATHER_FIRST) ? 1 : 2;
+    for (int r = 0; r < n; ++r) {
+      sdpgpu_handle* h = hs[r];
+      HIP_TRY(h0, hipSetDevice(h->device));
+      std::fill(h->period_done.begin(), h->period_done.end(), 0);
+      HIP_TRY(h0, hipEventRecord(h->ev_solve0, h->stream));
+    }
+    for (int period = h0->T; period >= 1; --period) {
+      for (int r = 0; r < n; ++r) {
+        sdpgpu_handle* h = hs[r];
+        h->err.clear();
+        int rc = run_period_impl(h, period);
+        if (rc) return h == h0 ? rc : fail(h0, rc, "rank %d: %s", r, h->err.c_str());
+        count_cells(h, period);
+      }
+      if (period < last) continue;
+      if (!want_copy) {
+        NCCL_TRY(h0, api, api->GroupStart());
+        for (int r = 0; r < n; ++r) {
+          sdpgpu_handle* h = hs[r];
+          int rc = enqueue_allgather(h, api, period, h->stream);
+          if (rc) {
+            (void)api->GroupEnd();
+            return h == h0 ? rc : fail(h0, rc, "rank %d: %s", r, h->err.c_str());
+          }
+        }
+        NCCL_TRY(h0, api, api->GroupEnd());
+      } else {
+        // rank q pulls slab r of the row from rank r once r's kernel has finished
+        const size_t cnt = (size_t)(h0->per[period - 1].S_pad / n);
+        for (int r = 0; r < n; ++r) {
+          HIP_TRY(h0, hipSetDevice(hs[r]->device));
+          HIP_TRY(h0, hipEventRecord(hs[r]->ev_comp, hs[r]->stream));
+        }
+        for (int q = 0; q < n && cnt; ++q) {
+          HIP_TRY(h0, hipSetDevice(hs[q]->device));
+          char* dst = (char*)exchange_row(hs[q], period);
+          for (int r = 0; r < n; ++r) {
+            if (r == q) continue;
+            const char* src = (const char*)exchange_row(hs[r], period);
+            HIP_TRY(h0, hipStreamWaitEvent(hs[q]->stream, hs[r]->ev_comp, 0));
+            HIP_TRY(h0, hipMemcpyAsync(dst + (size_t)r * cnt * 8, src + (size_t)r * cnt * 8, cnt * 8, hipMemcpyDeviceToDevice, hs[q]->stream));
+          }
+        }
+      }
+    }
+    for (int r = 0; r < n; ++r) {
+      sdpgpu_handle* h = hs[r];
+      int rc = ensure_device(h);
+      if (!rc) rc = flush_api(h);
+      if (rc) return h == h0 ? rc : fail(h0, rc, "rank %d: %s", r, h->err.c_str());
+      HIP_TRY(h0, hipEventRecord(h->ev_solve1, h->stream));
+      h->solve_timed = true;
+    }
+    if (flags & SDPGPU_SHARDED_SYNC)
+      for (int r = 0; r < n; ++r) {
+        HIP_TRY(h0, hipSetDevice(hs[r]->device));
+        HIP_TRY(h0, hipStreamSynchronize(hs[r]->stream));
+      }
+    return SDPGPU_OK;
+  } catch (const std::exception& e) {
+    return fail(h0, SDPGPU_ERR_ARG, "exception: %s", e.what());
+  } catch (...) {
+    return fail(h0, SDPGPU_ERR_ARG, "unknown exception");
+  }
+}
+
+}  // extern "C"

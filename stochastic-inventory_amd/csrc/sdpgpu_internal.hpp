@@ -7,6 +7,7 @@
 //   sdpgpu_cash.hip     F3 uniform-shift kernel and the cash row kernel (F3-F6)
 //   sdpgpu_staff.hip    STAFF family (workforce.StaffRecursion): level-dependent pmf tables, its period kernel
 //   sdpgpu_sparse.hip   reachable-set engine of the two-product lead-time family (own entry point)
+//   sdpgpu_comm.hip     multi-GPU: RCCL communicators (loaded on first use), per-period all-gather, sharded sweeps
 #pragma once
 #include "../../include/sdpgpu.h"
 
@@ -131,6 +132,13 @@ struct sdpgpu_handle {
   double* d_staff_val = nullptr;    // partial arg-min rows [group][slab]
   int32_t* d_staff_idx = nullptr;
   size_t staff_part_elems = 0;
+  // multi-GPU (sdpgpu_comm.hip): the communicator of this rank, a second stream for the overlapped schedule, and --
+  // sdpgpu_solve_multi with several ranks on ONE device -- the sibling handles whose rows are exchanged by copies
+  void* comm = nullptr;  // ncclComm_t
+  hipStream_t comm_stream = nullptr;
+  hipEvent_t ev_comp = nullptr, ev_comm = nullptr;
+  std::vector<sdpgpu_handle*> siblings;  // handles[0..n) of the last sdpgpu_solve_multi (set on every member)
+  bool multi_copy = false;               // exchange by device-to-device copies (ranks share a device)
   std::string err;
   int device = -1;
 };
@@ -189,10 +197,16 @@ struct WinPlan {
 };
 
 // ---- sdpgpu.hip ----------------------------------------------------------------------------------------
+int run_period_impl(sdpgpu_handle* h, int period, int part = SDPGPU_PART_ALL, int64_t range_lo = -1, int64_t range_hi = -1);
+void count_cells(sdpgpu_handle* h, int period);
+int flush_api(sdpgpu_handle* h);
 int layout(sdpgpu_handle* h);
 int ensure_device(sdpgpu_handle* h);
 int allocate(sdpgpu_handle* h);
 DevParams make_params(const sdpgpu_handle* h, int period);
+
+// ---- sdpgpu_comm.hip -----------------------------------------------------------------------------------
+void comm_release(sdpgpu_handle* h);  // sdpgpu_destroy: communicator, second stream, events
 
 // ---- sdpgpu_generic.hip ----------------------------------------------------------------------------------
 hipError_t launch_gather_grid(const DevParams& P, const double* v_next, double* v_cur, int32_t* pol, const double* pmf_d,

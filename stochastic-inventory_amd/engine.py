@@ -184,6 +184,49 @@ class SdpEngine:
     def run_period_part(self, period: int, part: int):
         self._check(self._lib.sdpgpu_run_period_part(self._h, period, part))
 
+    # -- multi-GPU through the C ABI (csrc/sdpgpu_comm.hip) -------------------------------------
+    @staticmethod
+    def comm_unique_id() -> bytes:
+        """ncclGetUniqueId: ONE rank calls this and hands the 128 bytes to the others."""
+        lib = _abi.load()
+        _abi.share_rccl_with_torch()
+        buf = C.create_string_buffer(_abi.UNIQUE_ID_BYTES)
+        rc = lib.sdpgpu_comm_unique_id(buf)
+        if rc:
+            raise SdpgpuError(rc, lib.sdpgpu_last_error(None).decode())
+        return buf.raw
+
+    def comm_init(self, unique_id: bytes, rank: int, world: int):
+        """Collective over the world's ranks (ncclCommInitRank on this handle's device)."""
+        if len(unique_id) != _abi.UNIQUE_ID_BYTES:
+            raise ValueError("unique id must be 128 bytes")
+        _abi.share_rccl_with_torch()
+        self._check(self._lib.sdpgpu_comm_init(self._h, C.c_char_p(unique_id), rank, world))
+
+    def comm_destroy(self):
+        self._check(self._lib.sdpgpu_comm_destroy(self._h))
+
+    def exchange(self, period: int):
+        """All-gather of the row of `period` on the handle's stream (needs comm_init)."""
+        self._check(self._lib.sdpgpu_exchange(self._h, period))
+
+    def solve_sharded(self, overlap: bool = False, sync: bool = True, gather_first: bool = False):
+        """This rank's whole sweep with the per-period all-gathers in between; every rank calls it."""
+        flags = (_abi.SHARDED_SYNC if sync else 0) | (_abi.SHARDED_OVERLAP if overlap else 0) | \
+                (_abi.SHARDED_GATHER_FIRST if gather_first else 0)
+        self._check(self._lib.sdpgpu_solve_sharded(self._h, flags))
+
+    @staticmethod
+    def solve_multi(engines, sync: bool = True, gather_first: bool = False):
+        """One process driving every rank: engines[r] is rank r of len(engines) (sdpgpu_solve_multi)."""
+        lib = _abi.load()
+        _abi.share_rccl_with_torch()
+        arr = (C.c_void_p * len(engines))(*[e._h for e in engines])
+        flags = (_abi.SHARDED_SYNC if sync else 0) | (_abi.SHARDED_GATHER_FIRST if gather_first else 0)
+        rc = lib.sdpgpu_solve_multi(arr, len(engines), flags)
+        if rc:
+            raise SdpgpuError(rc, lib.sdpgpu_last_error(engines[0]._h).decode())
+
     def synchronize(self):
         self._check(self._lib.sdpgpu_synchronize(self._h))
 

@@ -1,4 +1,9 @@
-"""State-axis sharding over the GPUs of one node: one process per GPU, torch.distributed over RCCL.
+"""State-axis sharding over the GPUs of one node: one process per GPU.
+
+The product path is native: `init_native_comm` + `ShardedSolver.solve_native` = sdpgpu_comm_init +
+sdpgpu_solve_sharded of include/sdpgpu.h (RCCL all-gather issued by libsdpgpu.so itself; torch.distributed only
+carries the 128-byte unique id).  `ShardedSolver.solve` / `solve_blocked` are the same sweep with the collective issued
+through torch.distributed instead: the seam the gloo CPU tests drive, and the K-periods-per-exchange schedules.
 
 Within a period every state is independent; between periods each rank needs the FULL V_{t+1}
 (the transition can land anywhere on the grid).  So: the flat state index of every period is cut
@@ -22,6 +27,18 @@ import torch
 import torch.distributed as dist
 
 from .engine import SdpEngine
+
+
+def init_native_comm(engine: SdpEngine, group=None) -> None:
+    """Give `engine` (this rank's handle) its RCCL communicator INSIDE libsdpgpu.so (sdpgpu_comm_init): rank 0 draws the
+    unique id through the C ABI, torch.distributed is only the channel that carries its 128 bytes to the other ranks
+    (any backend: gloo is enough).  After this the data path -- kernels and all-gathers -- is sdpgpu_solve_sharded."""
+    world = dist.get_world_size(group) if dist.is_initialized() else 1
+    rank = dist.get_rank(group) if dist.is_initialized() else 0
+    box = [SdpEngine.comm_unique_id() if rank == 0 else None]
+    if world > 1:
+        dist.broadcast_object_list(box, src=0, group=group)
+    engine.comm_init(box[0], rank, world)
 
 
 class SlabBackend:
@@ -178,6 +195,12 @@ class ShardedSolver:
             return None
         # in place: this rank's shard already sits at its offset inside `full`
         return dist.all_gather_into_tensor(full, shard, group=self.group, async_op=async_op)
+
+    def solve_native(self, overlap: bool = False, sync: bool = False) -> None:
+        """The whole sweep of this rank in ONE C-ABI call: kernels and RCCL all-gathers issued by libsdpgpu.so
+        (sdpgpu_solve_sharded; the communicator comes from init_native_comm).  The torch schedules below remain for
+        the K-periods-per-exchange variants and for the CPU test double."""
+        self.backend.engine.solve_sharded(overlap=overlap, sync=sync)
 
     def solve(self, first_period: int = 1, overlap: bool = True) -> None:
         """t = T..first_period.  With `overlap` (and more than one rank) the all-gather of V_{t+1} runs

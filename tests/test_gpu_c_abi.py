@@ -82,3 +82,25 @@ def test_c_caller_two_product(tmp_path, sia, oracle):
     parts = out[2].replace(",", "").split()
     assert int(parts[2]) == sum(states) and int(parts[4]) == cells
     assert abs(float(parts[-1]) - memo[:, 6].sum()) <= 1e-9 * max(1.0, abs(memo[:, 6].sum()))  # (row order differs)
+
+
+def _build_sharded(tmp_path):
+    exe = tmp_path / "c_abi_sharded"
+    libdir = os.path.join(ROOT, "stochastic-inventory_amd")
+    subprocess.run(["gcc", "-O1", "-std=c11", "-Wall", "-I", os.path.join(ROOT, "include"), "-o", str(exe),
+                    os.path.join(ROOT, "tests", "c_abi_sharded.c"), "-L", libdir, "-lsdpgpu", f"-Wl,-rpath,{libdir}", "-lm"],
+                   check=True)
+    return str(exe)
+
+
+@pytest.mark.parametrize("shape", [(1000, 40, 30, 5, 3), (20000, 64, 48, 4, 4), (130000, 24, 20, 3, 2)])
+def test_c_caller_sharded_solves(tmp_path, sia, shape):
+    """The collective behind the C ABI: RCCL communicator of one rank (sdpgpu_comm_init + sdpgpu_solve_sharded,
+    blocking and overlapped), ncclCommInitAll (sdpgpu_solve_multi, one handle), and N rank-handles on this device --
+    all bit-identical to sdpgpu_solve, from a C program (no Python, no torch in the process).  The small shape runs
+    on key rows (several tasks per tile), the large ones on fp64 rows."""
+    S, A, D, T, n = shape
+    r = subprocess.run([_build_sharded(tmp_path), str(S), str(A), str(D), str(T), str(n)], capture_output=True, text=True,
+                       timeout=300)
+    assert r.returncode == 0, r.stderr + r.stdout
+    assert r.stdout.strip().splitlines()[-1].split() == ["ok", str(S * A * D * T)]  # (RCCL prints a version banner first)

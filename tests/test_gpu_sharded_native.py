@@ -1,0 +1,117 @@
+"""The multi-GPU entry points of include/sdpgpu.h (csrc/sdpgpu_comm.hip) on ONE GPU, every family:
+
+* sdpgpu_solve_multi with N rank-handles that share the device (slabs exchanged by device copies inside the library),
+* sdpgpu_comm_init + sdpgpu_solve_sharded with a one-rank RCCL communicator (the collective path itself),
+
+each against the oracle, table for table, bit for bit.  What one GPU cannot show is RCCL between devices: the slab
+arithmetic, the row that travels (fp64 values or order-preserving keys), the in-place offsets and the deferred
+read-out are all exercised here; the collective's transport is RCCL's own business.
+"""
+import numpy as np
+import pytest
+
+import cases
+
+pytestmark = pytest.mark.gpu
+
+
+def _oracle_tables(oracle, w):
+    V, pol, _ = oracle.Problem(w.desc(), w.pmf, w.overhead()).solve()
+    return V, pol
+
+
+def _check_rank(eng, V, pol, T, first_full, label):
+    for period in range(1, T + 1):
+        _, lo, hi = eng.slab(period)
+        gv = eng.values(period)
+        a, b = (0, len(gv)) if period >= first_full else (lo, hi)
+        assert np.array_equal(gv[a:b], V[period - 1][a:b]), f"{label}: V_{period}"
+        assert np.array_equal(eng.policy(period), pol[period - 1][lo:hi]), f"{label}: policy of period {period}"
+
+
+@pytest.mark.parametrize("make,world", [(cases.f1_small, 2), (cases.f1_clsp_main, 4), (cases.f1_unclamped, 3),
+                                        (cases.f1_gapped, 2), (cases.f2_clamped, 3), (cases.f2_unclamped, 2),
+                                        (cases.f2_pipeline, 3), (cases.f3_tenths, 3), (cases.f3_dyadic, 2),
+                                        (cases.f3_testing, 5), (cases.f4_overdraft, 2), (cases.f5_cash_leadtime, 2),
+                                        (cases.f6_survival, 3)], ids=lambda v: getattr(v, "__name__", str(v)))
+def test_solve_multi_shared_device(sia, oracle, make, world):
+    w = make()
+    V, pol = _oracle_tables(oracle, w)
+    engs = []
+    try:
+        for r in range(world):
+            d = w.desc()
+            d.rank, d.world_size, d.device = r, world, 0
+            engs.append(sia.SdpEngine(d, w.pmf, w.overhead()))
+        for rep in range(2):  # the second call reuses the group
+            sia.SdpEngine.solve_multi(engs, sync=True)
+            cells = 0
+            for r, e in enumerate(engs):
+                _check_rank(e, V, pol, w.T, 2, f"rank {r}/{world} (call {rep})")
+                cells += int(e.stats().cells_evaluated)
+            assert cells == int(engs[0].stats().cells_all_ranks)
+        sia.SdpEngine.solve_multi(engs, sync=True, gather_first=True)
+        for r, e in enumerate(engs):
+            _check_rank(e, V, pol, w.T, 1, f"rank {r}/{world} (V_1 gathered)")
+    finally:
+        for e in engs:
+            e.close()
+
+
+@pytest.mark.parametrize("make", [cases.f1_clsp_main, cases.f2_clamped, cases.f3_tenths, cases.f5_cash_leadtime],
+                         ids=lambda v: v.__name__)
+@pytest.mark.parametrize("overlap", [False, True])
+def test_solve_sharded_one_rank_communicator(sia, oracle, make, overlap):
+    w = make()
+    V, pol = _oracle_tables(oracle, w)
+    d = w.desc()
+    d.device = 0
+    with sia.SdpEngine(d, w.pmf, w.overhead()) as eng:
+        eng.comm_init(sia.SdpEngine.comm_unique_id(), 0, 1)
+        eng.solve_sharded(overlap=overlap, sync=True, gather_first=True)
+        _check_rank(eng, V, pol, w.T, 1, "one-rank communicator")
+        eng.comm_destroy()
+        with pytest.raises(sia.SdpgpuError):
+            eng.solve_sharded()
+
+
+@pytest.mark.parametrize("make", ["staff_planning_small", "staff_testing_small", "staff_short_rows"])
+def test_staff_family_slabs(sia, make):
+    """The level-dependent pmf family cut into slabs (its footprint spans the whole table: blocking exchange)."""
+    from oracle import staffref
+    import staff_cases
+    staffref.build()
+    c = getattr(staff_cases, make)()
+    V, pol, _ = c.oracle_problem(staffref).solve()
+    engs = []
+    try:
+        for r in range(3):
+            d = c.functor.to_desc(c.T)
+            d.rank, d.world_size, d.device = r, 3, 0
+            engs.append(sia.SdpEngine(d, None, [float(m) for m in c.functor.minStaffNum], level_pmf=c.table,
+                                      level_row_len=c.row_len))
+        sia.SdpEngine.solve_multi(engs, sync=True)
+        for r, e in enumerate(engs):
+            _check_rank(e, V, pol, c.T, 2, f"{make} rank {r}/3")
+    finally:
+        for e in engs:
+            e.close()
+
+
+def test_comm_argument_errors(sia):
+    w = cases.f1_small()
+    d = w.desc()
+    d.device = 0
+    with sia.SdpEngine(d, w.pmf) as eng:
+        with pytest.raises(sia.SdpgpuError):
+            eng.solve_sharded()                    # no communicator
+        with pytest.raises(sia.SdpgpuError):
+            eng.exchange(1)
+        uid = sia.SdpEngine.comm_unique_id()
+        with pytest.raises(sia.SdpgpuError):
+            eng.comm_init(uid, 1, 2)               # the handle was created as rank 0 of 1
+    d2 = w.desc()
+    d2.rank, d2.world_size, d2.device = 1, 2, 0
+    with sia.SdpEngine(d2, w.pmf) as e1, sia.SdpEngine(w.desc(), w.pmf) as e0:
+        with pytest.raises(sia.SdpgpuError):
+            sia.SdpEngine.solve_multi([e0, e1])    # e0 is rank 0 of ONE
