@@ -1,20 +1,33 @@
 #!/usr/bin/env python3
-"""bench.py -- the hot path (backward Bellman sweep) on N MI355X GPUs of one node.
+"""bench.py -- the hot path (backward Bellman sweep t = T..1) on N MI355X GPUs of one node.
 
     python bench.py --gpus 1 --steps K --warmup W
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
 
-A "step" is one full backward sweep t = T..1 of the workload with every input (PMF tiles,
-descriptor) already resident in HBM.  Default workload at N = 1: BASELINE.json configs[1], the
-capacitated lot-sizing grid (1e4 states x 200 actions x 100 demands, 52 periods = 1.04e10
-cells).  For N > 1 the state axis is sharded (weak scaling: each rank keeps a 1e4-state slab, the
-grid grows to N * 1e4 states) with one RCCL all-gather of V_t per period.
+A "step" is one full backward sweep of the workload with every input (PMF tiles, descriptor) already resident
+in HBM.  Default workload: the grid BASELINE.json's target is quoted on -- 1e6 states x 500 actions x 200
+demands (F1, capacitated.CLSP's lambdas, CLSP.java:251-272), six periods = 6e11 cells per sweep.  For N > 1 the
+SAME grid is cut into N contiguous state slabs (strong scaling) with one RCCL all-gather of V_t per period, issued
+by libsdpgpu.so itself (sdpgpu_solve_sharded); torch.distributed carries the 128-byte communicator id and the
+contract's barrier, nothing else.
 
-Rank 0 prints ONE JSON line: the driver's contract plus `roofline` and `cpu_baseline`.
+Order of business ("parity gates run before any timing is accepted"):
+  1. one sweep, then the PARITY GATE: sampled states of every checked period (slab and grid edges + random) are
+     evaluated by the CPU oracle fed the GPU's own V_{t+1}; values and policy indices must be bit-identical.
+     A failed gate ends the run with a non-zero exit and no bench line.
+  2. W warm-up sweeps, K timed sweeps between barriers; max over ranks.
+  3. one more sweep with a HIP-event pair around every period launch (un-profiled per-launch times).
+  4. N = 1 on the default workload: the other BASELINE configs as `secondary` entries (each gated and timed the same
+     way, a few sweeps), then the CPU oracle timed on a bounded sample (`cpu_baseline`).
+
+Rank 0 prints ONE JSON line.  `roofline` names the unit that binds the dominant kernel: fp64 VALU issue (the
+reference's arithmetic executed without FMA, 16 lanes/clk/SIMD), with the HBM traffic from the rocprofv3 counters
+(profiles/) as a sub-block -- the 8-bytes-per-cell gather SURVEY 8(d) prices is served by LDS/L2, not HBM.
 """
 from __future__ import annotations
 
 import argparse
+import glob
 import json
 import os
 import sys
@@ -24,65 +37,133 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
-HBM_PEAK_GBPS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md, chip-level parameters)
+HBM_PEAK_GBPS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md, HBM)
+# fp64 add / mul issue (no FMA by contract): 16 lanes per clock per SIMD x 4 SIMDs x 256 CUs x 2.4 GHz
+# (= half the 78.6 TFLOP/s fp64 vector peak, which counts an FMA as two); tools/valu_probe.hip measures 3.8e13 at the
+# clock the chip holds.  Every VALU instruction of a wave64 occupies its SIMD for four cycles, so the same figure is
+# the issue bound for ALL vector instructions.
+VALU_PEAK_LANE_OPS = 16 * 4 * 256 * 2.4e9
+
+FAMILY_NAME = {"target": "F1 backorder (capacitated.CLSP.f lambdas)", "cfg2": "F1 backorder (capacitated.CLSP.f)",
+               "cfg5": "F1 backorder (capacitated.CLSP.f lambdas)", "cfg3": "F3 cash (CashRecursion, quantum 1)",
+               "cfg3t": "F3 cash (CashConstraint.main, quantum 0.1)", "cfg4": "F2 lead time (LeadtimeRecursion)",
+               "cfg4p": "F2 lead time 2 (pipeline state)"}
+REFERENCE_FLOPS_PER_CELL = {"target": 14, "cfg2": 14, "cfg5": 14, "cfg4": 14, "cfg4p": 14, "cfg3": 25, "cfg3t": 25}
 
 
 def parse_args():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--workload", default="cfg2", help="cfg2 (default) | cfg1 | cfg3 | cfg4 | cfg4p | cfg5")
-    ap.add_argument("--states", type=int, default=0, help="override the per-GPU state count (cfg2/cfg5)")
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--workload", default="target",
+                    help="target (default: 1e6 x 500 x 200, T = 6) | cfg2 | cfg3 | cfg3t | cfg4 | cfg4p | cfg5 (1e8 states)")
+    ap.add_argument("--states", type=int, default=0, help="override the state count of the F1 grids (target/cfg2/cfg5)")
     ap.add_argument("--periods", type=int, default=0, help="override the horizon")
+    ap.add_argument("--weak", action="store_true",
+                    help="weak scaling instead of strong: every rank keeps --states states (default 1e4 for cfg2, 1e6 otherwise)")
     ap.add_argument("--kernel", type=int, default=0, help="0 auto, 1 gather, 2 window, 3 separable (opt-in, F1)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--no-target-grid", action="store_true", help="skip the informational 1e6 x 500 x 200 probe")
-    ap.add_argument("--backend", default="nccl", help="nccl (RCCL, default) | gloo (debug: N ranks on one GPU, host-staged)")
+    ap.add_argument("--no-secondary", action="store_true", help="skip the other BASELINE configs (N = 1, default workload)")
+    ap.add_argument("--no-gate", action="store_true", help="skip the parity gate (profiling runs only: the line says so)")
+    ap.add_argument("--gate-cells", type=float, default=3e9, help="oracle work of the parity gate, in cells")
+    ap.add_argument("--exchange", default="native",
+                    help="N > 1: native (RCCL inside libsdpgpu.so, default) | torch (torch.distributed nccl, the schedules "
+                         "of sharded.py) | host (gloo, host-staged: rehearsal of N ranks on one GPU)")
+    ap.add_argument("--backend", default="", help="alias: --backend gloo = --exchange host")
     ap.add_argument("--split", action="store_true", help="rehearsal: force the interior/boundary split of every period")
-    ap.add_argument("--no-overlap", action="store_true", help="blocking all-gather between periods (no compute overlap)")
+    ap.add_argument("--no-overlap", action="store_true", help="blocking all-gather between periods")
     ap.add_argument("--schedule", default="auto",
-                    help="N > 1 exchange schedule: auto (time the candidates before the warm-up, keep the fastest) | overlap | "
-                         "blocking | blockedK (K periods per exchange on widened slabs, e.g. blocked4)")
-    ap.add_argument("--check", action="store_true", help="compare the sharded result with a single-rank sweep (rank 0)")
+                    help="N > 1: auto (time the candidates before the warm-up, keep the fastest) | overlap | blocking | "
+                         "blockedK (torch/host exchange only: K periods per exchange on widened slabs)")
+    ap.add_argument("--check", action="store_true", help="compare the sharded tables with a single-rank sweep (rank 0)")
     ap.add_argument("--cpu-seconds", type=float, default=15.0, help="target CPU time of the oracle sample")
-    return ap.parse_args()
+    a = ap.parse_args()
+    if a.backend == "gloo":
+        a.exchange = "host"
+    return a
 
 
-def make_workload(args, world):
+def make_workload(name: str, world: int, states: int = 0, periods: int = 0, weak: bool = False):
     from stochastic_inventory_amd import workloads
-    kw = {}
-    if args.periods:
-        kw["T"] = args.periods
-    if args.workload == "cfg2":
-        per_gpu = args.states or 10000
-        return workloads.cfg2_clsp(S=per_gpu * world, **kw)
-    if args.workload == "cfg5":
-        per_gpu = args.states or 1000000
-        return workloads.cfg5_scaled(S=per_gpu * world, **kw)
-    if args.workload == "cfg4":  # weak scaling along the inventory axis of every preQ row
-        return workloads.cfg4_leadtime(NX=(args.states or 1000) * world, **kw)
-    if args.workload == "cfg4p":  # the 3-D pipeline state (x, q1, q2): weak scaling along x
-        return workloads.cfg4_pipeline(NX=(args.states or 250) * world, **kw)
-    if args.workload == "cfg3":  # weak scaling along the inventory axis (cash rows stay whole)
-        return workloads.cfg3_cash(NX=(args.states or 200) * world, **kw)
-    if world > 1:
-        raise SystemExit(f"workload {args.workload} has no sharded bench definition")
-    return workloads.by_name(args.workload, **kw)
+    kw = {"T": periods} if periods else {}
+    if name in ("target", "cfg2", "cfg5"):
+        base = {"target": 1000000, "cfg2": 10000, "cfg5": 100000000}[name]
+        S = (states or (10000 if name == "cfg2" else 1000000)) * world if weak else (states or base)
+        if name == "cfg2":
+            return workloads.cfg2_clsp(S=S, **kw)
+        if name == "cfg5":
+            return workloads.cfg5_scaled(S=S, **kw)
+        return workloads.target_grid(S=S, **kw)
+    if weak:
+        raise SystemExit(f"--weak is defined for the F1 grids only (target/cfg2/cfg5), not {name}")
+    return workloads.by_name(name, **kw)
 
 
-def algorithmic_bytes(cells: int, states_periods: int) -> float:
-    """8 B per cell (one fp64 gather of V_{t+1}) + 12 B per state-period
-    (8 B V_t write + 4 B policy write).  The PMF tile (16*D B per period) is below 0.01 %."""
+def algorithmic_bytes(cells: float, states_periods: float) -> float:
+    """SURVEY.md section 8(d)'s byte MODEL: 8 B per cell (one fp64 gather of V_{t+1}) + 12 B per state-period."""
     return 8.0 * cells + 12.0 * states_periods
 
 
+# ---------------------------------------------------------------------------------------------------------------
+# parity gate
+# ---------------------------------------------------------------------------------------------------------------
+def parity_gate(eng, w, budget_cells: float, seed: int = 5):
+    """Sampled states of this rank's slab, every checked period, against the oracle (oracle/sdpref.c eval_state) fed
+    the GPU's own V_{t+1}.  Bit-exact on values and policy indices.  Returns (ok, record)."""
+    import numpy as np
+    from oracle import sdpref
+    T = w.T
+    P = sdpref.Problem(w.desc(), w.pmf, w.overhead())
+    periods = list(range(T, 0, -1)) if T <= 8 else sorted({T, T - 1, T // 2, 2, 1}, reverse=True)
+    st = eng.stats()
+    cells_per_state = max(1.0, float(st.cells_all_ranks) / max(1, int(st.states_total)))
+    n_samples = int(max(64, min(20000, budget_cells / len(periods) / cells_per_state)))
+    threads = min(os.cpu_count() or 1, 16)
+    rng = np.random.default_rng(seed)
+    step = w.desc().step
+    checked, bad = 0, []
+    t0 = time.perf_counter()
+    for period in periods:
+        x_lo, nx, nc, nq1, nq2 = eng.grid2(period)
+        S = nx * nc * nq1 * nq2
+        _, lo, hi = eng.slab(period)
+        if hi <= lo:
+            continue
+        edges = [lo, lo + 1, hi - 1, hi - 2, lo + nc - 1, lo + nc, hi - nc, (lo + hi) // 2,
+                 lo + 63, lo + 64, lo + 127, lo + 128, lo + 255, lo + 256]  # tile seams of the window kernels
+        edges = [e for e in edges if lo <= e < hi]
+        pick = np.unique(np.concatenate([rng.integers(lo, hi, size=n_samples), np.asarray(edges, dtype=np.int64)]))
+        ic = pick % nc
+        ix = (pick // nc) % nx
+        iq = pick // (nc * nx)
+        x = x_lo + ix.astype(np.float64) * step
+        cash = np.array([eng.cash_value(int(c)) for c in ic]) if nc > 1 else None
+        q1 = (iq % nq1).astype(np.float64) * step if nq1 > 1 else None
+        q2 = (iq // nq1).astype(np.float64) * step if nq2 > 1 else None
+        v_next = eng.values(period + 1) if period < T else None
+        ov, oa = P.eval_states(period, v_next, x, cash, q1, q2, nthreads=threads)
+        gv = eng.values(period)[pick]
+        gp = eng.policy(period)[pick - lo]
+        if not (np.array_equal(gv, ov) and np.array_equal(gp, oa)):
+            bad.append(period)
+        checked += len(pick)
+    rec = {"status": "ok" if not bad else "FAILED", "states_checked": checked, "periods_checked": periods,
+           "seconds": round(time.perf_counter() - t0, 2),
+           "against": "oracle/sdpref.c eval_state fed the GPU's own V_{t+1}; values and policy indices bit-identical"}
+    if bad:
+        rec["periods_failed"] = bad
+    return not bad, rec
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# CPU baseline
+# ---------------------------------------------------------------------------------------------------------------
 def cpu_baseline(w, target_seconds: float):
     """The CPU oracle ('port' of the Java recursion, oracle/sdpref.c) timed on a BOUNDED sample of the same workload on
     all host cores, sized from a probe to about `target_seconds`: whole periods from the end of the horizon when a
-    period fits the budget (the bench default), else a run of states of the last-but-one period (the big grids; the
-    successor values it reads are then zeros -- the arithmetic per cell is the same).  Reported baseline, not the
-    target."""
+    period fits the budget, else a run of states of the last-but-one period (the big grids; the successor values it
+    reads are then zeros -- the arithmetic per cell is the same).  Reported baseline, not the target."""
     from oracle import sdpref
     import numpy as np
     cores = min(os.cpu_count() or 1, 16)
@@ -91,7 +172,6 @@ def cpu_baseline(w, target_seconds: float):
     pf = max(T - 1, 1)  # a period with a future term (the only period of a single-period horizon has none)
     S_f = int(P.S[pf - 1])
     v0 = np.zeros(int(P.S[pf])) if pf < T else None
-    # probe: a thin slice of that period's states from the middle of the grid
     n_probe = max(1, min(S_f, max(cores * 4, S_f // 2048)))
     lo_p = (S_f - n_probe) // 2
     t0 = time.perf_counter()
@@ -122,45 +202,133 @@ def cpu_baseline(w, target_seconds: float):
         total_t = time.perf_counter() - t0
         sample = (f"states [{lo}, {lo + n}) of period {pf} of {w.name} (of {S_f}; successor values zero) = "
                   f"{total_cells:.3g} cells in {total_t:.1f} s on {cores} threads")
-    # a slice single-threaded for the like-for-like figure next to the single-threaded Java loop
     n1 = max(1, min(S_f, int(n_probe * 3.0 / max(t_probe * cores, 1e-6))))  # about three seconds of one thread
     lo1 = (S_f - n1) // 2
     t0 = time.perf_counter()
     _, _, c1 = P.period(pf, v0, lo=lo1, hi=lo1 + n1, nthreads=1)
     t1 = max(time.perf_counter() - t0, 1e-9)
-    return {
-        "value": total_cells / total_t,
-        "unit": "cells/s",
-        "cores": cores,
-        "kind": "port",
-        "sample": sample,
-        "single_thread_cells_per_s": c1 / t1,
+    return {"value": total_cells / total_t, "unit": "cells/s", "cores": cores, "kind": "port", "sample": sample,
+            "single_thread_cells_per_s": c1 / t1}
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# roofline
+# ---------------------------------------------------------------------------------------------------------------
+def load_pmc(workload_name: str):
+    """Counter summary of this workload written by tools/pmc_reduce.py (rocprofv3 --pmc passes, corrected as
+    MI355X_MICROARCH.md prescribes).  Newest round first."""
+    for path in sorted(glob.glob(os.path.join(ROOT, "profiles", f"r*_pmc_{workload_name}.json")), reverse=True):
+        try:
+            rec = json.load(open(path))
+            rec["_file"] = os.path.relpath(path, ROOT)
+            return rec
+        except Exception:
+            continue
+    return None
+
+
+def roofline_block(w, st, T, cells_rank, states_rank, dev_ms_per_sweep, per_launch_ms):
+    """`dev_ms_per_sweep`: HIP-event time of one timed sweep on the launch stream (average over the timed steps)."""
+    launches = T
+    avg_launch_ms = dev_ms_per_sweep / launches
+    fp64_ops = float(st.fp64_ops_executed)  # per sweep, this rank: cells x executed fp64 add/mul per cell
+    pmc = load_pmc(w.name)
+    alg_bytes_launch = algorithmic_bytes(cells_rank, states_rank) / launches
+    alg_gbps = alg_bytes_launch / (avg_launch_ms * 1e-3) / 1e9
+    hbm = None
+    if pmc and pmc.get("hbm_bytes_per_launch"):
+        b = float(pmc["hbm_bytes_per_launch"])
+        gb = b / (avg_launch_ms * 1e-3) / 1e9
+        hbm = {"bytes_per_launch": b, "GBps": gb, "peak_GBps": HBM_PEAK_GBPS, "frac": gb / HBM_PEAK_GBPS,
+               "source": pmc["_file"], "kernel": pmc.get("dominant_kernel"),
+               "note": "2 x FETCH_SIZE + WRITE_SIZE (KiB; gfx950 correction), separate --pmc passes"}
+    out = {
+        "avg_launch_ms": avg_launch_ms,
+        "launches_per_sweep": launches,
+        "per_launch_ms_events": [round(m, 5) for m in per_launch_ms],
+        "traffic": hbm["bytes_per_launch"] if hbm else None,
+        "hbm": hbm,
+        "algorithmic": {"bytes_per_launch": alg_bytes_launch, "GBps": alg_gbps, "frac_of_hbm_peak": alg_gbps / HBM_PEAK_GBPS,
+                        "note": "SURVEY 8(d) byte MODEL (8 B per cell + 12 B per state-period), not traffic: the per-cell "
+                                "read of V_{t+1} is served by LDS / L2, so this figure may exceed the HBM peak and is not "
+                                "a roofline fraction"},
     }
+    if fp64_ops > 0:
+        lane_ops = fp64_ops / (dev_ms_per_sweep * 1e-3)
+        ops_future = None
+        if int(st.window_r) > 0:
+            R_, S_ = int(st.window_r), int(st.window_s)
+            ops_future = [round(3.0 + 1.0 / S_ + (R_ + S_ - 1.0) / (R_ * S_), 4), round(2.0 + 1.0 / S_, 4)]
+        out.update({
+            "bound": "fp64-valu",
+            "achieved": lane_ops / 1e12, "peak": VALU_PEAK_LANE_OPS / 1e12, "unit": "T lane-op/s",
+            "frac": lane_ops / VALU_PEAK_LANE_OPS,
+            "ops_per_cell": fp64_ops / max(cells_rank, 1),
+            "ops_per_cell_future_last": ops_future,
+            "register_block": {"actions": int(st.window_r), "states_per_lane": int(st.window_s)} if int(st.window_r) else None,
+            "note": "executed fp64 add/mul per cell (no FMA by contract; operations that are identical in neighbouring "
+                    "cells are formed once) x cells / HIP-event time, against 16 lanes/clk/SIMD x 1024 SIMDs x 2.4 GHz",
+        })
+    elif pmc and pmc.get("valu_insts_per_launch"):
+        lane_ops = float(pmc["valu_insts_per_launch"]) * 64.0 / (avg_launch_ms * 1e-3)
+        out.update({
+            "bound": "valu-issue",
+            "achieved": lane_ops / 1e12, "peak": VALU_PEAK_LANE_OPS / 1e12, "unit": "T lane-op/s",
+            "frac": lane_ops / VALU_PEAK_LANE_OPS,
+            "valu_insts_per_cell": float(pmc["valu_insts_per_launch"]) * 64.0 / max(cells_rank / launches, 1),
+            "ta_busy_frac": pmc.get("ta_busy_frac"),
+            "note": f"SQ_INSTS_VALU x 64 lanes per launch ({pmc['_file']}) / HIP-event launch time; every wave64 VALU "
+                    "instruction holds its SIMD four cycles",
+        })
+    else:
+        out.update({"bound": "valu-issue", "achieved": None, "peak": VALU_PEAK_LANE_OPS / 1e12, "unit": "T lane-op/s",
+                    "frac": None, "note": "no instruction model and no counter summary in profiles/ for this workload"})
+    if out.get("frac") is not None and not (0.0 < out["frac"] <= 1.0):
+        raise SystemExit(f"roofline fraction {out['frac']} outside (0, 1]: the op model does not describe this kernel")
+    return out
 
 
-def target_grid_probe(sia, dev):
-    """Secondary, informational: the grid BASELINE.json's target sentence names (1e6 states x 500 actions x
-    200 demands) for 3 periods on this one GPU, same kernels, same accounting.  Not the bench metric."""
-    import torch
-    from stochastic_inventory_amd import workloads
-    w = workloads.cfg5_scaled(S=1000000, T=3)
+# ---------------------------------------------------------------------------------------------------------------
+# one workload on one GPU (the headline at N = 1 and every secondary entry)
+# ---------------------------------------------------------------------------------------------------------------
+def run_single(sia, torch, dev, name, w, steps, warmup, kernel, gate_cells, no_gate):
     d = w.desc()
     d.device = dev.index
-    with sia.SdpEngine(d, w.pmf) as eng:
+    d.kernel = kernel
+    T = w.T
+    with sia.SdpEngine(d, w.pmf, w.overhead()) as eng:
         eng.set_stream(torch.cuda.current_stream(dev).cuda_stream)
-        eng.solve(sync=True)  # warm-up
-        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        steps = 3
-        e0.record()
-        for _ in range(steps):
+        eng.solve(sync=True)
+        gate = {"status": "skipped (--no-gate)"}
+        if not no_gate:
+            ok, gate = parity_gate(eng, w, gate_cells)
+            if not ok:
+                raise SystemExit(f"PARITY GATE FAILED on {w.name}: {json.dumps(gate)} -- no timing accepted")
+        for _ in range(warmup):
             eng.solve(sync=False)
-        e1.record()
         torch.cuda.synchronize(dev)
-        ms = e0.elapsed_time(e1) / steps
-        cells = int(eng.stats().cells_evaluated)
-    gbps = algorithmic_bytes(cells, 3 * 1000000) / (ms * 1e-3) / 1e9
-    return {"workload": w.name, "value": cells / (ms * 1e-3), "unit": "cells/s", "ms_per_step": ms,
-            "algorithmic_GBps": gbps, "frac_of_hbm_peak": gbps / HBM_PEAK_GBPS}
+        ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(steps)]
+        t0 = time.perf_counter()
+        for k in range(steps):
+            ev[k][0].record()
+            eng.solve(sync=False)
+            ev[k][1].record()
+        torch.cuda.synchronize(dev)
+        elapsed = time.perf_counter() - t0
+        dev_ms = sum(a.elapsed_time(b) for a, b in ev) / steps
+        st = eng.stats()
+        eng.set_profiling(True)
+        eng.solve(sync=True)
+        per_launch = [eng.period_ms(p) for p in range(T, 0, -1)]
+        eng.set_profiling(False)
+        cells = int(st.cells_evaluated)
+        states = int(st.states_total)
+        rf = roofline_block(w, st, T, cells, states, dev_ms, per_launch)
+        x_lo, nx, nc, nq1, nq2 = eng.grid2(1)
+    return {"workload": w.name, "family": FAMILY_NAME.get(name, name), "value": cells * steps / elapsed, "unit": "cells/s",
+            "ms_per_step": elapsed / steps * 1e3, "steps": steps, "periods": T, "states": nx * nc * nq1 * nq2,
+            "cells_per_step": cells, "parity_gate": gate, "roofline": rf,
+            "kernel": {0: "auto", 1: "gather", 2: "specialised (window / shift / row)", 3: "separable"}[int(st.kernel_used)]}
 
 
 def main():
@@ -177,43 +345,105 @@ def main():
         raise SystemExit(f"WORLD_SIZE={world} but --gpus {args.gpus}")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the engine has no CPU path")
-    if args.backend == "gloo":
+    if args.exchange == "host":
         local_rank = local_rank % torch.cuda.device_count()  # rehearsal: several ranks share a GPU
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        if args.backend == "gloo":
-            dist.init_process_group("gloo")
-        else:
-            dist.init_process_group("nccl", device_id=dev)
+        # native exchange: the data path is RCCL inside libsdpgpu.so; the process group carries the communicator id,
+        # the barriers and the timing reductions, for which gloo is enough
+        dist.init_process_group("nccl", device_id=dev) if args.exchange == "torch" else dist.init_process_group("gloo")
 
     import stochastic_inventory_amd as sia
-    from stochastic_inventory_amd.sharded import GpuSlabBackend, ShardedSolver
 
-    w = make_workload(args, world)
+    w = make_workload(args.workload, world, args.states, args.periods, args.weak)
+    T = w.T
+
+    if world == 1:
+        head = run_single(sia, torch, dev, args.workload, w, args.steps, args.warmup, args.kernel, args.gate_cells,
+                          args.no_gate)
+        out = {
+            "metric": "(state,action,demand) cell evals/sec",
+            "value": head["value"], "unit": "cells/s", "n_gpus": 1, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": head["ms_per_step"], "higher_is_better": True,
+            "scaling": "weak" if args.weak else "strong", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+            "config": {"workload": w.name, "family": head["family"], "states": head["states"],
+                       "actions": int(w.functor.maxOrderQuantity) + 1, "demands": len(w.pmf[0]), "periods": T,
+                       "cells_per_step": head["cells_per_step"], "parallelism": "single GPU", "exchange": "single rank",
+                       "kernel": head["kernel"]},
+            "parity_gate": head["parity_gate"],
+            "roofline": head["roofline"],
+        }
+        flops = REFERENCE_FLOPS_PER_CELL.get(args.workload, 14)
+        out["side_by_side"] = {
+            "cells_per_s": out["value"],
+            "algorithmic_GBps": head["roofline"]["algorithmic"]["GBps"],
+            "hbm_measured_GBps": head["roofline"]["hbm"]["GBps"] if head["roofline"]["hbm"] else None,
+            "fp64_TFLOPs_at_reference_op_count": out["value"] * flops / 1e12,
+            "reference_fp64_ops_per_cell": flops,
+            "compulsory_bytes_per_launch": 20.0 * head["states"],
+            "note": "the reference's formulas spend 14 (F1/F2) / 25 (F3) fp64 operations per cell; the kernels execute fewer "
+                    "(identical operations are formed once): roofline.ops_per_cell",
+        }
+        if args.workload == "target" and not args.no_secondary and not args.weak and not args.states and not args.periods:
+            sec = []
+            for name, kw, st_ in (("cfg2", {}, 5), ("cfg3", {}, 2), ("cfg3t", {}, 2), ("cfg4", {}, 2), ("cfg4p", {}, 2)):
+                ws = make_workload(name, 1, 0, kw.get("T", 0))
+                sec.append(run_single(sia, torch, dev, name, ws, st_, 1, 0, args.gate_cells / 3, args.no_gate))
+            out["secondary"] = sec
+        if not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(w, args.cpu_seconds)
+        print(json.dumps(out), flush=True)
+        return
+
+    # ------------------------------------------------------------------------------------------------------
+    # N > 1
+    # ------------------------------------------------------------------------------------------------------
+    from stochastic_inventory_amd.sharded import GpuSlabBackend, ShardedSolver, init_native_comm
+
+    ctrl = dev if args.exchange == "torch" else torch.device("cpu")  # where the default group's tensors live
+
+    def barrier():
+        dist.barrier()
+        torch.cuda.synchronize(dev)
+
+    def all_agree(ok: bool) -> bool:
+        t = torch.tensor([1 if ok else 0], dtype=torch.int32, device=ctrl)
+        dist.all_reduce(t, op=dist.ReduceOp.MIN)
+        return bool(t.item())
+
+    def max_over_ranks(x: float) -> float:
+        t = torch.tensor([x], dtype=torch.float64, device=ctrl)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        return float(t.item())
+
     desc = w.desc()
     desc.rank, desc.world_size = rank, world
     desc.kernel = args.kernel
     backend = GpuSlabBackend(desc, w.pmf, w.overhead(), device=dev)
-    solver = ShardedSolver(backend, stage_through_host=(args.backend == "gloo"))
-    solver.force_split = args.split
     eng = backend.engine
-    T = w.T
+    exchange = args.exchange
+    note = ""
+    if exchange == "native":
+        try:
+            init_native_comm(eng)
+            ok, err = True, ""
+        except Exception as exc:  # e.g. librccl missing: every rank must take the same decision
+            ok, err = False, str(exc)
+        if not all_agree(ok):
+            exchange = "torch"
+            note = f" (native communicator failed{': ' + err if err else ' on another rank'}; fell back to torch.distributed nccl)"
+            if rank == 0:
+                print(f"[bench] native RCCL communicator unavailable{': ' + err if err else ''}; using torch.distributed",
+                      file=sys.stderr, flush=True)
+    group = dist.new_group(backend="nccl") if (exchange == "torch" and args.exchange != "torch") else None
+    solver = ShardedSolver(backend, group=group, stage_through_host=(exchange == "host"))
+    solver.force_split = args.split
 
-    def barrier():
-        if world > 1:
-            dist.barrier()
-        torch.cuda.synchronize(dev)
-
-    # ---- exchange schedule (N > 1) ------------------------------------------------------------------------
-    # overlap:  all-gather of V_{t+1} beside the interior tiles of period t, boundary tiles after it
-    # blocking: kernel, all-gather, kernel, ...
-    # blockedK: K periods per exchange on slabs widened by the dependency footprint (redundant work, a K-th of the waits)
-    # Which one wins depends on how this node's all-gather latency compares with a period's compute (30 us at the
-    # configs[1] slab), so `auto` times every candidate (untimed, before the warm-up) and keeps the fastest; every
-    # rank takes the same decision (max over ranks of each timing).
     def make_runner(name):
+        if exchange == "native":
+            return lambda: solver.solve_native(overlap=(name == "overlap"), sync=False)
         if name == "overlap":
             return lambda: solver.solve(overlap=True)
         if name == "blocking":
@@ -221,43 +451,55 @@ def main():
         k = int(name[len("blocked"):])
         return lambda: solver.solve_blocked(k)
 
-    sched_name = args.schedule
-    if args.no_overlap:
-        sched_name = "blocking"
-    if world == 1 or args.split:
-        sched_name = "overlap" if not args.no_overlap else "blocking"
-    blocked_ok = world > 1 and not args.split and solver.prepare_blocked(8)  # sizes the scratch rows for K <= 8
-    if sched_name.startswith("blocked") and not blocked_ok:
-        raise SystemExit("this workload has no bounded dependency footprint: no blocked schedule")
-    schedule = "single rank"
-    if world > 1 and sched_name == "auto":
-        candidates = ["overlap", "blocking"] + (["blocked2", "blocked4", "blocked8"] if blocked_ok else [])
-        if not (args.backend == "nccl" or os.environ.get("SDP_BENCH_CALIBRATE")):
+    sched = "blocking" if args.no_overlap else args.schedule
+    if args.split:
+        sched = "overlap"
+    blocked_ok = exchange != "native" and not args.split and solver.prepare_blocked(8)
+    if sched.startswith("blocked") and not blocked_ok:
+        raise SystemExit("blockedK needs --exchange torch|host and a workload with a bounded dependency footprint")
+    schedule_note = sched
+    if sched == "auto":
+        candidates = ["blocking", "overlap"]
+        if blocked_ok and (exchange == "torch" or os.environ.get("SDP_BENCH_CALIBRATE")):
+            candidates += ["blocked2", "blocked4", "blocked8"]
+        if exchange == "host" and not os.environ.get("SDP_BENCH_CALIBRATE"):
             candidates = ["overlap"]
         timing = {}
         for name in candidates:
             run_c = make_runner(name)
+            took, ok = float("inf"), True
             try:
                 run_c()
-                barrier()
-                t0c = time.perf_counter()
-                run_c()
-                run_c()
-                barrier()
-                took = time.perf_counter() - t0c
-            except Exception as exc:  # a schedule this node's stack cannot run is not a reason to lose the bench
-                if name in ("overlap", "blocking"):
-                    raise
+                torch.cuda.synchronize(dev)
+            except Exception as exc:
+                ok = False
                 print(f"[bench] schedule {name} failed on rank {rank}: {exc}", file=sys.stderr, flush=True)
-                took = float("inf")
-            tc = torch.tensor([took], dtype=torch.float64, device=dev)
-            dist.all_reduce(tc, op=dist.ReduceOp.MAX)
-            timing[name] = float(tc.item()) / 2
-        sched_name = min(timing, key=timing.get)
-        schedule = sched_name + " (calibrated, ms per sweep: " + ", ".join(f"{k} {v * 1e3:.3f}" for k, v in timing.items()) + ")"
-    elif world > 1:
-        schedule = sched_name
-    run_sweep = make_runner(sched_name)
+            # agree BEFORE any further collective: a rank that failed must not leave the others inside one
+            if not all_agree(ok):
+                if name in ("blocking",):
+                    raise SystemExit("the blocking schedule failed: nothing to fall back to")
+                continue
+            barrier()
+            t0c = time.perf_counter()
+            run_c()
+            run_c()
+            barrier()
+            took = (time.perf_counter() - t0c) / 2
+            timing[name] = max_over_ranks(took)
+        sched = min(timing, key=timing.get)
+        schedule_note = sched + " (calibrated, ms per sweep: " + ", ".join(f"{k} {v * 1e3:.3f}" for k, v in timing.items()) + ")"
+    run_sweep = make_runner(sched)
+
+    # parity gate on this rank's slab (every rank; all must pass)
+    run_sweep()
+    torch.cuda.synchronize(dev)
+    gate = {"status": "skipped (--no-gate)"}
+    if not args.no_gate:
+        ok, gate = parity_gate(eng, w, args.gate_cells / world, seed=5 + rank)
+        if not all_agree(ok):
+            raise SystemExit(f"PARITY GATE FAILED (rank {rank}: {json.dumps(gate)}) -- no timing accepted")
+        gate["ranks"] = world
+
     for _ in range(args.warmup):
         run_sweep()
     barrier()
@@ -268,143 +510,81 @@ def main():
         run_sweep()
         ev[k][1].record()
     barrier()
-    elapsed = time.perf_counter() - t0
-    t_max = torch.tensor([elapsed], dtype=torch.float64, device=dev)
-    if world > 1:
-        dist.all_reduce(t_max, op=dist.ReduceOp.MAX)
-    elapsed = float(t_max.item())
+    elapsed = max_over_ranks(time.perf_counter() - t0)
 
     st = eng.stats()
-    cells_step_all = int(st.cells_all_ranks)    # whole grid, all ranks, one sweep
-    cells_step_rank = int(st.cells_evaluated)   # this rank's slab
+    cells_step_all = int(st.cells_all_ranks)
+    cells_step_rank = int(st.cells_evaluated)
     states_step_rank = sum(backend.slab(p)[2] - backend.slab(p)[1] for p in range(1, T + 1))
-    dev_ms = sum(a.elapsed_time(b) for a, b in ev)  # HIP events on the launch stream, this rank
-    launches = args.steps * T
-    avg_launch_ms = dev_ms / launches
-    bytes_per_launch = algorithmic_bytes(cells_step_rank, states_step_rank) / T
-    achieved = bytes_per_launch / (avg_launch_ms * 1e-3) / 1e9
-
-    # per-kernel event times in a separate, un-timed pass (cross-check for the rocprofv3 summary)
+    dev_ms = sum(a.elapsed_time(b) for a, b in ev) / args.steps
     eng.set_profiling(True)
     run_sweep()
     torch.cuda.synchronize(dev)
-    per_kernel = [eng.period_ms(p) for p in range(1, T + 1)]
+    per_launch = [eng.period_ms(p) for p in range(T, 0, -1)]
     eng.set_profiling(False)
-    inner = [m for m in per_kernel[:-1]] or per_kernel
-    kernel_ms_avg = sum(per_kernel) / len(per_kernel)
+    compute_ms = sum(m for m in per_launch if m > 0)
+    # load balance: cells per rank (F3's action count depends on the cash balance, CashConstraint.java:96-99)
+    cells_t = torch.zeros(world, dtype=torch.float64, device=ctrl)
+    cells_t[rank] = float(cells_step_rank)
+    dist.all_reduce(cells_t)
+    comp_t = torch.zeros(world, dtype=torch.float64, device=ctrl)
+    comp_t[rank] = compute_ms
+    dist.all_reduce(comp_t)
 
     check = None
     if args.check:
         import numpy as np
-        v1 = eng.values(1)  # every rank holds the whole V_1 after finalize? V_1 is not exchanged: gather it
         pol_local = eng.policy(1)
-        if world > 1:
+        if exchange == "native":
+            eng.solve_sharded(sync=True, gather_first=True)
+        else:
             solver.exchange(1)
             torch.cuda.synchronize(dev)
             eng.finalize()
-            v1 = eng.values(1)
-            gathered = [None] * world
-            dist.all_gather_object(gathered, pol_local)
-            pol_all = np.concatenate(gathered)
-        else:
-            pol_all = pol_local
+        v1 = eng.values(1)
+        v2 = eng.values(2 if T > 1 else 1)
+        gathered = [None] * world
+        dist.all_gather_object(gathered, pol_local)
+        pol_all = np.concatenate(gathered)
         if rank == 0:
             d1 = w.desc()
             d1.device = dev.index
             with sia.SdpEngine(d1, w.pmf, w.overhead()) as ref:
                 ref.solve()
                 check = bool(np.array_equal(ref.values(1), v1) and np.array_equal(ref.policy(1), pol_all)
-                             and np.array_equal(ref.values(2 if T > 1 else 1), eng.values(2 if T > 1 else 1)))
+                             and np.array_equal(ref.values(2 if T > 1 else 1), v2))
     if rank == 0:
-        traffic = None
-        prof = os.path.join(ROOT, "profiles", "pmc_traffic.json")
-        if os.path.exists(prof):
-            try:
-                rec = json.load(open(prof))
-                if rec.get("workload") == w.name and rec.get("kernel_used") == st.kernel_used:
-                    traffic = rec.get("hbm_bytes_per_launch")
-            except Exception:
-                traffic = None
+        rf = roofline_block(w, st, T, cells_step_rank, states_step_rank, dev_ms, per_launch)
+        rf["note_multi"] = "rank 0's slab; the sweep time includes the per-period all-gathers"
         out = {
             "metric": "(state,action,demand) cell evals/sec",
-            "value": cells_step_all * args.steps / elapsed,
-            "unit": "cells/s",
-            "n_gpus": world,
-            "steps": args.steps,
-            "warmup": args.warmup,
-            "ms_per_step": elapsed / args.steps * 1e3,
-            "higher_is_better": True,
-            "scaling": "weak",
-            "vs_baseline": None,
-            "dtype": "f64",
-            "data": "synthetic",
+            "value": cells_step_all * args.steps / elapsed, "unit": "cells/s", "n_gpus": world, "steps": args.steps,
+            "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True,
+            "scaling": "weak" if args.weak else "strong", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
             "config": {
-                "workload": w.name,
-                "family": "F1 backorder (capacitated.CLSP.f)" if args.workload in ("cfg2", "cfg5") else args.workload,
-                "states": eng.num_states(1), "actions": int(w.functor.maxOrderQuantity) + 1,
-                "demands": len(w.pmf[0]), "periods": T,
-                "cells_per_step": cells_step_all,
-                "parallelism": f"state-sharded x{world}, all-gather V_t per period" if world > 1 else "single GPU",
-                "exchange": schedule,
-                "kernel": {0: "auto", 1: "gather", 2: "window", 3: "separable (opt-in, not the graded path)"}[int(st.kernel_used)],
+                "workload": w.name, "family": FAMILY_NAME.get(args.workload, args.workload),
+                "states": eng.num_states(1), "actions": int(w.functor.maxOrderQuantity) + 1, "demands": len(w.pmf[0]),
+                "periods": T, "cells_per_step": cells_step_all,
+                "parallelism": f"state axis cut into {world} slabs, one all-gather of V_t per period",
+                "exchange": {"native": "RCCL all-gather issued by libsdpgpu.so (sdpgpu_solve_sharded)",
+                             "torch": "torch.distributed nccl all_gather_into_tensor (sharded.py)",
+                             "host": "gloo, host-staged (rehearsal)"}[exchange] + note,
+                "schedule": schedule_note,
+                "cells_per_rank": [int(c) for c in cells_t.tolist()],
+                "kernel_ms_per_rank": [round(c, 4) for c in comp_t.tolist()],
+                "exchange_bytes_per_rank_per_period": 8 * (backend.slab(1)[0] // world),
+                "kernel": {0: "auto", 1: "gather", 2: "specialised (window / shift / row)", 3: "separable"}[int(st.kernel_used)],
             },
-            "roofline": {
-                "bound": "hbm",
-                "achieved": achieved,
-                "peak": HBM_PEAK_GBPS,
-                "unit": "GB/s",
-                "frac": achieved / HBM_PEAK_GBPS,
-                "traffic": traffic,
-                "algorithmic_bytes_per_launch": bytes_per_launch,
-                "avg_launch_ms": avg_launch_ms,
-                "kernel_ms_avg_events": kernel_ms_avg,
-                "launches_timed": launches,
-                "note": "algorithmic bytes = 8 B/cell + 12 B/state-period (SURVEY 8d); V_{t+1} is cache-resident, "
-                        "so HBM traffic is far below this figure and the true limiter is fp64 VALU issue",
-            },
-        }
-        if int(st.kernel_used) == 2 and args.workload in ("cfg2", "cfg5"):
-            # the bound that actually limits the window kernel: fp64 add/mul issue (no FMA by contract);
-            # peak = 16 lanes/clk/SIMD x 1024 SIMDs x 2.4 GHz (tools/valu_probe.hip measures 3.8e13 of it at the
-            # clock the chip holds).
-            # Operations the kernel executes per cell with R actions x S adjacent states per lane (sdp_window.hpp):
-            # c0 + M once per (action, m): 1/S; p * imm: 1; p * V once per window entry: (R + S - 1)/(R S); two
-            # accumulations: 2.  The last period has no future term.  Every one is an operation of the reference.
-            R_, S_ = max(int(st.window_r), 1), max(int(st.window_s), 1)
-            ops_future = 3.0 + 1.0 / S_ + (R_ + S_ - 1.0) / (R_ * S_)
-            ops_last = 2.0 + 1.0 / S_
-            ops_per_sweep = cells_step_rank * (ops_future * (T - 1) + ops_last) / T
-            lane_ops = ops_per_sweep * args.steps / (dev_ms * 1e-3)
-            out["valu_roofline"] = {"bound": "fp64 add/mul issue", "achieved": lane_ops / 1e12, "peak": 39.3,
-                                    "unit": "T lane-op/s", "frac": lane_ops / 39.3e12,
-                                    "ops_per_cell": [round(ops_future, 4), round(ops_last, 4)],
-                                    "register_block": {"actions": R_, "states_per_lane": S_},
-                                    "note": "secondary: the north star prices this path against HBM"}
-        # SURVEY.md section 8(d) asks for four numbers side by side
-        flops_per_cell = {"cfg2": 14, "cfg5": 14, "cfg4": 14, "cfg4p": 14, "cfg3": 25}.get(args.workload, 14)
-        out["side_by_side"] = {
-            "cells_per_s": out["value"],
-            "algorithmic_GBps": achieved * (world if world > 1 else 1),
-            "hbm_measured_GBps": (traffic / (avg_launch_ms * 1e-3) / 1e9) if (traffic and avg_launch_ms > 0) else None,
-            "fp64_TFLOPs_at_reference_op_count": out["value"] * flops_per_cell / 1e12,
-            "reference_fp64_ops_per_cell": flops_per_cell,
-            # what a period must move at the very least: read V_{t+1} once, write V_t and the policy (20 B per state)
-            "compulsory_bytes_per_launch": 20.0 * states_step_rank / T,
-            "compulsory_GBps": (20.0 * states_step_rank / T / (avg_launch_ms * 1e-3) / 1e9) if avg_launch_ms > 0 else None,
-            "note": "the reference's formulas spend 14 (F1/F2) / 25 (F3) fp64 operations per cell; the kernels execute fewer "
-                    "(identical operations are formed once), see valu_roofline",
+            "parity_gate": gate,
+            "roofline": rf,
         }
         if check is not None:
             out["check_vs_single_rank"] = check
         if not args.no_cpu_baseline:
-            wb = make_workload(args, 1)
-            out["cpu_baseline"] = cpu_baseline(wb, args.cpu_seconds)
-        if world == 1 and args.workload == "cfg2" and not args.no_target_grid:
-            out["north_star_grid"] = target_grid_probe(sia, dev)
+            out["cpu_baseline"] = cpu_baseline(make_workload(args.workload, 1, args.states, args.periods, args.weak), args.cpu_seconds)
         print(json.dumps(out), flush=True)
-    if world > 1:
-        dist.barrier()
-        dist.destroy_process_group()
+    dist.barrier()
+    dist.destroy_process_group()
     backend.close()
 
 

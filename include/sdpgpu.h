@@ -195,6 +195,10 @@ typedef struct sdpgpu_stats {
   int32_t kernel_used;      /* SDPGPU_KERNEL_* actually launched for the last period run */
   int32_t window_r;         /* F1 window kernel: actions per register block ... */
   int32_t window_s;         /* ... and adjacent states per lane of the plan used for period 1 (0: other kernel) */
+  double  fp64_ops_executed; /* sum over periods of THIS rank's cells x the fp64 add/mul operations the kernel that ran
+                                the period executes per cell (the reference's five per cell minus the ones that are the
+                                same operation on the same operands in neighbouring cells and are formed once; window
+                                and uniform-shift kernels).  0 when a period ran a kernel without such a model. */
 } sdpgpu_stats;
 
 typedef struct sdpgpu_handle sdpgpu_handle;

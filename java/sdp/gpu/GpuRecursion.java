@@ -66,6 +66,7 @@ public class GpuRecursion {
 	private final ImmediateValueFunction<State, Double, Double, Double> immediateValue;
 	private final Functor functor;
 	private long handle;
+	private long[] rankHandles; // nGpus > 1: one handle per device, rank r on device r (handle == rankHandles[0])
 	private boolean solved;
 	private final double[][] values;
 	private final int[][] policy;
@@ -73,6 +74,17 @@ public class GpuRecursion {
 	public GpuRecursion(OptDirection optDirection, double[][][] pmf, Function<State, double[]> getFeasibleAction,
 			StateTransitionFunction<State, Double, Double, State> stateTransition,
 			ImmediateValueFunction<State, Double, Double, Double> immediateValue, Functor functor) {
+		this(optDirection, pmf, getFeasibleAction, stateTransition, immediateValue, functor, 1);
+	}
+
+	/**
+	 * The same on nGpus devices of this node: the state axis is cut into nGpus slabs, getExpectedValue's first call
+	 * is still ONE native call (SdpGpu.solveMulti -> sdpgpu_solve_multi: per-slab kernels + RCCL all-gather of V_t
+	 * between periods).
+	 */
+	public GpuRecursion(OptDirection optDirection, double[][][] pmf, Function<State, double[]> getFeasibleAction,
+			StateTransitionFunction<State, Double, Double, State> stateTransition,
+			ImmediateValueFunction<State, Double, Double, Double> immediateValue, Functor functor, int nGpus) {
 		this.pmf = pmf;
 		this.getFeasibleActions = getFeasibleAction;
 		this.stateTransition = stateTransition;
@@ -80,15 +92,25 @@ public class GpuRecursion {
 		this.functor = functor;
 		functor.ints[1] = optDirection == OptDirection.MIN ? SdpGpu.MIN : SdpGpu.MAX;
 		functor.ints[2] = pmf.length;
-		this.handle = SdpGpu.create(functor.ints, functor.doubles);
-		for (int t = 0; t < pmf.length; t++) {
-			double[] d = new double[pmf[t].length], p = new double[pmf[t].length];
-			for (int j = 0; j < d.length; j++) {
-				d[j] = pmf[t][j][0];
-				p[j] = pmf[t][j][1];
+		this.rankHandles = new long[Math.max(1, nGpus)];
+		for (int r = 0; r < rankHandles.length; r++) {
+			int[] ints = functor.ints.clone();
+			if (rankHandles.length > 1) {
+				ints[8] = r; // device
+				ints[9] = r; // rank
+				ints[10] = rankHandles.length; // world size
 			}
-			SdpGpu.setPmf(handle, t, d, p);
+			rankHandles[r] = SdpGpu.create(ints, functor.doubles);
+			for (int t = 0; t < pmf.length; t++) {
+				double[] d = new double[pmf[t].length], p = new double[pmf[t].length];
+				for (int j = 0; j < d.length; j++) {
+					d[j] = pmf[t][j][0];
+					p[j] = pmf[t][j][1];
+				}
+				SdpGpu.setPmf(rankHandles[r], t, d, p);
+			}
 		}
+		this.handle = rankHandles[0];
 		this.values = new double[pmf.length][];
 		this.policy = new int[pmf.length][];
 	}
@@ -107,7 +129,10 @@ public class GpuRecursion {
 
 	private void table(int period) {
 		if (!solved) {
-			SdpGpu.solve(handle);
+			if (rankHandles.length > 1)
+				SdpGpu.solveMulti(rankHandles, true); // every V_t complete on rank 0, the policy stays sharded
+			else
+				SdpGpu.solve(handle);
 			solved = true;
 		}
 		if (values[period - 1] == null) {
@@ -115,7 +140,16 @@ public class GpuRecursion {
 			values[period - 1] = new double[n];
 			policy[period - 1] = new int[n];
 			SdpGpu.values(handle, period, values[period - 1]);
-			SdpGpu.policy(handle, period, policy[period - 1]);
+			if (rankHandles.length == 1) {
+				SdpGpu.policy(handle, period, policy[period - 1]);
+			} else {
+				for (long h : rankHandles) { // stitch the policy slabs together
+					long[] s = SdpGpu.slab(h, period);
+					int[] part = new int[(int) (s[2] - s[1])];
+					SdpGpu.policySlab(h, period, s[1], part);
+					System.arraycopy(part, 0, policy[period - 1], (int) s[1], part.length);
+				}
+			}
 		}
 	}
 
@@ -168,7 +202,8 @@ public class GpuRecursion {
 
 	public void close() {
 		if (handle != 0) {
-			SdpGpu.destroy(handle);
+			for (long h : rankHandles)
+				SdpGpu.destroy(h);
 			handle = 0;
 		}
 	}

@@ -53,6 +53,29 @@ public final class SdpGpu {
 
 	public static native void solve(long handle);
 
+	/**
+	 * sdpgpu_solve_multi: a JVM that owns every GPU of the node solves ONE problem on all of them with one call --
+	 * handles[r] was created with ints[8] = device r, ints[9] = rank r, ints[10] = worldSize = handles.length.  The state
+	 * axis is cut into handles.length slabs, the library creates the RCCL communicators itself (ncclCommInitAll) and
+	 * all-gathers V_t between periods.  With gatherFirst every handle ends up holding the whole V_1 as well.
+	 */
+	public static native void solveMulti(long[] handles, boolean gatherFirst);
+
+	/** One JVM per GPU instead: rank 0 draws the id (ncclGetUniqueId), the host ships the 128 bytes to the others. */
+	public static native byte[] commUniqueId();
+
+	/** sdpgpu_comm_init: collective over the ranks (ncclCommInitRank). */
+	public static native void commInit(long handle, byte[] uniqueId, int rank, int worldSize);
+
+	/** sdpgpu_solve_sharded: this rank's sweep with the per-period all-gathers; every rank calls it. */
+	public static native void solveSharded(long handle, boolean overlap, boolean gatherFirst);
+
+	/** {paddedRowLength, lo, hi}: this rank's slab of period t. */
+	public static native long[] slab(long handle, int period);
+
+	/** Policy indices of the slab [lo, lo + out.length) of this rank. */
+	public static native void policySlab(long handle, int period, long lo, int[] out);
+
 	public static native long numStates(long handle, int period);
 
 	/** {x_lo, nx, nc, nq} of the period's grid. */

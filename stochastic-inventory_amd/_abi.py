@@ -100,6 +100,7 @@ class SdpgpuStats(C.Structure):
         ("kernel_used", C.c_int32),
         ("window_r", C.c_int32),
         ("window_s", C.c_int32),
+        ("fp64_ops_executed", C.c_double),
     ]
 
 

@@ -400,6 +400,7 @@ int run_period_impl(sdpgpu_handle* h, int period, int part, int64_t range_lo, in
     }
   }
   hipError_t e;
+  p.ops_cell = 0;
   if (use_window) {
     e = launch_window(h, P, period, v_next, v_cur, pol, pd, h->d_pmf + p.pmf_win_off, ranged ? range_lo : p.lo,
                       ranged ? range_hi : p.hi, h->stream, part);
@@ -749,11 +750,14 @@ int64_t sdpgpu_state_index2(const sdpgpu_handle* hc, int32_t period, double x, d
   if (!h || period < 1 || period > h->T || layout(h)) return -1;
   const sdpgpu_desc& d = h->d;
   const Grid& g = h->per[period - 1].g;
+  // range (and NaN) checks come BEFORE the casts: converting a NaN or an out-of-range double to int64 is undefined
   double qx = (x - g.x_lo) / d.step;
+  if (!(qx >= 0.0 && qx < (double)g.nx)) return -1;
   int64_t ix = (int64_t)qx;
-  if ((double)ix != qx || ix < 0 || ix >= g.nx) return -1;
+  if ((double)ix != qx) return -1;
   int64_t ic = 0, iq = 0;
   if (has_cash(d.family)) {
+    if (!(std::fabs(cash) < 4.0e15)) return -1;  // NaN, infinities, beyond exact integers: not a grid point
     int64_t k = d.cash_round_int_div ? (int64_t)cash : java_round(cash * d.cash_round_mult);
     double back = d.cash_round_int_div ? (double)k : (double)k / d.cash_round_div;
     if (back != cash) return -1;
@@ -762,13 +766,15 @@ int64_t sdpgpu_state_index2(const sdpgpu_handle* hc, int32_t period, double x, d
   }
   if (has_preq(d.family)) {
     double qq = preq / d.step;
+    if (!(qq >= 0.0 && qq < (double)g.nq1)) return -1;
     iq = (int64_t)qq;
-    if ((double)iq != qq || iq < 0 || iq >= g.nq1) return -1;
+    if ((double)iq != qq) return -1;
   }
   if (d.lead_time == 2) {
     double qq = preq2 / d.step;
+    if (!(qq >= 0.0 && qq < (double)(g.nq / g.nq1))) return -1;
     int64_t iq2 = (int64_t)qq;
-    if ((double)iq2 != qq || iq2 < 0 || iq2 >= g.nq / g.nq1) return -1;
+    if ((double)iq2 != qq) return -1;
     iq += iq2 * g.nq1;
   } else if (preq2 != 0.0) {
     return -1;
@@ -1134,13 +1140,17 @@ int sdpgpu_stats_get(sdpgpu_handle* h, sdpgpu_stats* out) {
   h->err.clear();
   std::memset(out, 0, sizeof *out);
   if (layout(h)) return SDPGPU_ERR_STATE;
+  bool modelled = true;
   for (int t = 0; t < h->T; ++t) {
     const PeriodInfo& p = h->per[t];
     out->states_total += p.S;
     out->cells_evaluated += p.cells_rank;
     out->cells_all_ranks += p.cells_all;
     if (h->period_done[t]) out->periods_run++;
+    out->fp64_ops_executed += (double)p.cells_rank * p.ops_cell;
+    if (p.ops_cell == 0 && p.cells_rank > 0) modelled = false;
   }
+  if (!modelled) out->fp64_ops_executed = 0;
   out->kernel_used = h->per[0].kernel_used;
   if (!h->custom && h->d.family == SDPGPU_FAMILY_BACKORDER && h->per[0].kernel_used == SDPGPU_KERNEL_WINDOW &&
       window_eligible(h, 1)) {

@@ -91,6 +91,7 @@ hipError_t launch_cash_shift(sdpgpu_handle* h, const DevParams& P, int period, c
   const size_t dp8 = ((size_t)p.nD + 7) & ~(size_t)7;
   size_t smem = (size_t)p.nD * 16 + dp8 * 16 * 8 + (size_t)4 * TSZ * (sizeof(double) + sizeof(int));
   const bool last = period == h->T;
+  h->per[period - 1].ops_cell = last ? 1.0 : 3.0;  // acc += T1; acc += (p gamma) * V
 #define SDP_CS(MX, LS, SS, WW) hipLaunchKernelGGL((sdp::cash_shift_kernel<MX, LS, SS, WW>), grid, dim3(256), smem, st, C, v_next, v_cur, pol, pmf_d, pmf_p, lo, hi)
 #define SDP_CS_S(MX, LS)      \
   if (S == 4 && W == 2)       \

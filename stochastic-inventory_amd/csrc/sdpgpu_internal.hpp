@@ -58,6 +58,9 @@ struct PeriodInfo {
   hipEvent_t ev0 = nullptr, ev1 = nullptr;
   bool timed = false;
   int32_t kernel_used = 0;
+  // executed fp64 add/mul operations per cell of the kernel plan that ran this period (identical operations of
+  // neighbouring cells are formed once, see sdp_window.hpp / sdp_cash.hpp); 0 = the kernel has no such model
+  double ops_cell = 0;
 };
 
 struct sdpgpu_handle {

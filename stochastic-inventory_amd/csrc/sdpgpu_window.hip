@@ -195,6 +195,7 @@ hipError_t launch_row_window(sdpgpu_handle* h, const DevParams& P, int period, c
   if (SL == 4 && R == 8) SL = 2;  // (no 8 x 4 instantiation: too many registers)
   const int TSZ = 64 * SL;
   const bool future = period < h->T;
+  h->per[period - 1].ops_cell = future ? 4.0 + 1.0 / SL : 2.0 + 1.0 / SL;  // (c0 + M shared by SL cells, see window_f2_kernel)
   sdp::RowParams W{};
   W.lev0 = p.g.x_lo - h->pmf_d[period - 1][0];
   W.step = h->d.step;
@@ -302,6 +303,8 @@ hipError_t launch_window(sdpgpu_handle* h, const DevParams& P, int period, const
     std::fprintf(stderr, "[sdpgpu] window plan: R=%d S=%d chunks=%d blocks/chunk=%d tiles=%d tasks=%d lds=%zu\n", pl.R, pl.S,
                  pl.n_chunks, pl.chunk_blocks, pl.n_tiles, pl.n_tasks, pl.smem);
   const bool future = period < h->T;
+  // c0 + M once per (action, m): 1/S; p * imm: 1; p * V once per window entry: (R + S - 1)/(R S); two accumulations
+  p.ops_cell = future ? 3.0 + 1.0 / pl.S + (pl.R + pl.S - 1.0) / (pl.R * pl.S) : 2.0 + 1.0 / pl.S;
   const bool chunked = pl.n_chunks > 1;
   // a period is never re-run on top of its own pending rows, and a new sweep (period T) first
   // finalizes what the previous one left: the key rows are about to be reset

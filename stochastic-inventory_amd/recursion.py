@@ -12,7 +12,8 @@ with ONE addition: a `functor` descriptor (functors.py) naming the closed-form f
 lambdas belong to -- a GPU cannot call host closures per cell.  The lambdas are still accepted
 and kept (getStateTransitionFunction / getImmediateValueFunction serve the simulators exactly
 as in Simulation.java:39-40); `validateFunctor` checks on sampled cells that they compute what
-the functor computes.
+the functor computes, and runs by itself before the first solve whenever a lambda was supplied
+(`recursion.strict = False` turns that off).
 
 `getExpectedValue(state)` runs the full backward sweep on the GPU on its first call (the
 reference fills its memo maps on the first call too, Recursion.java:89-163) and answers from
@@ -43,6 +44,11 @@ class _GpuRecursionBase:
         self.functor = functor
         self.T = len(pmf)
         T = self.T
+        # lambdas the caller supplied are checked against the functor before the first solve (`strict`, on by
+        # default): a driver whose lambdas are NOT the closed-form family would otherwise get tables for a
+        # different model without a word, and the simulators would then roll the host lambdas against that policy
+        self._user_lambdas = any(f is not None for f in (getFeasibleAction, stateTransition, immediateValue))
+        self.strict = True
         self.getFeasibleActions = getFeasibleAction or (lambda s: functor.feasibleActions(s, T))
         self.stateTransition = stateTransition or (lambda s, a, r: functor.stateTransition(s, a, r, T))
         self.immediateValue = immediateValue or (lambda s, a, r: functor.immediateValue(s, a, r, T))
@@ -75,6 +81,9 @@ class _GpuRecursionBase:
 
     def _solve(self):
         if not self._solved:
+            if self._user_lambdas and self.strict and all(hasattr(self.functor, m) for m in
+                                                          ("feasibleActions", "immediateValue", "stateTransition")):
+                self.validateFunctor(nSamples=96)  # raises ValueError on the first cell that differs
             self._engine.solve(sync=True)
             self._solved = True
 

@@ -109,8 +109,31 @@ def cfg5_scaled(S: int, T: int = 3, A: int = 500, D: int = 200) -> Workload:
     return Workload(f"cfg5_f1_{S}x{A}x{D}x{T}", f, OptDirection.MIN, seasonal_pmf(T, D), "synthetic scaled F1")
 
 
+def target_grid(T: int = 6, S: int = 1000000, A: int = 500, D: int = 200) -> Workload:
+    """The grid BASELINE.json's target sentence is quoted on: 1e6 states x 500 actions x 200 demands (F1, the
+    lambdas of capacitated.CLSP, CLSP.java:251-272), six periods = 6e11 cells per sweep."""
+    w = cfg5_scaled(S=S, T=T, A=A, D=D)
+    w.name = f"target_f1_{S}x{A}x{D}x{T}"
+    w.note = "north-star target grid"
+    return w
+
+
+def cfg3_tenths(T: int = 6, NX: int = 501, maxCash: float = 2000.0, A: int = 101, D: int = 25) -> Workload:
+    """configs[2]'s family at the size and cash quantum of the reference's own driver, cash.singleItem.CashConstraint
+    .main (CashConstraint.java:44-68,131): cash in TENTHS (Math.round(cash * 10) / 10.0), inventory 0..500, cash
+    0..2000 = 501 x 20001 states, orders 0..100, Poisson(10) demand truncated to 25 points, six periods.  Nothing is
+    dyadic here, so the uniform-shift kernel does not apply: this is the cash row kernel's workload."""
+    f = CashFunctor(price=10, fixOrderCost=0, variCost=1, holdingCost=0, depositeRate=0, overheadCost=0, overheadRate=0,
+                    salvageValue=0.5, penaltyCost=0, discountFactor=1.0, maxOrderQuantity=A - 1, minInventoryState=0,
+                    maxInventoryState=NX - 1, minCashState=0, maxCashState=maxCash, iniInventory=0, iniCash=100)
+    pmf = [truncated_poisson_tile(10.0, D) for _ in range(T)]
+    return Workload(f"cfg3t_cash_tenths_{NX}x{int(maxCash * 10) + 1}x{A}x{D}x{T}", f, OptDirection.MAX, pmf,
+                    "CashConstraint.main: cash quantum 0.1")
+
+
 def by_name(name: str, **kw) -> Workload:
-    table = {"cfg1": cfg1_sS, "cfg2": cfg2_clsp, "cfg3": cfg3_cash, "cfg4": cfg4_leadtime, "cfg4p": cfg4_pipeline}
+    table = {"cfg1": cfg1_sS, "cfg2": cfg2_clsp, "cfg3": cfg3_cash, "cfg3t": cfg3_tenths, "cfg4": cfg4_leadtime,
+             "cfg4p": cfg4_pipeline, "target": target_grid}
     if name in table:
         return table[name](**kw)
     if name == "cfg5":

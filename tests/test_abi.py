@@ -189,3 +189,23 @@ def test_host_mirror_keeps_the_reference_api(sia):
 
 def test_java_round_host(sia):
     assert sia.java_round(-2.5) == -2 and sia.java_round(2.5) == 3 and sia.java_round(0.49999999999999994) == 0
+
+
+@pytest.mark.parametrize("make", [cases.f1_small, cases.f3_tenths, cases.f5_cash_leadtime, cases.f2_pipeline],
+                         ids=lambda m: m.__name__)
+def test_state_index_rejects_non_finite_and_huge_inputs(sia, make):
+    """NaN / infinite / astronomically large coordinates are 'not a grid point' (-1), never an index: the range checks
+    come before the double -> int64 casts (which are undefined for such inputs)."""
+    w = make()
+    with sia.SdpEngine(w.desc(), w.pmf, w.overhead()) as eng:
+        x_lo, nx, nc, nq1, nq2 = eng.grid2(1)
+        ok = eng.state_index(1, x_lo, eng.cash_value(0) if nc > 1 else 0.0, 0.0, 0.0)
+        assert ok == 0
+        for bad in (float("nan"), float("inf"), -float("inf"), 1e300, -1e300, 2.0 ** 63, -(2.0 ** 63)):
+            assert eng.state_index(1, bad, eng.cash_value(0) if nc > 1 else 0.0, 0.0, 0.0) == -1
+            if nc > 1:
+                assert eng.state_index(1, x_lo, bad, 0.0, 0.0) == -1
+            if nq1 > 1:
+                assert eng.state_index(1, x_lo, eng.cash_value(0) if nc > 1 else 0.0, bad, 0.0) == -1
+            if nq2 > 1:
+                assert eng.state_index(1, x_lo, 0.0, 0.0, bad) == -1

@@ -12,15 +12,28 @@ pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-@pytest.mark.parametrize("extra", [["--periods", "6"], ["--workload", "cfg5", "--states", "100000", "--periods", "3"],
-                                   ["--periods", "6", "--split"],
-                                   ["--workload", "cfg5", "--states", "100000", "--periods", "3", "--split"],
-                                   ["--periods", "6", "CALIBRATE"],
-                                   ["--periods", "7", "--schedule", "blocked3"],
-                                   ["--workload", "cfg5", "--states", "100000", "--periods", "4", "--schedule", "blocked2"]],
+W2 = ["--workload", "cfg2", "--weak"]
+W5 = ["--workload", "cfg5", "--weak", "--states", "100000"]
+
+
+@pytest.mark.parametrize("extra", [W2 + ["--periods", "6"], W5 + ["--periods", "3"],
+                                   W2 + ["--periods", "6", "--split"],
+                                   W5 + ["--periods", "3", "--split"],
+                                   W2 + ["--periods", "6", "CALIBRATE"],
+                                   W2 + ["--periods", "7", "--schedule", "blocked3"],
+                                   W5 + ["--periods", "4", "--schedule", "blocked2"],
+                                   ["--periods", "2"],
+                                   ["--workload", "cfg2", "--periods", "5"],
+                                   ["--workload", "cfg3", "--periods", "2"],
+                                   ["--workload", "cfg3t", "--periods", "2"],
+                                   ["--workload", "cfg4", "--periods", "3"],
+                                   ["--workload", "cfg4p", "--periods", "2"],
+                                   ["--workload", "cfg5", "--states", "3000000", "--periods", "2"]],
                          ids=["cfg2_small_slabs_key_rows", "f1_large_slabs", "cfg2_interior_boundary_split",
                               "f1_large_interior_boundary_split", "cfg2_schedule_calibration",
-                              "cfg2_three_periods_per_exchange", "f1_large_two_periods_per_exchange"])
+                              "cfg2_three_periods_per_exchange", "f1_large_two_periods_per_exchange",
+                              "strong_target_grid", "strong_cfg2", "strong_cfg3", "strong_cfg3_tenths", "strong_cfg4",
+                              "strong_cfg4_pipeline", "strong_cfg5_reduced_width"])
 def test_two_ranks_match_single_rank(extra):
     env = dict(os.environ)
     if "CALIBRATE" in extra:  # the N > 1 schedule calibration bench.py runs under RCCL, rehearsed over gloo
@@ -30,11 +43,13 @@ def test_two_ranks_match_single_rank(extra):
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr",
            "127.0.0.1", "--master-port", str(port), os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2",
            "--warmup", "1", "--backend", "gloo", "--check", "--no-cpu-baseline", *extra]
-    out = subprocess.run(cmd, capture_output=True, text=True, timeout=240, cwd=ROOT, env=env)
+    out = subprocess.run(cmd, capture_output=True, text=True, timeout=420, cwd=ROOT, env=env)
     assert out.returncode == 0, out.stderr[-2000:]
     line = [l for l in out.stdout.splitlines() if l.startswith("{")][-1]
     rec = json.loads(line)
     assert rec["n_gpus"] == 2 and rec["check_vs_single_rank"] is True
-    assert rec["scaling"] == "weak" and rec["value"] > 0
+    assert rec["scaling"] == ("weak" if "--weak" in extra else "strong") and rec["value"] > 0
+    assert rec["parity_gate"]["status"] == "ok" and rec["parity_gate"]["ranks"] == 2
+    assert len(rec["config"]["cells_per_rank"]) == 2 and sum(rec["config"]["cells_per_rank"]) == rec["config"]["cells_per_step"]
     if "SDP_BENCH_CALIBRATE" in env:
-        assert "calibrated" in rec["config"]["exchange"]
+        assert "calibrated" in rec["config"]["schedule"]

@@ -1,0 +1,91 @@
+#!/usr/bin/env python3
+"""Reduce the passes of tools/pmc_collect.sh: per kernel, the mean of every counter per launch, the rocprofv3 kernel
+stats and the bench line's own HIP-event times, into
+    <out>/<round>_pmc_<workload name>.json   (what bench.py's roofline.hbm / valu-issue blocks read from profiles/)
+    <out>/<round>_<workload>_summary.txt     (human-readable: the table quoted in DESIGN.md)
+gfx950 corrections (MI355X_MICROARCH.md, HBM): FETCH_SIZE and WRITE_SIZE are in KiB; FETCH_SIZE reports half the bytes
+of a wide coalesced read and is doubled.  usage: pmc_reduce.py <out dir> <round> <workload>"""
+import collections
+import csv
+import glob
+import json
+import os
+import statistics
+import sys
+
+
+def short(name):
+    return name.split("(")[0].replace("void ", "").strip()
+
+
+def main():
+    out, rnd, wl = sys.argv[1:4]
+    bench = None
+    try:
+        bench = json.loads([l for l in open(os.path.join(out, "bench.json")) if l.startswith("{")][-1])
+    except Exception as exc:
+        print("no bench line:", exc)
+    counters = collections.defaultdict(lambda: collections.defaultdict(list))  # kernel -> counter -> values
+    prof_us = collections.defaultdict(list)
+    for f in glob.glob(os.path.join(out, "pmc*", "**", "*counter_collection.csv"), recursive=True):
+        for r in csv.DictReader(open(f)):
+            k = short(r["Kernel_Name"])
+            if "sdp" not in k:
+                continue
+            counters[k][r["Counter_Name"]].append(float(r["Counter_Value"]))
+    stats = {}
+    for f in glob.glob(os.path.join(out, "stats", "**", "*kernel_stats.csv"), recursive=True):
+        for r in csv.DictReader(open(f)):
+            k = short(r["Name"])
+            if "sdp" in k:
+                stats[k] = {"calls": int(r["Calls"]), "avg_us": float(r["AverageNs"]) / 1e3, "total_ms": float(r["TotalDurationNs"]) / 1e6,
+                            "pct": float(r["Percentage"])}
+    kernels = {}
+    for k, cs in counters.items():
+        rec = {c: statistics.mean(v) for c, v in cs.items()}
+        rec["launches_seen"] = max(len(v) for v in cs.values())
+        if "FETCH_SIZE" in rec or "WRITE_SIZE" in rec:
+            rec["hbm_read_bytes_per_launch"] = 2.0 * rec.get("FETCH_SIZE", 0.0) * 1024.0
+            rec["hbm_write_bytes_per_launch"] = rec.get("WRITE_SIZE", 0.0) * 1024.0
+        if k in stats:
+            rec["rocprof"] = stats[k]
+        kernels[k] = rec
+    if not kernels:
+        print("no counters collected")
+        sys.exit(1)
+    # dominant kernel: most total time under --kernel-trace --stats, else most launches
+    dom = max(kernels, key=lambda k: (kernels[k].get("rocprof", {}).get("total_ms", 0.0), kernels[k]["launches_seen"]))
+    d = kernels[dom]
+    rec = {
+        "round": rnd, "workload": bench["config"]["workload"] if bench else wl, "dominant_kernel": dom,
+        "hbm_bytes_per_launch": d.get("hbm_read_bytes_per_launch", 0.0) + d.get("hbm_write_bytes_per_launch", 0.0),
+        "valu_insts_per_launch": d.get("SQ_INSTS_VALU"),
+        "ta_busy_frac": (d["TA_BUSY_avr"] / d["GRBM_GUI_ACTIVE"]) if d.get("TA_BUSY_avr") and d.get("GRBM_GUI_ACTIVE") else None,
+        "correction": "HBM bytes = 2 * FETCH_SIZE_KiB * 1024 + WRITE_SIZE_KiB * 1024 (gfx950: FETCH_SIZE counts half of a wide coalesced read)",
+        "kernels": kernels,
+        "bench_line": {k: bench[k] for k in ("value", "ms_per_step", "steps", "config", "parity_gate")} if bench else None,
+        "bench_per_launch_ms_events": bench["roofline"]["per_launch_ms_events"] if bench else None,
+        "command": "tools/pmc_collect.sh (separate rocprofv3 --pmc passes with --kernel-trace only; --kernel-trace --stats in its own run)",
+    }
+    name = rec["workload"]
+    json.dump(rec, open(os.path.join(out, f"{rnd}_pmc_{name}.json"), "w"), indent=1)
+    lines = [f"{rnd} {name}: dominant kernel {dom}"]
+    if bench:
+        rf = bench["roofline"]
+        lines.append(f"bench line: {bench['value']:.4g} cells/s, {bench['ms_per_step']:.4f} ms per sweep, avg launch {rf['avg_launch_ms'] * 1e3:.2f} us (HIP events, un-profiled); "
+                     f"sum of per-launch events {sum(rf['per_launch_ms_events']):.4f} ms; roofline {rf['bound']} frac {rf['frac']}")
+    for k, r in sorted(kernels.items(), key=lambda kv: -kv[1].get("rocprof", {}).get("total_ms", 0.0)):
+        rp = r.get("rocprof")
+        lines.append(f"-- {k}" + (f": {rp['calls']} calls, avg {rp['avg_us']:.2f} us under rocprofv3 ({rp['pct']:.1f} % of kernel time)" if rp else ""))
+        for c in sorted(r):
+            if c in ("rocprof", "launches_seen"):
+                continue
+            lines.append(f"     {c}: {r[c]:.6g}")
+        if r.get("SQ_INSTS_VALU") and r.get("SQ_BUSY_CYCLES"):
+            pass
+    open(os.path.join(out, f"{rnd}_{wl}_summary.txt"), "w").write("\n".join(lines) + "\n")
+    print("\n".join(lines))
+
+
+if __name__ == "__main__":
+    main()
