@@ -20,7 +20,11 @@ if _ROOT not in sys.path:
 
 from stochastic_inventory_amd._abi import SdpgpuDesc  # noqa: E402  (struct layout only)
 
-LIB_PATH = os.path.join(_HERE, "libsdpref.so")
+# SDPREF_SANITIZE=1: the AddressSanitizer + UBSan build of the same file (oracle/Makefile); the process must then have
+# gcc's libasan preloaded (tests/test_sanitizers.py runs the oracle tests that way)
+_SAN = os.environ.get("SDPREF_SANITIZE") == "1"
+LIB_NAME = "libsdpref_asan.so" if _SAN else "libsdpref.so"
+LIB_PATH = os.path.join(_HERE, LIB_NAME)
 
 
 def build(force: bool = False) -> str:
@@ -28,7 +32,7 @@ def build(force: bool = False) -> str:
         os.path.join(_ROOT, "include", "sdpgpu.h")]
     stale = (not os.path.exists(LIB_PATH)) or any(os.path.getmtime(f) > os.path.getmtime(LIB_PATH) for f in src)
     if force or stale:
-        subprocess.run(["make", "-C", _HERE, "-B" if force else "-s", "libsdpref.so"], check=True)
+        subprocess.run(["make", "-C", _HERE, "-B" if force else "-s", LIB_NAME], check=True)
     return LIB_PATH
 
 

@@ -9,7 +9,11 @@ import subprocess
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libstaffref.so")
+# SDPREF_SANITIZE=1: the AddressSanitizer + UBSan build of the same file (oracle/Makefile); the process must then have
+# gcc's libasan preloaded (tests/test_sanitizers.py runs the oracle tests that way)
+_SAN = os.environ.get("SDPREF_SANITIZE") == "1"
+LIB_NAME = "libstaffref_asan.so" if _SAN else "libstaffref.so"
+LIB_PATH = os.path.join(_HERE, LIB_NAME)
 _DP, _IP, _LP = C.POINTER(C.c_double), C.POINTER(C.c_int32), C.POINTER(C.c_int64)
 
 
@@ -25,7 +29,7 @@ def build(force: bool = False) -> str:
     src = [os.path.join(_HERE, f) for f in ("staffref.c", "staffref.h", "Makefile")]
     stale = (not os.path.exists(LIB_PATH)) or any(os.path.getmtime(f) > os.path.getmtime(LIB_PATH) for f in src)
     if force or stale:
-        subprocess.run(["make", "-C", _HERE, "-B" if force else "-s", "libstaffref.so"], check=True)
+        subprocess.run(["make", "-C", _HERE, "-B" if force else "-s", LIB_NAME], check=True)
     return LIB_PATH
 
 

@@ -10,7 +10,8 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libsdpgpu.so")
+# SDPGPU_LIB: load another build of the SAME library instead (tests/test_sanitizers.py points it at the host-ASan build)
+LIB_PATH = os.environ.get("SDPGPU_LIB") or os.path.join(_HERE, "libsdpgpu.so")
 
 SDPGPU_ABI_VERSION = 3
 

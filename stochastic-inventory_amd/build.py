@@ -75,5 +75,50 @@ def build(force: bool = False, extra_flags=(), verbose: bool = True) -> str:
     return OUT
 
 
+ASAN_DIR = os.path.join(HERE, "_build_asan")
+ASAN_OUT = os.path.join(ASAN_DIR, "libsdpgpu_hostasan.so")
+
+
+def asan_runtime() -> str:
+    """The shared AddressSanitizer runtime of ROCm's clang (LD_PRELOAD it to load the library below into Python)."""
+    import glob
+    hits = sorted(glob.glob("/opt/rocm/lib/llvm/lib/clang/*/lib/linux/libclang_rt.asan-x86_64.so"))
+    if not hits:
+        raise FileNotFoundError("libclang_rt.asan-x86_64.so not found under /opt/rocm/lib/llvm")
+    return hits[-1]
+
+
+def build_host_asan(force: bool = False, verbose: bool = False) -> str:
+    """HOST-side AddressSanitizer + UBSan build of the same sources (-fno-gpu-sanitize: device code is compiled as
+    usual; GPU ASan is not available on the pool).  It exists for the CPU checks of the host half of the library --
+    descriptor validation, per-period layout, slab and halo arithmetic, the window planner, footprints, state
+    indexing -- which tests/test_sanitizers.py drives through the C ABI without a GPU.  Not shipped, not loaded by
+    the product."""
+    if not force and os.path.exists(ASAN_OUT) and all(os.path.getmtime(f) <= os.path.getmtime(ASAN_OUT) for f in deps()):
+        return ASAN_OUT
+    from concurrent.futures import ThreadPoolExecutor
+    hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
+    os.makedirs(ASAN_DIR, exist_ok=True)
+    san = ["-fsanitize=address,undefined", "-fno-gpu-sanitize", "-fno-sanitize-recover=undefined", "-shared-libasan"]
+    flags = ["--offload-arch=gfx950", "-O1", "-g", "-std=c++17", "-ffp-contract=off", "-fno-fast-math", "-fPIC",
+             "-fvisibility=hidden", "-Wno-unused-function", *san]
+
+    def compile_one(src):
+        obj = os.path.join(ASAN_DIR, os.path.basename(src) + ".o")
+        cmd = [hipcc, *flags, "-c", "-o", obj, src]
+        if verbose:
+            print("+", " ".join(cmd), flush=True)
+        subprocess.run(cmd, check=True)
+        return obj
+
+    with ThreadPoolExecutor(max_workers=min(7, os.cpu_count() or 1)) as ex:
+        objs = list(ex.map(compile_one, sources()))
+    subprocess.run([hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", *san, "-o", ASAN_OUT, *objs, "-lhiprtc"], check=True)
+    return ASAN_OUT
+
+
 if __name__ == "__main__":
-    build(force="--force" in sys.argv)
+    if "--host-asan" in sys.argv:
+        print(build_host_asan(force="--force" in sys.argv, verbose=True))
+    else:
+        build(force="--force" in sys.argv)
