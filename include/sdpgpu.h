@@ -116,9 +116,11 @@ typedef enum sdpgpu_direction { SDPGPU_MIN = 0, SDPGPU_MAX = 1 } sdpgpu_directio
 #define SDPGPU_KERNEL_AUTO 0
 #define SDPGPU_KERNEL_GATHER 1 /* generic per-cell functor + gather from V_{t+1} in HBM/L2 */
 #define SDPGPU_KERNEL_WINDOW 2 /* F1/F2: LDS-staged {L(l), V(clamp l)} window, register sliding */
-#define SDPGPU_KERNEL_SEPARABLE 3 /* OPT-IN, F1 only, never chosen automatically: Q(x,a) = c(a) + G(x+a), O((S+A)D + SA)
-                                     per period.  Reassociates the reference's sum: values agree to rounding
-                                     (1e-9 relative), the arg-opt may differ on near-ties. */
+#define SDPGPU_KERNEL_SEPARABLE 3 /* OPT-IN, never chosen automatically.  F1: Q(x,a) = c(a) + G(x+a), O((S+A)D + SA) per
+                                     period.  F2 (lead time 1 or 2): V_t and the arg-min depend on (x + preQ[, q2])
+                                     only, O(A (nx+nq) D [nq]) for that table + one write per state.  Reassociates the
+                                     reference's sum: values agree to rounding (1e-9 relative), the arg-opt may differ
+                                     on near-ties. */
 
 /*
  * Problem descriptor: everything the reference's lambdas close over.  Field names

@@ -641,4 +641,107 @@ __global__ __launch_bounds__(256) void separable_f1_kernel(SepParams P, const do
   }
 }
 
+// ---------------------------------------------------------------------------------------------
+// OPT-IN separable mode for F2 (Leadtime.java:50-81) -- NOT the graded path.
+// The level y - d, y = x + preQ, does not depend on the action, and the action only picks the plane of V_{t+1}
+// (next preQ = action; with lead_time 2 the plane (q2' = action, q1' = q2)).  In real arithmetic
+//     Q(x, q1[, q2], a) = c(a) + L(y) + W_{a[,q2]}(y),   L(y) = sum_j p_j M(y - d_j),
+//     W_p(y) = sum_j p_j V_{t+1}[plane p][clamp(y - d_j)],
+// so V_t and the arg-min depend on (y[, q2]) only: a period costs O(A * NY * D [* nq]) for the table
+// G[q2][y] = L(y) + min_a (c(a) + W(y)) instead of O(S * A * D), plus one 12-byte write per state.
+// Same parity statement as the F1 mode: the sum is reassociated, so values agree with the brute-force path and the
+// oracle to rounding (1e-9 relative, tests/test_gpu_separable.py) and the arg-min may differ on near-ties.
+// Kernel 1: one workgroup = 64 values of y (lanes) x 4 action slots of one q2; kernel 2 expands G over the slab.
+// ---------------------------------------------------------------------------------------------
+struct SepF2Params {
+  double y_lo;        // level of e = 0: x_lo(cur)   (preQ starts at 0)
+  double step, inv_step, h, pi, K, v;
+  double min_inventory, max_inventory, next_x_lo;
+  int32_t clamp_inventory;
+  int32_t next_last;  // nx(next) - 1
+  int32_t next_nx;    // plane stride of V_{t+1}
+  int32_t next_nq1;   // lead_time 2: planes of V_{t+1} are (q2' = action) * nq1 + (q1' = q2)
+  int32_t lead2;
+  int32_t n_actions, n_demand;
+  int32_t ny;         // nx(cur) + nq1(cur) - 1
+  int32_t cur_nx, cur_nq1;
+};
+
+template <bool FUTURE>
+__global__ __launch_bounds__(256) void separable_f2_table_kernel(SepF2Params P, const double* __restrict__ v_next,
+                                                                 double* __restrict__ g_val, int32_t* __restrict__ g_idx,
+                                                                 const double* __restrict__ pmf_d,
+                                                                 const double* __restrict__ pmf_p) {
+  __shared__ double s_val[4 * 64];
+  __shared__ int s_k[4 * 64];
+  const int tid = threadIdx.x, sx = tid & 63, as = tid >> 6;
+  const int e = blockIdx.x * 64 + sx;
+  const int iq2 = blockIdx.y;  // 0 with lead time 1
+  const int ec = e < P.ny ? e : P.ny - 1;
+  const double y = P.y_lo + (double)ec * P.step;
+  double best = 1.7976931348623157e308;
+  int bestk = 0;
+  for (int k = as; k < P.n_actions; k += 4) {
+    const double a = (double)k * P.step;
+    double w = 0.0;
+    if constexpr (FUTURE) {
+      const double* plane = v_next + (int64_t)(P.lead2 ? k * P.next_nq1 + iq2 : k) * P.next_nx;
+      for (int j = 0; j < P.n_demand; ++j) {
+        double nx = y - pmf_d[j];
+        if (P.clamp_inventory) {
+          nx = nx > P.max_inventory ? P.max_inventory : nx;
+          nx = nx < P.min_inventory ? P.min_inventory : nx;
+        }
+        int idx = (int)((nx - P.next_x_lo) * P.inv_step);
+        idx = idx > P.next_last ? P.next_last : idx;  // (levels only padded lanes reach)
+        idx = idx < 0 ? 0 : idx;
+        w += pmf_p[j] * plane[idx];
+      }
+    }
+    const double q = ((a > 0 ? P.K : 0.0) + P.v * a) + w;
+    if (q < best) {  // LeadtimeRecursion is MIN only (LeadtimeRecursion.java:52,66)
+      best = q;
+      bestk = k;
+    }
+  }
+  s_val[as * 64 + sx] = best;
+  s_k[as * 64 + sx] = bestk;
+  __syncthreads();
+  if (tid < 64 && e < P.ny) {
+    double bv = s_val[tid];
+    int bk = s_k[tid];
+#pragma unroll
+    for (int w = 1; w < 4; ++w) {
+      const double ov = s_val[w * 64 + tid];
+      const int ok = s_k[w * 64 + tid];
+      if (better<false>(ov, ok, bv, bk)) {
+        bv = ov;
+        bk = ok;
+      }
+    }
+    double l = 0.0;  // L(y): expected holding / penalty cost
+    for (int j = 0; j < P.n_demand; ++j) {
+      const double lev = y - pmf_d[j];
+      l += pmf_p[j] * (P.h * jmax(lev, 0.0) + P.pi * jmax(-lev, 0.0));
+    }
+    g_val[(int64_t)iq2 * P.ny + e] = l + bv;
+    g_idx[(int64_t)iq2 * P.ny + e] = bk;
+  }
+}
+
+__global__ __launch_bounds__(256) void separable_f2_expand_kernel(SepF2Params P, const double* __restrict__ g_val,
+                                                                  const int32_t* __restrict__ g_idx,
+                                                                  double* __restrict__ v_cur, int32_t* __restrict__ pol,
+                                                                  int64_t lo, int64_t hi) {
+  const int64_t idx = lo + (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (idx >= hi) return;
+  const int64_t iq = idx / P.cur_nx;
+  const int ix = (int)(idx - iq * P.cur_nx);
+  const int iq2 = (int)(iq / P.cur_nq1);
+  const int iq1 = (int)(iq - (int64_t)iq2 * P.cur_nq1);
+  const int64_t g = (int64_t)iq2 * P.ny + ix + iq1;
+  v_cur[idx] = g_val[g];
+  pol[idx] = g_idx[g];
+}
+
 }  // namespace sdp

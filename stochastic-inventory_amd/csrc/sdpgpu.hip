@@ -366,8 +366,22 @@ int run_period_impl(sdpgpu_handle* h, int period, int part, int64_t range_lo, in
     if (!h->d.store_all_values && period + 2 <= h->T) h->period_done[period + 1] = 0;
     return SDPGPU_OK;
   }
+  if (h->d.kernel == SDPGPU_KERNEL_SEPARABLE && h->d.family == SDPGPU_FAMILY_LEADTIME) {
+    if (part == SDPGPU_PART_INTERIOR) return SDPGPU_OK;
+    hipError_t es = launch_separable_f2(h, P, period, v_next, v_cur, pol, pd, pp);
+    if (es != hipSuccess) return fail(h, SDPGPU_ERR_DEVICE, "period %d separable kernel (lead-time family): %s", period, hipGetErrorString(es));
+    p.kernel_used = SDPGPU_KERNEL_SEPARABLE;
+    if (h->profiling) {
+      HIP_TRY(h, hipEventRecord(p.ev1, h->stream));
+      p.timed = true;
+    }
+    h->period_done[period - 1] = 1;
+    h->policy_done[period - 1] = 1;
+    if (!h->d.store_all_values && period + 2 <= h->T) h->period_done[period + 1] = 0;
+    return SDPGPU_OK;
+  }
   if (h->d.kernel == SDPGPU_KERNEL_SEPARABLE) {
-    if (h->d.family != SDPGPU_FAMILY_BACKORDER) return fail(h, SDPGPU_ERR_UNSUPPORTED, "the separable mode exists for the backorder family only");
+    if (h->d.family != SDPGPU_FAMILY_BACKORDER) return fail(h, SDPGPU_ERR_UNSUPPORTED, "the separable mode exists for the backorder and lead-time families only");
     if (h->n_actions_full > 6000) return fail(h, SDPGPU_ERR_UNSUPPORTED, "separable mode: action range exceeds the LDS tile");
     if (part == SDPGPU_PART_INTERIOR) return SDPGPU_OK;
     bool too_big = false;
@@ -599,6 +613,8 @@ void sdpgpu_destroy(sdpgpu_handle* h) {
   for (void* q : h->staff_owned) (void)hipFree(q);
   if (h->d_staff_val) (void)hipFree(h->d_staff_val);
   if (h->d_staff_idx) (void)hipFree(h->d_staff_idx);
+  if (h->d_sep_val) (void)hipFree(h->d_sep_val);
+  if (h->d_sep_idx) (void)hipFree(h->d_sep_idx);
   if (h->d_custom_params) (void)hipFree(h->d_custom_params);
   if (h->d_custom_cells) (void)hipFree(h->d_custom_cells);
   if (h->d_custom_err) (void)hipFree(h->d_custom_err);

@@ -135,6 +135,9 @@ struct sdpgpu_handle {
   double* d_staff_val = nullptr;    // partial arg-min rows [group][slab]
   int32_t* d_staff_idx = nullptr;
   size_t staff_part_elems = 0;
+  double* d_sep_val = nullptr;      // opt-in separable mode, lead-time family: the table G[q2][y] and its arg-min
+  int32_t* d_sep_idx = nullptr;
+  size_t sep_elems = 0;
   // multi-GPU (sdpgpu_comm.hip): the communicator of this rank, a second stream for the overlapped schedule, and --
   // sdpgpu_solve_multi with several ranks on ONE device -- the sibling handles whose rows are exchanged by copies
   void* comm = nullptr;  // ncclComm_t
@@ -246,6 +249,8 @@ bool window_eligible(const sdpgpu_handle* h, int period);
 WinPlan plan_window(const sdpgpu_handle* h, int period, int64_t lo, int64_t hi);
 hipError_t flush_pending(sdpgpu_handle* h);
 bool window_interior_tiles(const sdpgpu_handle* h, int period, int64_t lo, int64_t hi, int* first, int* count);
+hipError_t launch_separable_f2(sdpgpu_handle* h, const DevParams& P, int period, const double* v_next, double* v_cur,
+                               int32_t* pol, const double* pd, const double* pp);
 hipError_t launch_separable(sdpgpu_handle* h, const DevParams& P, int period, const double* v_next, double* v_cur,
                             int32_t* pol, const double* pd, const double* pp, bool* too_big);
 // geometry of a period's chunk rows: element stride between chunks and the state index of element 0

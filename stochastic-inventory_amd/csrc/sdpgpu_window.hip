@@ -529,4 +529,71 @@ hipError_t launch_separable(sdpgpu_handle* h, const DevParams& P, int period, co
   return es;
 }
 
+// OPT-IN separable mode, lead-time family (see separable_f2_table_kernel): the table G[q2][y], then its expansion over
+// this rank's slab.  Every rank builds the whole table (it is S / nq times smaller than the period).
+hipError_t launch_separable_f2(sdpgpu_handle* h, const DevParams& P, int period, const double* v_next, double* v_cur,
+                               int32_t* pol, const double* pd, const double* pp) {
+  const PeriodInfo& p = h->per[period - 1];
+  hipError_t es = flush_pending(h);
+  if (es != hipSuccess) return es;
+  const bool lead2 = h->d.lead_time == 2;
+  const bool future = period < h->T;
+  sdp::SepF2Params S{};
+  S.y_lo = p.g.x_lo;
+  S.step = h->d.step;
+  S.inv_step = 1.0 / h->d.step;
+  S.h = h->d.holding_cost;
+  S.pi = h->d.penalty_cost;
+  S.K = h->d.fixed_order_cost;
+  S.v = h->d.unit_order_cost;
+  S.min_inventory = h->d.min_inventory;
+  S.max_inventory = h->d.max_inventory;
+  S.clamp_inventory = h->d.clamp_inventory;
+  S.lead2 = lead2;
+  S.n_actions = h->n_actions_full;
+  S.n_demand = p.nD;
+  S.cur_nx = (int32_t)p.g.nx;
+  S.cur_nq1 = (int32_t)p.g.nq1;
+  S.ny = (int32_t)(p.g.nx + p.g.nq1 - 1);
+  if (future) {
+    const Grid& gn = h->per[period].g;
+    S.next_x_lo = gn.x_lo;
+    S.next_last = (int32_t)(gn.nx - 1);
+    S.next_nx = (int32_t)gn.nx;
+    S.next_nq1 = (int32_t)gn.nq1;
+  }
+  const int64_t nq2 = lead2 ? p.g.nq / p.g.nq1 : 1;
+  const size_t need = (size_t)nq2 * (size_t)S.ny;
+  if (need > h->sep_elems) {
+    es = hipStreamSynchronize(h->stream);  // earlier launches may still read the old table
+    if (es != hipSuccess) return es;
+    if (h->d_sep_val) (void)hipFree(h->d_sep_val);
+    if (h->d_sep_idx) (void)hipFree(h->d_sep_idx);
+    h->d_sep_val = nullptr;
+    h->d_sep_idx = nullptr;
+    h->sep_elems = 0;
+    es = hipMalloc((void**)&h->d_sep_val, need * sizeof(double));
+    if (es != hipSuccess) return es;
+    es = hipMalloc((void**)&h->d_sep_idx, need * sizeof(int32_t));
+    if (es != hipSuccess) return es;
+    h->sep_elems = need;
+  }
+  if (nq2 > 65535) return hipErrorInvalidValue;
+  dim3 grid((unsigned)((S.ny + 63) / 64), (unsigned)nq2);
+  if (future)
+    hipLaunchKernelGGL((sdp::separable_f2_table_kernel<true>), grid, dim3(256), 0, h->stream, S, v_next, h->d_sep_val, h->d_sep_idx, pd, pp);
+  else
+    hipLaunchKernelGGL((sdp::separable_f2_table_kernel<false>), grid, dim3(256), 0, h->stream, S, v_next, h->d_sep_val, h->d_sep_idx, pd, pp);
+  es = hipGetLastError();
+  if (es != hipSuccess) return es;
+  const int64_t n = p.hi - p.lo;
+  if (n > 0) {
+    if (!grid_ok((n + 255) / 256)) return hipErrorInvalidValue;
+    hipLaunchKernelGGL(sdp::separable_f2_expand_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, h->stream, S,
+                       h->d_sep_val, h->d_sep_idx, v_cur, pol, p.lo, p.hi);
+    es = hipGetLastError();
+  }
+  return es;
+}
+
 }  // namespace sdpgpu_detail
