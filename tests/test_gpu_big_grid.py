@@ -35,3 +35,24 @@ def test_full_size_config_sampled_parity(name, periods):
                          capture_output=True, text=True, timeout=900)
     assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-2000:]
     assert out.stdout.count("bit-identical") == periods
+
+
+def test_target_grid_full_tables_two_periods():
+    """The north-star target grid (1e6 states x 500 actions x 200 demands), the bench headline's workload: EVERY state
+    of two periods (2e6 state-periods, 2e11 cells) against the oracle -- the period with a future term fed the GPU's own
+    V_2 -- values and policy indices bit-identical; the clamp edges of the grid are part of the table."""
+    import numpy as np
+    import stochastic_inventory_amd as sia
+    from oracle import sdpref
+    from stochastic_inventory_amd import workloads
+    w = workloads.target_grid(T=2)
+    threads = min(os.cpu_count() or 1, 16)
+    with sia.SdpEngine(w.desc(), w.pmf) as eng:
+        eng.solve()
+        assert eng.stats().cells_evaluated == 2 * 10 ** 11
+        P = sdpref.Problem(w.desc(), w.pmf)
+        v2, p2 = eng.values(2), eng.policy(2)
+        ov2, oa2, c2 = P.period(2, None, nthreads=threads)
+        assert np.array_equal(v2, ov2) and np.array_equal(p2, oa2) and c2 == 10 ** 11
+        ov1, oa1, _ = P.period(1, v2, nthreads=threads)
+        assert np.array_equal(eng.values(1), ov1) and np.array_equal(eng.policy(1), oa1)

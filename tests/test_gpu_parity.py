@@ -74,6 +74,20 @@ def test_cfg2_shape_reduced_horizon(sia, oracle, kernel):
     eng.close()
 
 
+def test_cfg2_full_horizon_full_tables(sia, oracle):
+    """configs[1] exactly as bench.py's secondary entry runs it: 1e4 x 200 x 100 at the FULL horizon of 52 periods
+    (1.04e10 cells; the oracle sweeps it in seconds on the box's threads) -- every table of every period, bit for bit."""
+    import os
+    from stochastic_inventory_amd import workloads
+    w = workloads.cfg2_clsp()
+    assert w.T == 52
+    eng, P, V, pol, cells = _solve_both(sia, oracle, w, 0, nthreads=min(os.cpu_count() or 1, 16))
+    assert cells == 10000 * 200 * 100 * 52 == eng.stats().cells_evaluated
+    for period in range(1, w.T + 1):
+        _assert_tables(eng.values(period), eng.policy(period), V[period - 1], pol[period - 1], f"cfg2 t={period}")
+    eng.close()
+
+
 def test_cfg3_shape_reduced(sia, oracle):
     """configs[2] family (2-D inventory x cash, ragged action counts) at 40 x 600 states."""
     from stochastic_inventory_amd import workloads
