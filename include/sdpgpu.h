@@ -88,7 +88,14 @@ typedef enum sdpgpu_family {
    * (x, q1, q2): q1 arrives this period, q2 the next; x' = x + q1 - d, q1' = q2, q2' = action. */
   SDPGPU_FAMILY_LEADTIME = 2,
   /* state (x, cash). CashConstraint.java:95-133 (cash_formula 0) and
-   * CashConstraintTesting.java:110-148 (cash_formula 1).  Lost sales, cash-limited orders. */
+   * CashConstraintTesting.java:110-148 (cash_formula 1).  Lost sales, cash-limited orders.
+   * cash_formula 2: sdp.cash.CashRecursionXR.getExpectedValue (CashRecursionXR.java:79-126) over the lambdas of
+   * cash.singleItem.CashConstraintXR (CashConstraintXR.java:84-125; Chao 2008): state (x, R) with working capital
+   * R = cash + variCost * x, actions = order-up-to levels y = x, x + 1, ... up to max(x, R / variCost).  The grid is
+   * (inventory, cash) as for formula 0 -- the transition rounds the cash balance (:120) before it forms R (:121) --
+   * and wherever this header says `cash` for a state of this family (ini_cash, sdpgpu_state_index,
+   * sdpgpu_eval_states) the value is R.  Policy indices k stand for y = x + k (getAction = x + k * step).
+   * max_order_quantity is not read (the reference's list is bounded by R / variCost only). */
   SDPGPU_FAMILY_CASH = 3,
   /* state (x, cash). CashOverdraft.java:72-118.  Piecewise overdraft interest. */
   SDPGPU_FAMILY_OVERDRAFT = 4,
@@ -166,7 +173,8 @@ typedef struct sdpgpu_desc {
   double cash_round_mult; /* Math.round(nextCash * mult) ... */
   double cash_round_div;  /* ... / div */
   int32_t cash_round_int_div; /* 1: `/ 10` long division (CashOverdraft.java:116); 0: `/ 10.0` */
-  int32_t cash_formula;       /* F3: 0 CashConstraint.java:103-119, 1 CashConstraintTesting.java:117-132 */
+  int32_t cash_formula;       /* F3: 0 CashConstraint.java:103-119, 1 CashConstraintTesting.java:117-132,
+                                 2 CashConstraintXR.java:91-105 (state (x, R), order-up-to actions) */
 
   /* overdraft interest schedule (F4/F5): CashOverdraft.java:86-95 */
   double r0;

@@ -126,6 +126,10 @@ static int32_t full_action_count(const sdpgpu_desc* d) {
   return jd2i(d->max_order_quantity / d->step) + 1;
 }
 
+/* sdp.cash.CashRecursionXR over cash.singleItem.CashConstraintXR's lambdas: family CASH with cash_formula 2.  The
+ * state is (period, x, R) -- st_t.cash holds R, literally what CashStateXR holds (CashStateXR.java:14-22). */
+static int is_xr(const sdpgpu_desc* d) { return d->family == SDPGPU_FAMILY_CASH && d->cash_formula == 2; }
+
 /* getFeasibleActions.apply(state).length */
 static int32_t n_actions(const ctx_t* c, const st_t* s) {
   const sdpgpu_desc* d = c->d;
@@ -138,6 +142,12 @@ static int32_t n_actions(const ctx_t* c, const st_t* s) {
     case SDPGPU_FAMILY_LEADTIME:  /* Leadtime.java:50-58 */
       return full_action_count(d);
     case SDPGPU_FAMILY_CASH: { /* CashConstraint.java:95-100 */
+      if (is_xr(d)) { /* CashConstraintXR.java:84-88 */
+        double variCost = d->unit_order_cost;
+        double maxY = s->cash / variCost < s->x ? s->x : s->cash / variCost; /* s.getIniR() / variCost */
+        int32_t length = jd2i(maxY - s->x) + 1;
+        return length;
+      }
       double maxQ = (double)jd2i(
           jmin(d->max_order_quantity,
                jmax(0.0, (s->cash - overhead_at(c, s->period) - d->fixed_order_cost) / d->unit_order_cost)));
@@ -160,8 +170,12 @@ static int32_t n_actions(const ctx_t* c, const st_t* s) {
 }
 
 /* DoubleStream.iterate(0, i -> i + stepSize): element k.  step is integer-valued so the
- * iterated sum equals k*step exactly. */
-static double action_value(const ctx_t* c, int32_t k) { return (double)k * c->d->step; }
+ * iterated sum equals k*step exactly.  CashConstraintXR.java:87 iterates from the inventory level instead: the
+ * action IS the order-up-to level y (x is an integer there, so x + k * step is the iterated sum too). */
+static double action_value(const ctx_t* c, const st_t* s, int32_t k) {
+  if (is_xr(c->d)) return s->x + (double)k * c->d->step;
+  return (double)k * c->d->step;
+}
 
 /* Piecewise interest, CashOverdraft.java:87-95 == SingleProductLeadtime.java:88-96. */
 static double overdraft_interest(const sdpgpu_desc* d, double cashBalanceBefore) {
@@ -205,6 +219,22 @@ static double imm_value(const ctx_t* c, const st_t* s, double action, double ran
       return totalCosts;
     }
     case SDPGPU_FAMILY_CASH: {
+      if (is_xr(d)) { /* CashConstraintXR.java:91-105; `action` is actionY, s->cash is iniR */
+        double actionY = action;
+        double variCost = d->unit_order_cost;
+        double revenue = d->price * jmin(actionY, randomDemand);
+        double act = actionY - s->x;
+        double fixedCost = actionY > s->x ? d->fixed_order_cost : 0;
+        double variableCost = variCost * act;
+        double initCash = s->cash - variCost * s->x;
+        double deposite = (initCash - fixedCost - variableCost) * (1 + d->deposit_rate);
+        double inventoryLevel = actionY - randomDemand;
+        double holdCosts = d->holding_cost * jmax(inventoryLevel, 0);
+        double cashIncrement = (1 - d->overhead_rate) * revenue + deposite - holdCosts - overhead_at(c, s->period) - initCash;
+        double salValue = s->period == c->T ? d->salvage_value * jmax(inventoryLevel, 0) : 0;
+        cashIncrement += salValue;
+        return cashIncrement;
+      }
       double revenue = d->price * jmin(s->x + action, randomDemand);
       double fixedCost = action > 0 ? d->fixed_order_cost : 0;
       double variableCost = d->unit_order_cost * action;
@@ -313,6 +343,22 @@ static void transition(const ctx_t* c, const st_t* s, double action, double rand
       return;
     }
     case SDPGPU_FAMILY_CASH:       /* CashConstraint.java:122-133 */
+      if (is_xr(d)) { /* CashConstraintXR.java:108-125; `action` is actionY */
+        double variCost = d->unit_order_cost;
+        double nextInventory = jmax(0, action - randomDemand);
+        double initCash = s->cash - variCost * s->x;
+        double nextCash = initCash + imm_value(c, s, action, randomDemand);
+        nextCash = nextCash > d->max_cash ? d->max_cash : nextCash;
+        nextCash = nextCash < d->min_cash ? d->min_cash : nextCash;
+        nextInventory = nextInventory > d->max_inventory ? d->max_inventory : nextInventory;
+        nextInventory = nextInventory < d->min_inventory ? d->min_inventory : nextInventory;
+        nextCash = round_cash(d, nextCash); /* :120 `Math.round(nextCash * 1) / 1` */
+        double nextR = nextCash + variCost * nextInventory;
+        out->x = nextInventory;
+        out->cash = nextR;
+        return;
+      }
+      /* fall through */
     case SDPGPU_FAMILY_SURVIVAL:   /* cashSurvival.java:128-143 (same statements; `Math.round(nextCash * 1) / 1`) */
     case SDPGPU_FAMILY_OVERDRAFT: { /* CashOverdraft.java:107-118 */
       double nextInventory = jmax(0, s->x + action - randomDemand);
@@ -368,7 +414,7 @@ static void eval_state(const ctx_t* c, const st_t* s, vlook_fn vlook, void* env,
      * multiplies by discountFactor: p * 1.0 == p, so discount_factor = 1 is RiskRecursion exactly). */
     val = -DBL_MAX; /* :70 */
     for (int32_t i = 0; i < nA; i++) {
-      double orderQty = action_value(c, i);
+      double orderQty = action_value(c, s, i);
       double thisQProb = 0;
       for (int32_t j = 0; j < n; j++) {
         double randomDemand = dem[j];
@@ -403,7 +449,7 @@ static void eval_state(const ctx_t* c, const st_t* s, vlook_fn vlook, void* env,
     return;
   }
   for (int32_t i = 0; i < nA; i++) {
-    double orderQty = action_value(c, i);
+    double orderQty = action_value(c, s, i);
     double thisQValue = 0;
     for (int32_t j = 0; j < n; j++) {
       if (cash_loop) { /* CashRecursion.java:113-122 */
@@ -505,8 +551,13 @@ static int64_t index_of(const sdpgpu_desc* d, const sdpref_grid* g, const st_t* 
   if ((double)ix != qx || ix < 0 || ix >= g->nx) return -1;
   int64_t ic = 0, iq = 0;
   if (has_cash(d->family)) {
-    int64_t k = cash_key(d, s->cash);
-    if (cash_of_key(d, k) != s->cash) return -1;
+    double cash = s->cash;
+    if (is_xr(d)) { /* key (x, R): the grid cash is the balance the transition rounded before it formed R */
+      cash = round_cash(d, s->cash - d->unit_order_cost * s->x);
+      if (cash + d->unit_order_cost * s->x != s->cash) return -1;
+    }
+    int64_t k = cash_key(d, cash);
+    if (cash_of_key(d, k) != cash) return -1;
     ic = k - g->k_lo;
     if (ic < 0 || ic >= g->nc) return -1;
   }
@@ -531,6 +582,7 @@ static void state_of(const sdpgpu_desc* d, const sdpref_grid* g, int32_t period,
   s->period = period;
   s->x = g->x_lo + (double)ix * d->step;
   s->cash = has_cash(d->family) ? cash_of_key(d, g->k_lo + ic) : 0;
+  if (is_xr(d)) s->cash = s->cash + d->unit_order_cost * s->x; /* R = nextCash + variCost * nextInventory */
   s->preq = has_preq(d->family) ? (double)(iq % g->nq1) * d->step : 0;
   s->preq2 = (double)(iq / g->nq1) * d->step;
 }
@@ -706,7 +758,7 @@ int sdpref_simulate(const sdpgpu_desc* d, const int32_t* pmf_off, const double* 
         int64_t idx = index_of(d, &grids[t], &state);
         double optQ;
         if (idx >= 0) {
-          optQ = action_value(&c, policy[values_off[t] + idx]);
+          optQ = action_value(&c, &state, policy[values_off[t] + idx]);
         } else if (t == 0) { /* recursion.getSurvProb(state); recursion.getAction(state) */
           dense_env env = {d, T > 1 ? &grids[1] : NULL, T > 1 ? values + values_off[1] : NULL, 0};
           double val;
@@ -742,7 +794,7 @@ int sdpref_simulate(const sdpgpu_desc* d, const int32_t* pmf_off, const double* 
       int64_t idx = index_of(d, &grids[t], &state);
       double optQ;
       if (idx >= 0) {
-        optQ = action_value(&c, policy[values_off[t] + idx]);
+        optQ = action_value(&c, &state, policy[values_off[t] + idx]);
       } else if (t == 0) { /* recursion.getExpectedValue(state); recursion.getAction(state) */
         dense_env env = {d, T > 1 ? &grids[1] : NULL, T > 1 ? values + values_off[1] : NULL, 0};
         double val;
@@ -807,7 +859,7 @@ int sdpref_reachable(const sdpgpu_desc* d, const int32_t* pmf_off, const double*
       for (int32_t i = 0; i < nA; i++)
         for (int32_t j = 0; j < n; j++) {
           st_t nx;
-          transition(&c, &s, action_value(&c, i), pmf_d[pmf_off[period - 1] + j], &nx);
+          transition(&c, &s, action_value(&c, &s, i), pmf_d[pmf_off[period - 1] + j], &nx);
           if (d->family == SDPGPU_FAMILY_SURVIVAL && nx.cash < 0) continue; /* RiskRecursion.java:90-92: not visited */
           int64_t ni = index_of(d, &grids[period], &nx);
           if (ni < 0) {

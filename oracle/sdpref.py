@@ -210,7 +210,9 @@ class Problem:
         return out, (valid & 1).astype(bool)
 
     def state_arrays(self, period: int):
-        """(x, cash, preq) value arrays of every grid state of `period`, in flat-index order."""
+        """(x, cash, preq) value arrays of every grid state of `period`, in flat-index order.  For the (x, R) state of
+        CashConstraintXR (family CASH, cash_formula 2) the `cash` column is R = cash + variCost * x: the state tuple
+        of that family, here as at the C ABI."""
         g = self.grids[period - 1]
         d = self.desc
         idx = np.arange(g.nx * g.nc * g.nq)
@@ -223,6 +225,8 @@ class Problem:
             cash = k if d.cash_round_int_div else k / d.cash_round_div
         else:
             cash = np.zeros(len(idx))
+        if d.family == 3 and d.cash_formula == 2:
+            cash = cash + d.unit_order_cost * x
         preq = (iq % g.nq1) * d.step if d.family in (2, 5) else np.zeros(len(idx))
         return x.astype(np.float64), cash.astype(np.float64), preq.astype(np.float64)
 

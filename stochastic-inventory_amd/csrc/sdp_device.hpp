@@ -64,12 +64,38 @@ __device__ __forceinline__ double jround_d(double x) {
 struct StateT {
   double x, cash, preq;
   double preq2 = 0;  // lead time 2: the order arriving next period
+  double r = 0;      // CASH family, cash_formula 2 (CashConstraintXR.java): working capital R = cash + variCost * x
 };
+
+// CASH family with cash_formula 2 = the (x, R) state of sdp.cash.CashRecursionXR over the lambdas of
+// cash.singleItem.CashConstraintXR (CashConstraintXR.java:84-125; Chao 2008).  The grid is still (inventory, cash key):
+// the transition rounds the cash balance to a grid value and stores R = nextCash + variCost * nextInventory (:121),
+// and every lambda starts from initCash = R - variCost * x (:94, :112), which need not equal the rounded balance bit
+// for bit when variCost * x is inexact -- so R is formed and subtracted exactly as the reference does.
+// from_grid: s.cash holds the grid's cash value; else (a queried state) s.cash holds R itself.
+template <int FAM>
+__device__ __forceinline__ void xr_state(const DevParams& P, StateT& s, bool from_grid) {
+  if constexpr (FAM == FAM_CASH) {
+    if (P.cash_formula == 2) {
+      const double cx = P.v * s.x;
+      s.r = from_grid ? s.cash + cx : s.cash;
+      s.cash = s.r - cx;
+    }
+  }
+}
 
 // getFeasibleActions.apply(state).length -- see n_actions() in oracle/sdpref.c for the citations.
 template <int FAM>
 __device__ __forceinline__ int n_actions(const DevParams& P, const StateT& s) {
   if constexpr (FAM == FAM_CASH) {
+    if (P.cash_formula == 2) {
+      // CashConstraintXR.java:84-88: order-up-to levels y = x, x + 1, ... , `(int) (maxY - x) + 1` of them with
+      // maxY = R / variCost < x ? x : R / variCost.  Action index k stands for y = x + k.
+      const double ry = s.r / P.v;
+      const double maxY = ry < s.x ? s.x : ry;
+      const double len = maxY - s.x;
+      return ((len != len) ? 0 : (int)len) + 1;
+    }
     // CashConstraint.java:96-99: (int) Math.min(maxOrderQuantity, Math.max(0, (cash - overhead - K) / v))
     double m = jmin(P.max_order_quantity, jmax(0.0, (s.cash - P.overhead - P.K) / P.v));
     int mq = (m != m) ? 0 : (int)m;  // Java (int)NaN == 0
@@ -188,7 +214,7 @@ __device__ __forceinline__ double cell(const DevParams& P, const StateT& s, cons
     double level = c.base - d;
     double hold = P.h * jmax(level, 0.0);
     double inc;
-    if (P.cash_formula == 0)
+    if (P.cash_formula != 1)  // formula 0 and the (x, R) state of CashConstraintXR.java:91-105 (s.cash = initCash there)
       inc = P.one_minus_overhead_rate * revenue + c.deposit - hold - P.overhead - s.cash;
     else
       inc = revenue - c.fixed - c.var - hold - P.overhead;
@@ -266,6 +292,7 @@ __device__ __forceinline__ void decode_state(const DevParams& P, int64_t idx, St
     double k = (double)(P.cur.k_lo + ic);
     s.cash = P.cash_round_int_div ? k : k / P.round_div;  // the double Math.round(c*m)/div yields
     if constexpr (FAM == FAM_CASH_LEADTIME) s.preq = (double)iq * P.step;
+    xr_state<FAM>(P, s, true);
   }
 }
 

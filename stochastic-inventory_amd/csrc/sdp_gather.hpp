@@ -67,6 +67,7 @@ __global__ __launch_bounds__(256) void gather_period_kernel(DevParams P, const d
     s.cash = (live && q.cash) ? q.cash[idx] : 0.0;
     s.preq = (live && q.preq) ? q.preq[idx] : 0.0;
     s.preq2 = (live && q.preq2) ? q.preq2[idx] : 0.0;
+    xr_state<FAM>(P, s, false);  // (x, R) family: the queried "cash" is R
   } else {
     decode_state<FAM>(P, live ? idx : lo, s);
   }
@@ -178,6 +179,7 @@ __global__ __launch_bounds__(256) void reach_kernel(DevParams P, const uint8_t* 
     s.cash = q.cash ? q.cash[idx] : 0.0;
     s.preq = q.preq ? q.preq[idx] : 0.0;
     s.preq2 = q.preq2 ? q.preq2[idx] : 0.0;
+    xr_state<FAM>(P, s, false);
   } else {
     if (!mask_cur[idx]) return;
     decode_state<FAM>(P, idx, s);

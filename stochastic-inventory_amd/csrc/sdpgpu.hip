@@ -47,6 +47,14 @@ int validate(const sdpgpu_desc& d) {
     if (d.cash_round_int_div && d.cash_round_div != std::floor(d.cash_round_div)) return fail(nullptr, SDPGPU_ERR_ARG, "integer cash divisor must be integral");
     if (std::fabs(d.min_cash * d.cash_round_mult) > 2.0e9 || std::fabs(d.max_cash * d.cash_round_mult) > 2.0e9) return fail(nullptr, SDPGPU_ERR_UNSUPPORTED, "cash keys exceed 32 bits");
   }
+  if (d.cash_formula < 0 || d.cash_formula > 2) return fail(nullptr, SDPGPU_ERR_ARG, "cash_formula %d (0 CashConstraint, 1 CashConstraintTesting, 2 CashConstraintXR)", d.cash_formula);
+  if (d.cash_formula == 2) {  // sdp.cash.CashRecursionXR over cash.singleItem.CashConstraintXR's lambdas: state (x, R)
+    if (d.family != SDPGPU_FAMILY_CASH) return fail(nullptr, SDPGPU_ERR_ARG, "cash_formula 2 (the (x, R) state of CashConstraintXR) belongs to the CASH family");
+    if (d.step != 1) return fail(nullptr, SDPGPU_ERR_UNSUPPORTED, "CashConstraintXR's action list has (int)(maxY - x) + 1 entries whatever the step (CashConstraintXR.java:86-87): step must be 1");
+    if (d.penalty_cost != 0) return fail(nullptr, SDPGPU_ERR_ARG, "CashConstraintXR's immediate value has no end-cash penalty: penalty_cost must be 0");
+    if (!(d.unit_order_cost > 0)) return fail(nullptr, SDPGPU_ERR_ARG, "CashConstraintXR divides by variCost: unit_order_cost must be positive");
+    if (d.min_inventory != std::floor(d.min_inventory)) return fail(nullptr, SDPGPU_ERR_ARG, "inventory bounds must be integers");
+  }
   if (d.lead_time < 0 || d.lead_time > 2) return fail(nullptr, SDPGPU_ERR_ARG, "lead_time %d (0/1 = the reference's lead time 1, 2 = two-stage pipeline)", d.lead_time);
   if (d.lead_time == 2) {
     if (d.family != SDPGPU_FAMILY_LEADTIME) return fail(nullptr, SDPGPU_ERR_UNSUPPORTED, "lead_time 2 exists for the LEADTIME family only");
@@ -280,8 +288,21 @@ void count_cells(sdpgpu_handle* h, int period) {
       if (d.family == SDPGPU_FAMILY_CASH_LEADTIME && d.zero_order_last_period && period == h->T) nA = 1;
       return (hi - lo) * nA * nD;
     }
-    // F3: nA depends on the cash index only; flat = ix * nc + ic
     int64_t nc = p.g.nc;
+    if (d.cash_formula == 2) {  // (x, R): the count depends on both coordinates (CashConstraintXR.java:84-88)
+      int64_t total = 0;
+      for (int64_t idx = lo; idx < hi; ++idx) {
+        const double x = p.g.x_lo + (double)(idx / nc) * d.step;
+        const double k = (double)(p.g.k_lo + idx % nc);
+        const double cash = d.cash_round_int_div ? k : k / d.cash_round_div;
+        const double R = cash + d.unit_order_cost * x;
+        const double ry = R / d.unit_order_cost;
+        const double maxY = ry < x ? x : ry;
+        total += (int64_t)java_d2i(maxY - x) + 1;
+      }
+      return total * nD;
+    }
+    // F3: nA depends on the cash index only; flat = ix * nc + ic
     std::vector<int64_t> pre((size_t)nc + 1, 0);
     for (int64_t ic = 0; ic < nc; ++ic) {
       double k = (double)(p.g.k_lo + ic);
@@ -774,9 +795,16 @@ int64_t sdpgpu_state_index2(const sdpgpu_handle* hc, int32_t period, double x, d
   int64_t ic = 0, iq = 0;
   if (has_cash(d.family)) {
     if (!(std::fabs(cash) < 4.0e15)) return -1;  // NaN, infinities, beyond exact integers: not a grid point
+    const bool xr = d.cash_formula == 2;  // the state tuple is (x, R): `cash` is R = gridCash + variCost * x
+    const double r_in = cash;
+    if (xr) {  // the grid cash nearest to R - variCost * x; the exact R is required below
+      const double approx = r_in - d.unit_order_cost * x;
+      cash = d.cash_round_int_div ? (double)java_round(approx) : (double)java_round(approx * d.cash_round_mult) / d.cash_round_div;
+    }
     int64_t k = d.cash_round_int_div ? (int64_t)cash : java_round(cash * d.cash_round_mult);
     double back = d.cash_round_int_div ? (double)k : (double)k / d.cash_round_div;
     if (back != cash) return -1;
+    if (xr && back + d.unit_order_cost * x != r_in) return -1;  // not the R the transition would have formed
     ic = k - g.k_lo;
     if (ic < 0 || ic >= g.nc) return -1;
   }
@@ -1089,6 +1117,10 @@ int sdpgpu_reachable(sdpgpu_handle* h, int32_t period, uint8_t* out, int64_t n) 
 
 int sdpgpu_simulate(sdpgpu_handle* h, int64_t n_paths, const double* demand, const double* discount, double ini_x,
                     double ini_cash, double ini_preq, double* out_sum, uint8_t* out_valid) {
+  if (h && h->d.cash_formula == 2) {
+    h->err.clear();
+    return fail(h, SDPGPU_ERR_UNSUPPORTED, "simulate: not built for the (x, R) state of CashConstraintXR (CashSimulationXR is out of scope)");
+  }
   if (!h) return SDPGPU_ERR_ARG;
   h->err.clear();
   if (n_paths < 0 || !demand || !discount || !out_sum || !out_valid) return fail(h, SDPGPU_ERR_ARG, "simulate: bad argument");

@@ -13,6 +13,7 @@ bool cash_shift_eligible(const sdpgpu_handle* h, int period) {
   const sdpgpu_desc& d = h->d;
   if (h->custom) return false;
   if (d.family != SDPGPU_FAMILY_CASH || !d.clamp_inventory) return false;
+  if (d.cash_formula == 2) return false;  // (x, R) state: its own feasible-action rule (cash row / generic kernel)
   if (d.deposit_rate != 0 || d.overhead_rate != 0 || d.penalty_cost != 0) return false;
   double q;
   if (d.cash_round_int_div) {
@@ -156,10 +157,11 @@ hipError_t launch_cash_row(sdpgpu_handle* h, const DevParams& P, int period, con
 #define SDP_ROWARGS P, last, intdiv, v_next, v_cur, pol, pmf_d, pmf_p, lo, hi, row_lo, tiles_per_row, grid, smem, st
   switch (P.family) {
     case sdp::FAM_CASH:
+      // (cash_formula 2, the (x, R) state of CashConstraintXR: formula 0's increment on initCash = R - variCost * x)
       if (P.pi != 0.0)
-        return P.cash_formula == 0 ? launch_cash_row_fam<sdp::FAM_CASH, false, true>(SDP_ROWARGS)
+        return P.cash_formula != 1 ? launch_cash_row_fam<sdp::FAM_CASH, false, true>(SDP_ROWARGS)
                                    : launch_cash_row_fam<sdp::FAM_CASH, true, true>(SDP_ROWARGS);
-      return P.cash_formula == 0 ? launch_cash_row_fam<sdp::FAM_CASH, false>(SDP_ROWARGS)
+      return P.cash_formula != 1 ? launch_cash_row_fam<sdp::FAM_CASH, false>(SDP_ROWARGS)
                                  : launch_cash_row_fam<sdp::FAM_CASH, true>(SDP_ROWARGS);
     case sdp::FAM_OVERDRAFT: return launch_cash_row_fam<sdp::FAM_OVERDRAFT, false>(SDP_ROWARGS);
     case sdp::FAM_CASH_LEADTIME: return launch_cash_row_fam<sdp::FAM_CASH_LEADTIME, false>(SDP_ROWARGS);

@@ -17,7 +17,7 @@ from dataclasses import dataclass, field
 from typing import List, Optional
 
 from . import _abi
-from .states import CashLeadtimeState, CashState, LeadtimeState, OptDirection, RiskState, State
+from .states import CashStateXR, CashLeadtimeState, CashState, LeadtimeState, OptDirection, RiskState, State
 
 
 def java_round(x: float) -> int:
@@ -280,6 +280,60 @@ class CashFunctor(_Base):
         nextInventory = self.minInventoryState if nextInventory < self.minInventoryState else nextInventory
         nextCash = self._round_cash(nextCash)
         return CashState(s.getPeriod() + 1, nextInventory, nextCash)
+
+
+@dataclass
+class CashXRFunctor(CashFunctor):
+    """The lambdas of cash.singleItem.CashConstraintXR (CashConstraintXR.java:84-125; Chao 2008) under
+    sdp.cash.CashRecursionXR: state (x, R) with R = cash + variCost * x, actions = order-up-to levels
+    y = x, x + 1, ... up to max(x, R / variCost), `Math.round(nextCash * 1) / 1`.  maxOrderQuantity is declared in the
+    driver (:50) and never read by its lambdas; iniCash is the R of the period-1 state (:132)."""
+
+    cashRoundMult: float = 1.0
+    cashRoundDiv: float = 1.0
+    cashRoundIntDiv: bool = True
+    cashFormula: int = 2
+
+    state_type = CashStateXR
+
+    def make_state(self, period, x, cash=0.0, preq=0.0):
+        """`cash` is R (the engine's convention for this family, include/sdpgpu.h)."""
+        return CashStateXR(period, x, cash, self.variCost)
+
+    def tuple_of(self, s):
+        return (s.getIniInventory(), s.getIniR(), 0.0)
+
+    def feasibleActions(self, s, T=None):
+        x = s.getIniInventory()
+        maxY = x if s.getIniR() / self.variCost < x else s.getIniR() / self.variCost
+        length = _d2i(maxY - x) + 1
+        return [x + k * self.stepSize for k in range(length)]
+
+    def immediateValue(self, s, actionY, randomDemand, T=None):
+        revenue = self.price * min(actionY, randomDemand)
+        action = actionY - s.getIniInventory()
+        fixedCost = self.fixOrderCost if actionY > s.getIniInventory() else 0.0
+        variableCost = self.variCost * action
+        initCash = s.getIniR() - self.variCost * s.getIniInventory()
+        deposite = (initCash - fixedCost - variableCost) * (1 + self.depositeRate)
+        inventoryLevel = actionY - randomDemand
+        holdCosts = self.holdingCost * max(inventoryLevel, 0.0)
+        cashIncrement = (1 - self.overheadRate) * revenue + deposite - holdCosts - self._oh(s.getPeriod()) - initCash
+        salValue = self.salvageValue * max(inventoryLevel, 0.0) if s.getPeriod() == T else 0.0
+        cashIncrement += salValue
+        return cashIncrement
+
+    def stateTransition(self, s, actionY, randomDemand, T=None):
+        nextInventory = max(0.0, actionY - randomDemand)
+        initCash = s.getIniR() - self.variCost * s.getIniInventory()
+        nextCash = initCash + self.immediateValue(s, actionY, randomDemand, T)
+        nextCash = self.maxCashState if nextCash > self.maxCashState else nextCash
+        nextCash = self.minCashState if nextCash < self.minCashState else nextCash
+        nextInventory = self.maxInventoryState if nextInventory > self.maxInventoryState else nextInventory
+        nextInventory = self.minInventoryState if nextInventory < self.minInventoryState else nextInventory
+        nextCash = self._round_cash(nextCash)
+        nextR = nextCash + self.variCost * nextInventory
+        return CashStateXR(s.getPeriod() + 1, nextInventory, nextR, self.variCost)
 
 
 @dataclass

@@ -80,6 +80,23 @@ class NormalDist(Distribution):
         return self.sigma
 
 
+class GammaDist(Distribution):
+    """umontreal.ssj.probdist.GammaDist(alpha, lambda): shape alpha, RATE lambda (mean alpha / lambda) -- the demand of
+    cash.singleItem.CashConstraintXR.main (CashConstraintXR.java:67: `new GammaDist(meanDemand[i], 2)`)."""
+
+    def __init__(self, alpha: float, lam: float):
+        self.alpha, self.lam = float(alpha), float(lam)
+
+    def cdf(self, x: float) -> float:
+        return float(stats.gamma.cdf(x, self.alpha, scale=1.0 / self.lam)) if x > 0 else 0.0
+
+    def inverseF(self, u: float) -> float:
+        return float(stats.gamma.ppf(u, self.alpha, scale=1.0 / self.lam))
+
+    def getMean(self) -> float:
+        return self.alpha / self.lam
+
+
 class UniformIntDist(Distribution):
     """umontreal.ssj.probdist.UniformIntDist(i, j)."""
 

@@ -287,6 +287,38 @@ class CashRecursion(_GpuRecursionBase):
         return 4
 
 
+class CashRecursionXR(CashRecursion):
+    """sdp.cash.CashRecursionXR (CashRecursionXR.java:39-56,79-126): the discounted loop of CashRecursion on
+    CashStateXR keys (period, x, R), R = cash + variCost * x; the actions ARE order-up-to levels, so getAction
+    returns y (`bestY`, :96,:103-113).  Rows of getOptTable are {period, x, S, R, y} with S = R - unitVariCost * x
+    (:185-200).  Functor: CashXRFunctor (the lambdas of cash.singleItem.CashConstraintXR)."""
+
+    def getAction(self, state) -> float:
+        return state.getIniInventory() + self._lookup(state)[1] * self.functor.stepSize
+
+    def _opt_columns(self, period, idx, q):
+        x_lo, nx, nc, nq = self._engine.grid(period)
+        ix, ic = idx // nc, idx % nc
+        x = x_lo + ix * self.functor.stepSize
+        cash_of = {int(c): self._engine.cash_value(int(c)) for c in np.unique(ic)}
+        cash = np.array([cash_of[int(c)] for c in ic])
+        R = cash + self.functor.variCost * x  # what the transition stores (CashConstraintXR.java:121)
+        return np.stack([np.full(len(idx), float(period)), x, R - self.functor.variCost * x, R, x + q], axis=1)
+
+    def _row_tuple(self, r):
+        return (r[1], r[3])
+
+    def _row_of_state(self, s, action):
+        return np.array([[float(s.getPeriod()), s.getIniInventory(), s.getIniR() - self.functor.variCost * s.getIniInventory(),
+                          s.getIniR(), action]])
+
+    def _ncols(self):
+        return 5
+
+    def getCacheActions(self):
+        return {self.functor.make_state(int(r[0]), r[1], r[3]): float(r[4]) for r in self.getOptTable()}
+
+
 class RiskRecursion(CashRecursion):
     """sdp.cash.RiskRecursion (RiskRecursion.java:31-46): the survival-probability recursion, MAX only, no
     discount; `getSurvProb` (:65-108) takes the place of getExpectedValue.  Rows of getOptTable are

@@ -84,6 +84,26 @@ class CashState(State):
         return f"period = {self.period}, iniInventory = {self.initialInventory}, iniCash = {self.iniCash}"
 
 
+class CashStateXR(State):
+    """sdp.cash.CashStateXR (CashStateXR.java:14-57): (period, inventory x, working capital R = cash + variCost * x);
+    the unit cost rides along for getOptTable's S column and takes no part in equality (:43-50)."""
+    __slots__ = ("iniR", "unitVariCost")
+
+    def __init__(self, period: int, iniInventory: float, R: float, variCost: float = 0.0):
+        super().__init__(period, iniInventory)
+        object.__setattr__(self, "iniR", float(R))
+        object.__setattr__(self, "unitVariCost", float(variCost))
+
+    def getIniR(self) -> float:
+        return self.iniR
+
+    def _key(self):
+        return (self.period, self.initialInventory, self.iniR)
+
+    def __repr__(self):
+        return f"period = {self.period}, iniInventory = {self.initialInventory}, iniR = {self.iniR}"
+
+
 class RiskState(CashState):
     """RiskState.java:12-52.  The constructor there ignores its `bankruptBefore` argument (`:17` assigns the
     literal false), and RiskRecursion's comparator (RiskRecursion.java:39-42) does not look at the flag."""

@@ -100,8 +100,10 @@ def test_layout_agrees_with_the_oracle(sia, oracle, make):
         assert eng.grid2(period) == (g.x_lo, g.nx, g.nc, g.nq1, g.nq // g.nq1)
         for idx in (0, len(x) // 3, len(x) - 1):
             assert eng.state_index(period, x[idx], cash[idx], preq[idx], preq2[idx]) == idx
-            if g.nc > 1:
+            if g.nc > 1 and w.desc().cash_formula != 2:
                 assert eng.cash_value(idx % g.nc) == cash[idx]
+            elif g.nc > 1:  # the (x, R) state: the tuple's second entry is R = grid cash + variCost * x
+                assert eng.cash_value(idx % g.nc) + w.functor.variCost * x[idx] == cash[idx]
     assert eng.state_index(1, 0.5, 0.0, 0.0) == -1
     eng.close()
 

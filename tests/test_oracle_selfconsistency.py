@@ -31,7 +31,8 @@ def test_dense_equals_memoised_on_reachable_set(oracle, make):
             continue
         assert reach[period - 1][idx]
         assert V[period - 1][idx] == m["values"][i], (period, idx)
-        assert pol[period - 1][idx] * step == m["actions"][i], (period, idx)
+        base = m["x"][i] if getattr(f, "cashFormula", 0) == 2 else 0.0  # (x, R) family: the action is the level y
+        assert base + pol[period - 1][idx] * step == m["actions"][i], (period, idx)
 
 
 def _ini_on_grid(P, w):
@@ -49,6 +50,11 @@ def _index(P, period, x, cash, preq, preq2=0.0):
         return -1
     ic = iq = 0
     if d.family in (3, 4, 5, 6):
+        if d.family == 3 and d.cash_formula == 2:  # the (x, R) state: `cash` is R = rounded balance + variCost * x
+            r_in = cash
+            cash = float(round(r_in - d.unit_order_cost * x))
+            if cash + d.unit_order_cost * x != r_in:
+                return -1
         k = int(cash) if d.cash_round_int_div else round(cash * d.cash_round_mult)
         back = float(k) if d.cash_round_int_div else k / d.cash_round_div
         if back != cash:
