@@ -274,33 +274,54 @@ __global__ __launch_bounds__(256) void cash_shift_kernel(CashShiftParams P, cons
 // cash_index() in sdp_device.hpp with fewer instructions: the two clamp ternaries become v_min/v_max (they differ
 // from the ternaries only in the sign of a zero, which Math.round maps to the same key) and the tie rule of
 // Math.round is folded into the integer add.
+// The clamp moves behind the quantiser: q(x) = Math.round(x * mult) [/ div] is monotone non-decreasing and the grid's end
+// keys are q(minCash), q(maxCash) (cash_key_of_bound on the host), so q(clamp(x, minCash, maxCash)) ==
+// clamp(q(x), q(minCash), q(maxCash)) for every x -- one v_med3_i32 instead of v_min_f64 + v_max_f64.  The launcher
+// only takes this kernel when |x * mult| stays far below 2^31 (cash_row_eligible), so the conversion never saturates.
 template <bool INTDIV>
-__device__ __forceinline__ int cash_key_row(double next_cash, double min_cash, double max_cash, double round_mult,
-                                            double round_div) {
-  const double c = fmax(fmin(next_cash, max_cash), min_cash);
-  const double xm = c * round_mult;
+__device__ __forceinline__ int cash_key_row(double next_cash, int key_lo, int key_hi, double round_mult, double round_div) {
+  const double xm = next_cash * round_mult;
   const double f = floor(xm);
   int k = (int)f + ((xm - f) >= 0.5 ? 1 : 0);
   if constexpr (INTDIV) k = (int)trunc((double)k / round_div);  // `/ 10`: long division (CashOverdraft.java:116)
-  return k;
+  return med3_i32(k, key_lo, key_hi);
 }
 
 struct alignas(16) RowEnt {
   double u;       // F3 formula 0: (1 - overheadRate) * revenue; formula 1: the whole increment; F4/F5/F6: revenue
   double hold;    // holdingCost * max(level, 0)
   double sal;     // salvageValue * max(level, 0) (period T)
-  int32_t rowoff; // flat offset of the next state's inventory row: inv_index * nc (0 in period T)
+  int32_t rowoff8; // BYTE offset of the next state's inventory row less the grid's first key: 8 * (inv_index * nc - k_lo),
+                   // so that a cell's gather address is v_next + (rowoff8 + 8 * key): one v_lshl_add_u32, scalar base
   int32_t pad;
 };
 
 // FORMULA1: F3 with CashConstraintTesting.java's increment (no cash term); INTDIV: the quantiser divides by an
-// integer other than 1; PEN: F3 with a non-zero end-cash penalty rate (CashConstraint.java:115-118).
-template <int FAM, bool LAST, bool FORMULA1, bool INTDIV, bool PEN = false>
+// integer other than 1; PEN: F3 with a non-zero end-cash penalty rate (CashConstraint.java:115-118); LEAN: F3 formula
+// 0 / 2 with holdingCost == +0.0 and overheadCost == +0.0 (CashConstraint.main, CashConstraintXR.main): the two
+// subtractions `- holdCosts - overheadCost` of the increment subtract +0.0, the identity on every double, and are skipped.
+//
+// Block -> tile map (RowTiling): the V_{t+1} table of these grids (1e7 states = 80 MB) is far larger than an XCD's
+// 4 MB L2, and a tile's cells read, per next-inventory row, a window of a few thousand cash points around its own
+// position.  With blocks numbered row-major the ~600 workgroups in flight span the whole cash axis of two rows, their
+// union of windows is the whole of ~125 rows (20 MB), and three L2 requests in four miss (rocprofv3: TCC_MISS 1.35e9 of
+// 1.79e9, 172 GB per launch through the fabric at 8 TB/s = the kernel's time).  So the cash axis is cut into 8 * nsub
+// bands of `tps` tiles: XCD i (blocks b with b % 8 == i, the dispatcher's round-robin) owns bands i*nsub .. , and walks
+// band by band, inside a band row by row: what is in flight on one XCD is a few rows of ONE narrow band, whose
+// windows (~125 rows x ~20 KB) fit its L2.  Placement only: any map is correct.
+struct RowTiling {
+  int32_t tiles_per_row;
+  int32_t n_rows;  // inventory(/preQ) rows launched
+  int32_t tps;     // tiles per band; 0 = plain row-major numbering (short rows)
+  int32_t nsub;    // bands per XCD
+};
+
+template <int FAM, bool LAST, bool FORMULA1, bool INTDIV, bool PEN = false, bool LEAN = false>
 __global__ __launch_bounds__(256) void cash_row_kernel(DevParams P, const double* __restrict__ v_next,
                                                        double* __restrict__ v_cur, int32_t* __restrict__ pol,
                                                        const double* __restrict__ pmf_d,
                                                        const double* __restrict__ pmf_p, int64_t lo, int64_t hi,
-                                                       int64_t row0, int tiles_per_row) {
+                                                       int64_t row0, RowTiling G) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int D = P.n_demand;
   double2* s_p = reinterpret_cast<double2*>(smem);                  // {p_j, p_j * gamma}
@@ -312,14 +333,26 @@ __global__ __launch_bounds__(256) void cash_row_kernel(DevParams P, const double
   const int tid = threadIdx.x;
   const int lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  int row_i, tile;
+  if (G.tps == 0) {
+    row_i = blockIdx.x / G.tiles_per_row;
+    tile = blockIdx.x % G.tiles_per_row;
+  } else {
+    const int xcd = blockIdx.x & 7, n = blockIdx.x >> 3;
+    const int per_band = G.n_rows * G.tps;
+    const int sub = n / per_band, rem = n - sub * per_band;
+    row_i = rem / G.tps;
+    tile = (xcd * G.nsub + sub) * G.tps + (rem - row_i * G.tps);
+    if (tile >= G.tiles_per_row) return;  // the bands cover a little more than the row (whole workgroup leaves)
+  }
   for (int j = tid; j < D; j += 256) {
     s_d[j] = pmf_d[j];
     s_p[j] = make_double2(pmf_p[j], pmf_p[j] * P.gamma);
   }
   __syncthreads();
 
-  const int64_t row = row0 + blockIdx.x / tiles_per_row;  // (iq * nx + ix)
-  const int ic0 = (blockIdx.x % tiles_per_row) * 64;
+  const int64_t row = row0 + row_i;  // (iq * nx + ix)
+  const int ic0 = tile * 64;
   const int nc = (int)P.cur.nc;
   const int ic = ic0 + lane;
   const int ic_c = ic < nc ? ic : nc - 1;
@@ -345,9 +378,14 @@ __global__ __launch_bounds__(256) void cash_row_kernel(DevParams P, const double
   double best = MAXDIR ? -1.7976931348623157e308 : 1.7976931348623157e308;
   int bestk = 0;
   // loop invariants of the cash quantiser, in registers
-  const double min_cash = P.min_cash, max_cash = P.max_cash, round_mult = P.round_mult, round_div = P.round_div;
+  const double round_mult = P.round_mult, round_div = P.round_div;
   const double overhead = P.overhead;
   const int k_lo_next = (int)P.next.k_lo;
+  // keys of minCash / maxCash, parked in VGPRs once (v_med3_i32 below takes vector operands; left to itself the
+  // compiler keeps the two wave-uniform values in SGPRs and copies them over in every cell)
+  int key_lo_v, key_hi_v;
+  asm volatile("v_mov_b32 %0, %1" : "=v"(key_lo_v) : "s"(k_lo_next));
+  asm volatile("v_mov_b32 %0, %1" : "=v"(key_hi_v) : "s"(k_lo_next + (int)P.next.nc - 1));
   for (int k = wave; k < nA_max; k += 4) {
     // ---- wave-uniform part, lanes = demand indices --------------------------------------------
     const double a = (double)k * P.step;
@@ -373,13 +411,13 @@ __global__ __launch_bounds__(256) void cash_row_kernel(DevParams P, const double
       } else {
         e.u = revenue;
       }
-      e.rowoff = 0;
+      e.rowoff8 = 0;
       e.pad = 0;
       if constexpr (!LAST) {
         double ninv = jmax(0.0, level);
         ninv = ninv > P.max_inventory ? P.max_inventory : ninv;
         ninv = ninv < P.min_inventory ? P.min_inventory : ninv;
-        e.rowoff = inv_index(P, ninv) * (int)P.next.nc - k_lo_next;  // + cash key = flat index
+        e.rowoff8 = (inv_index(P, ninv) * (int)P.next.nc - k_lo_next) * 8;  // + 8 * cash key = byte offset of the state
       }
       ent[j] = e;
     }
@@ -397,17 +435,26 @@ __global__ __launch_bounds__(256) void cash_row_kernel(DevParams P, const double
       const double before = s.cash - var - P.overhead;
       dep_or_bi = before - overdraft_interest(P, before);
     }
-    const int64_t qoff = (FAM == FAM_CASH_LEADTIME && !LAST) ? (int64_t)k * P.next.nx * P.next.nc : 0;
-
+    // the plane of the next pipeline quantity (F5: next preQ = action) goes into the scalar base address
+    const char* vbase = reinterpret_cast<const char*>(v_next + ((FAM == FAM_CASH_LEADTIME && !LAST) ? (int64_t)k * P.next.nx * P.next.nc : 0));
     // ---- the demand loop: serial in j, reference order -------------------------------------------
+    // U demand steps per trip: their cash-dependent tails are formed first and the U gathers issued back to back (a
+    // wave then has U loads in flight instead of one), and the accumulator takes the 2U addends afterwards in the
+    // reference's order -- the same operations on the same operands as the one-step loop.
+    constexpr int U = 4;
     double acc = 0.0;
-    for (int j = 0; j < D; ++j) {
-      const RowEnt e = ent[j];
-      const double2 pp = s_p[j];
+    // one step's tail: add1 = the first addend (p * imm; survival, period T: p * [final cash >= 0]), off = byte offset of
+    // the successor (or dead: a bankrupt successor of the survival family, worth 0)
+    auto tail = [&](const RowEnt& e, const double2 pp, double& add1, uint32_t& off, bool& dead) {
       double inc;
+      dead = false;
+      off = 0;
       if constexpr (FAM == FAM_CASH) {
         if constexpr (!FORMULA1) {
-          inc = e.u + dep_or_bi - e.hold - overhead - s.cash;
+          if constexpr (LEAN)
+            inc = e.u + dep_or_bi - s.cash;  // (- holdCosts - overheadCost: both +0.0)
+          else
+            inc = e.u + dep_or_bi - e.hold - overhead - s.cash;
           if constexpr (LAST) inc += e.sal;
         } else {
           inc = e.u;
@@ -416,30 +463,56 @@ __global__ __launch_bounds__(256) void cash_row_kernel(DevParams P, const double
           const double end_cash = s.cash + inc;
           if (end_cash < 0) inc += P.pi * end_cash;
         }  // (with a zero penalty rate `inc += 0 * endCash` changes nothing and is skipped)
-        acc += pp.x * inc;
-        if constexpr (!LAST) {
-          const double ncash = s.cash + inc;  // CashConstraint.java:125
-          acc += pp.y * v_next[(unsigned)(e.rowoff + cash_key_row<INTDIV>(ncash, min_cash, max_cash, round_mult, round_div))];
-        }
+        add1 = pp.x * inc;
       } else if constexpr (FAM == FAM_SURVIVAL) {
         inc = e.u + dep_or_bi - e.hold - overhead - s.cash;
         if constexpr (LAST) {
           inc += e.sal;
-          acc += pp.x * ((s.cash + inc) >= 0 ? 1.0 : 0.0);
+          add1 = pp.x * ((s.cash + inc) >= 0 ? 1.0 : 0.0);
         } else {
-          const int key = cash_key_row<INTDIV>(s.cash + inc, min_cash, max_cash, round_mult, round_div);
-          acc += pp.y * (key < 0 ? 0.0 : v_next[(unsigned)(e.rowoff + key)]);  // bankrupt: worth 0
+          add1 = 0.0;  // (not added: the survival recursion has no immediate term before period T)
         }
       } else {  // F4 / F5: CashOverdraft.java:99-104
         const double after = dep_or_bi + e.u;
         inc = after - s.cash;
         if constexpr (LAST) inc += e.sal;
-        acc += pp.x * inc;
-        if constexpr (!LAST) {
-          const double ncash = s.cash + inc;
-          acc += pp.y * v_next[qoff + (unsigned)(e.rowoff + cash_key_row<INTDIV>(ncash, min_cash, max_cash, round_mult, round_div))];
-        }
+        add1 = pp.x * inc;
       }
+      if constexpr (!LAST) {
+        const int key = cash_key_row<INTDIV>(s.cash + inc, key_lo_v, key_hi_v, round_mult, round_div);  // CashConstraint.java:125-131
+        if constexpr (FAM == FAM_SURVIVAL) dead = key < 0;
+        off = (uint32_t)(e.rowoff8 + (key << 3));
+      }
+    };
+    int j = 0;
+    for (; j + U <= D; j += U) {
+      double add1[U], pg[U], v[U];
+      uint32_t off[U];
+      bool dead[U];
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+        const double2 pp = s_p[j + u];
+        pg[u] = pp.y;
+        tail(ent[j + u], pp, add1[u], off[u], dead[u]);
+      }
+      if constexpr (!LAST) {
+#pragma unroll
+        for (int u = 0; u < U; ++u) v[u] = *reinterpret_cast<const double*>(vbase + off[u]);
+      }
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+        if constexpr (FAM != FAM_SURVIVAL || LAST) acc += add1[u];
+        if constexpr (!LAST) acc += pg[u] * (dead[u] ? 0.0 : v[u]);
+      }
+    }
+    for (; j < D; ++j) {
+      const double2 pp = s_p[j];
+      double add1;
+      uint32_t off;
+      bool dead;
+      tail(ent[j], pp, add1, off, dead);
+      if constexpr (FAM != FAM_SURVIVAL || LAST) acc += add1;
+      if constexpr (!LAST) acc += pp.y * (dead ? 0.0 : *reinterpret_cast<const double*>(vbase + off));
     }
     __builtin_amdgcn_wave_barrier();
     if (k < nA && (MAXDIR ? (acc > best) : (acc < best))) {

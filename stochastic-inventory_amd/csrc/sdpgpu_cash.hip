@@ -125,14 +125,30 @@ bool cash_row_eligible(const sdpgpu_handle* h, int period) {
   if (p.g.nc < 32) return false;                       // a wave is 64 consecutive cash points of one row
   if (p.S >= 2147483647LL) return false;               // 32-bit row offsets
   if ((size_t)p.nD * 152 + 4 * 64 * 12 > 64 * 1024) return false;  // per-wave entries of every demand point in LDS
+  if (period < h->T) {
+    // the kernel addresses V_{t+1} by a 32-bit BYTE offset from a scalar base (per pipeline plane for F5) ...
+    const PeriodInfo& n = h->per[period];
+    if ((n.g.nx * n.g.nc + 2 * n.g.nc) * 8 >= 2147483647LL) return false;
+    // ... and clamps the cash key AFTER the quantiser (cash_key_row): the rounded balance times the quantiser's factor
+    // must stay far inside int32.  A generous bound on |cash + increment| from the parameters:
+    const double ymax = std::fabs(d.max_inventory) + std::fabs(d.min_inventory) + d.max_order_quantity * d.step +
+                        (d.cash_formula == 2 ? std::fabs(d.max_cash) / std::max(d.unit_order_cost, 1e-300) : 0.0);
+    const double cmax = std::max(std::fabs(d.min_cash), std::fabs(d.max_cash));
+    const double spend = std::fabs(d.fixed_order_cost) + std::fabs(d.unit_order_cost) * ymax + std::fabs(p.overhead);
+    const double rate = std::max({std::fabs(d.r0), std::fabs(d.r2), std::fabs(d.r3), std::fabs(d.deposit_rate)});
+    double bound = (cmax + spend) * (1.0 + rate) + std::fabs(d.overdraft_limit) * rate +
+                   (std::fabs(d.price) + std::fabs(d.holding_cost) + std::fabs(d.salvage_value)) * ymax;
+    bound *= 1.0 + std::fabs(d.penalty_cost);
+    if (!(bound * d.cash_round_mult < 5.0e8)) return false;  // (NaN fails too) -> generic kernel
+  }
   return true;
 }
 
-template <int FAM, bool FORMULA1, bool PEN = false>
+template <int FAM, bool FORMULA1, bool PEN = false, bool LEAN = false>
 hipError_t launch_cash_row_fam(const DevParams& P, bool last, bool intdiv, const double* v_next, double* v_cur,
                                int32_t* pol, const double* pmf_d, const double* pmf_p, int64_t lo, int64_t hi,
-                               int64_t row0, int tiles_per_row, dim3 grid, size_t smem, hipStream_t st) {
-#define SDP_CR(LS, ID) hipLaunchKernelGGL((sdp::cash_row_kernel<FAM, LS, FORMULA1, ID, PEN>), grid, dim3(256), smem, st, P, v_next, v_cur, pol, pmf_d, pmf_p, lo, hi, row0, tiles_per_row)
+                               int64_t row0, sdp::RowTiling G, dim3 grid, size_t smem, hipStream_t st) {
+#define SDP_CR(LS, ID) hipLaunchKernelGGL((sdp::cash_row_kernel<FAM, LS, FORMULA1, ID, PEN, LEAN>), grid, dim3(256), smem, st, P, v_next, v_cur, pol, pmf_d, pmf_p, lo, hi, row0, G)
   if (intdiv) {
     if (last) SDP_CR(true, true); else SDP_CR(false, true);
   } else {
@@ -146,18 +162,34 @@ hipError_t launch_cash_row(sdpgpu_handle* h, const DevParams& P, int period, con
                            int32_t* pol, const double* pmf_d, const double* pmf_p, int64_t lo, int64_t hi, hipStream_t st) {
   if (hi <= lo) return hipSuccess;
   const PeriodInfo& p = h->per[period - 1];
-  const int tiles_per_row = (int)((p.g.nc + 63) / 64);
   const int64_t row_lo = lo / p.g.nc, row_hi = (hi - 1) / p.g.nc;
-  const int64_t blocks = (row_hi - row_lo + 1) * (int64_t)tiles_per_row;
+  sdp::RowTiling G{};
+  G.tiles_per_row = (int32_t)((p.g.nc + 63) / 64);
+  G.n_rows = (int32_t)(row_hi - row_lo + 1);
+  int64_t blocks = (int64_t)G.n_rows * G.tiles_per_row;
+  // cash bands per XCD (see RowTiling): rows of 16 tiles and more; ~12 tiles per band.  SDPGPU_CASH_BANDS=0 keeps the
+  // plain row-major numbering, =n forces n bands per XCD.
+  int nsub = -1;
+  if (const char* e = std::getenv("SDPGPU_CASH_BANDS")) nsub = std::atoi(e);
+  if (nsub != 0 && G.tiles_per_row >= 16 && row_hi - row_lo + 1 < (1LL << 24)) {
+    const int tpb = (G.tiles_per_row + 7) / 8;  // tiles per XCD and row
+    G.nsub = nsub > 0 ? std::min(nsub, tpb) : std::max(1, (tpb + 6) / 12);
+    G.tps = (tpb + G.nsub - 1) / G.nsub;
+    blocks = 8LL * G.nsub * G.tps * G.n_rows;
+  }
   if (!grid_ok(blocks)) return hipErrorInvalidValue;
   dim3 grid((unsigned)blocks);
   const size_t smem = (size_t)p.nD * 152 + 4 * 64 * (sizeof(double) + sizeof(int));
   const bool last = period == h->T;
   const bool intdiv = h->d.cash_round_int_div && h->d.cash_round_div != 1.0;
-#define SDP_ROWARGS P, last, intdiv, v_next, v_cur, pol, pmf_d, pmf_p, lo, hi, row_lo, tiles_per_row, grid, smem, st
+  // LEAN: `- holdCosts - overheadCost` subtract +0.0 in every cell (holdingCost and the period's overhead are +0.0)
+  const bool lean = P.family == sdp::FAM_CASH && P.cash_formula != 1 && P.pi == 0.0 && h->d.holding_cost == 0.0 &&
+                    !std::signbit(h->d.holding_cost) && P.overhead == 0.0 && !std::signbit(P.overhead);
+#define SDP_ROWARGS P, last, intdiv, v_next, v_cur, pol, pmf_d, pmf_p, lo, hi, row_lo, G, grid, smem, st
   switch (P.family) {
     case sdp::FAM_CASH:
       // (cash_formula 2, the (x, R) state of CashConstraintXR: formula 0's increment on initCash = R - variCost * x)
+      if (lean) return launch_cash_row_fam<sdp::FAM_CASH, false, false, true>(SDP_ROWARGS);
       if (P.pi != 0.0)
         return P.cash_formula != 1 ? launch_cash_row_fam<sdp::FAM_CASH, false, true>(SDP_ROWARGS)
                                    : launch_cash_row_fam<sdp::FAM_CASH, true, true>(SDP_ROWARGS);
