@@ -214,16 +214,32 @@ def cpu_baseline(w, target_seconds: float):
 # ---------------------------------------------------------------------------------------------------------------
 # roofline
 # ---------------------------------------------------------------------------------------------------------------
+def kernel_source_sha() -> str:
+    """Identity of the kernel sources a counter summary was measured on (tools/pmc_reduce.py stores it): counters of
+    another build say nothing about this one's instruction counts or traffic."""
+    import hashlib
+    h = hashlib.sha256()
+    d = os.path.join(ROOT, "stochastic-inventory_amd", "csrc")
+    for name in sorted(os.listdir(d)):
+        if name.endswith((".hip", ".hpp")):
+            h.update(name.encode())
+            h.update(open(os.path.join(d, name), "rb").read())
+    return h.hexdigest()[:16]
+
+
 def load_pmc(workload_name: str):
     """Counter summary of this workload written by tools/pmc_reduce.py (rocprofv3 --pmc passes, corrected as
-    MI355X_MICROARCH.md prescribes).  Newest round first."""
+    MI355X_MICROARCH.md prescribes), newest round first -- only if it was measured on THIS build of the kernels."""
+    sha = kernel_source_sha()
     for path in sorted(glob.glob(os.path.join(ROOT, "profiles", f"r*_pmc_{workload_name}.json")), reverse=True):
         try:
             rec = json.load(open(path))
-            rec["_file"] = os.path.relpath(path, ROOT)
-            return rec
         except Exception:
             continue
+        if rec.get("source_sha") != sha:
+            continue
+        rec["_file"] = os.path.relpath(path, ROOT)
+        return rec
     return None
 
 
@@ -284,7 +300,8 @@ def roofline_block(w, st, T, cells_rank, states_rank, dev_ms_per_sweep, per_laun
         out.update({"bound": "valu-issue", "achieved": None, "peak": VALU_PEAK_LANE_OPS / 1e12, "unit": "T lane-op/s",
                     "frac": None, "note": "no instruction model and no counter summary in profiles/ for this workload"})
     if out.get("frac") is not None and not (0.0 < out["frac"] <= 1.0):
-        raise SystemExit(f"roofline fraction {out['frac']} outside (0, 1]: the op model does not describe this kernel")
+        raise SystemExit(f"roofline fraction {out['frac']} outside (0, 1]: the op model / counter summary does not describe "
+                         "this kernel (a summary in profiles/ measured on another build would be skipped by its source_sha)")
     return out
 
 

@@ -83,6 +83,7 @@ __global__ __launch_bounds__(256) void cash_shift_kernel(CashShiftParams P, cons
   ShiftEntry2* s_ent2 = reinterpret_cast<ShiftEntry2*>(smem + (size_t)D * 16 + (size_t)DP * 16 * 4);  // [4 waves][DP]
   double* s_val = reinterpret_cast<double*>(smem + (size_t)D * 16 + (size_t)DP * 16 * 8);
   int* s_k = reinterpret_cast<int*>(s_val + 4 * TS);
+  int* s_flag = s_k + 4 * TS;  // [4 waves][DP / 2]: per trip of the demand loop, "no point of this wave's tiles clamps"
 
   const int tid = threadIdx.x;
   const int lane = tid & 63;
@@ -120,10 +121,13 @@ __global__ __launch_bounds__(256) void cash_shift_kernel(CashShiftParams P, cons
 
   ShiftEntry* ent = s_ent + (size_t)wave * DP;
   ShiftEntry2* ent2 = s_ent2 + (size_t)wave * DP;
+  int* flag = s_flag + (size_t)wave * (DP / 2);
   if (lane < DP - D) {  // t1 = 0, p = 0, a valid address: acc += 0.0; acc += 0.0 * V[0]
     ent[D + lane] = ShiftEntry{0.0, 0, 0};
     ent2[D + lane] = ShiftEntry2{0.0, 0, 0};
   }
+  constexpr int U = S == 1 ? 8 : (S == 2 ? 4 : 2);  // steps per trip: eight gathers in flight per wave
+  const bool tile_whole = ic0 + TS <= P.nc;  // every lane's points exist (no lane was folded onto the row's last point)
   const int nc18 = (P.nc - 1) * 8;
   const char* vbase = reinterpret_cast<const char*>(v_next);
   double best[S][W];
@@ -166,11 +170,35 @@ __global__ __launch_bounds__(256) void cash_shift_kernel(CashShiftParams P, cons
         e2.hi8 = e.lo8 + nc18;
         e2.pad = 0;
         ent2[j] = e2;
+        if constexpr (W == 2) {
+          // Does any point of this wave's tiles leave the row under this step's shift?  If none does for the U steps of
+          // a trip, the trip needs neither the clamp nor the selects that pick a clamped pair apart: the wave decides
+          // once per trip (a scalar branch) instead of every lane in every cell.
+          const bool fast = tile_whole && ic0 + delta >= 0 && ic0 + TS - 1 + delta <= P.nc - 1;
+          const unsigned long long m = __ballot(fast);
+          if ((lane % U) == 0) flag[j / U] = ((m >> lane) & ((1ull << U) - 1)) == ((1ull << U) - 1);
+        }
       }
       ent[j] = e;
     }
     __builtin_amdgcn_wave_barrier();
     __builtin_amdgcn_s_waitcnt(0xC07F);  // lgkmcnt(0): the wave's own LDS writes have landed
+    if constexpr (W == 2 && !LAST) {
+      // trips that hold padding entries (shift 0, row 0, probability 0): clamp-free iff the tile is whole and their real
+      // steps are -- the ballot above saw only the lanes with a real step
+      if ((D % U) != 0 || DP > D) {
+        if (lane == 0) {
+          for (int t = D / U; t < DP / U; ++t) {
+            bool ok = tile_whole;
+            for (int j = t * U; j < D && ok; ++j)
+              ok = ent[j].off8 - ent[j].lo8 + ic0 * 8 >= 0 && ent[j].off8 - ent[j].lo8 + (ic0 + TS - 1) * 8 <= nc18;
+            flag[t] = ok;
+          }
+        }
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_s_waitcnt(0xC07F);
+      }
+    }
     // ---- the demand loop: serial in j, reference order (CashRecursion.java:113-122) ----
     double acc[S][W];
 #pragma unroll
@@ -186,8 +214,25 @@ __global__ __launch_bounds__(256) void cash_shift_kernel(CashShiftParams P, cons
           for (int w = 0; w < W; ++w) acc[s][w] += t1;
       }
     } else {
-      constexpr int U = S == 1 ? 8 : (S == 2 ? 4 : 2);  // steps per trip: eight gathers in flight per wave
       for (int jb = 0; jb < DP; jb += U) {
+        if constexpr (W == 2) {
+          if (__builtin_amdgcn_readfirstlane(flag[jb / U])) {  // clamp-free trip: address = lane's base + shift
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+              const ShiftEntry e = ent[jb + u];
+              const ShiftEntry2 e2 = ent2[jb + u];
+#pragma unroll
+              for (int s = 0; s < S; ++s) {
+                const dpair_u v = *reinterpret_cast<const dpair_u*>(vbase + (uint32_t)(ic8[s] + e.off8));
+                acc[s][0] += e.t1;
+                acc[s][0] += e2.pg * v.x;
+                acc[s][1] += e.t1;
+                acc[s][1] += e2.pg * v.y;
+              }
+            }
+            continue;
+          }
+        }
 #pragma unroll
         for (int u = 0; u < U; ++u) {
           const ShiftEntry e = ent[jb + u];

@@ -90,7 +90,7 @@ hipError_t launch_cash_shift(sdpgpu_handle* h, const DevParams& P, int period, c
   if (!grid_ok((row_hi - row_lo + 1) * (int64_t)C.tiles_per_row)) return hipErrorInvalidValue;
   dim3 grid((unsigned)((row_hi - row_lo + 1) * C.tiles_per_row));
   const size_t dp8 = ((size_t)p.nD + 7) & ~(size_t)7;
-  size_t smem = (size_t)p.nD * 16 + dp8 * 16 * 8 + (size_t)4 * TSZ * (sizeof(double) + sizeof(int));
+  size_t smem = (size_t)p.nD * 16 + dp8 * 16 * 8 + (size_t)4 * TSZ * (sizeof(double) + sizeof(int)) + 4 * (dp8 / 2) * sizeof(int);
   const bool last = period == h->T;
   h->per[period - 1].ops_cell = last ? 1.0 : 3.0;  // acc += T1; acc += (p gamma) * V
 #define SDP_CS(MX, LS, SS, WW) hipLaunchKernelGGL((sdp::cash_shift_kernel<MX, LS, SS, WW>), grid, dim3(256), smem, st, C, v_next, v_cur, pol, pmf_d, pmf_p, lo, hi)

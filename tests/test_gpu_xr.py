@@ -28,7 +28,8 @@ def test_cash_constraint_xr_main_full_tables(sia, oracle, kernel):
         for period in range(1, w.T + 1):
             assert np.array_equal(eng.values(period), V[period - 1]), f"V_{period}"
             assert np.array_equal(eng.policy(period), pol[period - 1]), f"policy of period {period}"
-        assert int(eng.policy(1).max()) > 200  # the action list is bounded by R / variCost, not by maxOrderQuantity
+        # the action list is bounded by R / variCost (up to 1001 levels at cash 2000), not by maxOrderQuantity = 200
+        assert cells > 501 * 2101 * 300 * len(w.pmf[0]) * w.T
 
 
 def test_mirror_class_against_the_literal_recursion(sia, oracle):

@@ -14,6 +14,18 @@ import statistics
 import sys
 
 
+def kernel_source_sha(root):
+    """Same digest as bench.py's kernel_source_sha(): ties a summary to the kernel sources it was measured on."""
+    import hashlib
+    h = hashlib.sha256()
+    d = os.path.join(root, "stochastic-inventory_amd", "csrc")
+    for name in sorted(os.listdir(d)):
+        if name.endswith((".hip", ".hpp")):
+            h.update(name.encode())
+            h.update(open(os.path.join(d, name), "rb").read())
+    return h.hexdigest()[:16]
+
+
 def short(name):
     return name.split("(")[0].replace("void ", "").strip()
 
@@ -58,6 +70,7 @@ def main():
     d = kernels[dom]
     rec = {
         "round": rnd, "workload": bench["config"]["workload"] if bench else wl, "dominant_kernel": dom,
+        "source_sha": kernel_source_sha(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))),
         "hbm_bytes_per_launch": d.get("hbm_read_bytes_per_launch", 0.0) + d.get("hbm_write_bytes_per_launch", 0.0),
         "valu_insts_per_launch": d.get("SQ_INSTS_VALU"),
         "ta_busy_frac": (d["TA_BUSY_avr"] / d["GRBM_GUI_ACTIVE"]) if d.get("TA_BUSY_avr") and d.get("GRBM_GUI_ACTIVE") else None,
