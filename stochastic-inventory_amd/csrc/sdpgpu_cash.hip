@@ -167,13 +167,14 @@ hipError_t launch_cash_row(sdpgpu_handle* h, const DevParams& P, int period, con
   G.tiles_per_row = (int32_t)((p.g.nc + 63) / 64);
   G.n_rows = (int32_t)(row_hi - row_lo + 1);
   int64_t blocks = (int64_t)G.n_rows * G.tiles_per_row;
-  // cash bands per XCD (see RowTiling): rows of 16 tiles and more; ~12 tiles per band.  SDPGPU_CASH_BANDS=0 keeps the
-  // plain row-major numbering, =n forces n bands per XCD.
+  // cash bands per XCD (see RowTiling): rows of 16 tiles and more; ~20 tiles per band (CashConstraint.main, 313 tiles per
+  // row: 1 / 2 / 3 / 6 bands per XCD = 70.0 / 69.0 / 73.4 / 72.8 ms per sweep, row-major 119.8).  SDPGPU_CASH_BANDS=0
+  // keeps the plain row-major numbering, =n forces n bands per XCD.
   int nsub = -1;
   if (const char* e = std::getenv("SDPGPU_CASH_BANDS")) nsub = std::atoi(e);
   if (nsub != 0 && G.tiles_per_row >= 16 && row_hi - row_lo + 1 < (1LL << 24)) {
     const int tpb = (G.tiles_per_row + 7) / 8;  // tiles per XCD and row
-    G.nsub = nsub > 0 ? std::min(nsub, tpb) : std::max(1, (tpb + 6) / 12);
+    G.nsub = nsub > 0 ? std::min(nsub, tpb) : std::max(1, (tpb + 10) / 20);
     G.tps = (tpb + G.nsub - 1) / G.nsub;
     blocks = 8LL * G.nsub * G.tps * G.n_rows;
   }
