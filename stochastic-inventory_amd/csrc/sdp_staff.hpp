@@ -166,6 +166,51 @@ __global__ __launch_bounds__(64) void staff_block_kernel(StaffParams P, const do
 // row, the staff range) folds the two onto one entry.
 typedef double staff_pair_u __attribute__((ext_vector_type(2), aligned(8)));
 
+// One step k of the pair kernel: every cell of the step leaves n0 = ytop - k (state x) / n0 + 1 (state x + 1) behind.
+// FAST: the WAVE has established that in this step no lane's staff number is clamped and none is at or below
+// minStaffNum -- the selects that pick a clamped pair apart and the penalty arithmetic are skipped (the penalty is the
+// constant +0.0 the reference adds there).  FOLD: some lane's level sits on the table's last row (its pair is folded).
+// Addresses are a scalar base + a 32-bit byte offset (no 64-bit vector arithmetic): pk = table row k - (R - 1).
+template <int R, bool FUTURE, bool FAST, bool FOLD>
+__device__ __forceinline__ void staff_pair_step(const StaffParams& P, int n0, const char* __restrict__ pk,
+                                                const char* __restrict__ vb, const uint32_t (&poff8)[R],
+                                                const bool (&fold)[R], const double (&fv)[R], double (&acc)[2][R]) {
+  const double sal0 = P.salary * (double)n0;
+  const double sal1 = P.salary * (double)(n0 + 1);
+  double pen0 = 0.0, pen1 = 0.0;
+  if constexpr (!FAST) {
+    pen0 = n0 > P.min_staff ? 0.0 : P.pen * (double)(P.min_staff - n0);
+    pen1 = n0 + 1 > P.min_staff ? 0.0 : P.pen * (double)(P.min_staff - (n0 + 1));
+  }
+  double v0 = 0.0, v1 = 0.0;
+  if constexpr (FUTURE) {
+    if constexpr (FAST) {
+      const staff_pair_u v = *reinterpret_cast<const staff_pair_u*>(vb + (uint32_t)((n0 - P.next_x_lo) * 8));
+      v0 = v.x;
+      v1 = v.y;
+    } else {
+      // {V[c], V[c + 1]}, c = clamp(n0, lo, hi - 1): where the bounds fold both onto one entry, select it
+      int c = n0 > P.nn_hi - 1 ? P.nn_hi - 1 : n0;
+      c = c < P.nn_lo ? P.nn_lo : c;
+      const staff_pair_u v = *reinterpret_cast<const staff_pair_u*>(vb + (uint32_t)((c - P.next_x_lo) * 8));
+      v0 = n0 > P.nn_hi - 1 ? v.y : v.x;  // n0 >= hi: the last entry
+      v1 = n0 < P.nn_lo ? v.x : v.y;      // n0 + 1 <= lo: the first entry
+    }
+  }
+#pragma unroll
+  for (int r = 0; r < R; ++r) {
+    const staff_pair_u p = *reinterpret_cast<const staff_pair_u*>(pk + poff8[r]);
+    double p0 = p.x;
+    if constexpr (FOLD) p0 = fold[r] ? p.y : p.x;
+    const double imm0 = fv[r] + sal0 + pen0;
+    acc[0][r] += p0 * imm0;
+    if constexpr (FUTURE) acc[0][r] += p0 * v0;
+    const double imm1 = fv[r] + sal1 + pen1;
+    acc[1][r] += p.y * imm1;
+    if constexpr (FUTURE) acc[1][r] += p.y * v1;
+  }
+}
+
 template <int R, bool FUTURE>
 __global__ __launch_bounds__(64) void staff_pair_kernel(StaffParams P, const double* __restrict__ pT0,
                                                         const int32_t* __restrict__ row_len,
@@ -179,14 +224,17 @@ __global__ __launch_bounds__(64) void staff_pair_kernel(StaffParams P, const dou
   if (idx >= hi) return;
   const bool two = idx + 1 < hi;
   const int x = P.x_lo + (int)idx;
+  const int x_first = __builtin_amdgcn_readfirstlane(x);  // lane 0 holds the tile's lowest staff number; the wave spans x_first .. x_first + 127
   const int a_end = min(P.n_actions, (group + 1) * P.group_actions);
   const int last_row = P.n_rows - 1;
+  const int64_t row_bytes = (int64_t)P.n_rows * 8;
+  const char* vb = reinterpret_cast<const char*>(v_next);
   double best[2] = {1.7976931348623157e308, 1.7976931348623157e308};
   int bestk[2] = {0, 0};
   for (int a0 = group * P.group_actions; a0 < a_end; a0 += R) {
     double fv[R], acc[2][R];
-    int64_t poff[R];  // {p(y), p(y + 1)} of action r at step k: the pair at pT0[k * rows + poff[r]]
-    bool fold[R];     // y >= last row: both levels use the last row (the pair's second entry)
+    uint32_t poff8[R];  // {p(y), p(y + 1)} of action r at step k: the pair at byte offset poff8[r] from table row k - (R - 1)
+    bool fold[R];       // y >= last row: both levels use the last row (the pair's second entry)
     int kmax = 0;
 #pragma unroll
     for (int r = 0; r < R; ++r) {
@@ -203,37 +251,33 @@ __global__ __launch_bounds__(64) void staff_pair_kernel(StaffParams P, const dou
       acc[1][r] = 0.0;
       fold[r] = y >= last_row;
       const int c = y >= last_row ? last_row - 1 : y;  // rows >= 2 (the launcher checks)
-      poff[r] = (int64_t)c - (int64_t)(R - 1 - r) * P.n_rows;
+      poff8[r] = (uint32_t)((c + r * P.n_rows) * 8);   // action r is at j = k - (R-1-r): row (k - (R-1)) + r
     }
     const int ytop = x + a0 + R - 1;
-    for (int k = 0; k < kmax; ++k) {
-      const int n0 = ytop - k;  // nextStaffNum of state x at this step; state x + 1 leaves n0 + 1
-      const double sal0 = P.salary * (double)n0;
-      const double sal1 = P.salary * (double)(n0 + 1);
-      const double pen0 = n0 > P.min_staff ? 0.0 : P.pen * (double)(P.min_staff - n0);
-      const double pen1 = n0 + 1 > P.min_staff ? 0.0 : P.pen * (double)(P.min_staff - (n0 + 1));
-      double v0 = 0.0, v1 = 0.0;
-      if constexpr (FUTURE) {
-        // {V[c], V[c + 1]}, c = clamp(n0, lo, hi - 1): where the bounds fold both onto one entry, select it
-        int c = n0 > P.nn_hi - 1 ? P.nn_hi - 1 : n0;
-        c = c < P.nn_lo ? P.nn_lo : c;
-        const staff_pair_u v = *reinterpret_cast<const staff_pair_u*>(v_next + (c - P.next_x_lo));
-        v0 = n0 > P.nn_hi - 1 ? v.y : v.x;  // n0 >= hi: the last entry
-        v1 = n0 < P.nn_lo ? v.x : v.y;      // n0 + 1 <= lo: the first entry
-      }
-      const double* pk = pT0 + (int64_t)k * P.n_rows;
-#pragma unroll
-      for (int r = 0; r < R; ++r) {
-        const staff_pair_u p = *reinterpret_cast<const staff_pair_u*>(pk + poff[r]);
-        const double p0 = fold[r] ? p.y : p.x;
-        const double imm0 = fv[r] + sal0 + pen0;
-        acc[0][r] += p0 * imm0;
-        if constexpr (FUTURE) acc[0][r] += p0 * v0;
-        const double imm1 = fv[r] + sal1 + pen1;
-        acc[1][r] += p.y * imm1;
-        if constexpr (FUTURE) acc[1][r] += p.y * v1;
-      }
+    const bool any_fold = __ballot(fold[R - 1]) != 0;  // (the level grows with r: r = R - 1 folds first)
+    // Steps in which NO lane of the wave meets a clamp of the staff number or the penalty branch -- wave-uniform bounds:
+    // at step k the wave's staff numbers n0 span [nlo, nlo + 126] (n1 = n0 + 1), nlo = x_first + a0 + R - 1 - k.
+    //   top clamp free:    nlo + 126 <= nn_hi - 1  <=>  k >= ks
+    //   bottom clamp free: nlo >= nn_lo,  penalty free: nlo > min_staff  <=>  k < ke
+    const int ntop = x_first + a0 + R - 1;
+    int ks = ntop + 127 - P.nn_hi;
+    ks = ks < 0 ? 0 : ks;
+    if constexpr (!FUTURE) ks = 0;  // (no V read in the last period: only the penalty matters)
+    int ke = ntop - (FUTURE ? max(P.nn_lo - 1, P.min_staff) : P.min_staff);  // first step with nlo <= that bound
+    ke = ke < ks ? ks : ke;
+    const char* pk0 = reinterpret_cast<const char*>(pT0) - (int64_t)(R - 1) * row_bytes;
+    int k = 0;
+    for (const int e = min(kmax, ks); k < e; ++k)
+      staff_pair_step<R, FUTURE, false, true>(P, ytop - k, pk0 + (int64_t)k * row_bytes, vb, poff8, fold, fv, acc);
+    if (any_fold) {
+      for (const int e = min(kmax, ke); k < e; ++k)
+        staff_pair_step<R, FUTURE, true, true>(P, ytop - k, pk0 + (int64_t)k * row_bytes, vb, poff8, fold, fv, acc);
+    } else {
+      for (const int e = min(kmax, ke); k < e; ++k)
+        staff_pair_step<R, FUTURE, true, false>(P, ytop - k, pk0 + (int64_t)k * row_bytes, vb, poff8, fold, fv, acc);
     }
+    for (; k < kmax; ++k)
+      staff_pair_step<R, FUTURE, false, true>(P, ytop - k, pk0 + (int64_t)k * row_bytes, vb, poff8, fold, fv, acc);
 #pragma unroll
     for (int r = 0; r < R; ++r)
       if (a0 + r < P.n_actions) {

@@ -86,8 +86,11 @@ hipError_t launch_staff(sdpgpu_handle* h, int period, const double* v_next, doub
   static const bool plain = std::getenv("SDPGPU_STAFF_BLOCK") && std::atoi(std::getenv("SDPGPU_STAFF_BLOCK")) == 0;
   // (only where 128-state tiles x action blocks still make a few waves per SIMD: small staff ranges keep 64-state tiles)
   const bool roomy = ((hi - lo + 127) / 128) * (int64_t)((h->n_actions_full + 3) / 4) >= 4096;
+  // (the pair kernel addresses the table and V_{t+1} by 32-bit byte offsets from scalar bases)
+  const bool small_tables = ((int64_t)S.n_rows + 2 * sdp::kStaffPadJ) * S.n_rows * 8 < 2147483647LL &&
+                            (period == h->T || (int64_t)h->per[period].g.nx * 8 < 2147483647LL);
   const bool pair = !pair_off && !plain && staff_block() == 4 && S.n_rows >= 2 && (period == h->T || S.nn_hi > S.nn_lo) &&
-                    (roomy || std::getenv("SDPGPU_STAFF_PAIR"));
+                    small_tables && (roomy || std::getenv("SDPGPU_STAFF_PAIR"));
   const int tile_states = pair ? 128 : 64;
   staff_groups(h, hi - lo, tile_states, &S.n_groups, &S.group_actions);
   const int64_t tiles = (hi - lo + tile_states - 1) / tile_states;

@@ -38,12 +38,13 @@ WinPlan plan_window(const sdpgpu_handle* h, int period, int64_t lo, int64_t hi) 
     int r, s, occupancy;  // occupancy: waves a SIMD can hold within the register budget
   };
   // (84 / 62 / 54 VGPRs for S = 1, R = 8 / 5 / 4; 134 / 116 / 96 for S = 2; 130 for R = 4, S = 4)
-  const Cand cand[] = {{8, 1, 6}, {5, 1, 8}, {4, 1, 9}, {8, 2, 3}, {4, 2, 5}, {4, 4, 3}};
+  const Cand cand[] = {{8, 1, 6}, {5, 1, 8}, {4, 1, 9}, {8, 2, 3}, {4, 2, 5}, {4, 4, 3}, {8, 4, 2}, {4, 8, 2}};
   const bool may_chunk = h->fuse_combine && h->d.store_all_values;
   for (const Cand& c : cand) {
     const int r = c.r, sl = c.s, nw = r + sl - 1, ts = 64 * sl;
     if (h->win_r && r != h->win_r) continue;
     if (h->win_s && sl != h->win_s) continue;
+    if (r * sl >= 32 && !(h->win_r && h->win_s)) continue;  // the 32-cell blocks are opt-in (SDPGPU_WIN_R + SDPGPU_WIN_S): measured, see DESIGN
     const int64_t n_tiles = std::max<int64_t>(1, (nominal + ts - 1) / ts);
     const int64_t own_tiles = (hi - lo + ts - 1) / ts;
     const int d_pad = rup(D, nw);
@@ -456,6 +457,8 @@ hipError_t launch_window(sdpgpu_handle* h, const DevParams& P, int period, const
   SDP_WIN_R(8, 2)
   SDP_WIN_R(4, 2)
   SDP_WIN_R(4, 4)
+  SDP_WIN_R(8, 4)
+  SDP_WIN_R(4, 8)
   if (!launched) return hipErrorInvalidValue;
 #undef SDP_WIN_R
 #undef SDP_WIN_GO
