@@ -442,18 +442,13 @@ def main():
     eng = backend.engine
     exchange = args.exchange
     note = ""
-    if exchange == "native":
-        try:
-            init_native_comm(eng)
-            ok, err = True, ""
-        except Exception as exc:  # e.g. librccl missing: every rank must take the same decision
-            ok, err = False, str(exc)
-        if not all_agree(ok):
-            exchange = "torch"
-            note = f" (native communicator failed{': ' + err if err else ' on another rank'}; fell back to torch.distributed nccl)"
-            if rank == 0:
-                print(f"[bench] native RCCL communicator unavailable{': ' + err if err else ''}; using torch.distributed",
-                      file=sys.stderr, flush=True)
+    if exchange == "native" and not init_native_comm(eng):  # (the ranks agree inside: all or none)
+        exchange = "torch"
+        err = init_native_comm.last_error
+        note = f" (native communicator failed{': ' + err if err else ' on another rank'}; fell back to torch.distributed nccl)"
+        if rank == 0:
+            print(f"[bench] native RCCL communicator unavailable{': ' + err if err else ''}; using torch.distributed",
+                  file=sys.stderr, flush=True)
     group = dist.new_group(backend="nccl") if (exchange == "torch" and args.exchange != "torch") else None
     solver = ShardedSolver(backend, group=group, stage_through_host=(exchange == "host"))
     solver.force_split = args.split

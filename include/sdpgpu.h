@@ -272,6 +272,29 @@ int sdpgpu_set_pmf(sdpgpu_handle* h, int32_t t, const double* demand, const doub
 int sdpgpu_set_level_pmf(sdpgpu_handle* h, int32_t t, const double* prob, const int32_t* row_len, int32_t n_rows,
                          int32_t row_stride);
 
+/* ---- PMF construction: what a driver runs immediately before the recursion ---------------------
+ * `new GetPmf(distributions, truncationQuantile, stepSize).getpmf()[t]` (sdp/inventory/GetPmf.java:82-134; variant
+ * SDPGPU_PMF_GETPMF) and capacitated.CLSP.main's inline variant (CLSP.java:219-247; SDPGPU_PMF_CLSP), for the
+ * distributions the in-scope drivers use.  GetPmf's structure and quirks are reproduced exactly ((int) truncation of the
+ * quantiles, lower bound 0 for integer distributions, prob(j) indexed by position, covered mass as normaliser); the
+ * cdf / quantile functions are this library's own double-precision implementations, not SSJ's (parity unpinned at this
+ * boundary: the reference records no PMF).  Host arithmetic, no GPU needed.
+ * Call with capacity = 0 to learn the number of points of period t (n_out), then with arrays of that size; feed the
+ * result to sdpgpu_set_pmf.  Errors through sdpgpu_last_error(NULL). */
+#define SDPGPU_DIST_POISSON 1      /* PoissonDist(lambda = a) */
+#define SDPGPU_DIST_NORMAL 2       /* NormalDist(mu = a, sigma = b) */
+#define SDPGPU_DIST_UNIFORM_INT 3  /* UniformIntDist(i = a, j = b) */
+#define SDPGPU_DIST_GAMMA 4        /* GammaDist(alpha = a, lambda = b): shape, RATE (CashConstraintXR.java:67) */
+#define SDPGPU_PMF_GETPMF 0
+#define SDPGPU_PMF_CLSP 1
+typedef struct sdpgpu_dist_spec {
+  int32_t kind;
+  int32_t reserved;
+  double a, b;
+} sdpgpu_dist_spec;
+int sdpgpu_getpmf(const sdpgpu_dist_spec* distributions, int32_t T, double truncation_quantile, double step,
+                  int32_t variant, int32_t t, double* demand, double* prob, int32_t capacity, int32_t* n_out);
+
 /* Optional per-period overhead cost (CashOverdraft.java:38-39 keeps an array).  STAFF family: minStaffNum[t]. */
 int sdpgpu_set_overhead(sdpgpu_handle* h, int32_t t, double overhead_cost);
 

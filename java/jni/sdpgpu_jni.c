@@ -128,6 +128,64 @@ JNIEXPORT void JNICALL Java_sdp_gpu_SdpGpu_setLevelPmf(JNIEnv* env, jclass cls, 
   CHECK(env, h, rc);
 }
 
+/* sdpgpu_getpmf: sizing call, then the tile of period t as rows {demand, probability} */
+JNIEXPORT jobjectArray JNICALL Java_sdp_gpu_SdpGpu_getPmf(JNIEnv* env, jclass cls, jintArray kinds, jdoubleArray a, jdoubleArray b,
+                                                         jdouble q, jdouble step, jint variant, jint t) {
+  jsize T = kinds ? (*env)->GetArrayLength(env, kinds) : 0;
+  if (T < 1 || T > 4096 || !a || !b || (*env)->GetArrayLength(env, a) < T || (*env)->GetArrayLength(env, b) < T) {
+    throw_state(env, "getPmf: kinds / a / b must have one entry per period");
+    return NULL;
+  }
+  sdpgpu_dist_spec* spec = malloc(sizeof(sdpgpu_dist_spec) * (size_t)T);
+  jint* ki = malloc(sizeof(jint) * (size_t)T);
+  jdouble* av = malloc(sizeof(jdouble) * (size_t)T);
+  jdouble* bv = malloc(sizeof(jdouble) * (size_t)T);
+  double *dem = NULL, *pr = NULL;
+  jobjectArray out = NULL;
+  if (!spec || !ki || !av || !bv) goto oom;
+  (*env)->GetIntArrayRegion(env, kinds, 0, T, ki);
+  (*env)->GetDoubleArrayRegion(env, a, 0, T, av);
+  (*env)->GetDoubleArrayRegion(env, b, 0, T, bv);
+  for (jsize i = 0; i < T; i++) {
+    spec[i].kind = ki[i];
+    spec[i].reserved = 0;
+    spec[i].a = av[i];
+    spec[i].b = bv[i];
+  }
+  int32_t n = 0;
+  if (sdpgpu_getpmf(spec, T, q, step, variant, t, NULL, NULL, 0, &n) != 0) goto fail;
+  dem = malloc(sizeof(double) * (size_t)(n > 0 ? n : 1));
+  pr = malloc(sizeof(double) * (size_t)(n > 0 ? n : 1));
+  if (!dem || !pr) goto oom;
+  if (sdpgpu_getpmf(spec, T, q, step, variant, t, dem, pr, n, &n) != 0) goto fail;
+  {
+    jclass rowCls = (*env)->FindClass(env, "[D");
+    out = rowCls ? (*env)->NewObjectArray(env, n, rowCls, NULL) : NULL;
+    for (int32_t j = 0; j < n && out; j++) {
+      jdouble r[2] = {dem[j], pr[j]};
+      jdoubleArray row = (*env)->NewDoubleArray(env, 2);
+      if (!row) {
+        out = NULL;
+        break;
+      }
+      (*env)->SetDoubleArrayRegion(env, row, 0, 2, r);
+      (*env)->SetObjectArrayElement(env, out, j, row);
+      (*env)->DeleteLocalRef(env, row);
+    }
+  }
+  goto done;
+fail:
+  throw_state(env, sdpgpu_last_error(NULL));
+  goto done;
+oom : {
+  jclass c = (*env)->FindClass(env, "java/lang/OutOfMemoryError");
+  if (c) (*env)->ThrowNew(env, c, "getPmf");
+}
+done:
+  free(spec); free(ki); free(av); free(bv); free(dem); free(pr);
+  return out;
+}
+
 JNIEXPORT void JNICALL Java_sdp_gpu_SdpGpu_setOverhead(JNIEnv* env, jclass cls, jlong h, jint t, jdouble oh) {
   CHECK(env, h, sdpgpu_set_overhead(H(h), t, oh));
 }

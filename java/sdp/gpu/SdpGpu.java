@@ -51,6 +51,14 @@ public final class SdpGpu {
 
 	public static native void setOverhead(long handle, int t, double overheadCost);
 
+	/**
+	 * sdpgpu_getpmf: `new GetPmf(distributions, truncationQuantile, stepSize).getpmf()[t]` (variant 0, GetPmf.java:82-134)
+	 * or CLSP.main's inline pmf (variant 1, CLSP.java:219-247) without SSJ: kinds[i] in {1 Poisson(a), 2 Normal(a, b),
+	 * 3 UniformInt(a, b), 4 Gamma(shape a, rate b)}.  Returns rows {demand, probability}.
+	 */
+	public static native double[][] getPmf(int[] kinds, double[] a, double[] b, double truncationQuantile,
+			double stepSize, int variant, int t);
+
 	public static native void solve(long handle);
 
 	/**

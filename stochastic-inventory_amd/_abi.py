@@ -189,6 +189,16 @@ def multi_table_rows(t, arrs):
     return m[order]
 
 
+class SdpgpuDistSpec(C.Structure):
+    """struct sdpgpu_dist_spec (include/sdpgpu.h)."""
+
+    _fields_ = [("kind", C.c_int32), ("reserved", C.c_int32), ("a", C.c_double), ("b", C.c_double)]
+
+
+DIST_POISSON, DIST_NORMAL, DIST_UNIFORM_INT, DIST_GAMMA = 1, 2, 3, 4
+PMF_GETPMF, PMF_CLSP = 0, 1
+
+
 # every symbol include/sdpgpu.h declares: name -> (restype, argtypes)
 _P = C.c_void_p
 _DP = C.POINTER(C.c_double)
@@ -203,6 +213,8 @@ EXPORTS = {
     "sdpgpu_last_error": (C.c_char_p, [_P]),
     "sdpgpu_set_pmf": (C.c_int, [_P, C.c_int32, _DP, _DP, C.c_int32]),
     "sdpgpu_set_level_pmf": (C.c_int, [_P, C.c_int32, _DP, _IP, C.c_int32, C.c_int32]),
+    "sdpgpu_getpmf": (C.c_int, [C.POINTER(SdpgpuDistSpec), C.c_int32, C.c_double, C.c_double, C.c_int32, C.c_int32, _DP, _DP,
+                                C.c_int32, _IP]),
     "sdpgpu_set_overhead": (C.c_int, [_P, C.c_int32, C.c_double]),
     "sdpgpu_set_stream": (C.c_int, [_P, _P]),
     "sdpgpu_set_profiling": (C.c_int, [_P, C.c_int32]),

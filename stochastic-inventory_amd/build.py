@@ -30,7 +30,7 @@ HIPCC_FLAGS = [
 
 def sources():
     return [os.path.join(CSRC, f) for f in ("sdpgpu.hip", "sdpgpu_generic.hip", "sdpgpu_window.hip", "sdpgpu_cash.hip",
-                                            "sdpgpu_staff.hip", "sdpgpu_sparse.hip", "sdpgpu_comm.hip")]
+                                            "sdpgpu_staff.hip", "sdpgpu_sparse.hip", "sdpgpu_comm.hip", "sdpgpu_pmf.hip")]
 
 
 def deps():

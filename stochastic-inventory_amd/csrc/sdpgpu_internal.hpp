@@ -7,6 +7,7 @@
 //   sdpgpu_cash.hip     F3 uniform-shift kernel and the cash row kernel (F3-F6)
 //   sdpgpu_staff.hip    STAFF family (workforce.StaffRecursion): level-dependent pmf tables, its period kernel
 //   sdpgpu_sparse.hip   reachable-set engine of the two-product lead-time family (own entry point)
+//   sdpgpu_pmf.hip      GetPmf.getpmf / CLSP.main's inline pmf (host arithmetic) behind the ABI
 //   sdpgpu_comm.hip     multi-GPU: RCCL communicators (loaded on first use), per-period all-gather, sharded sweeps
 #pragma once
 #include "../../include/sdpgpu.h"

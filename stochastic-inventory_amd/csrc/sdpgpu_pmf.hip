@@ -1,0 +1,242 @@
+// sdpgpu_pmf.hip -- PMF construction behind the C ABI (host code): what a driver does
+// immediately before the recursion, `new GetPmf(distributions, truncationQuantile, stepSize).getpmf()`
+// (GetPmf.java:82-134), and capacitated.CLSP.main's inline variant (CLSP.java:219-247), so that a C or Java caller of
+// include/sdpgpu.h can go from distribution parameters to sdpgpu_set_pmf without SSJ.
+//
+// The reference gets cdf / inverseF / prob from umontreal.ssj 3.3.0, which is not under /root/reference: the functions
+// below are standard double-precision algorithms (log-gamma Poisson mass, erfc normal cdf, series / continued-fraction
+// incomplete gamma, Newton-refined quantiles), NOT a restatement of SSJ.  PARITY UNPINNED at this boundary (the
+// reference records no PMF values); what is reproduced exactly is GetPmf's STRUCTURE and its quirks: `(int)` truncation
+// of both quantiles (:87,:90), lower bound forced to 0 for integer distributions (:88-89, decided by distributions[0]),
+// prob(j) indexed by POSITION j not by the demand value (:124), the covered mass as normaliser (:123,:126-129),
+// UniformIntDist taken from distributions[0] for every period (:97-111); CLSP.main: un-truncated quantiles and the
+// cdf-difference branch for Poisson (PoissonDist is not a DiscreteDistribution, CLSP.java:236).
+// tests/test_pmf_abi.py compares with the Python restatement over scipy (stochastic-inventory_amd/pmf.py) to 1e-12.
+#include "sdpgpu_internal.hpp"
+
+using namespace sdpgpu_detail;
+
+namespace {
+
+constexpr double kPi = 3.14159265358979323846;
+
+struct Dist {
+  int kind;
+  double a, b;
+  bool discrete_int() const { return kind == SDPGPU_DIST_POISSON || kind == SDPGPU_DIST_UNIFORM_INT; }
+};
+
+// ---- Poisson(lambda) ------------------------------------------------------------------------------------------
+double poisson_prob(double lam, int64_t k) {
+  if (k < 0) return 0.0;
+  return std::exp(-lam + (double)k * std::log(lam) - std::lgamma((double)k + 1.0));
+}
+double poisson_cdf(double lam, double x) {
+  if (x < 0) return 0.0;
+  const int64_t n = (int64_t)std::floor(x);
+  double s = 0.0;
+  for (int64_t k = 0; k <= n; ++k) s += poisson_prob(lam, k);
+  return s > 1.0 ? 1.0 : s;
+}
+double poisson_inverse(double lam, double u) {  // smallest x with F(x) >= u
+  double s = 0.0;
+  for (int64_t k = 0; k < 100000000; ++k) {
+    s += poisson_prob(lam, k);
+    if (s >= u) return (double)k;
+  }
+  return 1e8;
+}
+
+// ---- Normal(mu, sigma) ----------------------------------------------------------------------------------------
+double normal_cdf(double mu, double sigma, double x) { return 0.5 * std::erfc(-(x - mu) / (sigma * std::sqrt(2.0))); }
+double std_normal_inverse(double p) {
+  // Acklam's rational approximation (relative error 1.15e-9), then two Newton steps on erfc: full double precision
+  static const double a[] = {-3.969683028665376e+01, 2.209460984245205e+02, -2.759285104469687e+02,
+                             1.383577518672690e+02,  -3.066479806614716e+01, 2.506628277459239e+00};
+  static const double b[] = {-5.447609879822406e+01, 1.615858368580409e+02, -1.556989798598866e+02, 6.680131188771972e+01,
+                             -1.328068155288572e+01};
+  static const double c[] = {-7.784894002430293e-03, -3.223964580411365e-01, -2.400758277161838e+00,
+                             -2.549732539343734e+00, 4.374664141464968e+00,  2.938163982698783e+00};
+  static const double d[] = {7.784695709041462e-03, 3.224671290700398e-01, 2.445134137142996e+00, 3.754408661907416e+00};
+  double x;
+  if (p < 0.02425) {
+    const double q = std::sqrt(-2 * std::log(p));
+    x = (((((c[0] * q + c[1]) * q + c[2]) * q + c[3]) * q + c[4]) * q + c[5]) / ((((d[0] * q + d[1]) * q + d[2]) * q + d[3]) * q + 1);
+  } else if (p > 1 - 0.02425) {
+    const double q = std::sqrt(-2 * std::log(1 - p));
+    x = -(((((c[0] * q + c[1]) * q + c[2]) * q + c[3]) * q + c[4]) * q + c[5]) / ((((d[0] * q + d[1]) * q + d[2]) * q + d[3]) * q + 1);
+  } else {
+    const double q = p - 0.5, r = q * q;
+    x = (((((a[0] * r + a[1]) * r + a[2]) * r + a[3]) * r + a[4]) * r + a[5]) * q /
+        (((((b[0] * r + b[1]) * r + b[2]) * r + b[3]) * r + b[4]) * r + 1);
+  }
+  for (int it = 0; it < 2; ++it) {
+    const double e = 0.5 * std::erfc(-x / std::sqrt(2.0)) - p;
+    const double u = e * std::sqrt(2 * kPi) * std::exp(x * x / 2);
+    x = x - u / (1 + x * u / 2);  // Halley
+  }
+  return x;
+}
+
+// ---- Gamma(alpha, lambda): shape alpha, RATE lambda (SSJ's GammaDist) -------------------------------------------
+double reg_lower_gamma(double a, double x) {  // P(a, x)
+  if (x <= 0) return 0.0;
+  const double gln = std::lgamma(a);
+  if (x < a + 1.0) {  // series
+    double ap = a, sum = 1.0 / a, del = sum;
+    for (int n = 0; n < 10000; ++n) {
+      ap += 1.0;
+      del *= x / ap;
+      sum += del;
+      if (std::fabs(del) < std::fabs(sum) * 1e-17) break;
+    }
+    return sum * std::exp(-x + a * std::log(x) - gln);
+  }
+  // continued fraction for Q(a, x) (modified Lentz)
+  const double tiny = 1e-300;
+  double bq = x + 1.0 - a, cq = 1.0 / tiny, dq = 1.0 / bq, hq = dq;
+  for (int i = 1; i < 10000; ++i) {
+    const double an = -(double)i * ((double)i - a);
+    bq += 2.0;
+    dq = an * dq + bq;
+    if (std::fabs(dq) < tiny) dq = tiny;
+    cq = bq + an / cq;
+    if (std::fabs(cq) < tiny) cq = tiny;
+    dq = 1.0 / dq;
+    const double del = dq * cq;
+    hq *= del;
+    if (std::fabs(del - 1.0) < 1e-17) break;
+  }
+  return 1.0 - std::exp(-x + a * std::log(x) - gln) * hq;
+}
+double gamma_cdf(double alpha, double lam, double x) { return x > 0 ? reg_lower_gamma(alpha, lam * x) : 0.0; }
+double gamma_inverse(double alpha, double lam, double u) {
+  // bracket + bisection on P(alpha, .), then Newton steps with the density
+  double lo = 0.0, hi = alpha + 10.0 * std::sqrt(alpha) + 10.0;
+  while (reg_lower_gamma(alpha, hi) < u) hi *= 2.0;
+  for (int it = 0; it < 200; ++it) {
+    const double mid = 0.5 * (lo + hi);
+    if (reg_lower_gamma(alpha, mid) < u) lo = mid; else hi = mid;
+    if (hi - lo <= 1e-15 * hi) break;
+  }
+  double x = 0.5 * (lo + hi);
+  for (int it = 0; it < 3 && x > 0; ++it) {
+    const double f = reg_lower_gamma(alpha, x) - u;
+    const double pdf = std::exp(-x + (alpha - 1.0) * std::log(x) - std::lgamma(alpha));
+    if (!(pdf > 0)) break;
+    const double xn = x - f / pdf;
+    if (!(xn > lo * 0.5) || !(xn < hi * 2.0)) break;
+    x = xn;
+  }
+  return x / lam;
+}
+
+// ---- the slice of SSJ's Distribution interface GetPmf uses -------------------------------------------------------
+double d_cdf(const Dist& d, double x) {
+  switch (d.kind) {
+    case SDPGPU_DIST_POISSON: return poisson_cdf(d.a, x);
+    case SDPGPU_DIST_NORMAL: return normal_cdf(d.a, d.b, x);
+    case SDPGPU_DIST_GAMMA: return gamma_cdf(d.a, d.b, x);
+    case SDPGPU_DIST_UNIFORM_INT: {
+      if (x < d.a) return 0.0;
+      if (x >= d.b) return 1.0;
+      return (std::floor(x) - d.a + 1.0) / (d.b - d.a + 1.0);
+    }
+  }
+  return 0.0;
+}
+double d_inverse(const Dist& d, double u) {
+  switch (d.kind) {
+    case SDPGPU_DIST_POISSON: return poisson_inverse(d.a, u);
+    case SDPGPU_DIST_NORMAL: return d.a + d.b * std_normal_inverse(u);
+    case SDPGPU_DIST_GAMMA: return gamma_inverse(d.a, d.b, u);
+    case SDPGPU_DIST_UNIFORM_INT: {
+      const double n = d.b - d.a + 1.0;
+      double k = std::ceil(u * n) - 1.0;  // smallest x with F(x) >= u
+      if (k < 0) k = 0;
+      return d.a + k;
+    }
+  }
+  return 0.0;
+}
+double d_prob(const Dist& d, int64_t j) {
+  switch (d.kind) {
+    case SDPGPU_DIST_POISSON: return poisson_prob(d.a, j);
+    case SDPGPU_DIST_UNIFORM_INT: return ((double)j >= d.a && (double)j <= d.b) ? 1.0 / (d.b - d.a + 1.0) : 0.0;
+  }
+  return 0.0;
+}
+
+int check(const sdpgpu_dist_spec* dists, int32_t T, double q, double step, int32_t t) {
+  if (!dists || T < 1 || t < 0 || t >= T) return fail(nullptr, SDPGPU_ERR_ARG, "getpmf: bad period / distribution list");
+  if (!(q > 0.5 && q < 1.0)) return fail(nullptr, SDPGPU_ERR_ARG, "getpmf: truncation quantile %g not in (0.5, 1)", q);
+  if (!(step > 0)) return fail(nullptr, SDPGPU_ERR_ARG, "getpmf: step %g", step);
+  for (int32_t i = 0; i < T; ++i) {
+    const sdpgpu_dist_spec& s = dists[i];
+    const bool ok = (s.kind == SDPGPU_DIST_POISSON && s.a > 0 && s.a < 1e7) || (s.kind == SDPGPU_DIST_NORMAL && s.b > 0) ||
+                    (s.kind == SDPGPU_DIST_GAMMA && s.a > 0 && s.b > 0) ||
+                    (s.kind == SDPGPU_DIST_UNIFORM_INT && s.a == std::floor(s.a) && s.b == std::floor(s.b) && s.b >= s.a);
+    if (!ok) return fail(nullptr, SDPGPU_ERR_ARG, "getpmf: distribution %d (kind %d, %g, %g)", i, s.kind, s.a, s.b);
+  }
+  return SDPGPU_OK;
+}
+
+}  // namespace
+
+extern "C" int sdpgpu_getpmf(const sdpgpu_dist_spec* dists, int32_t T, double truncation_quantile, double step,
+                             int32_t variant, int32_t t, double* demand, double* prob, int32_t capacity, int32_t* n_out) {
+  g_create_error.clear();
+  try {
+    int rc = check(dists, T, truncation_quantile, step, t);
+    if (rc) return rc;
+    if (!n_out || capacity < 0 || (capacity > 0 && (!demand || !prob))) return fail(nullptr, SDPGPU_ERR_ARG, "getpmf: null output");
+    if (variant != SDPGPU_PMF_GETPMF && variant != SDPGPU_PMF_CLSP) return fail(nullptr, SDPGPU_ERR_ARG, "getpmf: variant %d", variant);
+    const Dist d0{dists[0].kind, dists[0].a, dists[0].b};
+    const Dist d{dists[t].kind, dists[t].a, dists[t].b};
+    const double q = truncation_quantile;
+    std::vector<double> dv, pv;
+    if (variant == SDPGPU_PMF_GETPMF && d0.kind == SDPGPU_DIST_UNIFORM_INT) {  // GetPmf.java:97-111: distributions[0] every period
+      for (int64_t j = (int64_t)d0.a; j <= (int64_t)d0.b; ++j) {
+        dv.push_back((double)j);
+        pv.push_back(d_prob(d0, j));
+      }
+    } else if (variant == SDPGPU_PMF_GETPMF) {
+      double lb = (double)java_d2i(d_inverse(d, 1 - q));  // :87
+      if (d0.discrete_int()) lb = 0.0;                    // :88-89
+      const double ub = (double)java_d2i(d_inverse(d, q));  // :90
+      const int32_t n = java_d2i((ub - lb + 1) / step);     // :114
+      for (int32_t j = 0; j < n; ++j) {
+        const double dem = lb + (double)j * step;  // :119
+        double p;
+        if (d0.discrete_int()) {  // :120-124 (prob(j): indexed by j, not by the demand value)
+          const double sum = d_cdf(d, ub) - d_cdf(d, lb - 1);
+          p = d_prob(d, j) / sum;
+        } else {  // :125-129
+          const double sum = d_cdf(d, ub + 0.5 * step) - d_cdf(d, lb - 0.5 * step);
+          p = (d_cdf(d, dem + 0.5 * step) - d_cdf(d, dem - 0.5 * step)) / sum;
+        }
+        dv.push_back(dem);
+        pv.push_back(p);
+      }
+    } else {  // CLSP.java:219-247: quantiles not truncated; every in-scope distribution takes the cdf-difference branch
+      const double lb = d_inverse(d, 1 - q), ub = d_inverse(d, q);
+      const int32_t n = java_d2i((ub - lb + 1) / step);
+      const double sum = d_cdf(d, ub + 0.5 * step) - d_cdf(d, lb - 0.5 * step);
+      for (int32_t j = 0; j < n; ++j) {
+        const double dem = lb + (double)j * step;
+        dv.push_back(dem);
+        pv.push_back((d_cdf(d, dem + 0.5 * step) - d_cdf(d, dem - 0.5 * step)) / sum);
+      }
+    }
+    *n_out = (int32_t)dv.size();
+    if (capacity == 0) return SDPGPU_OK;  // sizing call
+    if ((size_t)capacity < dv.size()) return fail(nullptr, SDPGPU_ERR_ARG, "getpmf: %zu points, capacity %d", dv.size(), capacity);
+    std::memcpy(demand, dv.data(), dv.size() * sizeof(double));
+    std::memcpy(prob, pv.data(), pv.size() * sizeof(double));
+    return SDPGPU_OK;
+  } catch (const std::exception& e) {
+    return fail(nullptr, SDPGPU_ERR_ARG, "exception: %s", e.what());
+  } catch (...) {
+    return fail(nullptr, SDPGPU_ERR_ARG, "unknown exception");
+  }
+}

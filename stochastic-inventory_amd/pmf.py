@@ -263,3 +263,42 @@ def clsp_pmf(distributions: Sequence[Distribution], truncationQuantile: float, s
                 tile[j, 1] = (dist.cdf(tile[j, 0] + 0.5 * step) - dist.cdf(tile[j, 0] - 0.5 * step)) / probabilitySum
         pmf.append(tile)
     return pmf
+
+
+def getpmf_native(distributions: Sequence[Distribution], truncationQuantile: float, stepSize: float,
+                  clsp_variant: bool = False) -> List[np.ndarray]:
+    """The same tiles from libsdpgpu.so's own GetPmf (sdpgpu_getpmf, csrc/sdpgpu_pmf.hip: no scipy, no SSJ) -- what a C
+    or Java caller of the ABI gets.  Distributions: PoissonDist, NormalDist, UniformIntDist, GammaDist."""
+    import ctypes as C
+
+    from . import _abi
+    lib = _abi.load()
+    T = len(distributions)
+    specs = (_abi.SdpgpuDistSpec * T)()
+    for i, d in enumerate(distributions):
+        if isinstance(d, PoissonDist):
+            specs[i].kind, specs[i].a, specs[i].b = _abi.DIST_POISSON, d.lam, 0.0
+        elif isinstance(d, NormalDist):
+            specs[i].kind, specs[i].a, specs[i].b = _abi.DIST_NORMAL, d.mu, d.sigma
+        elif isinstance(d, UniformIntDist):
+            specs[i].kind, specs[i].a, specs[i].b = _abi.DIST_UNIFORM_INT, float(d.getI()), float(d.getJ())
+        elif isinstance(d, GammaDist):
+            specs[i].kind, specs[i].a, specs[i].b = _abi.DIST_GAMMA, d.alpha, d.lam
+        else:
+            raise TypeError(f"sdpgpu_getpmf has no {type(d).__name__}")
+    out = []
+    variant = _abi.PMF_CLSP if clsp_variant else _abi.PMF_GETPMF
+    for t in range(T):
+        n = C.c_int32(0)
+        rc = lib.sdpgpu_getpmf(specs, T, float(truncationQuantile), float(stepSize), variant, t, None, None, 0, C.byref(n))
+        if rc:
+            raise _abi.SdpgpuError(rc, lib.sdpgpu_last_error(None).decode())
+        dem = np.zeros(n.value)
+        pr = np.zeros(n.value)
+        rc = lib.sdpgpu_getpmf(specs, T, float(truncationQuantile), float(stepSize), variant, t,
+                               dem.ctypes.data_as(C.POINTER(C.c_double)), pr.ctypes.data_as(C.POINTER(C.c_double)),
+                               n.value, C.byref(n))
+        if rc:
+            raise _abi.SdpgpuError(rc, lib.sdpgpu_last_error(None).decode())
+        out.append(np.stack([dem, pr], axis=1))
+    return out

@@ -29,16 +29,50 @@ import torch.distributed as dist
 from .engine import SdpEngine
 
 
-def init_native_comm(engine: SdpEngine, group=None) -> None:
-    """Give `engine` (this rank's handle) its RCCL communicator INSIDE libsdpgpu.so (sdpgpu_comm_init): rank 0 draws the
-    unique id through the C ABI, torch.distributed is only the channel that carries its 128 bytes to the other ranks
-    (any backend: gloo is enough).  After this the data path -- kernels and all-gathers -- is sdpgpu_solve_sharded."""
+def init_native_comm(engine: SdpEngine, group=None) -> bool:
+    """Give `engine` (this rank's handle) its RCCL communicator INSIDE libsdpgpu.so (sdpgpu_comm_init).  rank 0's unique
+    id travels over torch.distributed (any backend: gloo is enough), which is only the channel for those 128 bytes: after
+    this the data path -- kernels and all-gathers -- is sdpgpu_solve_sharded.
+    Returns True when EVERY rank has its communicator, False when some rank could not get one (then none keeps one): the
+    ranks agree after each phase, so that a rank whose librccl does not load cannot leave the others waiting inside a
+    collective."""
     world = dist.get_world_size(group) if dist.is_initialized() else 1
     rank = dist.get_rank(group) if dist.is_initialized() else 0
-    box = [SdpEngine.comm_unique_id() if rank == 0 else None]
+
+    def agree(ok: bool) -> bool:
+        if world == 1:
+            return ok
+        flags = [None] * world
+        dist.all_gather_object(flags, bool(ok), group=group)
+        return all(flags)
+
+    try:  # phase 1, every rank: does RCCL load here?  (only rank 0's id is used)
+        uid = SdpEngine.comm_unique_id()
+        ok = True
+    except Exception as exc:
+        uid, ok = None, False
+        init_native_comm.last_error = str(exc)
+    if not agree(ok):
+        return False
+    box = [uid if rank == 0 else None]
     if world > 1:
         dist.broadcast_object_list(box, src=0, group=group)
-    engine.comm_init(box[0], rank, world)
+    try:  # phase 2: the collective ncclCommInitRank
+        engine.comm_init(box[0], rank, world)
+        ok = True
+    except Exception as exc:
+        ok = False
+        init_native_comm.last_error = str(exc)
+    if not agree(ok):
+        try:
+            engine.comm_destroy()
+        except Exception:
+            pass
+        return False
+    return True
+
+
+init_native_comm.last_error = ""
 
 
 class SlabBackend:

@@ -165,3 +165,34 @@ def test_blocked_schedule_gloo(tmp_path, oracle, world, case_name, k):
         for r in range(world):
             assert np.array_equal(ranks[r][f"v{p}"][:S], V[p - 1]), (p, r)
         assert np.array_equal(np.concatenate([ranks[r][f"p{p}"] for r in range(world)]), pol[p - 1])
+
+
+def _native_worker(rank, world, port, out_dir):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    import cases
+    import stochastic_inventory_amd as sia
+    from stochastic_inventory_amd.sharded import init_native_comm
+    w = cases.f1_small()
+    desc = w.desc()
+    desc.rank, desc.world_size = rank, world
+    with sia.SdpEngine(desc, w.pmf) as eng:
+        got = init_native_comm(eng)  # no GPU here: sdpgpu_comm_init fails on every rank -- and every rank must say so
+        with open(os.path.join(out_dir, f"native{rank}.txt"), "w") as f:
+            f.write(f"{got}|{init_native_comm.last_error}")
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_native_comm_setup_agrees_across_ranks_without_a_gpu(tmp_path):
+    """sharded.init_native_comm on CPU, world 3: librccl loads and rank 0's unique id reaches every rank (phase 1), the
+    communicator itself needs a device (phase 2 fails: the library has no CPU path), and the ranks AGREE on the failure
+    instead of leaving each other inside a collective -- which is what lets bench.py fall back together."""
+    world = 3
+    port = 29500 + (os.getpid() % 2000) + 77
+    mp.spawn(_native_worker, args=(world, port, str(tmp_path)), nprocs=world, join=True)
+    for r in range(world):
+        got, err = open(os.path.join(str(tmp_path), f"native{r}.txt")).read().split("|", 1)
+        assert got == "False"
+        assert "HIP" in err or "device" in err.lower()
