@@ -298,6 +298,17 @@ int sdpgpu_getpmf(const sdpgpu_dist_spec* distributions, int32_t T, double trunc
 /* Optional per-period overhead cost (CashOverdraft.java:38-39 keeps an array).  STAFF family: minStaffNum[t]. */
 int sdpgpu_set_overhead(sdpgpu_handle* h, int32_t t, double overhead_cost);
 
+/* Optional: the caller's own action-list LENGTHS.  The reference's `Function<State, double[]> getFeasibleAction`
+ * (Recursion.java:49,129) may return any array; every in-scope driver returns a prefix 0, step, 2 step, ... of the
+ * action grid whose length follows one of the families' closed forms.  A driver whose list is still such a prefix but
+ * with a length of its own (a storage capacity Q <= cap - x, a budget table, ...) hands the lengths over here:
+ * counts[i] = getFeasibleAction.apply(state i of period t+1).length for every grid state i (flat index order,
+ * n = sdpgpu_num_states), 0 <= counts[i] <= (int)(max_order_quantity / step) + 1; 0 = no feasible action (the value is
+ * then +-Double.MAX_VALUE and the action 0, Recursion.java:132-134).  Such a period runs on the generic kernel (the
+ * specialised kernels build on the family's rule); off-grid states (sdpgpu_eval_states) keep the family's rule.
+ * Before the first run.  Lists that are not prefixes of the action grid need sdpgpu_create_custom. */
+int sdpgpu_set_action_counts(sdpgpu_handle* h, int32_t t, const int32_t* counts, int64_t n);
+
 /* Launch kernels on a caller-owned hipStream_t (NULL = the legacy default stream).  Without this
  * call the library creates a non-blocking stream of its own. */
 int sdpgpu_set_stream(sdpgpu_handle* h, void* hip_stream);

@@ -130,9 +130,27 @@ static int32_t full_action_count(const sdpgpu_desc* d) {
  * state is (period, x, R) -- st_t.cash holds R, literally what CashStateXR holds (CashStateXR.java:14-22). */
 static int is_xr(const sdpgpu_desc* d) { return d->family == SDPGPU_FAMILY_CASH && d->cash_formula == 2; }
 
+/* Caller-supplied action-list lengths (sdpgpu_set_action_counts at the product's boundary): a
+ * `Function<State, double[]> getFeasibleAction` (Recursion.java:49,129) whose list is a prefix of the action grid with a
+ * length of its own.  The harness registers, per period, the length of every grid state; a state that is not a grid point
+ * keeps the family's rule (as in the product). */
+static struct {
+  const int32_t* counts;     /* concatenated per period */
+  const int64_t* off;        /* T + 1 offsets, off[t+1] == off[t]: period t+1 has none */
+  sdpref_grid* grids;        /* layout of the problem the table belongs to */
+  int32_t T;
+} g_counts = {0, 0, 0, 0};
+
+static int64_t index_of(const sdpgpu_desc* d, const sdpref_grid* g, const st_t* s);
+
 /* getFeasibleActions.apply(state).length */
 static int32_t n_actions(const ctx_t* c, const st_t* s) {
   const sdpgpu_desc* d = c->d;
+  if (g_counts.counts && s->period >= 1 && s->period <= g_counts.T &&
+      g_counts.off[s->period] > g_counts.off[s->period - 1]) {
+    int64_t idx = index_of(d, &g_counts.grids[s->period - 1], s);
+    if (idx >= 0) return g_counts.counts[g_counts.off[s->period - 1] + idx];
+  }
   if (g_user.count) {
     sdpref_user_ctx u = {s->period, c->T, d->step, g_user.params};
     return g_user.count(&u, s->x, s->cash, s->preq);
@@ -542,6 +560,28 @@ int sdpref_layout(const sdpgpu_desc* d, const int32_t* pmf_off, const double* pm
       hi = hi + qmax - dmin;
     }
   }
+  return 0;
+}
+
+/* NULL counts clears the registration.  The arrays must outlive the solves that use them. */
+int sdpref_set_action_counts(const sdpgpu_desc* d, const int32_t* pmf_off, const double* pmf_d, const int32_t* counts,
+                             const int64_t* off) {
+  free(g_counts.grids);
+  g_counts.grids = NULL;
+  g_counts.counts = NULL;
+  g_counts.off = NULL;
+  g_counts.T = 0;
+  if (!counts) return 0;
+  g_counts.grids = (sdpref_grid*)malloc(sizeof(sdpref_grid) * (size_t)d->periods);
+  int rc = sdpref_layout(d, pmf_off, pmf_d, g_counts.grids);
+  if (rc) {
+    free(g_counts.grids);
+    g_counts.grids = NULL;
+    return rc;
+  }
+  g_counts.counts = counts;
+  g_counts.off = off;
+  g_counts.T = d->periods;
   return 0;
 }
 

@@ -120,6 +120,10 @@ void sdpref_multixr_set_threads(int32_t n);
 /* User-defined lambdas: host-compiled versions of the three functions sdpgpu_create_custom takes (signatures in
  * sdpref.c).  Pass NULLs to return to the built-in families.  Not thread-safe: test harness use only. */
 void sdpref_register_custom(void* count_fn, void* imm_fn, void* trans_fn, const double* params);
+/* Caller-supplied action-list lengths per grid state (the oracle's twin of sdpgpu_set_action_counts): counts of the periods
+ * concatenated, off[t] .. off[t+1] the entries of period t+1 (empty: the family's rule).  NULL clears. */
+int sdpref_set_action_counts(const sdpgpu_desc* d, const int32_t* pmf_off, const double* pmf_d, const int32_t* counts,
+                             const int64_t* off);
 
 /* Java arithmetic helpers, exported so tests can probe their corner cases. */
 int64_t sdpref_java_round(double x);

@@ -109,6 +109,30 @@ class Problem:
     def _args(self):
         return (C.byref(self.desc), self.off.ctypes.data_as(_IP), _dp(self.pd), _dp(self.pp), _dp(self.oh))
 
+    def action_counts(self, per_period):
+        """Context manager: per_period[t] = array of action-list lengths of every grid state of period t+1 (or None: the
+        family's rule) -- the oracle's twin of sdpgpu_set_action_counts.  Registered globally while the block runs."""
+        prob = self
+
+        class _Ctx:
+            def __enter__(self_inner):
+                arrs = [np.zeros(0, np.int32) if c is None else np.ascontiguousarray(c, dtype=np.int32) for c in per_period]
+                self_inner.off = np.zeros(prob.T + 1, dtype=np.int64)
+                self_inner.off[1:] = np.cumsum([len(a) for a in arrs])
+                self_inner.flat = np.ascontiguousarray(np.concatenate(arrs) if arrs else np.zeros(0, np.int32), dtype=np.int32)
+                if len(self_inner.flat) == 0:
+                    self_inner.flat = np.zeros(1, np.int32)
+                rc = lib().sdpref_set_action_counts(C.byref(prob.desc), prob.off.ctypes.data_as(_IP), _dp(prob.pd),
+                                                    self_inner.flat.ctypes.data_as(_IP), self_inner.off.ctypes.data_as(_LP))
+                if rc:
+                    raise RuntimeError(f"sdpref_set_action_counts failed: {rc}")
+                return prob
+
+            def __exit__(self_inner, *exc):
+                lib().sdpref_set_action_counts(C.byref(prob.desc), prob.off.ctypes.data_as(_IP), _dp(prob.pd), None, None)
+
+        return _Ctx()
+
     def solve(self, nthreads: int = 1):
         """Dense backward sweep: returns (values per period, policy per period, cells)."""
         total = int(self.voff[-1])

@@ -216,6 +216,7 @@ EXPORTS = {
     "sdpgpu_getpmf": (C.c_int, [C.POINTER(SdpgpuDistSpec), C.c_int32, C.c_double, C.c_double, C.c_int32, C.c_int32, _DP, _DP,
                                 C.c_int32, _IP]),
     "sdpgpu_set_overhead": (C.c_int, [_P, C.c_int32, C.c_double]),
+    "sdpgpu_set_action_counts": (C.c_int, [_P, C.c_int32, _IP, C.c_int64]),
     "sdpgpu_set_stream": (C.c_int, [_P, _P]),
     "sdpgpu_set_profiling": (C.c_int, [_P, C.c_int32]),
     "sdpgpu_num_states": (C.c_int64, [_P, C.c_int32]),

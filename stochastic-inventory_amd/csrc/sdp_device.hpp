@@ -47,6 +47,9 @@ struct DevParams {
   double min_cash, max_cash, round_mult, round_div;
   double r0, r2, r3, limit, interest_free;
   Grid cur, next;
+  // sdpgpu_set_action_counts: getFeasibleActions.apply(state).length of every GRID state of this period, indexed by
+  // flat state index (nullptr: the family's own rule)
+  const int32_t* counts;
 };
 
 // java.lang.Math.max / min for the non-NaN operands that occur here.  v_max_f64 / v_min_f64

@@ -71,7 +71,10 @@ __global__ __launch_bounds__(256) void gather_period_kernel(DevParams P, const d
   } else {
     decode_state<FAM>(P, live ? idx : lo, s);
   }
-  const int nA = live ? n_actions<FAM>(P, s) : 0;
+  int nA = live ? n_actions<FAM>(P, s) : 0;
+  if constexpr (!QUERY) {
+    if (P.counts && live) nA = P.counts[idx];  // the caller's own list lengths (sdpgpu_set_action_counts)
+  }
 
   double best = MAXDIR ? -1.7976931348623157e308 : 1.7976931348623157e308;  // +-Double.MAX_VALUE
   int bestk = 0;                                                           // bestOrderQty = 0
@@ -184,7 +187,10 @@ __global__ __launch_bounds__(256) void reach_kernel(DevParams P, const uint8_t* 
     if (!mask_cur[idx]) return;
     decode_state<FAM>(P, idx, s);
   }
-  const int nA = n_actions<FAM>(P, s);
+  int nA = n_actions<FAM>(P, s);
+  if constexpr (!QUERY) {
+    if (P.counts) nA = P.counts[idx];
+  }
   for (int k = as; k < nA; k += 4) {
     ActionCtx c;
     action_setup<FAM>(P, s, k, c);

@@ -204,6 +204,13 @@ int allocate(sdpgpu_handle* h) {
         host[p.pmf_win_off + (size_t)((h->pmf_d[t][(size_t)j] - h->pmf_d[t][0]) / h->d.step)] = h->pmf_p[t][(size_t)j];
   }
   HIP_TRY(h, hipMemcpy(h->d_pmf, host.data(), pmf_elems * sizeof(double), hipMemcpyHostToDevice));
+  for (int t = 0; t < h->T; ++t) {
+    if (h->counts[(size_t)t].empty()) continue;
+    if ((int64_t)h->counts[(size_t)t].size() != h->per[t].S)
+      return fail(h, SDPGPU_ERR_ARG, "action counts of period %d: %zu entries for %lld grid states", t + 1, h->counts[(size_t)t].size(), (long long)h->per[t].S);
+    HIP_TRY(h, hipMalloc((void**)&h->d_counts[(size_t)t], h->counts[(size_t)t].size() * sizeof(int32_t)));
+    HIP_TRY(h, hipMemcpy(h->d_counts[(size_t)t], h->counts[(size_t)t].data(), h->counts[(size_t)t].size() * sizeof(int32_t), hipMemcpyHostToDevice));
+  }
   HIP_TRY(h, hipEventCreate(&h->ev_solve0));
   HIP_TRY(h, hipEventCreate(&h->ev_solve1));
   if (h->d.family == SDPGPU_FAMILY_STAFF) {
@@ -271,6 +278,7 @@ DevParams make_params(const sdpgpu_handle* h, int period) {
   P.interest_free = d.interest_free_amount;
   P.cur = p.g;
   if (period < h->T) P.next = h->per[period].g;
+  P.counts = h->d_counts[(size_t)period - 1];
   return P;
 }
 
@@ -282,6 +290,12 @@ void count_cells(sdpgpu_handle* h, int period) {
   int64_t nD = p.nD;
   auto range_cells = [&](int64_t lo, int64_t hi) -> int64_t {
     if (hi <= lo) return 0;
+    if (!h->counts[(size_t)period - 1].empty()) {  // the caller's own list lengths
+      int64_t total = 0;
+      const std::vector<int32_t>& c = h->counts[(size_t)period - 1];
+      for (int64_t i = lo; i < hi; ++i) total += c[(size_t)i];
+      return total * nD;
+    }
     if (d.family == SDPGPU_FAMILY_STAFF) return staff_cells(h, period, lo, hi);
     if (d.family != SDPGPU_FAMILY_CASH && d.family != SDPGPU_FAMILY_SURVIVAL) {
       int64_t nA = h->n_actions_full;
@@ -387,6 +401,9 @@ int run_period_impl(sdpgpu_handle* h, int period, int part, int64_t range_lo, in
     if (!h->d.store_all_values && period + 2 <= h->T) h->period_done[period + 1] = 0;
     return SDPGPU_OK;
   }
+  const bool own_counts = !h->counts[(size_t)period - 1].empty();  // the specialised kernels assume the family's action rule
+  if (own_counts && (h->d.kernel == SDPGPU_KERNEL_SEPARABLE || h->d.kernel == SDPGPU_KERNEL_WINDOW || ranged))
+    return fail(h, SDPGPU_ERR_UNSUPPORTED, "period %d has caller-supplied action counts: only the generic kernel evaluates those", period);
   if (h->d.kernel == SDPGPU_KERNEL_SEPARABLE && h->d.family == SDPGPU_FAMILY_LEADTIME) {
     if (part == SDPGPU_PART_INTERIOR) return SDPGPU_OK;
     hipError_t es = launch_separable_f2(h, P, period, v_next, v_cur, pol, pd, pp);
@@ -424,7 +441,7 @@ int run_period_impl(sdpgpu_handle* h, int period, int part, int64_t range_lo, in
     if (!window_eligible(h, period)) return fail(h, SDPGPU_ERR_UNSUPPORTED, "window kernel needs the backorder / lead-time family with a unit-stride demand grid");
     use_window = true;
   } else if (h->d.kernel == SDPGPU_KERNEL_AUTO) {
-    use_window = window_eligible(h, period);
+    use_window = !own_counts && window_eligible(h, period);
   }
   if (part != SDPGPU_PART_ALL) {
     // only the F1 window kernel has a bounded dependency footprint; everything else is "all boundary"
@@ -440,11 +457,11 @@ int run_period_impl(sdpgpu_handle* h, int period, int part, int64_t range_lo, in
     e = launch_window(h, P, period, v_next, v_cur, pol, pd, h->d_pmf + p.pmf_win_off, ranged ? range_lo : p.lo,
                       ranged ? range_hi : p.hi, h->stream, part);
     p.kernel_used = SDPGPU_KERNEL_WINDOW;
-  } else if (h->d.kernel != SDPGPU_KERNEL_GATHER && h->use_cash_shift && cash_shift_eligible(h, period)) {
+  } else if (!own_counts && h->d.kernel != SDPGPU_KERNEL_GATHER && h->use_cash_shift && cash_shift_eligible(h, period)) {
     e = flush_pending(h);
     if (e == hipSuccess) e = launch_cash_shift(h, P, period, v_next, v_cur, pol, pd, pp, p.lo, p.hi, h->stream);
     p.kernel_used = SDPGPU_KERNEL_WINDOW;  // reported as a specialised (non-gather) kernel
-  } else if (h->d.kernel != SDPGPU_KERNEL_GATHER && cash_row_eligible(h, period)) {
+  } else if (!own_counts && h->d.kernel != SDPGPU_KERNEL_GATHER && cash_row_eligible(h, period)) {
     e = flush_pending(h);
     if (e == hipSuccess) e = launch_cash_row(h, P, period, v_next, v_cur, pol, pd, pp, p.lo, p.hi, h->stream);
     p.kernel_used = SDPGPU_KERNEL_WINDOW;
@@ -542,6 +559,8 @@ int sdpgpu_create(const sdpgpu_desc* desc, sdpgpu_handle** out) {
     h->period_done.assign((size_t)h->T, 0);
     h->policy_done.assign((size_t)h->T, 0);
     h->pending_chunks.assign((size_t)h->T + 1, 0);
+    h->counts.resize((size_t)h->T);
+    h->d_counts.assign((size_t)h->T, nullptr);
     if (const char* e = std::getenv("SDPGPU_WIN_R")) h->win_r = std::atoi(e);
     if (const char* e = std::getenv("SDPGPU_WIN_NCH")) h->win_nch = std::atoi(e);
     if (const char* e = std::getenv("SDPGPU_WIN_S")) h->win_s = std::atoi(e);
@@ -634,6 +653,8 @@ void sdpgpu_destroy(sdpgpu_handle* h) {
   for (void* q : h->staff_owned) (void)hipFree(q);
   if (h->d_staff_val) (void)hipFree(h->d_staff_val);
   if (h->d_staff_idx) (void)hipFree(h->d_staff_idx);
+  for (int32_t* q : h->d_counts)
+    if (q) (void)hipFree(q);
   if (h->d_sep_val) (void)hipFree(h->d_sep_val);
   if (h->d_sep_idx) (void)hipFree(h->d_sep_idx);
   if (h->d_custom_params) (void)hipFree(h->d_custom_params);
@@ -706,6 +727,25 @@ int sdpgpu_set_overhead(sdpgpu_handle* h, int32_t t, double overhead_cost) {
   if (t < 0 || t >= h->T) return fail(h, SDPGPU_ERR_ARG, "set_overhead: t=%d", t);
   h->per[t].overhead = overhead_cost;
   h->per[t].overhead_set = true;
+  return SDPGPU_OK;
+}
+
+int sdpgpu_set_action_counts(sdpgpu_handle* h, int32_t t, const int32_t* counts, int64_t n) {
+  if (!h) return SDPGPU_ERR_ARG;
+  h->err.clear();
+  if (t < 0 || t >= h->T || !counts || n < 1) return fail(h, SDPGPU_ERR_ARG, "set_action_counts: bad argument");
+  if (h->allocated) return fail(h, SDPGPU_ERR_STATE, "set_action_counts must precede the first run");
+  if (h->custom) return fail(h, SDPGPU_ERR_UNSUPPORTED, "set_action_counts: a user functor has its own sdp_feasible_count");
+  if (h->d.family == SDPGPU_FAMILY_STAFF) return fail(h, SDPGPU_ERR_UNSUPPORTED, "set_action_counts: not for the staff family");
+  const int32_t cap = full_action_count(h->d);
+  try {
+    for (int64_t i = 0; i < n; ++i)
+      if (counts[i] < 0 || counts[i] > cap)
+        return fail(h, SDPGPU_ERR_ARG, "set_action_counts: state %lld has %d actions, the action grid has %d (max_order_quantity / step + 1)", (long long)i, counts[i], cap);
+    h->counts[(size_t)t].assign(counts, counts + n);  // (the length is checked against the grid once it is laid out)
+  } catch (...) {
+    return fail(h, SDPGPU_ERR_ARG, "out of host memory");
+  }
   return SDPGPU_OK;
 }
 

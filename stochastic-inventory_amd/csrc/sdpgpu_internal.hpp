@@ -136,6 +136,9 @@ struct sdpgpu_handle {
   double* d_staff_val = nullptr;    // partial arg-min rows [group][slab]
   int32_t* d_staff_idx = nullptr;
   size_t staff_part_elems = 0;
+  // sdpgpu_set_action_counts: per period the caller's action-list lengths of every grid state (empty: family rule)
+  std::vector<std::vector<int32_t>> counts;
+  std::vector<int32_t*> d_counts;
   double* d_sep_val = nullptr;      // opt-in separable mode, lead-time family: the table G[q2][y] and its arg-min
   int32_t* d_sep_idx = nullptr;
   size_t sep_elems = 0;

@@ -11,6 +11,7 @@ namespace sdpgpu_detail {
 // F1 / F2 on a unit-stride demand grid d_j = d_0 + j*step (supports with gaps are laid out on one, see PeriodInfo).
 bool window_eligible(const sdpgpu_handle* h, int period) {
   if (h->custom) return false;
+  if (!h->counts[(size_t)period - 1].empty()) return false;  // caller-supplied action counts: generic kernel
   if (h->d.family != SDPGPU_FAMILY_BACKORDER && h->d.family != SDPGPU_FAMILY_LEADTIME) return false;
   const PeriodInfo& p = h->per[period - 1];
   if (p.nD_win <= 0) return false;

@@ -138,6 +138,11 @@ class SdpEngine:
         return int(self._lib.sdpgpu_state_index2(self._h, period, float(x), float(cash), float(preq), float(preq2)))
 
     # -- execution --------------------------------------------------------------------------
+    def set_action_counts(self, t: int, counts):
+        """The caller's own action-list lengths of every grid state of period t+1 (sdpgpu_set_action_counts)."""
+        c = np.ascontiguousarray(counts, dtype=np.int32)
+        self._check(self._lib.sdpgpu_set_action_counts(self._h, t, _ip(c), len(c)))
+
     def set_stream(self, hip_stream: int):
         self._check(self._lib.sdpgpu_set_stream(self._h, C.c_void_p(hip_stream)))
 
