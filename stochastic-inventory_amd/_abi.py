@@ -299,22 +299,26 @@ def _share_hip_runtime_with_torch():
 
 
 def share_rccl_with_torch():
-    """One RCCL per process, the same way: libsdpgpu.so opens `librccl.so.1` on first use of a communicator
-    (sdpgpu_comm.hip) and takes a copy the process already holds.  When PyTorch is installed its bundled copy (same
-    SONAME, built against the HIP runtime loaded above) is loaded first so that both agree."""
+    """One RCCL (and one rocm_smi under it) per process: libsdpgpu.so opens `librccl.so.1` on first use of a communicator
+    (sdpgpu_comm.hip) and takes a copy the process already holds.  When PyTorch is installed, PyTorch is IMPORTED here,
+    so that its bundled ROCm libraries -- libamdhip64, librccl, librocm_smi64 -- come in in PyTorch's own order and
+    the library then finds that RCCL.  (Loading PyTorch's librccl.so by hand BEFORE a later `import torch` changed the
+    libraries' load order and with it the order of their exit-time destructors: librocm_smi64's global map was freed
+    twice and the process aborted at exit, after every test had passed.)  Without PyTorch the system RCCL is used."""
     import importlib.util
+    import sys
+    if "torch" in sys.modules:
+        return
     try:
         spec = importlib.util.find_spec("torch")
     except (ImportError, ValueError):
         spec = None
-    if spec is None or not spec.origin:
+    if spec is None:
         return
-    cand = os.path.join(os.path.dirname(spec.origin), "lib", "librccl.so")
-    if os.path.exists(cand):
-        try:
-            C.CDLL(cand, mode=C.RTLD_GLOBAL)
-        except OSError:
-            pass  # the system RCCL then
+    try:
+        import torch  # noqa: F401  (for its libraries only)
+    except Exception:
+        pass  # the system RCCL then
 
 
 def load():
