@@ -338,8 +338,9 @@ struct alignas(16) RowEnt {
   double sal;     // salvageValue * max(level, 0) (period T)
   int32_t rowoff8; // BYTE offset of the next state's inventory row less the grid's first key: 8 * (inv_index * nc - k_lo),
                    // so that a cell's gather address is v_next + (rowoff8 + 8 * key): one v_lshl_add_u32, scalar base
-  int32_t pad;
+  int32_t dkey;    // uniform key shift of this (action, demand), see "uniform-key trips" below; kNoShift: none
 };
+constexpr int32_t kNoShift = INT32_MIN;
 
 // FORMULA1: F3 with CashConstraintTesting.java's increment (no cash term); INTDIV: the quantiser divides by an
 // integer other than 1; PEN: F3 with a non-zero end-cash penalty rate (CashConstraint.java:115-118); LEAN: F3 formula
@@ -361,7 +362,17 @@ struct RowTiling {
   int32_t nsub;    // bands per XCD
 };
 
-template <int FAM, bool LAST, bool FORMULA1, bool INTDIV, bool PEN = false, bool LEAN = false>
+// UNI: uniform-key trips are compiled in (F3 without deposit rate, penalty and integer division -- CashConstraint.main,
+// CashConstraintTesting, CashConstraintXR.main).  With a zero deposit rate the cash balance cancels out of the increment in
+// REAL arithmetic: nextCash = cash + (u - fixed - var - hold - overhead) for every cash point.  If that real number times
+// the quantiser's factor is an integer delta (prices and costs on the cash grid, as in those drivers), then
+// Math.round(nextCash_fp * mult) -- the reference's rounded floating-point chain -- can only be key(cash) + delta: the
+// chain's error is below 2^-16 for the magnitudes the launcher admits (cash_row_eligible), and Math.round maps anything
+// within +-0.5 of an integer to it.  The per-action setup checks it per (action, demand) (|mult * inc - delta| < 2^-20,
+// formed from the same doubles), the wave ANDs the four steps of a trip, and such a trip replaces the eight instructions
+// of the quantiser (add, mul, floor, sub, cmp, cvt, addc, clamp) by an integer add and the clamp.  The increment itself
+// -- what enters the accumulator -- is still formed per lane exactly as the reference forms it.
+template <int FAM, bool LAST, bool FORMULA1, bool INTDIV, bool PEN = false, bool LEAN = false, bool UNI = false>
 __global__ __launch_bounds__(256) void cash_row_kernel(DevParams P, const double* __restrict__ v_next,
                                                        double* __restrict__ v_cur, int32_t* __restrict__ pol,
                                                        const double* __restrict__ pmf_d,
@@ -374,6 +385,7 @@ __global__ __launch_bounds__(256) void cash_row_kernel(DevParams P, const double
   double* s_d = reinterpret_cast<double*>(s_ent + (size_t)4 * D);   // d_j
   double* s_val = s_d + D;
   int* s_k = reinterpret_cast<int*>(s_val + 4 * 64);
+  int* s_uni = s_k + 4 * 64;  // [4 waves][(D + 3) / 4]: per trip of four steps, "all four have a uniform key shift"
 
   const int tid = threadIdx.x;
   const int lane = tid & 63;
@@ -457,12 +469,22 @@ __global__ __launch_bounds__(256) void cash_row_kernel(DevParams P, const double
         e.u = revenue;
       }
       e.rowoff8 = 0;
-      e.pad = 0;
+      e.dkey = kNoShift;
       if constexpr (!LAST) {
         double ninv = jmax(0.0, level);
         ninv = ninv > P.max_inventory ? P.max_inventory : ninv;
         ninv = ninv < P.min_inventory ? P.min_inventory : ninv;
         e.rowoff8 = (inv_index(P, ninv) * (int)P.next.nc - k_lo_next) * 8;  // + 8 * cash key = byte offset of the state
+        if constexpr (UNI) {
+          // the increment with the cash balance cancelled (real arithmetic), times the quantiser's factor
+          const double inc_u = FORMULA1 ? e.u : (LEAN ? e.u - fixed - var : e.u - fixed - var - e.hold - overhead);
+          const double dm = inc_u * round_mult;
+          const double dn = rint(dm);
+          const bool uni = fabs(dm - dn) < 9.5367431640625e-07 && fabs(dn) < 1.0e9;  // 2^-20
+          e.dkey = uni ? (int)dn : kNoShift;
+          const unsigned long long m4 = __ballot(uni);
+          if ((lane & 3) == 0) s_uni[wave * ((D + 3) / 4) + j / 4] = ((m4 >> lane) & 15ull) == 15ull;
+        }
       }
       ent[j] = e;
     }
@@ -529,11 +551,41 @@ __global__ __launch_bounds__(256) void cash_row_kernel(DevParams P, const double
         off = (uint32_t)(e.rowoff8 + (key << 3));
       }
     };
+    // the lane's own cash key, as a byte offset (uniform-key trips add the step's shift to it)
+    [[maybe_unused]] const int my_key = (int)P.cur.k_lo + ic_c;
+    [[maybe_unused]] const int* uni = s_uni + wave * ((D + 3) / 4);
     int j = 0;
     for (; j + U <= D; j += U) {
       double add1[U], pg[U], v[U];
       uint32_t off[U];
       bool dead[U];
+      if constexpr (UNI && !LAST) {
+        if (__builtin_amdgcn_readfirstlane(uni[j / U])) {  // all four steps shift every cash point by a fixed number of keys
+#pragma unroll
+          for (int u = 0; u < U; ++u) {
+            const RowEnt e = ent[j + u];
+            const double2 pp = s_p[j + u];
+            pg[u] = pp.y;
+            double inc;
+            if constexpr (FORMULA1)
+              inc = e.u;
+            else if constexpr (LEAN)
+              inc = e.u + dep_or_bi - s.cash;
+            else
+              inc = e.u + dep_or_bi - e.hold - overhead - s.cash;
+            add1[u] = pp.x * inc;
+            off[u] = (uint32_t)(e.rowoff8 + (med3_i32(my_key + e.dkey, key_lo_v, key_hi_v) << 3));
+          }
+#pragma unroll
+          for (int u = 0; u < U; ++u) v[u] = *reinterpret_cast<const double*>(vbase + off[u]);
+#pragma unroll
+          for (int u = 0; u < U; ++u) {
+            acc += add1[u];
+            acc += pg[u] * v[u];
+          }
+          continue;
+        }
+      }
 #pragma unroll
       for (int u = 0; u < U; ++u) {
         const double2 pp = s_p[j + u];

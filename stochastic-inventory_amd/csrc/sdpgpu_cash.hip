@@ -124,7 +124,7 @@ bool cash_row_eligible(const sdpgpu_handle* h, int period) {
   const PeriodInfo& p = h->per[period - 1];
   if (p.g.nc < 32) return false;                       // a wave is 64 consecutive cash points of one row
   if (p.S >= 2147483647LL) return false;               // 32-bit row offsets
-  if ((size_t)p.nD * 152 + 4 * 64 * 12 > 64 * 1024) return false;  // per-wave entries of every demand point in LDS
+  if ((size_t)p.nD * 156 + 4 * 64 * 12 > 64 * 1024) return false;  // per-wave entries of every demand point in LDS
   if (period < h->T) {
     // the kernel addresses V_{t+1} by a 32-bit BYTE offset from a scalar base (per pipeline plane for F5) ...
     const PeriodInfo& n = h->per[period];
@@ -144,11 +144,11 @@ bool cash_row_eligible(const sdpgpu_handle* h, int period) {
   return true;
 }
 
-template <int FAM, bool FORMULA1, bool PEN = false, bool LEAN = false>
+template <int FAM, bool FORMULA1, bool PEN = false, bool LEAN = false, bool UNI = false>
 hipError_t launch_cash_row_fam(const DevParams& P, bool last, bool intdiv, const double* v_next, double* v_cur,
                                int32_t* pol, const double* pmf_d, const double* pmf_p, int64_t lo, int64_t hi,
                                int64_t row0, sdp::RowTiling G, dim3 grid, size_t smem, hipStream_t st) {
-#define SDP_CR(LS, ID) hipLaunchKernelGGL((sdp::cash_row_kernel<FAM, LS, FORMULA1, ID, PEN, LEAN>), grid, dim3(256), smem, st, P, v_next, v_cur, pol, pmf_d, pmf_p, lo, hi, row0, G)
+#define SDP_CR(LS, ID) hipLaunchKernelGGL((sdp::cash_row_kernel<FAM, LS, FORMULA1, ID, PEN, LEAN, UNI && !(ID)>), grid, dim3(256), smem, st, P, v_next, v_cur, pol, pmf_d, pmf_p, lo, hi, row0, G)
   if (intdiv) {
     if (last) SDP_CR(true, true); else SDP_CR(false, true);
   } else {
@@ -180,7 +180,7 @@ hipError_t launch_cash_row(sdpgpu_handle* h, const DevParams& P, int period, con
   }
   if (!grid_ok(blocks)) return hipErrorInvalidValue;
   dim3 grid((unsigned)blocks);
-  const size_t smem = (size_t)p.nD * 152 + 4 * 64 * (sizeof(double) + sizeof(int));
+  const size_t smem = (size_t)p.nD * 152 + 4 * 64 * (sizeof(double) + sizeof(int)) + 4 * (((size_t)p.nD + 3) / 4) * sizeof(int);
   const bool last = period == h->T;
   const bool intdiv = h->d.cash_round_int_div && h->d.cash_round_div != 1.0;
   // LEAN: `- holdCosts - overheadCost` subtract +0.0 in every cell (holdingCost and the period's overhead are +0.0)
@@ -188,14 +188,23 @@ hipError_t launch_cash_row(sdpgpu_handle* h, const DevParams& P, int period, con
                     !std::signbit(h->d.holding_cost) && P.overhead == 0.0 && !std::signbit(P.overhead);
 #define SDP_ROWARGS P, last, intdiv, v_next, v_cur, pol, pmf_d, pmf_p, lo, hi, row_lo, G, grid, smem, st
   switch (P.family) {
-    case sdp::FAM_CASH:
+    case sdp::FAM_CASH: {
       // (cash_formula 2, the (x, R) state of CashConstraintXR: formula 0's increment on initCash = R - variCost * x)
+      // uniform-key trips (see cash_row_kernel): the cash balance cancels out of the increment only without a deposit rate
+      static const bool uni_off = std::getenv("SDPGPU_CASH_UNI") && std::atoi(std::getenv("SDPGPU_CASH_UNI")) == 0;
+      const bool uni = !uni_off && P.pi == 0.0 && !intdiv && (P.cash_formula == 1 || h->d.deposit_rate == 0.0);
+      if (uni) {
+        if (lean) return launch_cash_row_fam<sdp::FAM_CASH, false, false, true, true>(SDP_ROWARGS);
+        return P.cash_formula != 1 ? launch_cash_row_fam<sdp::FAM_CASH, false, false, false, true>(SDP_ROWARGS)
+                                   : launch_cash_row_fam<sdp::FAM_CASH, true, false, false, true>(SDP_ROWARGS);
+      }
       if (lean) return launch_cash_row_fam<sdp::FAM_CASH, false, false, true>(SDP_ROWARGS);
       if (P.pi != 0.0)
         return P.cash_formula != 1 ? launch_cash_row_fam<sdp::FAM_CASH, false, true>(SDP_ROWARGS)
                                    : launch_cash_row_fam<sdp::FAM_CASH, true, true>(SDP_ROWARGS);
       return P.cash_formula != 1 ? launch_cash_row_fam<sdp::FAM_CASH, false>(SDP_ROWARGS)
                                  : launch_cash_row_fam<sdp::FAM_CASH, true>(SDP_ROWARGS);
+    }
     case sdp::FAM_OVERDRAFT: return launch_cash_row_fam<sdp::FAM_OVERDRAFT, false>(SDP_ROWARGS);
     case sdp::FAM_CASH_LEADTIME: return launch_cash_row_fam<sdp::FAM_CASH_LEADTIME, false>(SDP_ROWARGS);
     case sdp::FAM_SURVIVAL: return launch_cash_row_fam<sdp::FAM_SURVIVAL, false>(SDP_ROWARGS);

@@ -119,6 +119,28 @@ def f3_row(T=3):
     return Workload("f3_row", f, OptDirection.MAX, _pmf([3, 4, 2][:T], 7))
 
 
+def f3_grid_prices(T=3):
+    """CashConstraint.main's structure (cash in tenths, formula 0, no deposit / overhead rate, no penalty) with prices and
+    costs that are multiples of the cash quantum: every (action, demand) shifts every cash point by a whole number of
+    keys -- the cash row kernel's uniform-key trips -- while the increment itself is not exact (0.1 is not a double)."""
+    f = CashFunctor(price=2.3, fixOrderCost=1.2, variCost=0.7, holdingCost=0.1, depositeRate=0.0, overheadCost=0.5,
+                    overheadRate=0.0, salvageValue=0.35, penaltyCost=0, discountFactor=0.97, maxOrderQuantity=9,
+                    minInventoryState=0, maxInventoryState=11, minCashState=-2, maxCashState=22, cashRoundMult=10.0,
+                    cashRoundDiv=10.0, cashRoundIntDiv=False, cashFormula=0, iniInventory=0, iniCash=5)
+    return Workload("f3_grid_prices", f, OptDirection.MAX, _pmf([3, 4, 2, 5, 3, 4, 2, 3, 5][:T], 9))
+
+
+def f3_half_grid_prices(T=3):
+    """The same with a price of 2.35: the shift is a whole number of keys for even sales and lands exactly BETWEEN two
+    keys for odd sales (Math.round's tie, decided by the rounding of the floating-point chain) -- uniform and
+    non-uniform steps mix inside one period."""
+    f = CashFunctor(price=2.35, fixOrderCost=1.0, variCost=0.5, holdingCost=0.0, depositeRate=0.0, overheadCost=0.0,
+                    overheadRate=0.0, salvageValue=0.3, penaltyCost=0, discountFactor=1.0, maxOrderQuantity=8,
+                    minInventoryState=0, maxInventoryState=10, minCashState=0, maxCashState=25, cashRoundMult=10.0,
+                    cashRoundDiv=10.0, cashRoundIntDiv=False, cashFormula=0, iniInventory=1, iniCash=6)
+    return Workload("f3_half_grid_prices", f, OptDirection.MAX, _pmf([3, 4, 2, 4, 3, 2, 4, 3][:T], 8))
+
+
 def f3_testing(T=4):
     """CashConstraintTesting.java shape: formula 1, integer cash (Math.round(c*1)/1)."""
     f = CashFunctor(price=5, fixOrderCost=10, variCost=1, holdingCost=0, overheadCost=0, salvageValue=0.5,
@@ -206,7 +228,7 @@ def f6_survival_gamma(T=3):
 
 
 ALL = [f1_small, f1_max, f1_gapped, f1_sparse_support, f1_unclamped, f1_edge_single, f2_unclamped, f2_clamped, f2_pipeline, f3_tenths, f3_row, f3_testing, f3_dyadic, f3_min_gamma,
-       f3_xr, f3_xr_fractional, f4_overdraft, f5_cash_leadtime, f6_survival, f6_survival_gamma]
+       f3_xr, f3_xr_fractional, f3_grid_prices, f3_half_grid_prices, f4_overdraft, f5_cash_leadtime, f6_survival, f6_survival_gamma]
 TINY = [f1_small, f1_max, f1_gapped, f1_unclamped, f2_unclamped, f3_testing, f3_min_gamma, f3_xr, f3_xr_fractional, f4_overdraft]
 
 
