@@ -638,4 +638,272 @@ __global__ __launch_bounds__(256) void cash_row_kernel(DevParams P, const double
   }
 }
 
+// ---------------------------------------------------------------------------------------------
+// Cash row kernel, TWO ADJACENT CASH POINTS PER LANE (F3: formulas 0, 1 and 2 without deposit rate, penalty and
+// integer division -- the CashConstraint / CashConstraintTesting / CashConstraintXR drivers).
+//
+// With the cash bands keeping the gathers in L2 and the uniform-key trips taking the quantiser out, what binds
+// cash_row_kernel on CashConstraint.main's grid is the gather unit: one 64-lane 8-byte gather per cell-step costs the TA
+// ~15 cycles whatever its width (2.1e12 cells/s = 82 % TA busy), exactly where the uniform-shift kernel stood before
+// it paired its points.  In a uniform-key trip the two points c, c + 1 of a lane go to the keys k + delta, k + delta + 1
+// of one row: ONE 16-byte gather serves both (picked apart where the grid's ends clamp them onto one entry; a trip in
+// which no point of the wave's 128 clamps needs neither the clamp nor the selects).  Trips that are not uniform fall
+// back to the quantiser and one 8-byte gather per point.  Everything that enters an accumulator is formed per point
+// exactly as in cash_row_kernel.
+// Trip flag (s_uni): 0 = not uniform, 1 = uniform, 2 = uniform and clamp-free for this wave's tile.
+// ---------------------------------------------------------------------------------------------
+template <bool LAST, bool FORMULA1, bool LEAN>
+__global__ __launch_bounds__(256) void cash_row_pair_kernel(DevParams P, const double* __restrict__ v_next,
+                                                            double* __restrict__ v_cur, int32_t* __restrict__ pol,
+                                                            const double* __restrict__ pmf_d,
+                                                            const double* __restrict__ pmf_p, int64_t lo, int64_t hi,
+                                                            int64_t row0, RowTiling G) {
+  constexpr int FAM = FAM_CASH;
+  constexpr int TS = 128;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int D = P.n_demand;
+  double2* s_p = reinterpret_cast<double2*>(smem);                  // {p_j, p_j * gamma}
+  RowEnt* s_ent = reinterpret_cast<RowEnt*>(s_p + D);               // [4 waves][D]
+  double* s_d = reinterpret_cast<double*>(s_ent + (size_t)4 * D);   // d_j
+  double* s_val = s_d + D;
+  int* s_k = reinterpret_cast<int*>(s_val + 4 * TS);
+  int* s_uni = s_k + 4 * TS;  // [4 waves][(D + 3) / 4]
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  int row_i, tile;
+  if (G.tps == 0) {
+    row_i = blockIdx.x / G.tiles_per_row;
+    tile = blockIdx.x % G.tiles_per_row;
+  } else {
+    const int xcd = blockIdx.x & 7, n = blockIdx.x >> 3;
+    const int per_band = G.n_rows * G.tps;
+    const int sub = n / per_band, rem = n - sub * per_band;
+    row_i = rem / G.tps;
+    tile = (xcd * G.nsub + sub) * G.tps + (rem - row_i * G.tps);
+    if (tile >= G.tiles_per_row) return;
+  }
+  for (int j = tid; j < D; j += 256) {
+    s_d[j] = pmf_d[j];
+    s_p[j] = make_double2(pmf_p[j], pmf_p[j] * P.gamma);
+  }
+  __syncthreads();
+
+  const int64_t row = row0 + row_i;
+  const int ic0 = tile * TS;
+  const int nc = (int)P.cur.nc;
+  StateT s[2];
+  int nA[2], icc[2];
+  int nA_max = 0;
+#pragma unroll
+  for (int w = 0; w < 2; ++w) {
+    const int ic = ic0 + 2 * lane + w;
+    icc[w] = ic < nc ? ic : nc - 1;
+    decode_state<FAM>(P, row * nc + icc[w], s[w]);  // x is the same in every lane and for both points
+    nA[w] = n_actions<FAM>(P, s[w]);
+    nA_max = nA[w] > nA_max ? nA[w] : nA_max;
+  }
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) {
+    int o = __shfl_xor(nA_max, off, 64);
+    nA_max = o > nA_max ? o : nA_max;
+  }
+  nA_max = __builtin_amdgcn_readfirstlane(nA_max);
+
+  RowEnt* ent = s_ent + (size_t)wave * D;
+  int* uni = s_uni + wave * ((D + 3) / 4);
+  const bool MAXDIR = P.maxdir != 0;
+  double best[2] = {MAXDIR ? -1.7976931348623157e308 : 1.7976931348623157e308,
+                    MAXDIR ? -1.7976931348623157e308 : 1.7976931348623157e308};
+  int bestk[2] = {0, 0};
+  const double round_mult = P.round_mult, round_div = P.round_div;
+  const double overhead = P.overhead;
+  const int k_lo_next = (int)P.next.k_lo;
+  const int k_hi_next = k_lo_next + (int)P.next.nc - 1;
+  int key_lo_v, key_hi_v, key_hi1_v;
+  asm volatile("v_mov_b32 %0, %1" : "=v"(key_lo_v) : "s"(k_lo_next));
+  asm volatile("v_mov_b32 %0, %1" : "=v"(key_hi_v) : "s"(k_hi_next));
+  asm volatile("v_mov_b32 %0, %1" : "=v"(key_hi1_v) : "s"(k_hi_next - 1));
+  const int my_key = (int)P.cur.k_lo + icc[0];  // key of the lane's first point; the second is my_key + 1 in a whole tile
+  const int my_key8 = my_key * 8;
+  // clamp-free trips need every point of the tile to exist and to stay inside the grid under the step's shift
+  const bool tile_whole = ic0 + TS <= nc;
+  const int key_first = (int)P.cur.k_lo + ic0, key_last = key_first + TS - 1;
+  for (int k = wave; k < nA_max; k += 4) {
+    // ---- wave-uniform part, lanes = demand indices (as cash_row_kernel) ---------------------------------------
+    const double a = (double)k * P.step;
+    const double y = s[0].x + a;
+    const double fixed = a > 0 ? P.K : 0.0;
+    const double var = P.v * a;
+    for (int j = lane; j < D; j += 64) {
+      const double d = s_d[j];
+      const double revenue = P.price * jmin(y, d);
+      const double level = y - d;
+      const double pos = jmax(level, 0.0);
+      RowEnt e;
+      e.hold = P.h * pos;
+      e.sal = LAST ? P.salvage * pos : 0.0;
+      if constexpr (!FORMULA1) {
+        e.u = P.one_minus_overhead_rate * revenue;
+      } else {
+        double inc = revenue - fixed - var - e.hold - P.overhead;
+        inc += e.sal;
+        e.u = inc;
+      }
+      e.rowoff8 = 0;
+      e.dkey = kNoShift;
+      if constexpr (!LAST) {
+        double ninv = jmax(0.0, level);
+        ninv = ninv > P.max_inventory ? P.max_inventory : ninv;
+        ninv = ninv < P.min_inventory ? P.min_inventory : ninv;
+        e.rowoff8 = (inv_index(P, ninv) * (int)P.next.nc - k_lo_next) * 8;
+        const double inc_u = FORMULA1 ? e.u : (LEAN ? e.u - fixed - var : e.u - fixed - var - e.hold - overhead);
+        const double dm = inc_u * round_mult;
+        const double dn = rint(dm);
+        const bool is_uni = fabs(dm - dn) < 9.5367431640625e-07 && fabs(dn) < 1.0e9;  // 2^-20, see cash_row_kernel
+        e.dkey = is_uni ? (int)dn : kNoShift;
+        const bool free_ = is_uni && tile_whole && (double)key_first + dn >= (double)k_lo_next &&
+                           (double)key_last + dn <= (double)k_hi_next;
+        const unsigned long long mu = __ballot(is_uni), mf = __ballot(free_);
+        if ((lane & 3) == 0)
+          uni[j / 4] = (((mf >> lane) & 15ull) == 15ull) ? 2 : ((((mu >> lane) & 15ull) == 15ull) ? 1 : 0);
+      }
+      ent[j] = e;
+    }
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_s_waitcnt(0xC07F);  // lgkmcnt(0): the wave's own LDS writes have landed
+
+    double dep[2];
+#pragma unroll
+    for (int w = 0; w < 2; ++w) dep[w] = (s[w].cash - fixed - var) * P.one_plus_deposit;
+    const char* vbase = reinterpret_cast<const char*>(v_next);
+
+    // the cash-dependent increment of one point, the reference's operations in the reference's order
+    auto increment = [&](const RowEnt& e, int w) -> double {
+      double inc;
+      if constexpr (FORMULA1)
+        inc = e.u;
+      else if constexpr (LEAN)
+        inc = e.u + dep[w] - s[w].cash;
+      else
+        inc = e.u + dep[w] - e.hold - overhead - s[w].cash;
+      if constexpr (LAST && !FORMULA1) inc += e.sal;
+      return inc;
+    };
+    constexpr int U = 4;
+    double acc[2] = {0.0, 0.0};
+    int j = 0;
+    for (; j + U <= D; j += U) {
+      double add1[U][2], pg[U];
+      if constexpr (!LAST) {
+        const int f = __builtin_amdgcn_readfirstlane(uni[j / U]);
+        if (f != 0) {
+          dpair_u v[U];
+          bool hi_fold[U], lo_fold[U];
+#pragma unroll
+          for (int u = 0; u < U; ++u) {
+            const RowEnt e = ent[j + u];
+            const double2 pp = s_p[j + u];
+            pg[u] = pp.y;
+            add1[u][0] = pp.x * increment(e, 0);
+            add1[u][1] = pp.x * increment(e, 1);
+            uint32_t off;
+            if (f == 2) {  // no point of the tile clamps: the pair sits at the lane's own offset plus the shift
+              off = (uint32_t)(e.rowoff8 + my_key8 + (e.dkey << 3));
+              hi_fold[u] = lo_fold[u] = false;
+            } else {       // {V[c], V[c + 1]}, c = clamp(key, lo, hi - 1): at the ends both points may fold onto one entry
+              const int ka = my_key + e.dkey;
+              off = (uint32_t)(e.rowoff8 + (med3_i32(ka, key_lo_v, key_hi1_v) << 3));
+              hi_fold[u] = ka > k_hi_next - 1;  // first point at or beyond the last key: it reads the pair's second entry
+              lo_fold[u] = ka < k_lo_next;      // second point at or below the first key: it reads the pair's first entry
+            }
+            v[u] = *reinterpret_cast<const dpair_u*>(vbase + off);
+          }
+#pragma unroll
+          for (int u = 0; u < U; ++u) {
+            const double v0 = hi_fold[u] ? v[u].y : v[u].x;
+            const double v1 = lo_fold[u] ? v[u].x : v[u].y;
+            acc[0] += add1[u][0];
+            acc[0] += pg[u] * v0;
+            acc[1] += add1[u][1];
+            acc[1] += pg[u] * v1;
+          }
+          continue;
+        }
+      }
+      // not a uniform trip (or period T): the quantiser and one gather per point
+      double v[U][2];
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+        const RowEnt e = ent[j + u];
+        const double2 pp = s_p[j + u];
+        pg[u] = pp.y;
+#pragma unroll
+        for (int w = 0; w < 2; ++w) {
+          const double inc = increment(e, w);
+          add1[u][w] = pp.x * inc;
+          if constexpr (!LAST) {
+            const int key = cash_key_row<false>(s[w].cash + inc, key_lo_v, key_hi_v, round_mult, round_div);
+            v[u][w] = *reinterpret_cast<const double*>(vbase + (uint32_t)(e.rowoff8 + (key << 3)));
+          }
+        }
+      }
+#pragma unroll
+      for (int u = 0; u < U; ++u)
+#pragma unroll
+        for (int w = 0; w < 2; ++w) {
+          acc[w] += add1[u][w];
+          if constexpr (!LAST) acc[w] += pg[u] * v[u][w];
+        }
+    }
+    for (; j < D; ++j) {
+      const RowEnt e = ent[j];
+      const double2 pp = s_p[j];
+#pragma unroll
+      for (int w = 0; w < 2; ++w) {
+        const double inc = increment(e, w);
+        acc[w] += pp.x * inc;
+        if constexpr (!LAST) {
+          const int key = cash_key_row<false>(s[w].cash + inc, key_lo_v, key_hi_v, round_mult, round_div);
+          acc[w] += pp.y * *reinterpret_cast<const double*>(vbase + (uint32_t)(e.rowoff8 + (key << 3)));
+        }
+      }
+    }
+    __builtin_amdgcn_wave_barrier();
+#pragma unroll
+    for (int w = 0; w < 2; ++w)
+      if (k < nA[w] && (MAXDIR ? (acc[w] > best[w]) : (acc[w] < best[w]))) {
+        best[w] = acc[w];
+        bestk[w] = k;
+      }
+  }
+
+#pragma unroll
+  for (int w = 0; w < 2; ++w) {
+    s_val[wave * TS + 2 * lane + w] = best[w];
+    s_k[wave * TS + 2 * lane + w] = bestk[w];
+  }
+  __syncthreads();
+  for (int q = tid; q < TS; q += 256) {
+    const int ic = ic0 + q;
+    const int64_t idx = row * nc + ic;
+    if (ic < nc && idx >= lo && idx < hi) {
+      double bv = s_val[q];
+      int bk = s_k[q];
+#pragma unroll
+      for (int w = 1; w < 4; ++w) {
+        const double ov = s_val[w * TS + q];
+        const int ok = s_k[w * TS + q];
+        if (MAXDIR ? better<true>(ov, ok, bv, bk) : better<false>(ov, ok, bv, bk)) {
+          bv = ov;
+          bk = ok;
+        }
+      }
+      v_cur[idx] = bv;
+      pol[idx] = bk;
+    }
+  }
+}
+
 }  // namespace sdp

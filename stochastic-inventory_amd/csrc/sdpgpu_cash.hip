@@ -163,26 +163,35 @@ hipError_t launch_cash_row(sdpgpu_handle* h, const DevParams& P, int period, con
   if (hi <= lo) return hipSuccess;
   const PeriodInfo& p = h->per[period - 1];
   const int64_t row_lo = lo / p.g.nc, row_hi = (hi - 1) / p.g.nc;
+  const bool last = period == h->T;
+  const bool intdiv = h->d.cash_round_int_div && h->d.cash_round_div != 1.0;
+  // uniform-key trips (see cash_row_kernel): the cash balance cancels out of the increment only without a deposit rate
+  static const bool uni_off = std::getenv("SDPGPU_CASH_UNI") && std::atoi(std::getenv("SDPGPU_CASH_UNI")) == 0;
+  static const bool pair_off = std::getenv("SDPGPU_CASH_PAIR") && std::atoi(std::getenv("SDPGPU_CASH_PAIR")) == 0;
+  const bool uni = P.family == sdp::FAM_CASH && !uni_off && P.pi == 0.0 && !intdiv &&
+                   (P.cash_formula == 1 || h->d.deposit_rate == 0.0);
+  // two adjacent cash points per lane (cash_row_pair_kernel): rows of two 128-point tiles and more
+  const bool pair = uni && !pair_off && p.g.nc >= 256 && (last || h->per[period].g.nc >= 2);
+  const int tile_pts = pair ? 128 : 64;
   sdp::RowTiling G{};
-  G.tiles_per_row = (int32_t)((p.g.nc + 63) / 64);
+  G.tiles_per_row = (int32_t)((p.g.nc + tile_pts - 1) / tile_pts);
   G.n_rows = (int32_t)(row_hi - row_lo + 1);
   int64_t blocks = (int64_t)G.n_rows * G.tiles_per_row;
-  // cash bands per XCD (see RowTiling): rows of 16 tiles and more; ~20 tiles per band (CashConstraint.main, 313 tiles per
-  // row: 1 / 2 / 3 / 6 bands per XCD = 70.0 / 69.0 / 73.4 / 72.8 ms per sweep, row-major 119.8).  SDPGPU_CASH_BANDS=0
-  // keeps the plain row-major numbering, =n forces n bands per XCD.
+  // cash bands per XCD (see RowTiling): rows of 16 tiles and more; ~1280 cash points per band (CashConstraint.main, 313
+  // 64-point tiles per row: 1 / 2 / 3 / 6 bands per XCD = 70.0 / 69.0 / 73.4 / 72.8 ms per sweep, row-major 119.8).
+  // SDPGPU_CASH_BANDS=0 keeps the plain row-major numbering, =n forces n bands per XCD.
   int nsub = -1;
   if (const char* e = std::getenv("SDPGPU_CASH_BANDS")) nsub = std::atoi(e);
   if (nsub != 0 && G.tiles_per_row >= 16 && row_hi - row_lo + 1 < (1LL << 24)) {
     const int tpb = (G.tiles_per_row + 7) / 8;  // tiles per XCD and row
-    G.nsub = nsub > 0 ? std::min(nsub, tpb) : std::max(1, (tpb + 10) / 20);
+    const int per_band = 1280 / tile_pts;       // tiles per band
+    G.nsub = nsub > 0 ? std::min(nsub, tpb) : std::max(1, (tpb + per_band / 2) / per_band);
     G.tps = (tpb + G.nsub - 1) / G.nsub;
     blocks = 8LL * G.nsub * G.tps * G.n_rows;
   }
   if (!grid_ok(blocks)) return hipErrorInvalidValue;
   dim3 grid((unsigned)blocks);
-  const size_t smem = (size_t)p.nD * 152 + 4 * 64 * (sizeof(double) + sizeof(int)) + 4 * (((size_t)p.nD + 3) / 4) * sizeof(int);
-  const bool last = period == h->T;
-  const bool intdiv = h->d.cash_round_int_div && h->d.cash_round_div != 1.0;
+  const size_t smem = (size_t)p.nD * 152 + (size_t)4 * tile_pts * (sizeof(double) + sizeof(int)) + 4 * (((size_t)p.nD + 3) / 4) * sizeof(int);
   // LEAN: `- holdCosts - overheadCost` subtract +0.0 in every cell (holdingCost and the period's overhead are +0.0)
   const bool lean = P.family == sdp::FAM_CASH && P.cash_formula != 1 && P.pi == 0.0 && h->d.holding_cost == 0.0 &&
                     !std::signbit(h->d.holding_cost) && P.overhead == 0.0 && !std::signbit(P.overhead);
@@ -190,9 +199,18 @@ hipError_t launch_cash_row(sdpgpu_handle* h, const DevParams& P, int period, con
   switch (P.family) {
     case sdp::FAM_CASH: {
       // (cash_formula 2, the (x, R) state of CashConstraintXR: formula 0's increment on initCash = R - variCost * x)
-      // uniform-key trips (see cash_row_kernel): the cash balance cancels out of the increment only without a deposit rate
-      static const bool uni_off = std::getenv("SDPGPU_CASH_UNI") && std::atoi(std::getenv("SDPGPU_CASH_UNI")) == 0;
-      const bool uni = !uni_off && P.pi == 0.0 && !intdiv && (P.cash_formula == 1 || h->d.deposit_rate == 0.0);
+      if (pair) {
+#define SDP_PAIR(LS, F1, LN) hipLaunchKernelGGL((sdp::cash_row_pair_kernel<LS, F1, LN>), grid, dim3(256), smem, st, P, v_next, v_cur, pol, pmf_d, pmf_p, lo, hi, row_lo, G)
+        if (P.cash_formula == 1) {
+          if (last) SDP_PAIR(true, true, false); else SDP_PAIR(false, true, false);
+        } else if (lean) {
+          if (last) SDP_PAIR(true, false, true); else SDP_PAIR(false, false, true);
+        } else {
+          if (last) SDP_PAIR(true, false, false); else SDP_PAIR(false, false, false);
+        }
+#undef SDP_PAIR
+        return hipGetLastError();
+      }
       if (uni) {
         if (lean) return launch_cash_row_fam<sdp::FAM_CASH, false, false, true, true>(SDP_ROWARGS);
         return P.cash_formula != 1 ? launch_cash_row_fam<sdp::FAM_CASH, false, false, false, true>(SDP_ROWARGS)

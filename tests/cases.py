@@ -122,10 +122,11 @@ def f3_row(T=3):
 def f3_grid_prices(T=3):
     """CashConstraint.main's structure (cash in tenths, formula 0, no deposit / overhead rate, no penalty) with prices and
     costs that are multiples of the cash quantum: every (action, demand) shifts every cash point by a whole number of
-    keys -- the cash row kernel's uniform-key trips -- while the increment itself is not exact (0.1 is not a double)."""
+    keys -- the cash row kernels' uniform-key trips -- while the increment itself is not exact (0.1 is not a double).
+    336 cash points: two 128-point tiles and a ragged third (the two-points-per-lane kernel, clamped and clamp-free trips)."""
     f = CashFunctor(price=2.3, fixOrderCost=1.2, variCost=0.7, holdingCost=0.1, depositeRate=0.0, overheadCost=0.5,
                     overheadRate=0.0, salvageValue=0.35, penaltyCost=0, discountFactor=0.97, maxOrderQuantity=9,
-                    minInventoryState=0, maxInventoryState=11, minCashState=-2, maxCashState=22, cashRoundMult=10.0,
+                    minInventoryState=0, maxInventoryState=11, minCashState=-2, maxCashState=31.5, cashRoundMult=10.0,
                     cashRoundDiv=10.0, cashRoundIntDiv=False, cashFormula=0, iniInventory=0, iniCash=5)
     return Workload("f3_grid_prices", f, OptDirection.MAX, _pmf([3, 4, 2, 5, 3, 4, 2, 3, 5][:T], 9))
 
@@ -136,7 +137,7 @@ def f3_half_grid_prices(T=3):
     non-uniform steps mix inside one period."""
     f = CashFunctor(price=2.35, fixOrderCost=1.0, variCost=0.5, holdingCost=0.0, depositeRate=0.0, overheadCost=0.0,
                     overheadRate=0.0, salvageValue=0.3, penaltyCost=0, discountFactor=1.0, maxOrderQuantity=8,
-                    minInventoryState=0, maxInventoryState=10, minCashState=0, maxCashState=25, cashRoundMult=10.0,
+                    minInventoryState=0, maxInventoryState=10, minCashState=0, maxCashState=27.3, cashRoundMult=10.0,
                     cashRoundDiv=10.0, cashRoundIntDiv=False, cashFormula=0, iniInventory=1, iniCash=6)
     return Workload("f3_half_grid_prices", f, OptDirection.MAX, _pmf([3, 4, 2, 4, 3, 2, 4, 3][:T], 8))
 
