@@ -405,9 +405,9 @@ def main():
         }
         if args.workload == "target" and not args.no_secondary and not args.weak and not args.states and not args.periods:
             sec = []
-            for name, kw, st_ in (("cfg2", {}, 5), ("cfg3", {}, 2), ("cfg3t", {}, 2), ("cfg4", {}, 2), ("cfg4p", {}, 2)):
-                ws = make_workload(name, 1, 0, kw.get("T", 0))
-                sec.append(run_single(sia, torch, dev, name, ws, st_, 1, 0, args.gate_cells / 3, args.no_gate))
+            for name, st_, wu_ in (("cfg2", 20, 5), ("cfg3", 3, 1), ("cfg3t", 3, 1), ("cfg4", 3, 1), ("cfg4p", 2, 1)):
+                ws = make_workload(name, 1)
+                sec.append(run_single(sia, torch, dev, name, ws, st_, wu_, 0, args.gate_cells / 3, args.no_gate))
             out["secondary"] = sec
         if not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(w, args.cpu_seconds)
