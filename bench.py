@@ -77,6 +77,9 @@ def parse_args():
                     help="N > 1: auto (time the candidates before the warm-up, keep the fastest) | overlap | blocking | "
                          "blockedK (torch/host exchange only: K periods per exchange on widened slabs)")
     ap.add_argument("--check", action="store_true", help="compare the sharded tables with a single-rank sweep (rank 0)")
+    ap.add_argument("--rehearse-sharded", action="store_true",
+                    help="N = 1 only: take the N > 1 code path with a world of one (gloo group of one, one-rank RCCL communicator "
+                         "inside libsdpgpu.so, sdpgpu_solve_sharded, per-rank gate) -- what one rank of eight executes")
     ap.add_argument("--cpu-seconds", type=float, default=15.0, help="target CPU time of the oracle sample")
     a = ap.parse_args()
     if a.backend == "gloo":
@@ -366,6 +369,14 @@ def main():
         local_rank = local_rank % torch.cuda.device_count()  # rehearsal: several ranks share a GPU
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
+    sharded_path = world > 1 or args.rehearse_sharded
+    if args.rehearse_sharded and world == 1:
+        import socket
+        with socket.socket() as sock:
+            sock.bind(("127.0.0.1", 0))
+            os.environ.setdefault("MASTER_PORT", str(sock.getsockname()[1]))
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("gloo", rank=0, world_size=1)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         # native exchange: the data path is RCCL inside libsdpgpu.so; the process group carries the communicator id,
@@ -377,7 +388,7 @@ def main():
     w = make_workload(args.workload, world, args.states, args.periods, args.weak)
     T = w.T
 
-    if world == 1:
+    if not sharded_path:
         head = run_single(sia, torch, dev, args.workload, w, args.steps, args.warmup, args.kernel, args.gate_cells,
                           args.no_gate)
         out = {

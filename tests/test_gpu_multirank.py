@@ -53,3 +53,20 @@ def test_two_ranks_match_single_rank(extra):
     assert len(rec["config"]["cells_per_rank"]) == 2 and sum(rec["config"]["cells_per_rank"]) == rec["config"]["cells_per_step"]
     if "SDP_BENCH_CALIBRATE" in env:
         assert "calibrated" in rec["config"]["schedule"]
+
+
+@pytest.mark.parametrize("extra", [["--periods", "3"], ["--workload", "cfg2", "--periods", "8"], ["--workload", "cfg3", "--periods", "2"],
+                                   ["--workload", "cfg2", "--periods", "6", "--schedule", "overlap"]],
+                         ids=["target", "cfg2_key_rows", "cfg3", "cfg2_overlapped"])
+def test_native_sharded_path_with_a_world_of_one(extra):
+    """bench.py's N > 1 branch on one GPU with a world of ONE: the gloo control group, the one-rank RCCL communicator
+    created inside libsdpgpu.so (sdpgpu_comm_init), sdpgpu_solve_sharded (blocking / overlapped, calibrated), the per-rank
+    parity gate, the per-rank reductions and the JSON line -- everything one rank of eight executes except a peer."""
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1", "--steps", "2", "--warmup", "1", "--rehearse-sharded",
+           "--check", "--no-cpu-baseline", *extra]
+    out = subprocess.run(cmd, capture_output=True, text=True, timeout=420, cwd=ROOT)
+    assert out.returncode == 0, out.stderr[-2000:]
+    rec = json.loads([l for l in out.stdout.splitlines() if l.startswith("{")][-1])
+    assert rec["n_gpus"] == 1 and rec["check_vs_single_rank"] is True and rec["parity_gate"]["status"] == "ok"
+    assert "RCCL all-gather issued by libsdpgpu.so" in rec["config"]["exchange"]
+    assert rec["config"]["cells_per_rank"] == [rec["config"]["cells_per_step"]]
