@@ -412,7 +412,84 @@ static void transition(const ctx_t* c, const st_t* s, double action, double rand
  * CashRecursion.java:98-138, CashLeadtimeRecursion.java:50-77).  `vlook` is what
  * getExpectedValue(newState) resolves to: a dense-table read or a recursive call.
  * ---------------------------------------------------------------------------------------- */
+/* ------------------------------------------------------------------------------------------
+ * THE LOOP TEMPLATE.  Every recursion class of the reference is one loop, copied from class to class:
+ *     Recursion.java:129-161 == CLSP.java:111-136 == LeadtimeRecursion.java:49-73 == CashRecursion.java:98-138 ==
+ *     CashLeadtimeRecursion.java:50-77 == CashRecursionXR.java:91-121 == CashRecursionMultiLead.java:61-88
+ * -- for every feasible action, accumulate over the demand list `q += p * imm; if (period < T) q += p [* discount] * V(next)`
+ * in that interleaved order, then keep the first action that improves on the incumbent (`<` for MIN, `> val [+ 0.1]` for
+ * MAX).  bellman_loop is that loop, once, for the whole oracle: eval_state (the single-item classes a1-a5 and
+ * CashRecursionXR) and ml_value (CashRecursionMultiLead) both run it with their own lambdas plugged in.  ml_value reproduces
+ * the outputs the reference itself records (KAT-1 and the others of MultiProductLeadtime.java:30-50,
+ * tests/test_oracle_kat.py), so the loop the single-item classes are checked with -- accumulation order, discount
+ * association, first-best rule, the +-Double.MAX_VALUE / action-0 initial incumbent -- is PINNED by reference-held
+ * numbers; what no reference artefact covers is the arithmetic inside the single-item lambdas (imm / transition).
+ *   prob[j]      dAndP[j][1]  (dAndP[j][2] for the two-product classes: GetPmfMulti stores the product)
+ *   discount     multiplies the future term as `p * discount * V` (left to right); the classes without a discount factor
+ *                pass 1.0: p * 1.0 == p exactly
+ *   tol          0.1 for the two-product classes' `thisActionsValue > val + 0.1` (CashRecursionMultiLead.java:82), 0.0 for
+ *                the strict `>` of the others (val + 0.0 == val for every val the loop can hold)
+ * ---------------------------------------------------------------------------------------- */
+typedef void (*bl_begin_fn)(void* env, int32_t action_index); /* `double orderQty = feasibleActions[i]` (Recursion.java:136) */
+typedef double (*bl_imm_fn)(void* env, int32_t action_index, int32_t demand_index);
+typedef double (*bl_next_fn)(void* env, int32_t action_index, int32_t demand_index); /* getExpectedValue(stateTransition.apply(...)) */
+
+static inline __attribute__((always_inline)) void bellman_loop(int32_t n_actions, int32_t n_demands, const double* prob, double discount, int has_future,
+                                int maxdir, double tol, bl_begin_fn begin, bl_imm_fn imm, bl_next_fn next, void* env,
+                                double* val_out, int32_t* best_out) {
+  double val = maxdir ? -DBL_MAX : DBL_MAX; /* Recursion.java:132-133 */
+  int32_t best = 0;                         /* bestOrderQty = 0, :134 (index 0 <-> quantity 0) */
+  for (int32_t i = 0; i < n_actions; i++) {
+    begin(env, i);
+    double thisQValue = 0;
+    for (int32_t j = 0; j < n_demands; j++) {
+      double thisDValue = imm(env, i, j);
+      thisQValue += prob[j] * thisDValue;                             /* Recursion.java:139, CashRecursion.java:117 */
+      if (has_future) thisQValue += prob[j] * discount * next(env, i, j); /* :140-143, CashRecursion.java:118-121 */
+    }
+    if (!maxdir) { /* Recursion.java:146-151 */
+      if (thisQValue < val) {
+        val = thisQValue;
+        best = i;
+      }
+    } else { /* :152-157; CashRecursionMultiLead.java:82 with tol = 0.1 */
+      if (thisQValue > val + tol) {
+        val = thisQValue;
+        best = i;
+      }
+    }
+  }
+  *val_out = val;
+  *best_out = best;
+}
+
 typedef double (*vlook_fn)(void* env, const st_t* next);
+
+/* eval_state's lambdas for the loop template: action i / demand j of the state being evaluated */
+typedef struct es_env {
+  const ctx_t* c;
+  const st_t* s;
+  const double* dem;
+  vlook_fn vlook;
+  void* venv;
+  double orderQty; /* feasibleActions[i] of the action the loop is at */
+} es_env;
+static inline __attribute__((always_inline)) void es_begin(void* env, int32_t i) {
+  es_env* e = (es_env*)env;
+  e->orderQty = action_value(e->c, e->s, i);
+}
+static inline __attribute__((always_inline)) double es_imm(void* env, int32_t i, int32_t j) {
+  const es_env* e = (const es_env*)env;
+  (void)i;
+  return imm_value(e->c, e->s, e->orderQty, e->dem[j]);
+}
+static inline __attribute__((always_inline)) double es_next(void* env, int32_t i, int32_t j) {
+  const es_env* e = (const es_env*)env;
+  (void)i;
+  st_t newState;
+  transition(e->c, e->s, e->orderQty, e->dem[j], &newState);
+  return e->vlook(e->venv, &newState);
+}
 
 static void eval_state(const ctx_t* c, const st_t* s, vlook_fn vlook, void* env, double* val_out,
                        double* best_out, int32_t* bestk_out, int64_t* cells) {
@@ -466,43 +543,12 @@ static void eval_state(const ctx_t* c, const st_t* s, vlook_fn vlook, void* env,
     if (bestk_out) *bestk_out = bestk;
     return;
   }
-  for (int32_t i = 0; i < nA; i++) {
-    double orderQty = action_value(c, s, i);
-    double thisQValue = 0;
-    for (int32_t j = 0; j < n; j++) {
-      if (cash_loop) { /* CashRecursion.java:113-122 */
-        double randomDemand = dem[j];
-        double thisDValue = imm_value(c, s, orderQty, randomDemand);
-        double dProb = prob[j];
-        thisQValue += dProb * thisDValue;
-        if (s->period < c->T) {
-          st_t newState;
-          transition(c, s, orderQty, dem[j], &newState);
-          thisQValue += prob[j] * d->discount_factor * vlook(env, &newState);
-        }
-      } else { /* Recursion.java:138-144 */
-        thisQValue += prob[j] * imm_value(c, s, orderQty, dem[j]);
-        if (s->period < c->T) {
-          st_t newState;
-          transition(c, s, orderQty, dem[j], &newState);
-          thisQValue += prob[j] * vlook(env, &newState);
-        }
-      }
-    }
-    if (!maxdir) { /* Recursion.java:146-151 */
-      if (thisQValue < val) {
-        val = thisQValue;
-        bestOrderQty = orderQty;
-        bestk = i;
-      }
-    } else { /* Recursion.java:152-157 */
-      if (thisQValue > val) {
-        val = thisQValue;
-        bestOrderQty = orderQty;
-        bestk = i;
-      }
-    }
-  }
+  /* Recursion.java:129-161 / CashRecursion.java:98-138 (p * discountFactor * V; the classes without a discount factor:
+   * discount 1.0) through the loop template */
+  es_env ev = {c, s, dem, vlook, env, 0};
+  bellman_loop(nA, n, prob, cash_loop ? d->discount_factor : 1.0, s->period < c->T, maxdir, 0.0, es_begin, es_imm, es_next,
+               &ev, &val, &bestk);
+  bestOrderQty = nA > 0 ? action_value(c, s, bestk) : 0; /* (empty list: bestOrderQty stays 0, :134) */
   if (cells) *cells += (int64_t)nA * n;
   *val_out = val;
   if (best_out) *best_out = bestOrderQty;
@@ -1159,34 +1205,46 @@ static void ml_trans(const sdpref_multilead* k, const mst_t* s, int32_t a1, int3
   out->cash = nextCash;
 }
 
-/* CashRecursionMultiLead.java:54-90 */
+/* CashRecursionMultiLead.java:54-90 through the loop template (bellman_loop, above eval_state): action index
+ * i = ai * Qbound + aj enumerates buildActionList's double loop (MultiProductLeadtime.java:150-158), demand index
+ * j = di * n2 + dj the rows of GetPmfMulti.getPmf (GetPmfMulti.java:157-172), whose third column is the product of the two
+ * probabilities. */
+static double ml_value(mlmemo* m, const mst_t* s);
+typedef struct ml_env {
+  mlmemo* m;
+  const mst_t* s;
+} ml_env;
+static void ml_cb_begin(void* env, int32_t i) {
+  (void)env;
+  (void)i;
+}
+static double ml_cb_imm(void* env, int32_t i, int32_t j) {
+  const ml_env* e = (const ml_env*)env;
+  const sdpref_multilead* k = e->m->k;
+  e->m->cells++;
+  return ml_imm(k, e->s, i / k->q_bound, i % k->q_bound, jd2i(k->v1[j / k->n2]), jd2i(k->v2[j % k->n2]));
+}
+static double ml_cb_next(void* env, int32_t i, int32_t j) {
+  const ml_env* e = (const ml_env*)env;
+  const sdpref_multilead* k = e->m->k;
+  mst_t ns;
+  ml_trans(k, e->s, i / k->q_bound, i % k->q_bound, jd2i(k->v1[j / k->n2]), jd2i(k->v2[j % k->n2]), &ns);
+  return ml_value(e->m, &ns);
+}
+
 static double ml_value(mlmemo* m, const mst_t* s) {
   mlentry* e = ml_find(m, s);
   if (e->used) return e->value;
   const sdpref_multilead* k = m->k;
-  double val = -DBL_MAX;
-  int32_t b1 = 0, b2 = 0;
-  for (int32_t ai = 0; ai < k->q_bound; ai++)
-    for (int32_t aj = 0; aj < k->q_bound; aj++) { /* buildActionList, MultiProductLeadtime.java:150-158 */
-      double thisActionsValue = 0;
-      for (int32_t i = 0; i < k->n1; i++)
-        for (int32_t j = 0; j < k->n2; j++) { /* GetPmfMulti.java:157-172: index = i*n2 + j */
-          double prob = k->p1[i] * k->p2[j];
-          int32_t dm1 = jd2i(k->v1[i]), dm2 = jd2i(k->v2[j]);
-          thisActionsValue += prob * ml_imm(k, s, ai, aj, dm1, dm2);
-          if (s->period < k->T) {
-            mst_t ns;
-            ml_trans(k, s, ai, aj, dm1, dm2, &ns);
-            thisActionsValue += prob * k->discount * ml_value(m, &ns);
-          }
-          m->cells++;
-        }
-      if (thisActionsValue > val + 0.1) { /* CashRecursionMultiLead.java:82 */
-        val = thisActionsValue;
-        b1 = ai;
-        b2 = aj;
-      }
-    }
+  double prob[256]; /* dAndP[j][2] = p1 * p2 (n1, n2 <= 16) */
+  for (int32_t i = 0; i < k->n1; i++)
+    for (int32_t j = 0; j < k->n2; j++) prob[i * k->n2 + j] = k->p1[i] * k->p2[j];
+  double val;
+  int32_t best;
+  ml_env ev = {m, s};
+  bellman_loop(k->q_bound * k->q_bound, k->n1 * k->n2, prob, k->discount, s->period < k->T, 1, 0.1, ml_cb_begin, ml_cb_imm,
+               ml_cb_next, &ev, &val, &best);
+  int32_t b1 = best / k->q_bound, b2 = best % k->q_bound;
   if ((m->n + 1) * 2 > m->cap) ml_grow(m);
   e = ml_find(m, s);
   e->key = *s;

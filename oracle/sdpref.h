@@ -6,18 +6,19 @@
  * and only as the checker / the timed CPU baseline -- never as the thing shipped.
  *
  * Parity pin status (see DESIGN.md "Oracle"):
- *   - loop template (interleaved accumulation, memo recursion, arg-opt scan, interest schedule,
- *     lead-time transition): PINNED by KAT-1, the reference's own recorded output
- *     "final optimal cash is -17.800000000000008, Q1 = 40, Q2 = 20"
- *     (src/cash/overdraft/MultiProductLeadtime.java:41-43), reproduced bit for bit by
- *     sdpref_kat_multilead() in tests/test_oracle_kat.py.  (The GPU product's reachable-set engine
- *     reproduces that value and three more recorded ones directly, tests/test_gpu_multilead.py; the
- *     three-period ones are ~1e11..1e12 cells, hours for this single-threaded recursion.)
- *   - single-item classes (Recursion, CLSP.f, LeadtimeRecursion, CashRecursion,
- *     CashLeadtimeRecursion): PARITY UNPINNED by the reference -- it stores no outputs for
- *     them and cannot be run here (no JDK).  They are pinned only against this line-by-line
- *     restatement, which is itself protected by dense-sweep == literal-memoised-recursion tests
- *     and hand-computed 1- and 2-period cases.
+ *   - THE LOOP (bellman_loop in sdpref.c: interleaved accumulation `q += p * imm; q += p * discount * V`, first-best scan
+ *     from the +-Double.MAX_VALUE / action-0 incumbent, memoised recursion): PINNED by KAT-1, the reference's own recorded
+ *     output "final optimal cash is -17.800000000000008, Q1 = 40, Q2 = 20"
+ *     (src/cash/overdraft/MultiProductLeadtime.java:41-43), reproduced bit for bit by sdpref_kat_multilead() in
+ *     tests/test_oracle_kat.py.  Since round 2 that function and eval_state -- what every single-item class (Recursion,
+ *     CLSP.f, LeadtimeRecursion, CashRecursion, CashRecursionXR, CashLeadtimeRecursion) is compared with -- run the SAME
+ *     bellman_loop with their own lambdas plugged in, so the loop the single-item tables are checked with is the pinned one.
+ *     (The GPU product's reachable-set engine reproduces that value and five more recorded ones directly,
+ *     tests/test_gpu_multilead.py; the three-period ones are ~1e11..1e12 cells, hours for this single-threaded recursion.)
+ *   - the LAMBDAS of the single-item classes (immediate value, transition, feasible actions) and the survival loop
+ *     (RiskRecursion.getSurvProb): PARITY UNPINNED by the reference -- it stores no outputs for any driver of those
+ *     classes and cannot be run here (no JDK).  They are protected by dense-sweep == literal-memoised-recursion tests, an
+ *     independent pure-Python translation, hand-computed instances and frozen tables (tests/).
  */
 #ifndef SDPREF_H
 #define SDPREF_H
