@@ -80,6 +80,24 @@ def main():
         "bench_per_launch_ms_events": bench["roofline"]["per_launch_ms_events"] if bench else None,
         "command": "tools/pmc_collect.sh (separate rocprofv3 --pmc passes with --kernel-trace only; --kernel-trace --stats in its own run)",
     }
+    # In-run calibration of the two traffic counters on byte counts this code knows exactly: key_fill_kernel
+    # writes 8 B per state and period of the key arena -- WRITE_SIZE must read that, as is; finalize_kernel reads, per state
+    # and period, its 8-byte key plus the (value, action) rows it scans (12 B per row that decides) -- with FETCH_SIZE
+    # DOUBLED that comes out at a whole number of rows (1.0005 on the target grid), un-doubled it would be half a key short.
+    if bench and "sdp::key_fill_kernel" in kernels and "WRITE_SIZE" in kernels["sdp::key_fill_kernel"]:
+        cfg = bench["config"]
+        st = float(cfg["states"]) * float(cfg["periods"])
+        cal = {"key_fill_write_ratio": kernels["sdp::key_fill_kernel"]["WRITE_SIZE"] * 1024.0 / (8.0 * st)}
+        fk = kernels.get("sdp::finalize_kernel")
+        if fk and "FETCH_SIZE" in fk:
+            cal["finalize_rows_read_per_state"] = (2.0 * fk["FETCH_SIZE"] * 1024.0 - 8.0 * st) / (12.0 * st)
+        rec["calibration"] = cal
+        if not (0.98 <= cal["key_fill_write_ratio"] <= 1.02):
+            print("WRITE_SIZE calibration failed:", cal)
+            sys.exit(2)
+        if "finalize_rows_read_per_state" in cal and cal["finalize_rows_read_per_state"] < 0.9:
+            print("FETCH_SIZE calibration failed (the doubling does not hold):", cal)
+            sys.exit(2)
     name = rec["workload"]
     json.dump(rec, open(os.path.join(out, f"{rnd}_pmc_{name}.json"), "w"), indent=1)
     lines = [f"{rnd} {name}: dominant kernel {dom}"]
