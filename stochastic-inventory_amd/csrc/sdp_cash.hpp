@@ -652,14 +652,17 @@ __global__ __launch_bounds__(256) void cash_row_kernel(DevParams P, const double
 // exactly as in cash_row_kernel.
 // Trip flag (s_uni): 0 = not uniform, 1 = uniform, 2 = uniform and clamp-free for this wave's tile.
 // ---------------------------------------------------------------------------------------------
-template <bool LAST, bool FORMULA1, bool LEAN>
+// S = 128-point tiles per wave: lane l owns the pairs at ic0 + 128 s + 2 l, s < S.  The per-action setup (lanes = demand
+// indices: with 25 demand points only 25 of 64 lanes work) and the LDS reads of a step's entries are shared by the S pairs.
+template <bool LAST, bool FORMULA1, bool LEAN, int S>
 __global__ __launch_bounds__(256) void cash_row_pair_kernel(DevParams P, const double* __restrict__ v_next,
                                                             double* __restrict__ v_cur, int32_t* __restrict__ pol,
                                                             const double* __restrict__ pmf_d,
                                                             const double* __restrict__ pmf_p, int64_t lo, int64_t hi,
                                                             int64_t row0, RowTiling G) {
   constexpr int FAM = FAM_CASH;
-  constexpr int TS = 128;
+  constexpr int TS = 128 * S;
+  constexpr int NP = 2 * S;  // cash points per lane: point p = 2 s + w is ic0 + 128 s + 2 lane + w
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int D = P.n_demand;
   double2* s_p = reinterpret_cast<double2*>(smem);                  // {p_j, p_j * gamma}
@@ -693,12 +696,12 @@ __global__ __launch_bounds__(256) void cash_row_pair_kernel(DevParams P, const d
   const int64_t row = row0 + row_i;
   const int ic0 = tile * TS;
   const int nc = (int)P.cur.nc;
-  StateT s[2];
-  int nA[2], icc[2];
+  StateT s[NP];
+  int nA[NP], icc[NP];
   int nA_max = 0;
 #pragma unroll
-  for (int w = 0; w < 2; ++w) {
-    const int ic = ic0 + 2 * lane + w;
+  for (int w = 0; w < NP; ++w) {
+    const int ic = ic0 + 128 * (w >> 1) + 2 * lane + (w & 1);
     icc[w] = ic < nc ? ic : nc - 1;
     decode_state<FAM>(P, row * nc + icc[w], s[w]);  // x is the same in every lane and for both points
     nA[w] = n_actions<FAM>(P, s[w]);
@@ -714,9 +717,13 @@ __global__ __launch_bounds__(256) void cash_row_pair_kernel(DevParams P, const d
   RowEnt* ent = s_ent + (size_t)wave * D;
   int* uni = s_uni + wave * ((D + 3) / 4);
   const bool MAXDIR = P.maxdir != 0;
-  double best[2] = {MAXDIR ? -1.7976931348623157e308 : 1.7976931348623157e308,
-                    MAXDIR ? -1.7976931348623157e308 : 1.7976931348623157e308};
-  int bestk[2] = {0, 0};
+  double best[NP];
+  int bestk[NP];
+#pragma unroll
+  for (int w = 0; w < NP; ++w) {
+    best[w] = MAXDIR ? -1.7976931348623157e308 : 1.7976931348623157e308;
+    bestk[w] = 0;
+  }
   const double round_mult = P.round_mult, round_div = P.round_div;
   const double overhead = P.overhead;
   const int k_lo_next = (int)P.next.k_lo;
@@ -725,8 +732,12 @@ __global__ __launch_bounds__(256) void cash_row_pair_kernel(DevParams P, const d
   asm volatile("v_mov_b32 %0, %1" : "=v"(key_lo_v) : "s"(k_lo_next));
   asm volatile("v_mov_b32 %0, %1" : "=v"(key_hi_v) : "s"(k_hi_next));
   asm volatile("v_mov_b32 %0, %1" : "=v"(key_hi1_v) : "s"(k_hi_next - 1));
-  const int my_key = (int)P.cur.k_lo + icc[0];  // key of the lane's first point; the second is my_key + 1 in a whole tile
-  const int my_key8 = my_key * 8;
+  int my_key[S], my_key8[S];  // key of each pair's first point; the second is my_key + 1 in a whole tile
+#pragma unroll
+  for (int t = 0; t < S; ++t) {
+    my_key[t] = (int)P.cur.k_lo + icc[2 * t];
+    my_key8[t] = my_key[t] * 8;
+  }
   // clamp-free trips need every point of the tile to exist and to stay inside the grid under the step's shift
   const bool tile_whole = ic0 + TS <= nc;
   const int key_first = (int)P.cur.k_lo + ic0, key_last = key_first + TS - 1;
@@ -774,9 +785,9 @@ __global__ __launch_bounds__(256) void cash_row_pair_kernel(DevParams P, const d
     __builtin_amdgcn_wave_barrier();
     __builtin_amdgcn_s_waitcnt(0xC07F);  // lgkmcnt(0): the wave's own LDS writes have landed
 
-    double dep[2];
+    double dep[NP];
 #pragma unroll
-    for (int w = 0; w < 2; ++w) dep[w] = (s[w].cash - fixed - var) * P.one_plus_deposit;
+    for (int w = 0; w < NP; ++w) dep[w] = (s[w].cash - fixed - var) * P.one_plus_deposit;
     const char* vbase = reinterpret_cast<const char*>(v_next);
 
     // the cash-dependent increment of one point, the reference's operations in the reference's order
@@ -792,55 +803,62 @@ __global__ __launch_bounds__(256) void cash_row_pair_kernel(DevParams P, const d
       return inc;
     };
     constexpr int U = 4;
-    double acc[2] = {0.0, 0.0};
+    double acc[NP];
+#pragma unroll
+    for (int w = 0; w < NP; ++w) acc[w] = 0.0;
     int j = 0;
     for (; j + U <= D; j += U) {
-      double add1[U][2], pg[U];
+      double add1[U][NP], pg[U];
       if constexpr (!LAST) {
         const int f = __builtin_amdgcn_readfirstlane(uni[j / U]);
         if (f != 0) {
-          dpair_u v[U];
-          bool hi_fold[U], lo_fold[U];
+          dpair_u v[U][S];
+          bool hi_fold[U][S], lo_fold[U][S];
 #pragma unroll
           for (int u = 0; u < U; ++u) {
             const RowEnt e = ent[j + u];
             const double2 pp = s_p[j + u];
             pg[u] = pp.y;
-            add1[u][0] = pp.x * increment(e, 0);
-            add1[u][1] = pp.x * increment(e, 1);
-            uint32_t off;
-            if (f == 2) {  // no point of the tile clamps: the pair sits at the lane's own offset plus the shift
-              off = (uint32_t)(e.rowoff8 + my_key8 + (e.dkey << 3));
-              hi_fold[u] = lo_fold[u] = false;
-            } else {       // {V[c], V[c + 1]}, c = clamp(key, lo, hi - 1): at the ends both points may fold onto one entry
-              const int ka = my_key + e.dkey;
-              off = (uint32_t)(e.rowoff8 + (med3_i32(ka, key_lo_v, key_hi1_v) << 3));
-              hi_fold[u] = ka > k_hi_next - 1;  // first point at or beyond the last key: it reads the pair's second entry
-              lo_fold[u] = ka < k_lo_next;      // second point at or below the first key: it reads the pair's first entry
+#pragma unroll
+            for (int w = 0; w < NP; ++w) add1[u][w] = pp.x * increment(e, w);
+#pragma unroll
+            for (int t = 0; t < S; ++t) {
+              uint32_t off;
+              if (f == 2) {  // no point of the wave's tiles clamps: the pair sits at the lane's own offset plus the shift
+                off = (uint32_t)(e.rowoff8 + my_key8[t] + (e.dkey << 3));
+                hi_fold[u][t] = lo_fold[u][t] = false;
+              } else {       // {V[c], V[c + 1]}, c = clamp(key, lo, hi - 1): at the ends both points may fold onto one entry
+                const int ka = my_key[t] + e.dkey;
+                off = (uint32_t)(e.rowoff8 + (med3_i32(ka, key_lo_v, key_hi1_v) << 3));
+                hi_fold[u][t] = ka > k_hi_next - 1;  // first point at or beyond the last key: it reads the pair's second entry
+                lo_fold[u][t] = ka < k_lo_next;      // second point at or below the first key: it reads the pair's first entry
+              }
+              v[u][t] = *reinterpret_cast<const dpair_u*>(vbase + off);
             }
-            v[u] = *reinterpret_cast<const dpair_u*>(vbase + off);
           }
 #pragma unroll
-          for (int u = 0; u < U; ++u) {
-            const double v0 = hi_fold[u] ? v[u].y : v[u].x;
-            const double v1 = lo_fold[u] ? v[u].x : v[u].y;
-            acc[0] += add1[u][0];
-            acc[0] += pg[u] * v0;
-            acc[1] += add1[u][1];
-            acc[1] += pg[u] * v1;
-          }
+          for (int u = 0; u < U; ++u)
+#pragma unroll
+            for (int t = 0; t < S; ++t) {
+              const double v0 = hi_fold[u][t] ? v[u][t].y : v[u][t].x;
+              const double v1 = lo_fold[u][t] ? v[u][t].x : v[u][t].y;
+              acc[2 * t] += add1[u][2 * t];
+              acc[2 * t] += pg[u] * v0;
+              acc[2 * t + 1] += add1[u][2 * t + 1];
+              acc[2 * t + 1] += pg[u] * v1;
+            }
           continue;
         }
       }
       // not a uniform trip (or period T): the quantiser and one gather per point
-      double v[U][2];
+      double v[U][NP];
 #pragma unroll
       for (int u = 0; u < U; ++u) {
         const RowEnt e = ent[j + u];
         const double2 pp = s_p[j + u];
         pg[u] = pp.y;
 #pragma unroll
-        for (int w = 0; w < 2; ++w) {
+        for (int w = 0; w < NP; ++w) {
           const double inc = increment(e, w);
           add1[u][w] = pp.x * inc;
           if constexpr (!LAST) {
@@ -852,7 +870,7 @@ __global__ __launch_bounds__(256) void cash_row_pair_kernel(DevParams P, const d
 #pragma unroll
       for (int u = 0; u < U; ++u)
 #pragma unroll
-        for (int w = 0; w < 2; ++w) {
+        for (int w = 0; w < NP; ++w) {
           acc[w] += add1[u][w];
           if constexpr (!LAST) acc[w] += pg[u] * v[u][w];
         }
@@ -861,7 +879,7 @@ __global__ __launch_bounds__(256) void cash_row_pair_kernel(DevParams P, const d
       const RowEnt e = ent[j];
       const double2 pp = s_p[j];
 #pragma unroll
-      for (int w = 0; w < 2; ++w) {
+      for (int w = 0; w < NP; ++w) {
         const double inc = increment(e, w);
         acc[w] += pp.x * inc;
         if constexpr (!LAST) {
@@ -872,7 +890,7 @@ __global__ __launch_bounds__(256) void cash_row_pair_kernel(DevParams P, const d
     }
     __builtin_amdgcn_wave_barrier();
 #pragma unroll
-    for (int w = 0; w < 2; ++w)
+    for (int w = 0; w < NP; ++w)
       if (k < nA[w] && (MAXDIR ? (acc[w] > best[w]) : (acc[w] < best[w]))) {
         best[w] = acc[w];
         bestk[w] = k;
@@ -880,9 +898,9 @@ __global__ __launch_bounds__(256) void cash_row_pair_kernel(DevParams P, const d
   }
 
 #pragma unroll
-  for (int w = 0; w < 2; ++w) {
-    s_val[wave * TS + 2 * lane + w] = best[w];
-    s_k[wave * TS + 2 * lane + w] = bestk[w];
+  for (int w = 0; w < NP; ++w) {
+    s_val[wave * TS + 128 * (w >> 1) + 2 * lane + (w & 1)] = best[w];
+    s_k[wave * TS + 128 * (w >> 1) + 2 * lane + (w & 1)] = bestk[w];
   }
   __syncthreads();
   for (int q = tid; q < TS; q += 256) {

@@ -166,13 +166,17 @@ hipError_t launch_cash_row(sdpgpu_handle* h, const DevParams& P, int period, con
   const bool last = period == h->T;
   const bool intdiv = h->d.cash_round_int_div && h->d.cash_round_div != 1.0;
   // uniform-key trips (see cash_row_kernel): the cash balance cancels out of the increment only without a deposit rate
-  static const bool uni_off = std::getenv("SDPGPU_CASH_UNI") && std::atoi(std::getenv("SDPGPU_CASH_UNI")) == 0;
-  static const bool pair_off = std::getenv("SDPGPU_CASH_PAIR") && std::atoi(std::getenv("SDPGPU_CASH_PAIR")) == 0;
+  const bool uni_off = std::getenv("SDPGPU_CASH_UNI") && std::atoi(std::getenv("SDPGPU_CASH_UNI")) == 0;
+  const bool pair_off = std::getenv("SDPGPU_CASH_PAIR") && std::atoi(std::getenv("SDPGPU_CASH_PAIR")) == 0;
   const bool uni = P.family == sdp::FAM_CASH && !uni_off && P.pi == 0.0 && !intdiv &&
                    (P.cash_formula == 1 || h->d.deposit_rate == 0.0);
   // two adjacent cash points per lane (cash_row_pair_kernel): rows of two 128-point tiles and more
   const bool pair = uni && !pair_off && p.g.nc >= 256 && (last || h->per[period].g.nc >= 2);
-  const int tile_pts = pair ? 128 : 64;
+  // ... and two such tiles per wave (setup and entry reads shared) where that still leaves a few thousand workgroups
+  int pair_s = 1;
+  if (pair && p.g.nc >= 512 && (row_hi - row_lo + 1) * ((p.g.nc + 255) / 256) >= 2048) pair_s = 2;
+  if (const char* e = std::getenv("SDPGPU_CASH_PAIR_S")) pair_s = std::atoi(e) == 2 ? 2 : 1;
+  const int tile_pts = pair ? 128 * pair_s : 64;
   sdp::RowTiling G{};
   G.tiles_per_row = (int32_t)((p.g.nc + tile_pts - 1) / tile_pts);
   G.n_rows = (int32_t)(row_hi - row_lo + 1);
@@ -200,7 +204,15 @@ hipError_t launch_cash_row(sdpgpu_handle* h, const DevParams& P, int period, con
     case sdp::FAM_CASH: {
       // (cash_formula 2, the (x, R) state of CashConstraintXR: formula 0's increment on initCash = R - variCost * x)
       if (pair) {
-#define SDP_PAIR(LS, F1, LN) hipLaunchKernelGGL((sdp::cash_row_pair_kernel<LS, F1, LN>), grid, dim3(256), smem, st, P, v_next, v_cur, pol, pmf_d, pmf_p, lo, hi, row_lo, G)
+#define SDP_PAIR(LS, F1, LN)                                                                                                    \
+  do {                                                                                                                        \
+    if (pair_s == 2)                                                                                                          \
+      hipLaunchKernelGGL((sdp::cash_row_pair_kernel<LS, F1, LN, 2>), grid, dim3(256), smem, st, P, v_next, v_cur, pol, pmf_d, \
+                         pmf_p, lo, hi, row_lo, G);                                                                           \
+    else                                                                                                                      \
+      hipLaunchKernelGGL((sdp::cash_row_pair_kernel<LS, F1, LN, 1>), grid, dim3(256), smem, st, P, v_next, v_cur, pol, pmf_d, \
+                         pmf_p, lo, hi, row_lo, G);                                                                           \
+  } while (0)
         if (P.cash_formula == 1) {
           if (last) SDP_PAIR(true, true, false); else SDP_PAIR(false, true, false);
         } else if (lean) {

@@ -88,6 +88,27 @@ def test_cfg2_full_horizon_full_tables(sia, oracle):
     eng.close()
 
 
+@pytest.mark.parametrize("env", [{"SDPGPU_CASH_PAIR_S": "2"}, {"SDPGPU_CASH_PAIR_S": "1"}, {"SDPGPU_CASH_PAIR": "0"},
+                                 {"SDPGPU_CASH_PAIR": "0", "SDPGPU_CASH_UNI": "0"}, {"SDPGPU_CASH_BANDS": "0"},
+                                 {"SDPGPU_CASH_BANDS": "3", "SDPGPU_CASH_PAIR_S": "2"}],
+                         ids=lambda e: ",".join(f"{k[12:]}={v}" for k, v in e.items()))
+@pytest.mark.parametrize("make", [cases.f3_grid_prices, cases.f3_half_grid_prices, cases.f3_testing, cases.f3_xr],
+                         ids=lambda f: f.__name__)
+def test_cash_row_kernel_variants(sia, oracle, monkeypatch, make, env):
+    """Every variant of the cash row kernels (one / two points per lane, one / two tiles per wave, with and without the
+    uniform-key trips, banded and row-major block order) gives the oracle's tables bit for bit -- on grids with on-grid
+    prices (all trips uniform), half-grid prices (uniform and tie steps mixed), integer cash and the (x, R) state."""
+    for k, v in env.items():
+        monkeypatch.setenv(k, v)
+    w = make()
+    if make is cases.f3_testing or make is cases.f3_xr:  # widen the cash axis so that the two-point kernels apply
+        w.functor.maxCashState = 700.0
+    eng, P, V, pol, _ = _solve_both(sia, oracle, w)
+    for period in range(1, w.T + 1):
+        _assert_tables(eng.values(period), eng.policy(period), V[period - 1], pol[period - 1], f"{w.name} t={period}")
+    eng.close()
+
+
 def test_cfg3_shape_reduced(sia, oracle):
     """configs[2] family (2-D inventory x cash, ragged action counts) at 40 x 600 states."""
     from stochastic_inventory_amd import workloads
