@@ -19,6 +19,8 @@
 // bit-identical to the general kernel's because nothing was rounded in the first place; the
 // accumulation order is untouched.  Bound: L1/TA gather rate (8 B per cell out of L2), then VALU.
 #pragma once
+#include <type_traits>
+
 #include "sdp_device.hpp"
 
 namespace sdp {
@@ -811,9 +813,12 @@ __global__ __launch_bounds__(256) void cash_row_pair_kernel(DevParams P, const d
       double add1[U][NP], pg[U];
       if constexpr (!LAST) {
         const int f = __builtin_amdgcn_readfirstlane(uni[j / U]);
-        if (f != 0) {
+        // one uniform-key trip; FREE: no point of the wave's tiles clamps (decided for the whole trip, so that the four
+        // steps are straight-line code: the compiler turned a per-step choice into mask arithmetic on every step)
+        auto uni_trip = [&](auto free_tag) {
+          constexpr bool FREE = decltype(free_tag)::value;
           dpair_u v[U][S];
-          bool hi_fold[U][S], lo_fold[U][S];
+          [[maybe_unused]] bool hi_fold[U][S], lo_fold[U][S];
 #pragma unroll
           for (int u = 0; u < U; ++u) {
             const RowEnt e = ent[j + u];
@@ -824,10 +829,9 @@ __global__ __launch_bounds__(256) void cash_row_pair_kernel(DevParams P, const d
 #pragma unroll
             for (int t = 0; t < S; ++t) {
               uint32_t off;
-              if (f == 2) {  // no point of the wave's tiles clamps: the pair sits at the lane's own offset plus the shift
+              if constexpr (FREE) {  // the pair sits at the lane's own offset plus the shift
                 off = (uint32_t)(e.rowoff8 + my_key8[t] + (e.dkey << 3));
-                hi_fold[u][t] = lo_fold[u][t] = false;
-              } else {       // {V[c], V[c + 1]}, c = clamp(key, lo, hi - 1): at the ends both points may fold onto one entry
+              } else {  // {V[c], V[c + 1]}, c = clamp(key, lo, hi - 1): at the ends both points may fold onto one entry
                 const int ka = my_key[t] + e.dkey;
                 off = (uint32_t)(e.rowoff8 + (med3_i32(ka, key_lo_v, key_hi1_v) << 3));
                 hi_fold[u][t] = ka > k_hi_next - 1;  // first point at or beyond the last key: it reads the pair's second entry
@@ -840,13 +844,23 @@ __global__ __launch_bounds__(256) void cash_row_pair_kernel(DevParams P, const d
           for (int u = 0; u < U; ++u)
 #pragma unroll
             for (int t = 0; t < S; ++t) {
-              const double v0 = hi_fold[u][t] ? v[u][t].y : v[u][t].x;
-              const double v1 = lo_fold[u][t] ? v[u][t].x : v[u][t].y;
+              double v0 = v[u][t].x, v1 = v[u][t].y;
+              if constexpr (!FREE) {
+                v0 = hi_fold[u][t] ? v[u][t].y : v[u][t].x;
+                v1 = lo_fold[u][t] ? v[u][t].x : v[u][t].y;
+              }
               acc[2 * t] += add1[u][2 * t];
               acc[2 * t] += pg[u] * v0;
               acc[2 * t + 1] += add1[u][2 * t + 1];
               acc[2 * t + 1] += pg[u] * v1;
             }
+        };
+        if (f == 2) {
+          uni_trip(std::true_type{});
+          continue;
+        }
+        if (f == 1) {
+          uni_trip(std::false_type{});
           continue;
         }
       }
