@@ -368,6 +368,7 @@ struct RowParams {
   int32_t d_pad;
   int32_t n_chunks;
   int32_t chunk_actions;
+  int32_t waves_active; // waves of a workgroup that take action blocks (4 unless the LDS budget for 4 x R row segments says fewer)
   int32_t n_tiles;      // tiles launched (a contiguous run of row tiles)
   int32_t tile0;        // first tile of the run (tile = iq * tiles_per_row + ix / 64)
   int32_t nq1;          // inner pipeline axis: iq = iq2 * nq1 + iq1 (lead time 1: nq1 = nq, iq2 = 0)
@@ -389,8 +390,8 @@ __global__ __launch_bounds__(256) void window_f2_kernel(RowParams W, const doubl
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int span = TS + W.d_pad + 1;                   // slots per row segment (slot 0 spare)
   double* s_m = reinterpret_cast<double*>(smem);       // M(m)
-  double* s_v = s_m + span;                            // [chunk_actions][span]
-  double* s_val = s_v + (size_t)(FUTURE ? W.chunk_actions : 0) * span;
+  double* s_v = s_m + span;                            // [waves_active][R][span]: every wave stages the rows of its own block
+  double* s_val = s_v + (size_t)(FUTURE ? W.waves_active * R : 0) * span;
   int* s_k = reinterpret_cast<int*>(s_val + 4 * TS);
 
   const int tid = threadIdx.x;
@@ -410,20 +411,7 @@ __global__ __launch_bounds__(256) void window_f2_kernel(RowParams W, const doubl
     double l = W.lev0 + (double)(m_lo + q) * W.step;
     s_m[q] = W.h * jmax(l, 0.0) + W.pi * jmax(-l, 0.0);
   }
-  if constexpr (FUTURE) {
-    const int total = W.chunk_actions * span;
-    for (int e = tid; e < total; e += 256) {
-      const int row = e / span;
-      const int q = e - row * span;
-      int k = kA + row;
-      k = k < W.n_actions ? k : W.n_actions - 1;  // padded actions read a valid plane, never selected
-      int idx = m_lo + q + W.idx_off;
-      idx = idx > W.next_last ? W.next_last : idx;
-      idx = idx < 0 ? 0 : idx;
-      s_v[e] = v_next[(int64_t)k * W.plane_stride + row_off + idx];
-    }
-  }
-  __syncthreads();
+  __syncthreads();  // the only workgroup barrier before the read-out: the V rows below are wave-private
 
   double best[S];
   int bestk[S];
@@ -434,13 +422,38 @@ __global__ __launch_bounds__(256) void window_f2_kernel(RowParams W, const doubl
   }
   const int blocks_in_chunk = W.chunk_actions / R;
   const int base = S * lane + W.d_pad;  // slot of (lane, s, j): base + s - j
-  for (int rb = wave; rb < blocks_in_chunk; rb += 4) {
+  double* my_rows = s_v + (size_t)(wave * R) * span;
+  for (int rb = wave; rb < blocks_in_chunk && wave < W.waves_active; rb += W.waves_active) {
     const int k0 = kA + rb * R;
     if (k0 >= W.n_actions) break;
+    if constexpr (FUTURE) {
+      // the block's R row segments V_{t+1}[plane(k0 + r)][clamp(m)], m = m_lo + q: one scalar base per row, R loads in
+      // flight per pass over q (the wave does not wait for the other waves of the workgroup, nor they for it)
+      __builtin_amdgcn_wave_barrier();
+      const double* src[R];
+#pragma unroll
+      for (int r = 0; r < R; ++r) {
+        int k = k0 + r;
+        k = k < W.n_actions ? k : W.n_actions - 1;  // padded actions read a valid plane, never selected
+        src[r] = v_next + ((int64_t)k * W.plane_stride + row_off);
+      }
+      for (int q = lane; q < span; q += 64) {
+        int idx = m_lo + q + W.idx_off;
+        idx = idx > W.next_last ? W.next_last : idx;
+        idx = idx < 0 ? 0 : idx;
+        double tmp[R];
+#pragma unroll
+        for (int r = 0; r < R; ++r) tmp[r] = src[r][idx];
+#pragma unroll
+        for (int r = 0; r < R; ++r) my_rows[r * span + q] = tmp[r];
+      }
+      __builtin_amdgcn_wave_barrier();
+      __builtin_amdgcn_s_waitcnt(0xC07F);  // lgkmcnt(0): the wave's own LDS writes have landed
+    }
     double c0[R], acc[S][R];
     // ring[u][r]: {imm, V} of state 0 at the step j with j mod S == u; state s at step j uses ring[(j - s) mod S]
     double ring_i[S][R], ring_v[S][R];
-    const double* rows = s_v + (size_t)(rb * R) * span + base;
+    const double* rows = my_rows + base;
 #pragma unroll
     for (int r = 0; r < R; ++r) {
       double a = (double)(k0 + r) * W.step;

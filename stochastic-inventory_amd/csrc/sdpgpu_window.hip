@@ -218,12 +218,15 @@ hipError_t launch_row_window(sdpgpu_handle* h, const DevParams& P, int period, c
   W.d_pad = rup(D, 4);  // the demand loop is unrolled by S (1, 2 or 4); padded steps carry p = 0
   const int span = TSZ + W.d_pad + 1;
   const int blocks_total = rup(A, R) / R;
-  // one R-block per wave: chunks of 4 R-blocks, fewer if the LDS budget (rows of `span` doubles) says so
-  int bpc = std::min(4, blocks_total);
+  // one R-block per wave: chunks of 4 R-blocks; every wave stages the R row segments of its own block in its own LDS
+  // region, so the budget (rows of `span` doubles) bounds the number of waves that take blocks, not the chunk
+  int waves = std::min(4, blocks_total);
+  auto lds = [&](int wv) { return (size_t)span * 8 * (1 + (future ? wv * R : 0)) + (size_t)4 * TSZ * 12; };
+  while (waves > 1 && lds(waves) > 60 * 1024) --waves;
+  if (lds(waves) > 64 * 1024) return hipErrorInvalidValue;
+  int bpc = waves;
   if (h->win_nch) bpc = std::max(1, (blocks_total + h->win_nch - 1) / h->win_nch);
-  auto lds = [&](int b) { return (size_t)span * 8 * (1 + (future ? b * R : 0)) + (size_t)4 * TSZ * 12; };
-  while (bpc > 1 && lds(bpc) > 60 * 1024) --bpc;
-  if (lds(bpc) > 64 * 1024) return hipErrorInvalidValue;
+  W.waves_active = waves;
   W.chunk_actions = bpc * R;
   W.n_chunks = (blocks_total + bpc - 1) / bpc;
   // the run of row tiles that covers [lo, hi)
@@ -242,7 +245,7 @@ hipError_t launch_row_window(sdpgpu_handle* h, const DevParams& P, int period, c
     out_idx = h->d_part_idx[b] - lo;
   }
   hipError_t e = hipErrorInvalidValue;
-  size_t smem = lds(bpc);
+  size_t smem = lds(waves);
 #define SDP_ROW(RR, SS)                                                                                          \
   if (R == RR && SL == SS)                                                                                       \
     e = P.maxdir ? launch_row_r<RR, SS, true>(W, smem, future, v_next, out_val, out_idx, pmf_p, lo, hi, st)      \
