@@ -382,17 +382,25 @@ struct RowParams {
 // formed / read once, for state 0 of the lane, and reused by state s at step j + s (a ring of S register
 // sets, the demand loop unrolled by S so that the ring needs no moves): 4 + 1/S fp64 operations and
 // 8(R+1)/(R S) B of LDS per cell.
+#ifndef SDP_F2_WAVES_ATTR
+#define SDP_F2_WAVES_ATTR
+#endif
 template <int R, int S, bool MAXDIR, bool FUTURE>
-__global__ __launch_bounds__(256) void window_f2_kernel(RowParams W, const double* __restrict__ v_next,
+__global__ __launch_bounds__(256) SDP_F2_WAVES_ATTR void window_f2_kernel(RowParams W, const double* __restrict__ v_next,
                                                         double* __restrict__ out_val, int32_t* __restrict__ out_idx,
                                                         const double* __restrict__ pmf_p, int64_t lo, int64_t hi) {
   constexpr int TS = 64 * S;
   extern __shared__ __attribute__((aligned(16))) char smem[];
-  const int span = TS + W.d_pad + 1;                   // slots per row segment (slot 0 spare)
+  const int span = TS + W.d_pad + 2;                   // slots per row segment (slots 0, 1 spare; even: rows stay 16-byte aligned)
   double* s_m = reinterpret_cast<double*>(smem);       // M(m)
   double* s_v = s_m + span;                            // [waves_active][R][span]: every wave stages the rows of its own block
-  double* s_val = s_v + (size_t)(FUTURE ? W.waves_active * R : 0) * span;
-  int* s_k = reinterpret_cast<int*>(s_val + 4 * TS);
+  // read-out scratch of wave w ({best value, best action} of its TS states): inside the wave's own row region, which it has
+  // finished reading by then (R rows of span doubles >= 12 TS bytes for every R >= 2); waves without a region get one behind
+  char* s_extra = reinterpret_cast<char*>(s_v + (size_t)(FUTURE ? W.waves_active * R : 0) * span);
+  auto scratch = [&](int w) -> char* {
+    if (FUTURE && w < W.waves_active) return reinterpret_cast<char*>(s_v + (size_t)(w * R) * span);
+    return s_extra + (size_t)(w - (FUTURE ? W.waves_active : 0)) * (TS * 12);
+  };
 
   const int tid = threadIdx.x;
   const int lane = tid & 63;
@@ -404,7 +412,7 @@ __global__ __launch_bounds__(256) void window_f2_kernel(RowParams W, const doubl
   const int kA = chunk * W.chunk_actions;
   const int iq2 = iq / W.nq1;
   const int iq1 = iq - iq2 * W.nq1;     // the quantity arriving this period
-  const int m_lo = ix0 + iq1 - W.d_pad;  // slot q <-> m = m_lo + q
+  const int m_lo = ix0 + iq1 - W.d_pad - 1;  // slot q <-> m = m_lo + q
   const int64_t row_off = (int64_t)iq2 * W.next_nx;
 
   for (int q = tid; q < span; q += 256) {
@@ -421,7 +429,10 @@ __global__ __launch_bounds__(256) void window_f2_kernel(RowParams W, const doubl
     bestk[s] = 0;
   }
   const int blocks_in_chunk = W.chunk_actions / R;
-  const int base = S * lane + W.d_pad;  // slot of (lane, s, j): base + s - j
+  // slot of (lane, s, j): base + s - j.  With S >= 2 the slots of two consecutive steps (base - j - 1, base - j), j even, start on an
+  // even slot: ONE 16-byte read per row and two steps, consecutive lanes reading consecutive 16-byte pieces -- no bank conflicts
+  // (an 8-byte read with the lanes 8 S bytes apart is 2- or 4-way conflicted, and the LDS pipe was 84 % busy with those).
+  const int base = S * lane + W.d_pad + 1;
   double* my_rows = s_v + (size_t)(wave * R) * span;
   for (int rb = wave; rb < blocks_in_chunk && wave < W.waves_active; rb += W.waves_active) {
     const int k0 = kA + rb * R;
@@ -470,20 +481,49 @@ __global__ __launch_bounds__(256) void window_f2_kernel(RowParams W, const doubl
     // (four demand steps per trip -- d_pad is a multiple of 4, S divides 4 -- so that the loop control and the
     // LDS address updates are paid once per four steps)
     for (int jb = 0; jb < W.d_pad; jb += 4) {
+      if constexpr (S >= 2) {
 #pragma unroll
-      for (int t = 0; t < 4; ++t) {
-        const int u = t % S;
-        const int j = jb + t;
-        const double p = pmf_p[j];
-        const double mj = s_m[base - j];
+        for (int t2 = 0; t2 < 4; t2 += 2) {
+          const int j = jb + t2;
+          const double2 mm = *reinterpret_cast<const double2*>(s_m + base - j - 1);  // {M of step j + 1, M of step j}
+          double2 vv[R];
+          if constexpr (FUTURE) {
 #pragma unroll
-        for (int r = 0; r < R; ++r) {
-          ring_i[u][r] = c0[r] + mj;
-          if constexpr (FUTURE) ring_v[u][r] = rows[r * span - j];
+            for (int r = 0; r < R; ++r) vv[r] = *reinterpret_cast<const double2*>(rows + r * span - j - 1);
+          }
 #pragma unroll
-          for (int s = 0; s < S; ++s) {
-            acc[s][r] += p * ring_i[(u - s + S) % S][r];
-            if constexpr (FUTURE) acc[s][r] += p * ring_v[(u - s + S) % S][r];
+          for (int tt = 0; tt < 2; ++tt) {
+            const int u = (t2 + tt) % S;
+            const double p = pmf_p[j + tt];
+            const double mj = tt ? mm.x : mm.y;
+#pragma unroll
+            for (int r = 0; r < R; ++r) {
+              ring_i[u][r] = c0[r] + mj;
+              if constexpr (FUTURE) ring_v[u][r] = tt ? vv[r].x : vv[r].y;
+#pragma unroll
+              for (int s = 0; s < S; ++s) {
+                acc[s][r] += p * ring_i[(u - s + S) % S][r];
+                if constexpr (FUTURE) acc[s][r] += p * ring_v[(u - s + S) % S][r];
+              }
+            }
+          }
+        }
+      } else {
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+          const int u = t % S;
+          const int j = jb + t;
+          const double p = pmf_p[j];
+          const double mj = s_m[base - j];
+#pragma unroll
+          for (int r = 0; r < R; ++r) {
+            ring_i[u][r] = c0[r] + mj;
+            if constexpr (FUTURE) ring_v[u][r] = rows[r * span - j];
+#pragma unroll
+            for (int s = 0; s < S; ++s) {
+              acc[s][r] += p * ring_i[(u - s + S) % S][r];
+              if constexpr (FUTURE) acc[s][r] += p * ring_v[(u - s + S) % S][r];
+            }
           }
         }
       }
@@ -503,20 +543,20 @@ __global__ __launch_bounds__(256) void window_f2_kernel(RowParams W, const doubl
 
 #pragma unroll
   for (int s = 0; s < S; ++s) {
-    s_val[wave * TS + S * lane + s] = best[s];
-    s_k[wave * TS + S * lane + s] = bestk[s];
+    reinterpret_cast<double*>(scratch(wave))[S * lane + s] = best[s];
+    reinterpret_cast<int*>(scratch(wave) + TS * 8)[S * lane + s] = bestk[s];
   }
   __syncthreads();
   for (int q = tid; q < TS; q += 256) {
     const int ix = ix0 + q;
     const int64_t idx = (int64_t)iq * W.cur_nx + ix;
     if (ix < W.cur_nx && idx >= lo && idx < hi) {
-      double bv = s_val[q];
-      int bk = s_k[q];
+      double bv = reinterpret_cast<const double*>(scratch(0))[q];
+      int bk = reinterpret_cast<const int*>(scratch(0) + TS * 8)[q];
 #pragma unroll
       for (int w = 1; w < 4; ++w) {
-        double ov = s_val[w * TS + q];
-        int ok = s_k[w * TS + q];
+        double ov = reinterpret_cast<const double*>(scratch(w))[q];
+        int ok = reinterpret_cast<const int*>(scratch(w) + TS * 8)[q];
         if (better<MAXDIR>(ov, ok, bv, bk)) {
           bv = ov;
           bk = ok;

@@ -191,10 +191,23 @@ hipError_t launch_row_window(sdpgpu_handle* h, const DevParams& P, int period, c
     }
   }
   if (!R) R = 8;
-  // states per lane: 2 (tiles of 128) unless the inventory axis is short or overridden (SDPGPU_WIN_S)
-  int SL = h->win_s ? h->win_s : (p.g.nx >= 96 ? 2 : 1);
+  // states per lane (tiles of 64 S states; SDPGPU_WIN_S overrides): the S that minimises padded states x operations per cell
+  // (4 + 1/S), ties to the larger S.  Measured on configs[3] (wave-private rows, 16-byte LDS reads): S = 2 / 4 -> 6.93 / 7.31e12
+  // cells/s, its pipeline shape 7.98 / 8.57e12.
+  int SL = h->win_s;
+  if (!SL) {
+    double best_c = 0;
+    for (int sl : {1, 2, 4}) {
+      if (sl == 4 && R == 8) continue;  // (no 8 x 4 instantiation: too many registers)
+      const double c = (double)rup((int)p.g.nx, 64 * sl) * (4.0 + 1.0 / sl);
+      if (!SL || c <= best_c) {
+        best_c = c;
+        SL = sl;
+      }
+    }
+  }
   if (SL != 1 && SL != 2 && SL != 4) SL = 2;
-  if (SL == 4 && R == 8) SL = 2;  // (no 8 x 4 instantiation: too many registers)
+  if (SL == 4 && R == 8) SL = 2;
   const int TSZ = 64 * SL;
   const bool future = period < h->T;
   h->per[period - 1].ops_cell = future ? 4.0 + 1.0 / SL : 2.0 + 1.0 / SL;  // (c0 + M shared by SL cells, see window_f2_kernel)
@@ -216,12 +229,13 @@ hipError_t launch_row_window(sdpgpu_handle* h, const DevParams& P, int period, c
   W.tiles_per_row = (int32_t)((p.g.nx + TSZ - 1) / TSZ);
   W.n_actions = A;
   W.d_pad = rup(D, 4);  // the demand loop is unrolled by S (1, 2 or 4); padded steps carry p = 0
-  const int span = TSZ + W.d_pad + 1;
+  const int span = TSZ + W.d_pad + 2;  // (window_f2_kernel: two spare slots, even)
   const int blocks_total = rup(A, R) / R;
   // one R-block per wave: chunks of 4 R-blocks; every wave stages the R row segments of its own block in its own LDS
   // region, so the budget (rows of `span` doubles) bounds the number of waves that take blocks, not the chunk
   int waves = std::min(4, blocks_total);
-  auto lds = [&](int wv) { return (size_t)span * 8 * (1 + (future ? wv * R : 0)) + (size_t)4 * TSZ * 12; };
+  // (the read-out scratch of a wave that stages rows lies inside its row region)
+  auto lds = [&](int wv) { return (size_t)span * 8 * (1 + (future ? wv * R : 0)) + (size_t)(future ? 4 - wv : 4) * TSZ * 12; };
   while (waves > 1 && lds(waves) > 60 * 1024) --waves;
   if (lds(waves) > 64 * 1024) return hipErrorInvalidValue;
   int bpc = waves;
