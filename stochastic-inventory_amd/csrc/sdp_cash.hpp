@@ -303,6 +303,369 @@ __global__ __launch_bounds__(256) void cash_shift_kernel(CashShiftParams P, cons
 }
 
 // ---------------------------------------------------------------------------------------------
+// "Diagonal" form of the uniform-shift kernel (same family, same exactness argument; periods before T).
+//
+// What bounds cash_shift_kernel is the vector L1: every cell reads its 8 bytes of V_{t+1} through it (64 B/clk/CU,
+// 94 % of that measured).  But the cells (action a, demand d) and (a + 1, d + 1) of one inventory row leave the SAME
+// inventory y - d behind -- the same row of V_{t+1} -- and their cash shifts differ by the constant
+// q (price - v): along a diagonal of the (action, demand) plane the reads of a tile slide over one row.  So a wave
+// takes DR CONSECUTIVE ACTIONS at once, skewed by one demand step each (action k0 + i is at demand tau + i in step
+// tau): the DR reads of a step fall into one row segment of 128 S + (shift spread) entries, which the wave stages in
+// its own LDS region ONCE (clamped to the row's ends while staging, so that the cells need neither clamp nor select)
+// and reads DR times: L1 traffic per cell falls by DR x 128 S / (128 S + spread), the per-cell read moves to the LDS
+// (128 B/clk/CU, conflict-free: lane l owns the points c0 + 64 w + l).  The wave-uniform operands of a step --
+// t1 = p_j * inc per action, the shifts, the row -- come from a table (DiagStep, 128 B per step) that a pre-pass
+// builds per (row, action block) with the very operations of cash_shift_kernel's per-action setup, and reach the
+// wave through the scalar cache: no LDS broadcasts, no per-action setup in the kernel.  Accumulation per cell is
+// unchanged (acc += t1; acc += (p gamma) V, demand ascending); steps outside an action's demand range carry
+// t1 = 0 and p = 0 and add exact zeros.  While the demand exceeds y (stock-out) neither row nor shifts change from
+// step to step and the staged segment is kept.  The launcher takes this kernel only when the shifts of a block's cells
+// in one step provably stay within DIAG_CAP points of each other -- q K + (DIAG_R - 1) q |price - v| + 2 <= DIAG_CAP: the
+// slide along the diagonal, the action-0 break of a fixed cost, the rounding -- and cash_shift_kernel otherwise.
+// ---------------------------------------------------------------------------------------------
+constexpr int DIAG_R = 8;      // actions per block
+constexpr int DIAG_CAP = 128;  // largest shift spread a staged segment covers
+// One demand step of one action block: 160 bytes, read by the wave through the scalar cache one step ahead of its use.
+struct alignas(16) DiagHalf {  // four actions of a step
+  double t1[4];  // p_j * inc of (action k0 + i, demand tau + i); 0 outside the demand range
+  double pg[4];  // p_j * gamma of the same cells; 0 outside the demand range
+};
+struct alignas(16) DiagHead {
+  uint32_t rel[2];  // shift_i - dmin, one byte per action: where action i reads inside the staged segment
+  int32_t nbase8;   // the segment of the step AFTER NEXT (segments are requested two steps ahead): 8 * next inventory index * nc,
+  int32_t ndmin;    // and its smallest shift (cash grid points)
+  int32_t base8;    // the same two of this step (the prologue stages steps 0 and 1 from them)
+  int32_t dmin;
+  int32_t bmin, bmax;  // step 0 of a block: smallest and largest dmin of the block's steps (is every segment inside the row?)
+};
+struct alignas(16) DiagStep {
+  DiagHalf h[2];  // actions 0..3, 4..7
+  DiagHead hd;
+};
+static_assert(sizeof(DiagStep) == 160 && sizeof(DiagHalf) == 64 && sizeof(DiagHead) == 32, "DiagStep is one 160-byte record");
+
+struct DiagParams {
+  CashShiftParams C;
+  int32_t n_blocks;  // action blocks per row: ceil(n_actions_cap / DIAG_R)
+  int32_t n_steps;   // D + DIAG_R - 1 rounded up to an even number (the kernel's step loop is unrolled by two)
+  int32_t n_rows;    // inventory rows launched
+};
+
+// shift, row and t1 of one (action, demand): the operations of cash_shift_kernel's per-action setup, in its order
+__device__ __forceinline__ void diag_cell(const CashShiftParams& P, double x, int k, double d, double p, double& t1,
+                                          int& delta, int& base8) {
+  const double a = (double)k * P.step;
+  const double y = x + a;
+  const double fixed = a > 0 ? P.K : 0.0;
+  const double var = P.v * a;
+  const double level = y - d;
+  const double pos = jmax(level, 0.0);
+  const double inc = P.price * jmin(y, d) - fixed - var - P.h * pos - P.overhead;
+  t1 = p * inc;
+  double ninv = jmax(0.0, level);
+  ninv = ninv > P.max_inventory ? P.max_inventory : ninv;
+  ninv = ninv < P.min_inventory ? P.min_inventory : ninv;
+  base8 = (int)((ninv - P.next_x_lo) / P.step) * P.nc * 8;
+  delta = (int)jmax(jmin(jround_d(inc * P.q), (double)P.nc), -(double)P.nc);
+}
+
+// geometry of one step: row, smallest shift, spread (and, when `e` is given, the record but its look-ahead fields).  Steps
+// behind the last real one (the even padding, the look-ahead of the last steps) have no valid action: row 0, shift 0.
+__device__ __forceinline__ void diag_step(const DiagParams& Q, double x, int k0, int t, const double* __restrict__ pmf_d,
+                                          const double* __restrict__ pmf_p, int& base8, int& dmin, int& spread, DiagStep* e) {
+  const int D = Q.C.n_demand;
+  int delta[DIAG_R];
+  bool valid[DIAG_R];
+  int lo = 0x7fffffff, hi = -0x7fffffff;
+  base8 = 0;
+#pragma unroll
+  for (int i = 0; i < DIAG_R; ++i) {
+    const int j = t - (DIAG_R - 1) + i;
+    valid[i] = j >= 0 && j < D;
+    double t1 = 0.0;
+    delta[i] = 0;
+    if (valid[i]) {
+      int b8;
+      diag_cell(Q.C, x, k0 + i, pmf_d[j], pmf_p[j], t1, delta[i], b8);
+      lo = delta[i] < lo ? delta[i] : lo;
+      hi = delta[i] > hi ? delta[i] : hi;
+      base8 = b8;  // (every valid action of a step leaves the same inventory behind: same row)
+    }
+    if (e) {
+      e->h[i >> 2].t1[i & 3] = t1;
+      e->h[i >> 2].pg[i & 3] = valid[i] ? pmf_p[j] * Q.C.gamma : 0.0;
+    }
+  }
+  if (hi < lo) lo = hi = 0;
+  dmin = lo;
+  spread = hi - lo;
+  if (e) {
+    e->hd.rel[0] = e->hd.rel[1] = 0;
+    if (spread <= DIAG_CAP) {
+#pragma unroll
+      for (int i = 0; i < DIAG_R; ++i)
+        if (valid[i]) e->hd.rel[i >> 2] |= (uint32_t)(delta[i] - lo) << (8 * (i & 3));
+    }
+    e->hd.base8 = base8;
+    e->hd.dmin = dmin;
+  }
+}
+
+// pre-pass: one thread per (row, action block, step)
+__global__ __launch_bounds__(256) void cash_diag_table_kernel(DiagParams Q, int n_rows, DiagStep* __restrict__ table,
+                                                              const double* __restrict__ pmf_d,
+                                                              const double* __restrict__ pmf_p, int* __restrict__ overflow) {
+  const int64_t g = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  const int64_t total = (int64_t)n_rows * Q.n_blocks * Q.n_steps;
+  if (g >= total) return;
+  const int t = (int)(g % Q.n_steps);
+  const int64_t rb = g / Q.n_steps;
+  const int kb = (int)(rb % Q.n_blocks);
+  const int row = Q.C.row0 + (int)(rb / Q.n_blocks);
+  const double x = Q.C.x_lo + (double)row * Q.C.step;
+  const int k0 = kb * DIAG_R;
+  DiagStep e;
+  int base8, dmin, spread;
+  diag_step(Q, x, k0, t, pmf_d, pmf_p, base8, dmin, spread, &e);
+  // (the launcher only takes this kernel when q K + (DIAG_R - 1) q |price - v| + 2 <= DIAG_CAP, which bounds every spread:
+  // shifts held at +-nc only move closer together.  The word is the guard behind that argument, read by the launcher's
+  // SDPGPU_CASH_DIAG_CHECK mode and by the tests.)
+  if (spread > DIAG_CAP) atomicOr(overflow, 1);
+  int b2, s2;
+  diag_step(Q, x, k0, t + 2, pmf_d, pmf_p, b2, e.hd.ndmin, s2, nullptr);
+  e.hd.nbase8 = b2;
+  e.hd.bmin = e.hd.bmax = dmin;
+  if (t == 0) {
+    for (int u = 1; u < Q.n_steps + 2; ++u) {
+      int ub, ud, us;
+      diag_step(Q, x, k0, u, pmf_d, pmf_p, ub, ud, us, nullptr);
+      e.hd.bmin = ud < e.hd.bmin ? ud : e.hd.bmin;
+      e.hd.bmax = ud > e.hd.bmax ? ud : e.hd.bmax;
+    }
+  }
+  table[g] = e;
+}
+
+// The step loop of one action block.  INTERIOR: every segment of the block lies inside the row (decided per wave and block
+// from the block's smallest and largest shift): a piece is read at scalar base + lane, without the clamp.
+// Software pipeline, one basic block per two steps.  LDS reads and scalar loads share one counter (lgkmcnt) and scalar loads
+// return out of order, so every wait for LDS data also drains the scalar loads in flight: the waits sit at the TOP of a
+// phase, ahead of the new requests, and every request (the other half's LDS reads, the next record's scalar loads) has one
+// half step of arithmetic to arrive.  The segment of step t + 2 is requested (vector loads, their own counter) during step
+// t into one of two register sets and stored behind the first half of step t + 1.
+template <int S, bool INTERIOR>
+__device__ __forceinline__ void diag_block(const DiagStep* __restrict__ tab, int n_steps, const char* vbase, char* my_lds,
+                                           int lane8, int lane, int ic0, int nc1, double (&acc)[DIAG_R][2 * S]) {
+  constexpr int NP = 2 * S;
+  constexpr int TS = 64 * NP;
+  constexpr int SEG = TS + DIAG_CAP;
+  constexpr int NU = SEG / 64;
+  auto seg_load = [&](int base8, int dmin, double (&tmp)[NU]) {
+    const int first = ic0 + dmin;
+    if constexpr (INTERIOR) {
+      const char* src = vbase + ((int64_t)base8 + (int64_t)first * 8);
+#pragma unroll
+      for (int u = 0; u < NU; ++u) tmp[u] = *reinterpret_cast<const double*>(src + (uint32_t)(lane8 + u * 512));
+    } else {
+#pragma unroll
+      for (int u = 0; u < NU; ++u) {
+        const int c = med3_i32(first + u * 64 + lane, 0, nc1);
+        tmp[u] = *reinterpret_cast<const double*>(vbase + (uint32_t)(base8 + c * 8));
+      }
+    }
+  };
+  auto seg_store = [&](const double (&tmp)[NU], int buf) {
+#pragma unroll
+    for (int u = 0; u < NU; ++u) *reinterpret_cast<double*>(my_lds + (uint32_t)(buf + u * 512 + lane8)) = tmp[u];
+  };
+  auto lds_reads = [&](double (&v)[4][NP], uint32_t rel, int buf) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int rel8 = (int)((rel >> (8 * i)) & 0xffu) * 8 + buf;
+      const double* src = reinterpret_cast<const double*>(my_lds + (uint32_t)(lane8 + rel8));
+#pragma unroll
+      for (int w = 0; w < NP; ++w) v[i][w] = src[64 * w];
+    }
+  };
+  auto half_step = [&](const DiagHalf& hh, const double (&v)[4][NP], int i0) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const double t1 = hh.t1[i];
+      const double pgi = hh.pg[i];
+#pragma unroll
+      for (int w = 0; w < NP; ++w) {
+        acc[i0 + i][w] += t1;
+        acc[i0 + i][w] += pgi * v[i][w];
+      }
+    }
+  };
+  // prologue: segments of steps 0 and 1 (step 0 into buffer 0 at once), records of step 0, first reads
+  double tmp_a[NU], tmp_b[NU];
+  uint32_t rel0, rel1;
+  int nb8, ndm;
+  {
+    const DiagHead h0 = tab[0].hd;
+    const DiagHead h1 = tab[1].hd;
+    seg_load(h0.base8, h0.dmin, tmp_b);
+    seg_load(h1.base8, h1.dmin, tmp_a);
+    seg_store(tmp_b, 0);
+    rel0 = h0.rel[0];
+    rel1 = h0.rel[1];
+    nb8 = h0.nbase8;
+    ndm = h0.ndmin;
+  }
+  DiagHalf ha = tab[0].h[0];
+  DiagHalf hb = tab[0].h[1];
+  double va[4][NP], vb[4][NP];
+  __builtin_amdgcn_wave_barrier();
+  lds_reads(va, rel0, 0);
+  // one step: reads buffer `cur`, stores `tst` (the segment of step t + 1) into the other buffer, loads the segment of step
+  // t + 2 into `tld`
+  auto step = [&](int t, int cur, double (&tst)[NU], double (&tld)[NU]) {
+    const int tn = t + 1 < n_steps ? t + 1 : t;
+    __builtin_amdgcn_s_waitcnt(0xC07F);  // lgkmcnt(0): va (requested before the previous half's arithmetic)
+    __builtin_amdgcn_sched_barrier(0);
+    lds_reads(vb, rel1, cur);
+    const uint32_t nrel0 = tab[tn].hd.rel[0], nrel1 = tab[tn].hd.rel[1];
+    const int nnb8 = tab[tn].hd.nbase8, nndm = tab[tn].hd.ndmin;
+    const DiagHalf han = tab[tn].h[0];
+    seg_load(nb8, ndm, tld);
+    __builtin_amdgcn_sched_barrier(0);
+    half_step(ha, va, 0);
+    __builtin_amdgcn_sched_barrier(0);
+    __builtin_amdgcn_s_waitcnt(0xC07F);  // vb, the next head and first half
+    __builtin_amdgcn_sched_barrier(0);
+    seg_store(tst, cur ^ (SEG * 8));
+    lds_reads(va, nrel0, cur ^ (SEG * 8));
+    const DiagHalf hbn = tab[tn].h[1];
+    __builtin_amdgcn_sched_barrier(0);
+    half_step(hb, vb, 4);
+    __builtin_amdgcn_sched_barrier(0);
+    rel0 = nrel0;
+    rel1 = nrel1;
+    nb8 = nnb8;
+    ndm = nndm;
+    ha = han;
+    hb = hbn;
+  };
+  for (int t = 0; t < n_steps; t += 2) {
+    step(t, 0, tmp_a, tmp_b);
+    step(t + 1, SEG * 8, tmp_b, tmp_a);
+  }
+  __builtin_amdgcn_s_waitcnt(0xC07F);
+}
+
+template <bool MAXDIR, int S>
+__global__ __launch_bounds__(256) void cash_diag_kernel(DiagParams Q, const DiagStep* __restrict__ table,
+                                                        const double* __restrict__ v_next, double* __restrict__ v_cur,
+                                                        int32_t* __restrict__ pol, int64_t lo, int64_t hi) {
+  constexpr int R = DIAG_R;
+  constexpr int NP = 2 * S;              // points per lane: c0 + 64 w + lane
+  constexpr int TS = 64 * NP;            // points per tile
+  constexpr int SEG = TS + DIAG_CAP;     // entries of one staged segment
+  const CashShiftParams& P = Q.C;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  // [4 waves][2 buffers][SEG] doubles, then the read-out scratch
+  double* s_val = reinterpret_cast<double*>(smem + (size_t)4 * 2 * SEG * 8);
+  int* s_k = reinterpret_cast<int*>(s_val + 4 * TS);
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  // Block -> (row, tile): XCD i (blocks b with b % 8 == i, the dispatcher's round-robin) takes the rows i, i + 8, ... one after
+  // the other, all tiles of a row in a run.  The workgroups of one row stream the same DiagStep records: kept on one XCD
+  // and close in time they find them in its L2 (numbered row-major, the tiles of a row sat on eight XCDs and ~25 rows were in
+  // flight: 9 GB per launch came through the fabric and every scalar load waited for it).  Placement only.
+  const int xcd = blockIdx.x & 7, seq = blockIdx.x >> 3;
+  const int rowi = (seq / P.tiles_per_row) * 8 + xcd;
+  if (rowi >= Q.n_rows) return;
+  const int row = P.row0 + rowi;
+  const int ic0 = (seq % P.tiles_per_row) * TS;
+  const int nc1 = P.nc - 1;
+
+  // feasible action count per point (CashConstraint.java:96-99) and the wave's maximum
+  int nA[NP];
+  int nA_max = 0;
+#pragma unroll
+  for (int w = 0; w < NP; ++w) {
+    const int ic = ic0 + 64 * w + lane;
+    const int ic_c = ic < P.nc ? ic : nc1;
+    const double cash = (double)(P.k_lo + ic_c) / P.q;  // exact: q is a power of two
+    double m = jmin(P.max_order_quantity, jmax(0.0, (cash - P.overhead - P.K) / P.v));
+    nA[w] = ((m != m) ? 0 : (int)m) + 1;
+    nA_max = nA[w] > nA_max ? nA[w] : nA_max;
+  }
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) {
+    int o = __shfl_xor(nA_max, off, 64);
+    nA_max = o > nA_max ? o : nA_max;
+  }
+  nA_max = __builtin_amdgcn_readfirstlane(nA_max);
+
+  double best[NP];
+  int bestk[NP];
+#pragma unroll
+  for (int w = 0; w < NP; ++w) {
+    best[w] = MAXDIR ? -1.7976931348623157e308 : 1.7976931348623157e308;
+    bestk[w] = 0;
+  }
+  const char* vbase = reinterpret_cast<const char*>(v_next);
+  char* my_lds = smem + (size_t)wave * 2 * SEG * 8;
+  const int lane8 = lane * 8;
+
+  for (int kb = wave; kb * R < nA_max; kb += 4) {
+    const DiagStep* tab = table + ((size_t)rowi * Q.n_blocks + kb) * Q.n_steps;
+    double acc[R][NP];
+#pragma unroll
+    for (int i = 0; i < R; ++i)
+#pragma unroll
+      for (int w = 0; w < NP; ++w) acc[i][w] = 0.0;
+    const int bmin = tab[0].hd.bmin, bmax = tab[0].hd.bmax;
+    if (ic0 + bmin >= 0 && ic0 + bmax + SEG - 1 <= nc1)
+      diag_block<S, true>(tab, Q.n_steps, vbase, my_lds, lane8, lane, ic0, nc1, acc);
+    else
+      diag_block<S, false>(tab, Q.n_steps, vbase, my_lds, lane8, lane, ic0, nc1, acc);
+    __builtin_amdgcn_wave_barrier();
+#pragma unroll
+    for (int i = 0; i < R; ++i) {
+      const int k = kb * R + i;
+#pragma unroll
+      for (int w = 0; w < NP; ++w)
+        if (k < nA[w] && (MAXDIR ? (acc[i][w] > best[w]) : (acc[i][w] < best[w]))) {
+          best[w] = acc[i][w];
+          bestk[w] = k;
+        }
+    }
+  }
+
+#pragma unroll
+  for (int w = 0; w < NP; ++w) {
+    s_val[wave * TS + 64 * w + lane] = best[w];
+    s_k[wave * TS + 64 * w + lane] = bestk[w];
+  }
+  __syncthreads();
+  for (int q = tid; q < TS; q += 256) {
+    const int ic = ic0 + q;
+    const int64_t idx = (int64_t)row * P.nc + ic;
+    if (ic < P.nc && idx >= lo && idx < hi) {
+      double bv = s_val[q];
+      int bk = s_k[q];
+#pragma unroll
+      for (int w = 1; w < 4; ++w) {
+        double ov = s_val[w * TS + q];
+        int ok = s_k[w * TS + q];
+        if (better<MAXDIR>(ov, ok, bv, bk)) {
+          bv = ov;
+          bk = ok;
+        }
+      }
+      v_cur[idx] = bv;
+      pol[idx] = bk;
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
 // "Cash row" period kernel: the cash families F3 (both formulas), F4, F5, F6 on ANY cash grid
 // (tenths, hundredths, non-dyadic prices: the cases the uniform-shift kernel must refuse).
 //

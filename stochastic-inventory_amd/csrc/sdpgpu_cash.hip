@@ -70,6 +70,71 @@ hipError_t launch_cash_shift(sdpgpu_handle* h, const DevParams& P, int period, c
   C.n_demand = p.nD;
   C.max_order_quantity = d.max_order_quantity;
   C.is_last = period == h->T;
+  // Periods before T on rows of 256 points and more: the diagonal form (cash_diag_kernel) -- DIAG_R consecutive actions
+  // per wave read ONE staged row segment per demand step -- when the shifts of neighbouring actions on a diagonal,
+  // q (price - v) apart, keep a block's reads within DIAG_CAP points of each other.  SDPGPU_CASH_DIAG=0 turns it off.
+  {
+    const char* env = std::getenv("SDPGPU_CASH_DIAG");
+    const bool diag_on = !env || std::atoi(env) != 0;
+    const double slide = std::fabs(C.q * (d.price - d.unit_order_cost) * d.step), brk = std::fabs(C.q * d.fixed_order_cost);
+    const int64_t rows = (hi - 1) / p.g.nc - lo / p.g.nc + 1;
+    const int n_blocks = ((int)d.max_order_quantity + 1 + sdp::DIAG_R - 1) / sdp::DIAG_R;
+    const int n_steps = (p.nD + sdp::DIAG_R - 1 + 1) & ~1;  // (even: the step loop is unrolled by two)
+    const size_t table_bytes = (size_t)rows * n_blocks * n_steps * sizeof(sdp::DiagStep) + 256;  // (+ the overflow word)
+    if (diag_on && period < h->T && p.g.nc >= 256 && brk + slide * (sdp::DIAG_R - 1) + 2 <= sdp::DIAG_CAP &&
+        table_bytes <= ((size_t)2 << 30)) {
+      int S = 1;  // (two tiles per wave, 176 VGPRs: 48.4 against 44.3 ms per sweep on configs[2]; opt-in)
+      if (const char* e = std::getenv("SDPGPU_CASH_DIAG_S")) S = std::atoi(e) == 2 ? 2 : 1;
+      const int TSZ = 128 * S;
+      C.tiles_per_row = (int32_t)((p.g.nc + TSZ - 1) / TSZ);
+      const int64_t row_lo = lo / p.g.nc;
+      C.row0 = (int32_t)row_lo;
+      if (!grid_ok(8 * ((rows + 7) / 8) * (int64_t)C.tiles_per_row)) return hipErrorInvalidValue;
+      if (h->diag_bytes < table_bytes) {
+        hipError_t e = hipStreamSynchronize(st);  // (an earlier launch may still read the old table)
+        if (e != hipSuccess) return e;
+        if (h->d_diag) (void)hipFree(h->d_diag);
+        h->d_diag = nullptr;
+        h->diag_bytes = 0;
+        e = hipMalloc(&h->d_diag, table_bytes);
+        if (e != hipSuccess) return e;
+        h->diag_bytes = table_bytes;
+        e = hipMemsetAsync(h->d_diag, 0, 256, st);
+        if (e != hipSuccess) return e;
+      }
+      int* overflow = reinterpret_cast<int*>(h->d_diag);
+      sdp::DiagStep* table = reinterpret_cast<sdp::DiagStep*>(reinterpret_cast<char*>(h->d_diag) + 256);
+      sdp::DiagParams Q{};
+      Q.C = C;
+      Q.n_blocks = n_blocks;
+      Q.n_steps = n_steps;
+      Q.n_rows = (int32_t)rows;
+      const int64_t entries = rows * n_blocks * n_steps;
+      if (!grid_ok((entries + 255) / 256)) return hipErrorInvalidValue;
+      hipLaunchKernelGGL(sdp::cash_diag_table_kernel, dim3((unsigned)((entries + 255) / 256)), dim3(256), 0, st, Q, (int)rows,
+                         table, pmf_d, pmf_p, overflow);
+      hipError_t e = hipGetLastError();
+      if (e != hipSuccess) return e;
+      const dim3 grid((unsigned)(8 * ((rows + 7) / 8) * C.tiles_per_row));  // (XCD i: rows i, i + 8, ...)
+      const size_t smem = (size_t)4 * 2 * (TSZ + sdp::DIAG_CAP) * 8 + (size_t)4 * TSZ * (sizeof(double) + sizeof(int));
+      h->per[period - 1].ops_cell = 3.0;  // acc += T1; acc += (p gamma) * V
+      if (P.maxdir) {
+        if (S == 2) hipLaunchKernelGGL((sdp::cash_diag_kernel<true, 2>), grid, dim3(256), smem, st, Q, table, v_next, v_cur, pol, lo, hi);
+        else hipLaunchKernelGGL((sdp::cash_diag_kernel<true, 1>), grid, dim3(256), smem, st, Q, table, v_next, v_cur, pol, lo, hi);
+      } else {
+        if (S == 2) hipLaunchKernelGGL((sdp::cash_diag_kernel<false, 2>), grid, dim3(256), smem, st, Q, table, v_next, v_cur, pol, lo, hi);
+        else hipLaunchKernelGGL((sdp::cash_diag_kernel<false, 1>), grid, dim3(256), smem, st, Q, table, v_next, v_cur, pol, lo, hi);
+      }
+      e = hipGetLastError();
+      if (e == hipSuccess && std::getenv("SDPGPU_CASH_DIAG_CHECK")) {  // tests: the guard word behind the spread bound
+        int word = 0;
+        e = hipStreamSynchronize(st);
+        if (e == hipSuccess) e = hipMemcpy(&word, overflow, sizeof(int), hipMemcpyDeviceToHost);
+        if (e == hipSuccess && word != 0) return hipErrorAssert;
+      }
+      return e;
+    }
+  }
   // points per lane (W) and tiles per wave (S), see cash_shift_kernel.  W = 2 whenever the row has two points: the
   // gather unit is the bound and a 16-byte gather serves two cells (configs[2]: 101 -> 64 ms per sweep).  With the
   // gathers halved the LDS broadcasts of the operands show: S tiles share them (64 -> 57 ms at S = 2) where the grid
@@ -172,10 +237,14 @@ hipError_t launch_cash_row(sdpgpu_handle* h, const DevParams& P, int period, con
                    (P.cash_formula == 1 || h->d.deposit_rate == 0.0);
   // two adjacent cash points per lane (cash_row_pair_kernel): rows of two 128-point tiles and more
   const bool pair = uni && !pair_off && p.g.nc >= 256 && (last || h->per[period].g.nc >= 2);
-  // (two such tiles per wave -- setup and entry reads shared -- measured 63.7 against 61.7 ms on CashConstraint.main's grid:
-  // opt-in, SDPGPU_CASH_PAIR_S=2)
+  // ... and S such tiles per wave (per-action setup and entry reads shared) where that still leaves a few thousand workgroups.
+  // CashConstraint.main's grid, after the clamp-free trips became straight-line code: S = 1 / 2 -> 46.9 / 39.7 ms per sweep
+  // (before: 61.7 / 63.7; S = 4 needs 260 VGPRs: 96 ms, not instantiated).  SDPGPU_CASH_PAIR_S=1|2 overrides.
   int pair_s = 1;
-  if (const char* e = std::getenv("SDPGPU_CASH_PAIR_S")) pair_s = std::atoi(e) == 2 ? 2 : 1;
+  if (pair && p.g.nc >= 512 && (row_hi - row_lo + 1) * ((p.g.nc + 255) / 256) >= 2048) pair_s = 2;
+  if (const char* e = std::getenv("SDPGPU_CASH_PAIR_S")) {
+    pair_s = std::atoi(e) == 2 ? 2 : 1;
+  }
   const int tile_pts = pair ? 128 * pair_s : 64;
   sdp::RowTiling G{};
   G.tiles_per_row = (int32_t)((p.g.nc + tile_pts - 1) / tile_pts);

@@ -104,6 +104,8 @@ struct sdpgpu_handle {
   int n_pending = 0;
   sdp::FinalizeJob* d_jobs = nullptr;
   std::vector<unsigned char> jobs_host;  // upload source of d_jobs: T FinalizeJobs at a fixed address (flush_pending)
+  void* d_diag = nullptr;  // cash_diag_kernel: the DiagStep table of the period being run, and its padded p * gamma row
+  size_t diag_bytes = 0;
   bool fuse_combine = true;
   bool use_cash_shift = true;
   bool use_cash_row = true;   // SDPGPU_CASH_ROW=0 turns the cash row kernel off (generic kernel instead)

@@ -162,6 +162,28 @@ def f3_dyadic(T=3):
     return Workload("f3_dyadic", f, OptDirection.MAX, _pmf([3, 5, 4][:T], 9))
 
 
+def f3_dyadic_wide(T=3):
+    """f3_dyadic on 309 cash points (two 128-point tiles and a ragged third): rows wide enough for the diagonal form of the
+    uniform-shift kernel.  Shifts of neighbouring actions on a diagonal are 5.5 grid steps apart (rounded per cell), the
+    fixed cost breaks the progression at action 0, holding cost and overhead vary the rows."""
+    w = f3_dyadic(T)
+    w.functor.maxCashState = 150.0
+    w.functor.maxOrderQuantity = 21
+    w.name = "f3_dyadic_wide"
+    return w
+
+
+def f3_dyadic_big_fixed(T=3):
+    """Integer cash grid, fixed cost 140: action 0's shift lies more than the staged segment's reach from action 1's, so the
+    first action block of every row takes the direct-gather steps; gamma != 1, a demand support that does
+    not start at 0 (d0 = 2), maxInventory binding."""
+    f = CashFunctor(price=8, fixOrderCost=140, variCost=2, holdingCost=1, overheadCost=3, salvageValue=0.5,
+                    penaltyCost=0, discountFactor=0.875, maxOrderQuantity=60, minInventoryState=0,
+                    maxInventoryState=40, minCashState=-40, maxCashState=299, cashRoundMult=1.0, cashRoundDiv=1.0,
+                    cashRoundIntDiv=True, cashFormula=0, iniInventory=2, iniCash=160)
+    return Workload("f3_dyadic_big_fixed", f, OptDirection.MAX, _pmf([30, 26, 33][:T], 45, d0=2))
+
+
 def f3_min_gamma(T=3):
     f = CashFunctor(price=4, fixOrderCost=2, variCost=1, holdingCost=0.5, overheadCost=1, salvageValue=0.25,
                     penaltyCost=1.5, discountFactor=0.95, maxOrderQuantity=6, minInventoryState=0,

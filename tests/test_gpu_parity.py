@@ -109,6 +109,29 @@ def test_cash_row_kernel_variants(sia, oracle, monkeypatch, make, env):
     eng.close()
 
 
+def _cfg3_small():
+    from stochastic_inventory_amd import workloads
+    return workloads.cfg3_cash(T=3, NX=24, NC=700, A=70, D=30)
+
+
+@pytest.mark.parametrize("env", [{}, {"SDPGPU_CASH_DIAG_S": "2"}, {"SDPGPU_CASH_DIAG_S": "1"}, {"SDPGPU_CASH_DIAG": "0"}],
+                         ids=lambda e: ",".join(f"{k[12:]}={v}" for k, v in e.items()) or "default")
+@pytest.mark.parametrize("make", [_cfg3_small, cases.f3_dyadic_wide, cases.f3_dyadic_big_fixed], ids=lambda f: f.__name__)
+def test_cash_diag_kernel_variants(sia, oracle, monkeypatch, make, env):
+    """The diagonal form of the uniform-shift kernel (cash_diag_kernel: a block of consecutive actions reads one staged row
+    segment per demand step; one and two tiles per wave) and the per-cell gather form it replaces give the oracle's tables
+    bit for bit: configs[2]'s family on 700 cash points, a half-unit grid with fractional slides and a fixed-cost break, and
+    a grid whose fixed cost forces the direct-gather steps."""
+    for k, v in env.items():
+        monkeypatch.setenv(k, v)
+    w = make()
+    eng, P, V, pol, cells = _solve_both(sia, oracle, w)
+    assert eng.stats().cells_evaluated == cells
+    for period in range(1, w.T + 1):
+        _assert_tables(eng.values(period), eng.policy(period), V[period - 1], pol[period - 1], f"{w.name} t={period}")
+    eng.close()
+
+
 def test_cfg3_shape_reduced(sia, oracle):
     """configs[2] family (2-D inventory x cash, ragged action counts) at 40 x 600 states."""
     from stochastic_inventory_amd import workloads
