@@ -336,7 +336,7 @@ struct alignas(16) DiagHead {
   int32_t ndmin;    // and its smallest shift (cash grid points)
   int32_t base8;    // the same two of this step (the prologue stages steps 0 and 1 from them)
   int32_t dmin;
-  int32_t bmin, bmax;  // step 0 of a block: smallest and largest dmin of the block's steps (is every segment inside the row?)
+  int32_t pad[2];
 };
 struct alignas(16) DiagStep {
   DiagHalf h[2];  // actions 0..3, 4..7
@@ -349,6 +349,7 @@ struct DiagParams {
   int32_t n_blocks;  // action blocks per row: ceil(n_actions_cap / DIAG_R)
   int32_t n_steps;   // D + DIAG_R - 1 rounded up to an even number (the kernel's step loop is unrolled by two)
   int32_t n_rows;    // inventory rows launched
+  int32_t cap;       // largest shift spread of a step the launch stages for (64 or DIAG_CAP: one 64-entry piece less)
 };
 
 // shift, row and t1 of one (action, demand): the operations of cash_shift_kernel's per-action setup, in its order
@@ -412,9 +413,13 @@ __device__ __forceinline__ void diag_step(const DiagParams& Q, double x, int k0,
 }
 
 // pre-pass: one thread per (row, action block, step)
+// bounds[2 b], bounds[2 b + 1]: DIAG_BIAS + largest dmin and DIAG_BIAS - smallest dmin over the steps of block b (atomicMax
+// on zero-filled words): is every segment of the block inside the row?
+constexpr int DIAG_BIAS = 1 << 30;
 __global__ __launch_bounds__(256) void cash_diag_table_kernel(DiagParams Q, int n_rows, DiagStep* __restrict__ table,
                                                               const double* __restrict__ pmf_d,
-                                                              const double* __restrict__ pmf_p, int* __restrict__ overflow) {
+                                                              const double* __restrict__ pmf_p, int* __restrict__ overflow,
+                                                              int* __restrict__ bounds) {
   const int64_t g = (int64_t)blockIdx.x * 256 + threadIdx.x;
   const int64_t total = (int64_t)n_rows * Q.n_blocks * Q.n_steps;
   if (g >= total) return;
@@ -427,22 +432,19 @@ __global__ __launch_bounds__(256) void cash_diag_table_kernel(DiagParams Q, int 
   DiagStep e;
   int base8, dmin, spread;
   diag_step(Q, x, k0, t, pmf_d, pmf_p, base8, dmin, spread, &e);
-  // (the launcher only takes this kernel when q K + (DIAG_R - 1) q |price - v| + 2 <= DIAG_CAP, which bounds every spread:
+  // (the launcher only takes this kernel when q K + (DIAG_R - 1) q |price - v| (+ 2 unless every shift is a whole number of
+  // grid steps before rounding) <= Q.cap, which bounds every spread:
   // shifts held at +-nc only move closer together.  The word is the guard behind that argument, read by the launcher's
   // SDPGPU_CASH_DIAG_CHECK mode and by the tests.)
-  if (spread > DIAG_CAP) atomicOr(overflow, 1);
+  if (spread > Q.cap) atomicOr(overflow, 1);
   int b2, s2;
   diag_step(Q, x, k0, t + 2, pmf_d, pmf_p, b2, e.hd.ndmin, s2, nullptr);
   e.hd.nbase8 = b2;
-  e.hd.bmin = e.hd.bmax = dmin;
-  if (t == 0) {
-    for (int u = 1; u < Q.n_steps + 2; ++u) {
-      int ub, ud, us;
-      diag_step(Q, x, k0, u, pmf_d, pmf_p, ub, ud, us, nullptr);
-      e.hd.bmin = ud < e.hd.bmin ? ud : e.hd.bmin;
-      e.hd.bmax = ud > e.hd.bmax ? ud : e.hd.bmax;
-    }
-  }
+  e.hd.pad[0] = e.hd.pad[1] = 0;
+  // (the look-ahead steps behind the last one have dmin 0)
+  const int dhi = t + 2 >= Q.n_steps ? (dmin > 0 ? dmin : 0) : dmin, dlo = t + 2 >= Q.n_steps ? (dmin < 0 ? dmin : 0) : dmin;
+  atomicMax(bounds + 2 * rb, DIAG_BIAS + dhi);
+  atomicMax(bounds + 2 * rb + 1, DIAG_BIAS - dlo);
   table[g] = e;
 }
 
@@ -453,13 +455,12 @@ __global__ __launch_bounds__(256) void cash_diag_table_kernel(DiagParams Q, int 
 // phase, ahead of the new requests, and every request (the other half's LDS reads, the next record's scalar loads) has one
 // half step of arithmetic to arrive.  The segment of step t + 2 is requested (vector loads, their own counter) during step
 // t into one of two register sets and stored behind the first half of step t + 1.
-template <int S, bool INTERIOR>
+template <int S, bool INTERIOR, int NU>
 __device__ __forceinline__ void diag_block(const DiagStep* __restrict__ tab, int n_steps, const char* vbase, char* my_lds,
                                            int lane8, int lane, int ic0, int nc1, double (&acc)[DIAG_R][2 * S]) {
   constexpr int NP = 2 * S;
   constexpr int TS = 64 * NP;
-  constexpr int SEG = TS + DIAG_CAP;
-  constexpr int NU = SEG / 64;
+  constexpr int SEG = TS + DIAG_CAP;  // (buffer stride; NU pieces of 64 entries are staged: spreads up to 64 NU - TS)
   auto seg_load = [&](int base8, int dmin, double (&tmp)[NU]) {
     const int first = ic0 + dmin;
     if constexpr (INTERIOR) {
@@ -535,8 +536,11 @@ __device__ __forceinline__ void diag_block(const DiagStep* __restrict__ tab, int
     __builtin_amdgcn_sched_barrier(0);
     __builtin_amdgcn_s_waitcnt(0xC07F);  // vb, the next head and first half
     __builtin_amdgcn_sched_barrier(0);
+    // (pin: what is derived from the record just waited for is formed here, not ahead of the wait)
+    uint32_t nrel0p = nrel0;
+    asm volatile("" : "+s"(nrel0p));
     seg_store(tst, cur ^ (SEG * 8));
-    lds_reads(va, nrel0, cur ^ (SEG * 8));
+    lds_reads(va, nrel0p, cur ^ (SEG * 8));
     const DiagHalf hbn = tab[tn].h[1];
     __builtin_amdgcn_sched_barrier(0);
     half_step(hb, vb, 4);
@@ -555,8 +559,9 @@ __device__ __forceinline__ void diag_block(const DiagStep* __restrict__ tab, int
   __builtin_amdgcn_s_waitcnt(0xC07F);
 }
 
-template <bool MAXDIR, int S>
+template <bool MAXDIR, int S, int NU>
 __global__ __launch_bounds__(256) void cash_diag_kernel(DiagParams Q, const DiagStep* __restrict__ table,
+                                                        const int* __restrict__ bounds,
                                                         const double* __restrict__ v_next, double* __restrict__ v_cur,
                                                         int32_t* __restrict__ pol, int64_t lo, int64_t hi) {
   constexpr int R = DIAG_R;
@@ -620,11 +625,12 @@ __global__ __launch_bounds__(256) void cash_diag_kernel(DiagParams Q, const Diag
     for (int i = 0; i < R; ++i)
 #pragma unroll
       for (int w = 0; w < NP; ++w) acc[i][w] = 0.0;
-    const int bmin = tab[0].hd.bmin, bmax = tab[0].hd.bmax;
+    const int bmax = bounds[2 * ((size_t)rowi * Q.n_blocks + kb)] - DIAG_BIAS;
+    const int bmin = DIAG_BIAS - bounds[2 * ((size_t)rowi * Q.n_blocks + kb) + 1];
     if (ic0 + bmin >= 0 && ic0 + bmax + SEG - 1 <= nc1)
-      diag_block<S, true>(tab, Q.n_steps, vbase, my_lds, lane8, lane, ic0, nc1, acc);
+      diag_block<S, true, NU>(tab, Q.n_steps, vbase, my_lds, lane8, lane, ic0, nc1, acc);
     else
-      diag_block<S, false>(tab, Q.n_steps, vbase, my_lds, lane8, lane, ic0, nc1, acc);
+      diag_block<S, false, NU>(tab, Q.n_steps, vbase, my_lds, lane8, lane, ic0, nc1, acc);
     __builtin_amdgcn_wave_barrier();
 #pragma unroll
     for (int i = 0; i < R; ++i) {

@@ -80,8 +80,15 @@ hipError_t launch_cash_shift(sdpgpu_handle* h, const DevParams& P, int period, c
     const int64_t rows = (hi - 1) / p.g.nc - lo / p.g.nc + 1;
     const int n_blocks = ((int)d.max_order_quantity + 1 + sdp::DIAG_R - 1) / sdp::DIAG_R;
     const int n_steps = (p.nD + sdp::DIAG_R - 1 + 1) & ~1;  // (even: the step loop is unrolled by two)
-    const size_t table_bytes = (size_t)rows * n_blocks * n_steps * sizeof(sdp::DiagStep) + 256;  // (+ the overflow word)
-    if (diag_on && period < h->T && p.g.nc >= 256 && brk + slide * (sdp::DIAG_R - 1) + 2 <= sdp::DIAG_CAP &&
+    const size_t head_bytes = (256 + (size_t)rows * n_blocks * 8 + 255) & ~(size_t)255;  // the overflow word, the blocks' bounds
+    const size_t table_bytes = (size_t)rows * n_blocks * n_steps * sizeof(sdp::DiagStep) + head_bytes;
+    // every shift a whole number of grid steps before Math.round (then the spread bound needs no rounding margin)
+    auto whole = [&](double v) { return v * C.q == std::floor(v * C.q); };
+    const bool exact = whole(d.price * d.step) && whole(d.unit_order_cost * d.step) && whole(d.holding_cost * d.step) &&
+                       whole(d.fixed_order_cost) && whole(p.overhead) && whole(d.price * h->pmf_d[period - 1][0]) &&
+                       whole(d.price * p.g.x_lo) && whole(d.holding_cost * p.g.x_lo) && whole(d.holding_cost * h->pmf_d[period - 1][0]);
+    const double spread_bound = brk + slide * (sdp::DIAG_R - 1) + (exact ? 0 : 2);
+    if (diag_on && period < h->T && p.g.nc >= 256 && spread_bound <= sdp::DIAG_CAP &&
         table_bytes <= ((size_t)2 << 30)) {
       int S = 1;  // (two tiles per wave, 176 VGPRs: 48.4 against 44.3 ms per sweep on configs[2]; opt-in)
       if (const char* e = std::getenv("SDPGPU_CASH_DIAG_S")) S = std::atoi(e) == 2 ? 2 : 1;
@@ -99,32 +106,40 @@ hipError_t launch_cash_shift(sdpgpu_handle* h, const DevParams& P, int period, c
         e = hipMalloc(&h->d_diag, table_bytes);
         if (e != hipSuccess) return e;
         h->diag_bytes = table_bytes;
-        e = hipMemsetAsync(h->d_diag, 0, 256, st);
+      }
+      {
+        hipError_t e = hipMemsetAsync(h->d_diag, 0, head_bytes, st);  // (bounds are reduced with atomicMax from zero)
         if (e != hipSuccess) return e;
       }
       int* overflow = reinterpret_cast<int*>(h->d_diag);
-      sdp::DiagStep* table = reinterpret_cast<sdp::DiagStep*>(reinterpret_cast<char*>(h->d_diag) + 256);
+      int* bounds = reinterpret_cast<int*>(reinterpret_cast<char*>(h->d_diag) + 256);
+      sdp::DiagStep* table = reinterpret_cast<sdp::DiagStep*>(reinterpret_cast<char*>(h->d_diag) + head_bytes);
       sdp::DiagParams Q{};
       Q.C = C;
       Q.n_blocks = n_blocks;
       Q.n_steps = n_steps;
       Q.n_rows = (int32_t)rows;
+      Q.cap = spread_bound <= 64 ? 64 : sdp::DIAG_CAP;  // 64-entry pieces staged per step: 2 S + 1 or 2 S + 2
       const int64_t entries = rows * n_blocks * n_steps;
       if (!grid_ok((entries + 255) / 256)) return hipErrorInvalidValue;
       hipLaunchKernelGGL(sdp::cash_diag_table_kernel, dim3((unsigned)((entries + 255) / 256)), dim3(256), 0, st, Q, (int)rows,
-                         table, pmf_d, pmf_p, overflow);
+                         table, pmf_d, pmf_p, overflow, bounds);
       hipError_t e = hipGetLastError();
       if (e != hipSuccess) return e;
       const dim3 grid((unsigned)(8 * ((rows + 7) / 8) * C.tiles_per_row));  // (XCD i: rows i, i + 8, ...)
       const size_t smem = (size_t)4 * 2 * (TSZ + sdp::DIAG_CAP) * 8 + (size_t)4 * TSZ * (sizeof(double) + sizeof(int));
       h->per[period - 1].ops_cell = 3.0;  // acc += T1; acc += (p gamma) * V
+#define SDP_DIAG(MX, SS, NN) \
+  hipLaunchKernelGGL((sdp::cash_diag_kernel<MX, SS, NN>), grid, dim3(256), smem, st, Q, table, bounds, v_next, v_cur, pol, lo, hi)
+      const bool narrow = Q.cap == 64;
       if (P.maxdir) {
-        if (S == 2) hipLaunchKernelGGL((sdp::cash_diag_kernel<true, 2>), grid, dim3(256), smem, st, Q, table, v_next, v_cur, pol, lo, hi);
-        else hipLaunchKernelGGL((sdp::cash_diag_kernel<true, 1>), grid, dim3(256), smem, st, Q, table, v_next, v_cur, pol, lo, hi);
+        if (S == 2) { if (narrow) SDP_DIAG(true, 2, 5); else SDP_DIAG(true, 2, 6); }
+        else { if (narrow) SDP_DIAG(true, 1, 3); else SDP_DIAG(true, 1, 4); }
       } else {
-        if (S == 2) hipLaunchKernelGGL((sdp::cash_diag_kernel<false, 2>), grid, dim3(256), smem, st, Q, table, v_next, v_cur, pol, lo, hi);
-        else hipLaunchKernelGGL((sdp::cash_diag_kernel<false, 1>), grid, dim3(256), smem, st, Q, table, v_next, v_cur, pol, lo, hi);
+        if (S == 2) { if (narrow) SDP_DIAG(false, 2, 5); else SDP_DIAG(false, 2, 6); }
+        else { if (narrow) SDP_DIAG(false, 1, 3); else SDP_DIAG(false, 1, 4); }
       }
+#undef SDP_DIAG
       e = hipGetLastError();
       if (e == hipSuccess && std::getenv("SDPGPU_CASH_DIAG_CHECK")) {  // tests: the guard word behind the spread bound
         int word = 0;
