@@ -43,6 +43,8 @@ HBM_PEAK_GBPS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md, HBM)
 # clock the chip holds.  Every VALU instruction of a wave64 occupies its SIMD for four cycles, so the same figure is
 # the issue bound for ALL vector instructions.
 VALU_PEAK_LANE_OPS = 16 * 4 * 256 * 2.4e9
+LDS_PEAK_BPS = 128 * 256 * 2.4e9  # 128 B/clk/CU: the rate of ds_read2_b64, the read the LDS-bound kernel issues (MI355X_MICROARCH.md, LDS)
+L1_PEAK_BPS = 64 * 256 * 2.4e9    # vector L1: 64 B/clk/CU
 
 FAMILY_NAME = {"target": "F1 backorder (capacitated.CLSP.f lambdas)", "cfg2": "F1 backorder (capacitated.CLSP.f)",
                "cfg5": "F1 backorder (capacitated.CLSP.f lambdas)", "cfg3": "F3 cash (CashRecursion, quantum 1)",
@@ -272,6 +274,15 @@ def roofline_block(w, st, T, cells_rank, states_rank, dev_ms_per_sweep, per_laun
                                 "read of V_{t+1} is served by LDS / L2, so this figure may exceed the HBM peak and is not "
                                 "a roofline fraction"},
     }
+    # on-chip data paths of the CUs: 128 B/clk/CU of LDS, 64 B/clk/CU of vector L1 (MI355X_MICROARCH.md), 256 CUs at 2.4 GHz
+    lds_bytes, l1_bytes = float(getattr(st, "lds_bytes", 0.0)), float(getattr(st, "l1_bytes", 0.0))
+    units = {}
+    if lds_bytes > 0:
+        units["lds"] = {"achieved": lds_bytes / (dev_ms_per_sweep * 1e-3) / 1e12, "peak": LDS_PEAK_BPS / 1e12, "unit": "TB/s",
+                        "bytes_per_cell": lds_bytes / max(cells_rank, 1)}
+    if l1_bytes > 0:
+        units["vector-l1"] = {"achieved": l1_bytes / (dev_ms_per_sweep * 1e-3) / 1e12, "peak": L1_PEAK_BPS / 1e12, "unit": "TB/s",
+                              "bytes_per_cell": l1_bytes / max(cells_rank, 1)}
     if fp64_ops > 0:
         lane_ops = fp64_ops / (dev_ms_per_sweep * 1e-3)
         ops_future = None
@@ -302,6 +313,21 @@ def roofline_block(w, st, T, cells_rank, states_rank, dev_ms_per_sweep, per_laun
     else:
         out.update({"bound": "valu-issue", "achieved": None, "peak": VALU_PEAK_LANE_OPS / 1e12, "unit": "T lane-op/s",
                     "frac": None, "note": "no instruction model and no counter summary in profiles/ for this workload"})
+    # the unit that binds is the one closest to its peak: a kernel whose per-cell read goes through the LDS (cash_diag_kernel)
+    # or the vector L1 (cash_shift_kernel) is priced against that path, with the fp64 issue fraction kept beside it
+    for u in units.values():
+        u["frac"] = u["achieved"] / u["peak"]
+    if units:
+        out["units"] = dict(units)
+        if out.get("frac") is not None:
+            out["units"]["fp64-valu" if out["bound"] == "fp64-valu" else out["bound"]] = {
+                "achieved": out["achieved"], "peak": out["peak"], "unit": out["unit"], "frac": out["frac"]}
+        name, top = max(units.items(), key=lambda kv: kv[1]["frac"])
+        if out.get("frac") is None or top["frac"] > out["frac"]:
+            out.update({"bound": name, "achieved": top["achieved"], "peak": top["peak"], "unit": top["unit"], "frac": top["frac"],
+                        "note": f"bytes the kernel's cells move through the {name} path (library model: "
+                                f"{top['bytes_per_cell']:.3g} B per cell) / HIP-event time, against "
+                                + ("128" if name == "lds" else "64") + " B/clk/CU x 256 CUs x 2.4 GHz; the other units: `units`"})
     if out.get("frac") is not None and not (0.0 < out["frac"] <= 1.0):
         raise SystemExit(f"roofline fraction {out['frac']} outside (0, 1]: the op model / counter summary does not describe "
                          "this kernel (a summary in profiles/ measured on another build would be skipped by its source_sha)")

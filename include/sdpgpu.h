@@ -69,7 +69,7 @@ extern "C" {
 #pragma GCC visibility push(default) /* the library is built with -fvisibility=hidden: only this header is exported */
 #endif
 
-#define SDPGPU_ABI_VERSION 3
+#define SDPGPU_ABI_VERSION 4
 
 /* status codes */
 #define SDPGPU_OK 0
@@ -209,6 +209,10 @@ typedef struct sdpgpu_stats {
                                 the period executes per cell (the reference's five per cell minus the ones that are the
                                 same operation on the same operands in neighbouring cells and are formed once; window
                                 and uniform-shift kernels).  0 when a period ran a kernel without such a model. */
+  double  lds_bytes;        /* ABI 4: bytes THIS rank's cells moved through the LDS (reads and staging writes) and through the */
+  double  l1_bytes;         /* vector L1 (per-cell gathers, staging loads), by the same per-kernel models; 0 where a kernel has
+                               none.  bench.py prices the kernels these units bind (cash_diag_kernel: LDS; cash_shift_kernel: L1)
+                               against 128 and 64 B/clk/CU. */
 } sdpgpu_stats;
 
 typedef struct sdpgpu_handle sdpgpu_handle;

@@ -13,7 +13,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 # SDPGPU_LIB: load another build of the SAME library instead (tests/test_sanitizers.py points it at the host-ASan build)
 LIB_PATH = os.environ.get("SDPGPU_LIB") or os.path.join(_HERE, "libsdpgpu.so")
 
-SDPGPU_ABI_VERSION = 3
+SDPGPU_ABI_VERSION = 4
 
 FAMILY_BACKORDER = 1
 FAMILY_LEADTIME = 2
@@ -102,6 +102,8 @@ class SdpgpuStats(C.Structure):
         ("window_r", C.c_int32),
         ("window_s", C.c_int32),
         ("fp64_ops_executed", C.c_double),
+        ("lds_bytes", C.c_double),
+        ("l1_bytes", C.c_double),
     ]
 
 

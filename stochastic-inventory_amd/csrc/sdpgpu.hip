@@ -453,6 +453,7 @@ int run_period_impl(sdpgpu_handle* h, int period, int part, int64_t range_lo, in
   }
   hipError_t e;
   p.ops_cell = 0;
+  p.lds_cell = p.l1_cell = 0;
   if (use_window) {
     e = launch_window(h, P, period, v_next, v_cur, pol, pd, h->d_pmf + p.pmf_win_off, ranged ? range_lo : p.lo,
                       ranged ? range_hi : p.hi, h->stream, part);
@@ -1237,6 +1238,8 @@ int sdpgpu_stats_get(sdpgpu_handle* h, sdpgpu_stats* out) {
     out->cells_all_ranks += p.cells_all;
     if (h->period_done[t]) out->periods_run++;
     out->fp64_ops_executed += (double)p.cells_rank * p.ops_cell;
+    out->lds_bytes += (double)p.cells_rank * p.lds_cell;
+    out->l1_bytes += (double)p.cells_rank * p.l1_cell;
     if (p.ops_cell == 0 && p.cells_rank > 0) modelled = false;
   }
   if (!modelled) out->fp64_ops_executed = 0;

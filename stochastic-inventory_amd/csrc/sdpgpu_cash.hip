@@ -5,6 +5,7 @@
 namespace sdpgpu_detail {
 
 // ---- uniform-shift kernel (F3 on dyadic grids) ---------------------------------------------------
+static inline int narrow_pieces(int cap, int S) { return 2 * S + (cap == 64 ? 1 : 2); }  // 64-entry pieces of a staged segment
 bool dyadic(double x, double scale, double max_abs) { return std::fabs(x) <= max_abs && x * scale == std::floor(x * scale); }
 
 // All arithmetic of the F3 lambdas is exact (see sdp_cash.hpp) iff the rates and the penalty are zero, the
@@ -129,6 +130,11 @@ hipError_t launch_cash_shift(sdpgpu_handle* h, const DevParams& P, int period, c
       const dim3 grid((unsigned)(8 * ((rows + 7) / 8) * C.tiles_per_row));  // (XCD i: rows i, i + 8, ...)
       const size_t smem = (size_t)4 * 2 * (TSZ + sdp::DIAG_CAP) * 8 + (size_t)4 * TSZ * (sizeof(double) + sizeof(int));
       h->per[period - 1].ops_cell = 3.0;  // acc += T1; acc += (p gamma) * V
+      {  // one 8-byte LDS read per cell; per step and wave NU pieces of 64 entries are loaded (L1) and stored (LDS) for DIAG_R * TSZ cells
+        const double stage = 8.0 * 64 * (narrow_pieces(Q.cap, S)) / (double)(sdp::DIAG_R * TSZ);
+        h->per[period - 1].lds_cell = 8.0 + stage;
+        h->per[period - 1].l1_cell = stage;
+      }
 #define SDP_DIAG(MX, SS, NN) \
   hipLaunchKernelGGL((sdp::cash_diag_kernel<MX, SS, NN>), grid, dim3(256), smem, st, Q, table, bounds, v_next, v_cur, pol, lo, hi)
       const bool narrow = Q.cap == 64;
@@ -173,6 +179,7 @@ hipError_t launch_cash_shift(sdpgpu_handle* h, const DevParams& P, int period, c
   size_t smem = (size_t)p.nD * 16 + dp8 * 16 * 8 + (size_t)4 * TSZ * (sizeof(double) + sizeof(int)) + 4 * (dp8 / 2) * sizeof(int);
   const bool last = period == h->T;
   h->per[period - 1].ops_cell = last ? 1.0 : 3.0;  // acc += T1; acc += (p gamma) * V
+  h->per[period - 1].l1_cell = last ? 0.0 : 8.0;      // one 8-byte entry per cell through the vector L1 (16-byte gathers of pairs)
 #define SDP_CS(MX, LS, SS, WW) hipLaunchKernelGGL((sdp::cash_shift_kernel<MX, LS, SS, WW>), grid, dim3(256), smem, st, C, v_next, v_cur, pol, pmf_d, pmf_p, lo, hi)
 #define SDP_CS_S(MX, LS)      \
   if (S == 4 && W == 2)       \

@@ -62,6 +62,7 @@ struct PeriodInfo {
   // executed fp64 add/mul operations per cell of the kernel plan that ran this period (identical operations of
   // neighbouring cells are formed once, see sdp_window.hpp / sdp_cash.hpp); 0 = the kernel has no such model
   double ops_cell = 0;
+  double lds_cell = 0, l1_cell = 0;  // bytes per cell through the LDS / the vector L1 of the kernel that ran the period (0: no model)
 };
 
 struct sdpgpu_handle {

@@ -211,6 +211,7 @@ hipError_t launch_row_window(sdpgpu_handle* h, const DevParams& P, int period, c
   const int TSZ = 64 * SL;
   const bool future = period < h->T;
   h->per[period - 1].ops_cell = future ? 4.0 + 1.0 / SL : 2.0 + 1.0 / SL;  // (c0 + M shared by SL cells, see window_f2_kernel)
+  h->per[period - 1].lds_cell = 8.0 * ((future ? R : 0) + 1) / (double)(R * SL);  // M and one V entry per action, per SL states
   sdp::RowParams W{};
   W.lev0 = p.g.x_lo - h->pmf_d[period - 1][0];
   W.step = h->d.step;
@@ -324,6 +325,7 @@ hipError_t launch_window(sdpgpu_handle* h, const DevParams& P, int period, const
   const bool future = period < h->T;
   // c0 + M once per (action, m): 1/S; p * imm: 1; p * V once per window entry: (R + S - 1)/(R S); two accumulations
   p.ops_cell = future ? 3.0 + 1.0 / pl.S + (pl.R + pl.S - 1.0) / (pl.R * pl.S) : 2.0 + 1.0 / pl.S;
+  p.lds_cell = 16.0 / (pl.R * pl.S);  // one {M, V} entry per demand step and lane
   const bool chunked = pl.n_chunks > 1;
   // a period is never re-run on top of its own pending rows, and a new sweep (period T) first
   // finalizes what the previous one left: the key rows are about to be reset

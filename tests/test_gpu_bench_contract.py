@@ -21,8 +21,14 @@ def _run(*extra):
 
 
 def _check_roofline(rf):
-    assert rf["bound"] in ("fp64-valu", "valu-issue") and rf["unit"] == "T lane-op/s"
-    assert abs(rf["peak"] - 39.3216) < 1e-6
+    # the unit that binds the kernel: fp64 issue (lane-op/s), or an on-chip data path (LDS 128 B/clk/CU, vector L1 64 B/clk/CU)
+    peaks = {"fp64-valu": ("T lane-op/s", 39.3216), "valu-issue": ("T lane-op/s", 39.3216), "lds": ("TB/s", 78.6432),
+             "vector-l1": ("TB/s", 39.3216)}
+    assert rf["bound"] in peaks and rf["unit"] == peaks[rf["bound"]][0]
+    assert abs(rf["peak"] - peaks[rf["bound"]][1]) < 1e-6
+    for name, u in rf.get("units", {}).items():
+        assert 0.0 < u["frac"] <= 1.0 and abs(u["frac"] - u["achieved"] / u["peak"]) < 1e-9, name
+        assert rf["frac"] is None or u["frac"] <= rf["frac"] + 1e-12, "`bound` names the unit closest to its peak"
     if rf["frac"] is not None:
         assert 0.0 < rf["frac"] <= 1.0, "a roofline fraction is a fraction"
         assert abs(rf["frac"] - rf["achieved"] / rf["peak"]) < 1e-9

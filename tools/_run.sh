@@ -1,4 +1,11 @@
-SDPGPU_CASH_DIAG_CHECK=1 timeout -k 10 600 python -m pytest tests/test_gpu_parity.py tests/test_gpu_big_grid.py -m gpu -x -q -k "diag or cfg3 or cash" > gpurun_out/diag_tests.log 2>&1; tail -5 gpurun_out/diag_tests.log
-show() { python -c "
-import json,sys;d=json.load(open(sys.argv[1]));print(sys.argv[2],d['config']['workload'],'%.4g'%d['value'],'%.3f'%d['ms_per_step'],d['parity_gate']['status'],d['roofline'].get('frac'), d['roofline']['per_launch_ms_events'])" $1 "$2"; }
-timeout -k 10 300 python bench.py --workload cfg3 --no-cpu-baseline --steps 3 --warmup 1 > gpurun_out/c3_diag1.json 2> gpurun_out/c3_diag1.err && show gpurun_out/c3_diag1.json diagS1
+SDPGPU_CASH_DIAG_CHECK=1 timeout -k 10 900 python -m pytest tests -m gpu -x -q > gpurun_out/all_tests.log 2>&1; tail -4 gpurun_out/all_tests.log
+timeout -k 10 600 python bench.py > gpurun_out/bench_default.json 2> gpurun_out/bench_default.err; python - <<'PY'
+import json
+d=json.load(open('gpurun_out/bench_default.json'))
+def line(e,name):
+    r=e['roofline']; print(name,'%.4g'%e['value'],'%.3f ms'%e['ms_per_step'],e['parity_gate']['status'],r.get('bound'),None if r.get('frac') is None else round(r['frac'],3),{k:round(v['frac'],3) for k,v in r.get('units',{}).items()})
+line(d,d['config']['workload'])
+for e in d.get('secondary',[]): line(e,e['workload'])
+print(d['cpu_baseline']['value'])
+PY
+bash tools/pmc_collect.sh x5 cfg4 > /dev/null 2>&1; head -28 gpurun_out/prof_x5_cfg4/*summary.txt
