@@ -219,23 +219,17 @@ def cpu_baseline(w, target_seconds: float):
 # ---------------------------------------------------------------------------------------------------------------
 # roofline
 # ---------------------------------------------------------------------------------------------------------------
-def kernel_source_sha() -> str:
-    """Identity of the kernel sources a counter summary was measured on (tools/pmc_reduce.py stores it): counters of
-    another build say nothing about this one's instruction counts or traffic."""
-    import hashlib
-    h = hashlib.sha256()
-    d = os.path.join(ROOT, "stochastic-inventory_amd", "csrc")
-    for name in sorted(os.listdir(d)):
-        if name.endswith((".hip", ".hpp")):
-            h.update(name.encode())
-            h.update(open(os.path.join(d, name), "rb").read())
-    return h.hexdigest()[:16]
+def kernel_source_sha(workload_name: str) -> str:
+    """Digest of the kernel sources this workload runs on (tools/kernel_sha.py): a counter summary measured on another
+    build says nothing about this one's instruction counts or traffic."""
+    from tools.kernel_sha import kernel_source_sha as sha
+    return sha(ROOT, workload_name)
 
 
 def load_pmc(workload_name: str):
     """Counter summary of this workload written by tools/pmc_reduce.py (rocprofv3 --pmc passes, corrected as
     MI355X_MICROARCH.md prescribes), newest round first -- only if it was measured on THIS build of the kernels."""
-    sha = kernel_source_sha()
+    sha = kernel_source_sha(workload_name)
     for path in sorted(glob.glob(os.path.join(ROOT, "profiles", f"r*_pmc_{workload_name}.json")), reverse=True):
         try:
             rec = json.load(open(path))
@@ -313,6 +307,9 @@ def roofline_block(w, st, T, cells_rank, states_rank, dev_ms_per_sweep, per_laun
     else:
         out.update({"bound": "valu-issue", "achieved": None, "peak": VALU_PEAK_LANE_OPS / 1e12, "unit": "T lane-op/s",
                     "frac": None, "note": "no instruction model and no counter summary in profiles/ for this workload"})
+    if pmc:
+        out["counters"] = {k: pmc.get(k) for k in ("valu_busy_frac", "lds_busy_frac", "ta_busy_frac")}
+        out["counters"]["source"] = pmc["_file"]
     # the unit that binds is the one closest to its peak: a kernel whose per-cell read goes through the LDS (cash_diag_kernel)
     # or the vector L1 (cash_shift_kernel) is priced against that path, with the fp64 issue fraction kept beside it
     for u in units.values():

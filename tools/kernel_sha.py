@@ -1,0 +1,22 @@
+"""Digest of the kernel sources a bench workload runs on: ties a counter summary in profiles/ to the build it was measured
+on (bench.py uses a summary only if the digest matches; tools/pmc_reduce.py writes it).  Per workload, so that work on
+one kernel family does not retire the summaries of the others."""
+import hashlib
+import os
+
+COMMON = ["sdp_device.hpp", "sdpgpu_internal.hpp"]
+WINDOW = ["sdp_window.hpp", "sdpgpu_window.hip"]   # F1 / F2 window kernels: target, cfg2, cfg4, cfg4p, cfg5
+CASH = ["sdp_cash.hpp", "sdpgpu_cash.hip"]         # uniform-shift, diagonal and cash row kernels: cfg3, cfg3t
+
+
+def kernel_files(workload_name: str):
+    return sorted(COMMON + (CASH if workload_name.startswith("cfg3") else WINDOW))
+
+
+def kernel_source_sha(root: str, workload_name: str) -> str:
+    h = hashlib.sha256()
+    d = os.path.join(root, "stochastic-inventory_amd", "csrc")
+    for name in kernel_files(workload_name):
+        h.update(name.encode())
+        h.update(open(os.path.join(d, name), "rb").read())
+    return h.hexdigest()[:16]

@@ -14,16 +14,8 @@ import statistics
 import sys
 
 
-def kernel_source_sha(root):
-    """Same digest as bench.py's kernel_source_sha(): ties a summary to the kernel sources it was measured on."""
-    import hashlib
-    h = hashlib.sha256()
-    d = os.path.join(root, "stochastic-inventory_amd", "csrc")
-    for name in sorted(os.listdir(d)):
-        if name.endswith((".hip", ".hpp")):
-            h.update(name.encode())
-            h.update(open(os.path.join(d, name), "rb").read())
-    return h.hexdigest()[:16]
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+from kernel_sha import kernel_source_sha  # noqa: E402  (same digest as bench.py's)
 
 
 def short(name):
@@ -70,10 +62,17 @@ def main():
     d = kernels[dom]
     rec = {
         "round": rnd, "workload": bench["config"]["workload"] if bench else wl, "dominant_kernel": dom,
-        "source_sha": kernel_source_sha(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))),
+        "source_sha": kernel_source_sha(os.path.dirname(os.path.dirname(os.path.abspath(__file__))),
+                                        bench["config"]["workload"] if bench else wl),
         "hbm_bytes_per_launch": d.get("hbm_read_bytes_per_launch", 0.0) + d.get("hbm_write_bytes_per_launch", 0.0),
         "valu_insts_per_launch": d.get("SQ_INSTS_VALU"),
         "ta_busy_frac": (d["TA_BUSY_avr"] / d["GRBM_GUI_ACTIVE"]) if d.get("TA_BUSY_avr") and d.get("GRBM_GUI_ACTIVE") else None,
+        # GRBM_GUI_ACTIVE sums the eight XCDs: GUI / 8 cycles per launch on 256 CUs x 4 SIMDs; a wave64 VALU instruction holds its
+        # SIMD four cycles; SQ_LDS_IDX_ACTIVE counts LDS-array cycles per CU
+        "valu_busy_frac": (d["SQ_ACTIVE_INST_VALU"] * 4.0 / (d["GRBM_GUI_ACTIVE"] / 8.0 * 1024.0))
+        if d.get("SQ_ACTIVE_INST_VALU") and d.get("GRBM_GUI_ACTIVE") else None,
+        "lds_busy_frac": (d["SQ_LDS_IDX_ACTIVE"] / (d["GRBM_GUI_ACTIVE"] / 8.0 * 256.0))
+        if d.get("SQ_LDS_IDX_ACTIVE") and d.get("GRBM_GUI_ACTIVE") else None,
         "correction": "HBM bytes = 2 * FETCH_SIZE_KiB * 1024 + WRITE_SIZE_KiB * 1024 (gfx950: FETCH_SIZE counts half of a wide coalesced read)",
         "kernels": kernels,
         "bench_line": {k: bench[k] for k in ("value", "ms_per_step", "steps", "config", "parity_gate")} if bench else None,
