@@ -66,7 +66,7 @@ def main():
                                         bench["config"]["workload"] if bench else wl),
         "hbm_bytes_per_launch": d.get("hbm_read_bytes_per_launch", 0.0) + d.get("hbm_write_bytes_per_launch", 0.0),
         "valu_insts_per_launch": d.get("SQ_INSTS_VALU"),
-        "ta_busy_frac": (d["TA_BUSY_avr"] / d["GRBM_GUI_ACTIVE"]) if d.get("TA_BUSY_avr") and d.get("GRBM_GUI_ACTIVE") else None,
+        "ta_busy_frac": (d["TA_BUSY_avr"] / (d["GRBM_GUI_ACTIVE"] / 8.0)) if d.get("TA_BUSY_avr") and d.get("GRBM_GUI_ACTIVE") else None,
         # GRBM_GUI_ACTIVE sums the eight XCDs: GUI / 8 cycles per launch on 256 CUs x 4 SIMDs; a wave64 VALU instruction holds its
         # SIMD four cycles; SQ_LDS_IDX_ACTIVE counts LDS-array cycles per CU
         "valu_busy_frac": (d["SQ_ACTIVE_INST_VALU"] * 4.0 / (d["GRBM_GUI_ACTIVE"] / 8.0 * 1024.0))
