@@ -626,8 +626,7 @@ def main():
         }
         if check is not None:
             out["check_vs_single_rank"] = check
-        if not args.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline(make_workload(args.workload, 1, args.states, args.periods, args.weak), args.cpu_seconds)
+        # (cpu_baseline is the N = 1 line's: the oracle timed on rank 0 while seven GPUs wait would only lengthen the scaling run)
         print(json.dumps(out), flush=True)
     dist.barrier()
     dist.destroy_process_group()
