@@ -294,11 +294,16 @@ def roofline_block(w, st, T, cells_rank, states_rank, dev_ms_per_sweep, per_laun
                     "cells are formed once) x cells / HIP-event time, against 16 lanes/clk/SIMD x 1024 SIMDs x 2.4 GHz",
         })
     elif pmc and pmc.get("valu_insts_per_launch"):
-        lane_ops = float(pmc["valu_insts_per_launch"]) * 64.0 / (avg_launch_ms * 1e-3)
+        # (the counted kernel is the one of the periods before T: priced against ITS launches, not the sweep average, which
+        # the cheaper period-T launch would flatter)
+        dom = [m for m in per_launch_ms[1:] if m > 0] or [avg_launch_ms]
+        dom_ms = sum(dom) / len(dom)
+        lane_ops = float(pmc["valu_insts_per_launch"]) * 64.0 / (dom_ms * 1e-3)
         out.update({
             "bound": "valu-issue",
             "achieved": lane_ops / 1e12, "peak": VALU_PEAK_LANE_OPS / 1e12, "unit": "T lane-op/s",
             "frac": lane_ops / VALU_PEAK_LANE_OPS,
+            "dominant_launch_ms": dom_ms,
             "valu_insts_per_cell": float(pmc["valu_insts_per_launch"]) * 64.0 / max(cells_rank / launches, 1),
             "ta_busy_frac": pmc.get("ta_busy_frac"),
             "note": f"SQ_INSTS_VALU x 64 lanes per launch ({pmc['_file']}) / HIP-event launch time; every wave64 VALU "

@@ -300,6 +300,200 @@ __global__ __launch_bounds__(64) void staff_pair_kernel(StaffParams P, const dou
   }
 }
 
+// ---------------------------------------------------------------------------------------------
+// Window form (large staff ranges).  The pair kernel fetches one probability per cell through the vector L1 (8 B per
+// cell, plus the V pairs): that path, not the arithmetic, is what bounds it (TA 74 % busy at 15 VALU instructions per
+// cell).  But everything a cell reads depends on TWO integers only, the level y = x + a and the realisation j: the
+// probability p(y, j), and -- through n = y - j -- the staff left, its salary, its penalty and V_{t+1}[n].  A lane that
+// owns S ADJACENT states and carries R consecutive actions has R S cells per step but only R + S - 1 distinct levels
+// (state s, action r: level Y + r + s), so per step it needs R + S - 1 probabilities, not R S; the products p V are
+// formed once per level; and the cells (s, r, j) and (s + 1, r, j + 1) leave the same n behind with the same action, so
+// the immediate cost (fv[r] + salary n) + penalty(n) -- the reference's two additions, on identical operands -- is
+// formed once per (r, n) and handed down the lane's states one step at a time, exactly as the F1 window kernel does
+// (sdp_window.hpp).  Executed fp64 operations per cell: 3 + 2/S + (R + S - 1)/(R S) = 3.94 for R = S = 4, against 6.
+// The R + S - 1 entries {V, salary, penalty} over n slide by ONE new entry per step (registers, rotating slots); the
+// probabilities of a step are one contiguous piece of row j of the transposed table (64 S + R + S - 2 levels), which
+// the wave loads with 16-byte loads into LDS -- stored by residue class of the level modulo S, so that the lanes'
+// reads, S levels apart, fall on consecutive slots (no bank conflicts) -- one step ahead of its use.  Every value that
+// enters an accumulator is the reference's, in the reference's order (j ascending; zero-probability steps beyond a
+// row's length add +0.0).
+// ---------------------------------------------------------------------------------------------
+#ifndef SDP_STAFF_WIN_ATTR
+#define SDP_STAFF_WIN_ATTR
+#endif
+template <int R, int S, bool FUTURE>
+__global__ __launch_bounds__(64) SDP_STAFF_WIN_ATTR void staff_window_kernel(StaffParams P, const double* __restrict__ pT0,
+                                                          const int32_t* __restrict__ row_len,
+                                                          const double* __restrict__ v_next,
+                                                          double* __restrict__ out_val, int32_t* __restrict__ out_idx,
+                                                          int64_t lo, int64_t hi) {
+  constexpr int NW = R + S - 1;          // levels per lane and step = window entries
+  constexpr int TS = 64 * S;             // states per tile
+  constexpr int NLEV = TS + NW - 1;      // levels per step: Y0 .. Y0 + NLEV - 1
+  constexpr int NPAIR = (NLEV + 1) / 2;  // ... loaded as pairs of adjacent levels
+  constexpr int NPC = (NPAIR + 63) / 64;
+  constexpr int H = (NLEV + S - 1) / S + 7;  // slots per residue class (odd multiple-free padding)
+  static_assert(NW <= kStaffPadJ, "table padding behind the last row of realisations");
+  __shared__ __attribute__((aligned(16))) double s_p[2][S * H];
+  const int lane = threadIdx.x;
+  const int64_t tile = blockIdx.x / P.n_groups;
+  const int group = (int)(blockIdx.x - tile * P.n_groups);
+  const int64_t idx0 = lo + tile * TS + (int64_t)S * lane;  // this lane: states idx0 .. idx0 + S - 1
+  const int x0 = P.x_lo + (int)(lo + tile * TS);             // the tile's lowest staff number
+  const int a_end = min(P.n_actions, (group + 1) * P.group_actions);
+  const int last_row = P.n_rows - 1;
+  const int64_t row_bytes = (int64_t)P.n_rows * 8;
+  const char* vb = reinterpret_cast<const char*>(v_next);
+  const char* pb = reinterpret_cast<const char*>(pT0);
+  double best[S];
+  int bestk[S];
+#pragma unroll
+  for (int s = 0; s < S; ++s) {
+    best[s] = 1.7976931348623157e308;
+    bestk[s] = 0;
+  }
+  // staging: pair m = 64 c + lane holds the levels Y0 + 2 m, Y0 + 2 m + 1; level q goes to slot (q mod S) H + q / S
+  // (lanes past the last pair of the last piece repeat it: the same values to the same slots, and no divergent branch in the loop)
+  int w_slot[NPC], w_pair[NPC];
+#pragma unroll
+  for (int c = 0; c < NPC; ++c) {
+    w_pair[c] = 64 * c + lane < NPAIR ? 64 * c + lane : NPAIR - 1;
+    const int q0 = 2 * w_pair[c];
+    w_slot[c] = (q0 % S) * H + q0 / S;  // (S even: the pair's second level sits one class further, same slot)
+  }
+  auto salary_of = [&](int n) { return P.salary * (double)n; };
+  auto penalty_of = [&](int n) { return n > P.min_staff ? 0.0 : P.pen * (double)(P.min_staff - n); };
+  auto v_of = [&](int n) {
+    int nn = n > P.nn_hi ? P.nn_hi : n;
+    nn = nn < P.nn_lo ? P.nn_lo : nn;
+    return *reinterpret_cast<const double*>(vb + (uint32_t)((nn - P.next_x_lo) * 8));
+  };
+  for (int a0 = group * P.group_actions; a0 < a_end; a0 += R) {
+    const int Y0 = x0 + a0;        // lowest level of the block
+    const int Yl = Y0 + S * lane;  // this lane's lowest level
+    // steps: the longest row among the block's levels, rounded up to whole trips of NW steps (zero rows behind the table)
+    int kmax = 0;
+#pragma unroll
+    for (int u = 0; u < NW; ++u) {
+      const int y = Yl + u;
+      kmax = max(kmax, row_len[y >= last_row ? last_row : y]);
+    }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) kmax = max(kmax, __shfl_xor(kmax, off, 64));
+    kmax = __builtin_amdgcn_readfirstlane(kmax);
+    const int ksteps = (kmax + NW - 1) / NW * NW;
+    double fv[R], acc[S][R], immc[S][R];
+    double vw[NW], salw[NW], penw[NW];
+#pragma unroll
+    for (int u = 0; u < NW; ++u) {
+      vw[u] = FUTURE ? v_of(Yl + u) : 0.0;
+      salw[u] = salary_of(Yl + u);
+      penw[u] = penalty_of(Yl + u);
+    }
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+      const int a = a0 + r;
+      fv[r] = (a > 0 ? P.K : 0.0) + P.v * (double)a;
+#pragma unroll
+      for (int s = 0; s < S; ++s) {
+        acc[s][r] = 0.0;
+        immc[s][r] = fv[r] + salw[r + s] + penw[r + s];  // (s = 0 unused)
+      }
+    }
+    // one row piece: pairs {p(y), p(y + 1)} of row j; a level on or beyond the table's last row reads the last row
+    staff_pair_u tmp[NPC];
+    const bool folds = Y0 + NLEV >= last_row;
+    auto row_load = [&](int j) {
+      const char* pk = pb + (int64_t)j * row_bytes;
+#pragma unroll
+      for (int c = 0; c < NPC; ++c) {
+        const int e0 = Y0 + 2 * w_pair[c];
+        const int cc = e0 >= last_row ? last_row - 1 : e0;
+        staff_pair_u t = *reinterpret_cast<const staff_pair_u*>(pk + (uint32_t)(cc * 8));
+        if (folds) t.x = e0 >= last_row ? t.y : t.x;  // (wave-uniform: only blocks that reach the table's last row)
+        tmp[c] = t;
+      }
+    };
+    auto row_store = [&](int buf) {
+#pragma unroll
+      for (int c = 0; c < NPC; ++c) {
+        s_p[buf][w_slot[c]] = tmp[c].x;
+        s_p[buf][w_slot[c] + H] = tmp[c].y;
+      }
+    };
+    __builtin_amdgcn_wave_barrier();  // (the previous block's reads of the buffers are done)
+    row_load(0);
+    row_store(0);
+    __builtin_amdgcn_wave_barrier();
+    int cur = 0;
+    for (int jb = 0; jb < ksteps; jb += NW) {
+#pragma unroll
+      for (int t = 0; t < NW; ++t) {
+        const int j = jb + t;
+        row_load(j + 1);
+        double vnew = 0.0;
+        if constexpr (FUTURE) vnew = v_of(Yl - (j + 1));
+        // by level (anti-diagonal u = r + s): one probability read and one product p V per level, used by its cells at once
+        double imm0[R];
+#pragma unroll
+        for (int r = 0; r < R; ++r) {
+          const int w0 = (r - t + NW) % NW;
+          imm0[r] = fv[r] + salw[w0] + penw[w0];
+        }
+#pragma unroll
+        for (int u = 0; u < NW; ++u) {
+          const double pu = s_p[cur][(u % S) * H + lane + u / S];
+          double pvu = 0.0;
+          if constexpr (FUTURE) pvu = pu * vw[(u - t + NW) % NW];
+#pragma unroll
+          for (int s2 = 0; s2 < S; ++s2) {
+            const int r = u - s2;
+            if (r >= 0 && r < R) {
+              acc[s2][r] += pu * (s2 == 0 ? imm0[r] : immc[s2][r]);
+              if constexpr (FUTURE) acc[s2][r] += pvu;
+            }
+          }
+        }
+#pragma unroll
+        for (int r = 0; r < R; ++r) {
+#pragma unroll
+          for (int s2 = S - 1; s2 > 1; --s2) immc[s2][r] = immc[s2 - 1][r];
+          if constexpr (S > 1) immc[1][r] = imm0[r];
+        }
+        // slide: the entry of level Yl at step j + 1 replaces the one of level Yl + NW - 1 just used
+        const int nn = Yl - (j + 1);
+        vw[(NW - 1 - t) % NW] = vnew;
+        salw[(NW - 1 - t) % NW] = salary_of(nn);
+        penw[(NW - 1 - t) % NW] = penalty_of(nn);
+        __builtin_amdgcn_wave_barrier();
+        row_store(cur ^ 1);
+        __builtin_amdgcn_wave_barrier();
+        cur ^= 1;
+        __builtin_amdgcn_sched_barrier(0);  // (one step at a time: left alone, the scheduler hoists the loads of all NW steps -- 330 VGPRs)
+      }
+    }
+#pragma unroll
+    for (int r = 0; r < R; ++r)
+      if (a0 + r < P.n_actions) {
+#pragma unroll
+        for (int s = 0; s < S; ++s)
+          if (acc[s][r] < best[s]) {
+            best[s] = acc[s][r];
+            bestk[s] = a0 + r;
+          }
+      }
+  }
+#pragma unroll
+  for (int s = 0; s < S; ++s) {
+    const int64_t idx = idx0 + s;
+    if (idx < hi) {
+      const int64_t at = (int64_t)group * P.part_stride + idx;
+      out_val[at] = best[s];
+      out_idx[at] = bestk[s];
+    }
+  }
+}
+
 // groups in ascending action order, strict compare: the first best wins (StaffRecursion.java:110-113)
 __global__ __launch_bounds__(256) void combine_staff_kernel(const double* __restrict__ part_val,
                                                             const int32_t* __restrict__ part_idx, int n_groups,

@@ -91,7 +91,15 @@ hipError_t launch_staff(sdpgpu_handle* h, int period, const double* v_next, doub
                             (period == h->T || (int64_t)h->per[period].g.nx * 8 < 2147483647LL);
   const bool pair = !pair_off && !plain && staff_block() == 4 && S.n_rows >= 2 && (period == h->T || S.nn_hi > S.nn_lo) &&
                     small_tables && (roomy || std::getenv("SDPGPU_STAFF_PAIR"));
-  const int tile_states = pair ? 128 : 64;
+  // window form (staff_window_kernel: S adjacent states per lane, one probability per LEVEL instead of one per cell) on staff
+  // ranges of a thousand numbers and more; SDPGPU_STAFF_WIN=0 turns it off, =2 / =4 picks the states per lane
+  int win_s = 0;
+  if (pair && hi - lo >= 1024) win_s = 4;
+  if (const char* e = std::getenv("SDPGPU_STAFF_WIN")) {
+    const int v = std::atoi(e);
+    win_s = (v == 2 || v == 4) && pair ? v : 0;
+  }
+  const int tile_states = win_s ? 64 * win_s : (pair ? 128 : 64);
   staff_groups(h, hi - lo, tile_states, &S.n_groups, &S.group_actions);
   const int64_t tiles = (hi - lo + tile_states - 1) / tile_states;
   const int64_t blocks = tiles * S.n_groups;
@@ -118,7 +126,13 @@ hipError_t launch_staff(sdpgpu_handle* h, int period, const double* v_next, doub
   }
   const double* pT = h->d_lvl_p[period - 1];
   const int32_t* len = h->d_lvl_len[period - 1];
-  if (pair) {
+  if (win_s) {
+#define SDP_SW(SS, FU) \
+  hipLaunchKernelGGL((sdp::staff_window_kernel<4, SS, FU>), dim3((unsigned)blocks), dim3(64), 0, st, S, pT, len, v_next, out_val, out_idx, lo, hi)
+    if (win_s == 4) { if (period < h->T) SDP_SW(4, true); else SDP_SW(4, false); }
+    else { if (period < h->T) SDP_SW(2, true); else SDP_SW(2, false); }
+#undef SDP_SW
+  } else if (pair) {
     if (period < h->T)
       hipLaunchKernelGGL((sdp::staff_pair_kernel<4, true>), dim3((unsigned)blocks), dim3(64), 0, st, S, pT, len, v_next,
                          out_val, out_idx, lo, hi);

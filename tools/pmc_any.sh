@@ -6,7 +6,8 @@
 set -e
 RND=$1; TAG=$2; shift 2
 R=$GRAFT_REPO_ROOT
-OUT=$R/gpurun_out/prof_${RND}_$TAG
+TOP=$R/gpurun_out/prof_${RND}_$TAG
+OUT=$TOP/run_$(date +%Y%m%d%H%M%S)  # (one directory per collection: see pmc_collect.sh)
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
 timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats -- python3 $R/$1 "${@:2}" > $OUT/stats.log 2>&1
@@ -19,3 +20,6 @@ for grp in "FETCH_SIZE" "WRITE_SIZE" "SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS S
   timeout -k 10 300 rocprofv3 --pmc $grp --kernel-trace --output-format csv -d $OUT/pmc$i -- python3 $R/$1 "${@:2}" > $OUT/pmc$i.log 2>&1 || echo "pass $i ($grp) failed" >> $OUT/failed.txt
 done
 python3 $R/tools/pmc_reduce.py $OUT $RND $TAG
+cp $OUT/${RND}_* $TOP/ 2>/dev/null
+f=$(ls $OUT/stats/*/*kernel_stats.csv 2>/dev/null | head -1); [ -n "$f" ] && cp $f $TOP/kernel_stats.csv
+true

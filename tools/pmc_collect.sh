@@ -9,7 +9,10 @@
 set -e
 RND=$1; W=$2; shift 2
 R=$GRAFT_REPO_ROOT
-OUT=$R/gpurun_out/prof_${RND}_$W
+TOP=$R/gpurun_out/prof_${RND}_$W
+# every collection in its own directory: gpurun MERGES gpurun_out/ back into the local copy, and a reduce over the union of
+# two collections would average counters of different builds
+OUT=$TOP/run_$(date +%Y%m%d%H%M%S)
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
 BENCH="python3 $R/bench.py --workload $W --no-secondary $*"
@@ -25,3 +28,6 @@ for grp in "FETCH_SIZE" "WRITE_SIZE" "SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS S
   timeout -k 10 300 rocprofv3 --pmc $grp --kernel-trace --output-format csv -d $OUT/pmc$i -- python3 $R/bench.py $PROF > $OUT/pmc$i.log 2>&1 || echo "pass $i ($grp) failed" >> $OUT/failed.txt
 done
 python3 $R/tools/pmc_reduce.py $OUT $RND $W
+cp $OUT/${RND}_* $OUT/bench.json $TOP/ 2>/dev/null
+f=$(ls $OUT/stats/*/*kernel_stats.csv 2>/dev/null | head -1); [ -n "$f" ] && cp $f $TOP/kernel_stats.csv
+true

@@ -8,7 +8,6 @@ for W in "$@"; do
   cp $D/${RND}_pmc_*.json profiles/ 2>/dev/null
   cp $D/${RND}_${W}_summary.txt profiles/ 2>/dev/null
   cp $D/bench.json profiles/${RND}_${W}_bench.json 2>/dev/null
-  f=$(ls $D/stats/*/*kernel_stats.csv 2>/dev/null | head -1)
-  [ -n "$f" ] && cp $f profiles/${RND}_${W}_kernel_stats.csv
+  [ -f $D/kernel_stats.csv ] && cp $D/kernel_stats.csv profiles/${RND}_${W}_kernel_stats.csv
 done
 ls profiles | grep "^$RND" | head -40
