@@ -3,7 +3,6 @@ reference, and must print the oracle's numbers."""
 import os
 import subprocess
 
-import numpy as np
 import pytest
 
 import cases

@@ -114,9 +114,18 @@ def _cfg3_small():
     return workloads.cfg3_cash(T=3, NX=24, NC=700, A=70, D=30)
 
 
+def _dyadic_wide_min():
+    """f3_dyadic_wide under OptDirection.MIN (the arg-min instantiation of the diagonal kernel)."""
+    from stochastic_inventory_amd.functors import OptDirection
+    w = cases.f3_dyadic_wide()
+    w.direction = OptDirection.MIN
+    w.name = "f3_dyadic_wide_min"
+    return w
+
+
 @pytest.mark.parametrize("env", [{}, {"SDPGPU_CASH_DIAG_S": "2"}, {"SDPGPU_CASH_DIAG_S": "1"}, {"SDPGPU_CASH_DIAG": "0"}],
                          ids=lambda e: ",".join(f"{k[12:]}={v}" for k, v in e.items()) or "default")
-@pytest.mark.parametrize("make", [_cfg3_small, cases.f3_dyadic_wide, cases.f3_dyadic_big_fixed], ids=lambda f: f.__name__)
+@pytest.mark.parametrize("make", [_cfg3_small, cases.f3_dyadic_wide, _dyadic_wide_min, cases.f3_dyadic_big_fixed], ids=lambda f: f.__name__)
 def test_cash_diag_kernel_variants(sia, oracle, monkeypatch, make, env):
     """The diagonal form of the uniform-shift kernel (cash_diag_kernel: a block of consecutive actions reads one staged row
     segment per demand step; one and two tiles per wave) and the per-cell gather form it replaces give the oracle's tables

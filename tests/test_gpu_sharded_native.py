@@ -33,7 +33,8 @@ def _check_rank(eng, V, pol, T, first_full, label):
                                         (cases.f1_gapped, 2), (cases.f2_clamped, 3), (cases.f2_unclamped, 2),
                                         (cases.f2_pipeline, 3), (cases.f3_tenths, 3), (cases.f3_dyadic, 2),
                                         (cases.f3_testing, 5), (cases.f4_overdraft, 2), (cases.f5_cash_leadtime, 2),
-                                        (cases.f6_survival, 3)], ids=lambda v: getattr(v, "__name__", str(v)))
+                                        (cases.f6_survival, 3), (cases.f3_dyadic_wide, 3), (cases.f3_grid_prices, 4),
+                                        (cases.f2_clamped, 5)], ids=lambda v: getattr(v, "__name__", str(v)))
 def test_solve_multi_shared_device(sia, oracle, make, world):
     w = make()
     V, pol = _oracle_tables(oracle, w)

@@ -1,6 +1,5 @@
 """GetPmf restatement.  SSJ is absent, so PMF parity is unpinned; these tests pin
 the STRUCTURE GetPmf.java:82-134 prescribes (support, truncation, normalisation, quirks)."""
-import math
 
 import numpy as np
 

@@ -2,7 +2,7 @@
 """Diagnostic only: run one cfg2 sweep on the SDP_STAMPS build (tools/libsdpgpu_stamps.so) and print the
 per-wave timeline of one mid-sweep window-kernel launch: when waves start, how long staging and the
 demand loop take, how many waves each SIMD hosted.  Never part of the product or of any timing."""
-import collections, os, shutil, sys
+import collections, os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 import stochastic_inventory_amd as sia
