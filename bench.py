@@ -331,8 +331,13 @@ def roofline_block(w, st, T, cells_rank, states_rank, dev_ms_per_sweep, per_laun
                                 f"{top['bytes_per_cell']:.3g} B per cell) / HIP-event time, against "
                                 + ("128" if name == "lds" else "64") + " B/clk/CU x 256 CUs x 2.4 GHz; the other units: `units`"})
     if out.get("frac") is not None and not (0.0 < out["frac"] <= 1.0):
-        raise SystemExit(f"roofline fraction {out['frac']} outside (0, 1]: the op model / counter summary does not describe "
-                         "this kernel (a summary in profiles/ measured on another build would be skipped by its source_sha)")
+        # a fraction above 1 is not a roofline fraction: the op model / counter summary does not describe this kernel (a
+        # summary in profiles/ measured on another build is skipped by its source_sha).  Never printed: the line keeps its
+        # measured throughput and says why the fraction is missing.
+        msg = f"roofline fraction {out['frac']:.4f} outside (0, 1] withheld: the model / counter summary does not describe this kernel"
+        print("[bench] " + msg, file=sys.stderr, flush=True)
+        out.update({"frac": None, "achieved": None, "error": msg})
+        out.pop("units", None)
     return out
 
 
