@@ -89,8 +89,22 @@ hipError_t launch_cash_shift(sdpgpu_handle* h, const DevParams& P, int period, c
                        whole(d.fixed_order_cost) && whole(p.overhead) && whole(d.price * h->pmf_d[period - 1][0]) &&
                        whole(d.price * p.g.x_lo) && whole(d.holding_cost * p.g.x_lo) && whole(d.holding_cost * h->pmf_d[period - 1][0]);
     const double spread_bound = brk + slide * (sdp::DIAG_R - 1) + (exact ? 0 : 2);
-    if (diag_on && period < h->T && p.g.nc >= 256 && spread_bound <= sdp::DIAG_CAP &&
-        table_bytes <= ((size_t)2 << 30)) {
+    bool table_ok = diag_on && period < h->T && p.g.nc >= 256 && spread_bound <= sdp::DIAG_CAP && table_bytes <= ((size_t)2 << 30);
+    if (table_ok && h->diag_bytes < table_bytes) {
+      hipError_t e = hipStreamSynchronize(st);  // (an earlier launch may still read the old table)
+      if (e != hipSuccess) return e;
+      if (h->d_diag) (void)hipFree(h->d_diag);
+      h->d_diag = nullptr;
+      h->diag_bytes = 0;
+      if (hipMalloc(&h->d_diag, table_bytes) == hipSuccess) {
+        h->diag_bytes = table_bytes;
+      } else {  // no room for the table: the uniform-shift kernel below needs none
+        (void)hipGetLastError();
+        h->d_diag = nullptr;
+        table_ok = false;
+      }
+    }
+    if (table_ok) {
       int S = 1;  // (two tiles per wave, 176 VGPRs: 48.4 against 44.3 ms per sweep on configs[2]; opt-in)
       if (const char* e = std::getenv("SDPGPU_CASH_DIAG_S")) S = std::atoi(e) == 2 ? 2 : 1;
       const int TSZ = 128 * S;
@@ -98,16 +112,6 @@ hipError_t launch_cash_shift(sdpgpu_handle* h, const DevParams& P, int period, c
       const int64_t row_lo = lo / p.g.nc;
       C.row0 = (int32_t)row_lo;
       if (!grid_ok(8 * ((rows + 7) / 8) * (int64_t)C.tiles_per_row)) return hipErrorInvalidValue;
-      if (h->diag_bytes < table_bytes) {
-        hipError_t e = hipStreamSynchronize(st);  // (an earlier launch may still read the old table)
-        if (e != hipSuccess) return e;
-        if (h->d_diag) (void)hipFree(h->d_diag);
-        h->d_diag = nullptr;
-        h->diag_bytes = 0;
-        e = hipMalloc(&h->d_diag, table_bytes);
-        if (e != hipSuccess) return e;
-        h->diag_bytes = table_bytes;
-      }
       {
         hipError_t e = hipMemsetAsync(h->d_diag, 0, head_bytes, st);  // (bounds are reduced with atomicMax from zero)
         if (e != hipSuccess) return e;
