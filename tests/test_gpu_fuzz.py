@@ -131,3 +131,43 @@ def test_random_instances_bit_exact(sia, oracle, family):
                     assert np.array_equal(gv, V[period - 1]), f"{w.name} kernel {kernel} t={period}: values"
     if not any(os.environ.get(k) == "0" for k in ("SDPGPU_CASH_ROW", "SDPGPU_CASH_SHIFT")):
         assert 2 in kernels_seen  # the specialised kernels took part
+
+
+def make_wide_cash_instance(seed):
+    """F3 on WIDE cash rows (256 points and more: the rows the two-points-per-lane kernels and the diagonal form of the
+    uniform-shift kernel take), dyadic or on-grid parameters so that those kernels are eligible: random quantum, prices,
+    fixed cost (zero, small, and beyond the staged segment's reach), holding cost, horizon, demand support, direction."""
+    rng = np.random.default_rng(77000 + seed)
+    T = int(rng.integers(2, 4))
+    dyadic = bool(rng.integers(0, 3))           # two in three: every parameter dyadic (uniform-shift / diagonal kernels)
+    q = float(rng.choice([1, 1, 2, 4])) if dyadic else 10.0
+    unit = 1.0 / 8 if dyadic else 0.1
+    money = lambda lo, hi: float(round(rng.uniform(lo, hi) / unit) * unit)
+    price = money(2, 9)
+    vari = max(unit, money(0.25, min(price, 3)))
+    fix = float(rng.choice([0.0, money(0, 4), money(20, 60)]))
+    nc = int(rng.integers(256, 620))
+    min_cash = -float(rng.integers(0, 20))
+    f = CashFunctor(price=price, fixOrderCost=fix, variCost=vari, holdingCost=float(rng.choice([0.0, money(0, 1)])),
+                    depositeRate=0.0, overheadRate=0.0, penaltyCost=0.0, salvageValue=money(0, 1),
+                    discountFactor=float(rng.choice([1.0, 0.9375])), cashFormula=int(rng.integers(0, 2)),
+                    overheadCosts=[money(0, 3) for _ in range(T)], cashRoundMult=q, cashRoundDiv=q,
+                    cashRoundIntDiv=bool(q == 1.0 and rng.integers(0, 2)), maxOrderQuantity=float(rng.integers(3, 40)),
+                    minInventoryState=0.0, maxInventoryState=float(rng.integers(3, 25)), minCashState=min_cash,
+                    maxCashState=min_cash + (nc - 1) / q, iniInventory=0.0, iniCash=float(rng.integers(0, 15)))
+    direction = OptDirection.MAX if rng.integers(0, 4) else OptDirection.MIN
+    return Workload(f"fuzz_wide_cash_{seed}", f, direction, _pmf(rng, T, unit_stride=True, d_max=int(rng.integers(3, 40))))
+
+
+def test_random_wide_cash_rows_bit_exact(sia, oracle, monkeypatch):
+    monkeypatch.setenv("SDPGPU_CASH_DIAG_CHECK", "1")  # (the guard word behind the diagonal kernel's spread bound)
+    n = int(os.environ.get("SDP_FUZZ_N", "24"))
+    for seed in range(n):
+        w = make_wide_cash_instance(seed)
+        V, pol, cells = oracle.Problem(w.desc(), w.pmf, w.overhead()).solve(nthreads=8)
+        with sia.SdpEngine(w.desc(), w.pmf, w.overhead()) as eng:
+            eng.solve()
+            assert eng.stats().cells_evaluated == cells and eng.stats().kernel_used == 2, w.name
+            for period in range(1, w.T + 1):
+                assert np.array_equal(eng.policy(period), pol[period - 1]), f"{w.name} t={period}: policy"
+                assert np.array_equal(eng.values(period), V[period - 1]), f"{w.name} t={period}: values"

@@ -1,5 +1,2 @@
-SDPGPU_CASH_DIAG_CHECK=1 timeout -k 10 600 python -m pytest tests/test_gpu_parity.py -m gpu -x -q -k "diag or cfg3 or cash" > gpurun_out/diag_tests.log 2>&1; tail -3 gpurun_out/diag_tests.log
-for w in cfg3 cfg3t; do
-  bash tools/pmc_collect.sh r02 $w > gpurun_out/collect_$w.log 2>&1 || echo "collect $w failed"
-  head -3 gpurun_out/prof_r02_$w/r02_${w}_summary.txt
-done
+timeout -k 10 900 python -m pytest tests/test_gpu_fuzz.py -m gpu -x -q -k "wide" > gpurun_out/fuzz_wide.log 2>&1; tail -5 gpurun_out/fuzz_wide.log
+SDP_FUZZ_N=150 timeout -k 10 900 python -m pytest tests/test_gpu_fuzz.py -m gpu -x -q -k "wide" > gpurun_out/fuzz_wide150.log 2>&1; tail -5 gpurun_out/fuzz_wide150.log
