@@ -161,6 +161,22 @@ def test_cfg4_shape_reduced(sia, oracle):
     eng.close()
 
 
+@pytest.mark.parametrize("win_s", [None, "4", "2", "1"], ids=["planned", "S4", "S2", "S1"])
+@pytest.mark.parametrize("pipeline", [False, True], ids=["leadtime1", "pipeline"])
+def test_f2_row_window_states_per_lane(sia, oracle, monkeypatch, pipeline, win_s):
+    """The F2 row-window kernel with one, two and four adjacent states per lane (wave-private row staging, 16-byte LDS reads
+    of two demand steps for S >= 2) on rows wide enough for 256-state tiles, ragged at the end: every table against the oracle."""
+    from stochastic_inventory_amd import workloads
+    if win_s:
+        monkeypatch.setenv("SDPGPU_WIN_S", win_s)
+    w = workloads.cfg4_pipeline(T=3, NX=300, A=10, D=22) if pipeline else workloads.cfg4_leadtime(T=3, NX=300, A=37, D=30)
+    eng, P, V, pol, cells = _solve_both(sia, oracle, w)
+    assert eng.stats().cells_evaluated == cells and eng.stats().kernel_used == 2
+    for period in range(1, w.T + 1):
+        _assert_tables(eng.values(period), eng.policy(period), V[period - 1], pol[period - 1], f"{w.name} S={win_s} t={period}")
+    eng.close()
+
+
 @pytest.mark.parametrize("kernel", [0, 1], ids=["auto", "gather"])
 def test_cfg4_pipeline_shape_reduced(sia, oracle, kernel):
     """configs[3] as a two-stage pipeline (x, q1, q2) at 90 x 24 x 24 states (the full shape is 250 x 200 x 200)."""

@@ -1,2 +1,1 @@
-timeout -k 10 900 python -m pytest tests/test_gpu_fuzz.py -m gpu -x -q -k "wide" > gpurun_out/fuzz_wide.log 2>&1; tail -5 gpurun_out/fuzz_wide.log
-SDP_FUZZ_N=150 timeout -k 10 900 python -m pytest tests/test_gpu_fuzz.py -m gpu -x -q -k "wide" > gpurun_out/fuzz_wide150.log 2>&1; tail -5 gpurun_out/fuzz_wide150.log
+timeout -k 10 600 python -m pytest tests/test_gpu_parity.py -m gpu -q -k "states_per_lane" > gpurun_out/f2s.log 2>&1; tail -5 gpurun_out/f2s.log
