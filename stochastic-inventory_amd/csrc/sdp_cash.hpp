@@ -1044,7 +1044,7 @@ __global__ __launch_bounds__(256) void cash_row_pair_kernel(DevParams P, const d
   double* s_d = reinterpret_cast<double*>(s_ent + (size_t)4 * D);   // d_j
   double* s_val = s_d + D;
   int* s_k = reinterpret_cast<int*>(s_val + 4 * TS);
-  int* s_uni = s_k + 4 * TS;  // [4 waves][(D + 3) / 4]
+  int* s_uni = s_k + 4 * TS;  // [4 waves][(D + 3) / 4 trips + 3 single steps]
 
   const int tid = threadIdx.x;
   const int lane = tid & 63;
@@ -1089,7 +1089,7 @@ __global__ __launch_bounds__(256) void cash_row_pair_kernel(DevParams P, const d
   nA_max = __builtin_amdgcn_readfirstlane(nA_max);
 
   RowEnt* ent = s_ent + (size_t)wave * D;
-  int* uni = s_uni + wave * ((D + 3) / 4);
+  int* uni = s_uni + wave * ((D + 3) / 4 + 3);
   const bool MAXDIR = P.maxdir != 0;
   double best[NP];
   int bestk[NP];
@@ -1153,6 +1153,8 @@ __global__ __launch_bounds__(256) void cash_row_pair_kernel(DevParams P, const d
         const unsigned long long mu = __ballot(is_uni), mf = __ballot(free_);
         if ((lane & 3) == 0)
           uni[j / 4] = (((mf >> lane) & 15ull) == 15ull) ? 2 : ((((mu >> lane) & 15ull) == 15ull) ? 1 : 0);
+        // the D mod 4 steps behind the last whole trip carry a flag each (they run one at a time)
+        if (j >= (D & ~3)) uni[(D + 3) / 4 + (j & 3)] = free_ ? 2 : (is_uni ? 1 : 0);
       }
       ent[j] = e;
     }
@@ -1264,6 +1266,27 @@ __global__ __launch_bounds__(256) void cash_row_pair_kernel(DevParams P, const d
     for (; j < D; ++j) {
       const RowEnt e = ent[j];
       const double2 pp = s_p[j];
+      if constexpr (!LAST) {
+        // a uniform-key step on its own (D is not a multiple of four: D = 25 in CashConstraint.main): the pair gather at the
+        // shifted key instead of the quantiser and one gather per point
+        const int f = __builtin_amdgcn_readfirstlane(uni[(D + 3) / 4 + (j & 3)]);
+        if (f != 0) {
+#pragma unroll
+          for (int t = 0; t < S; ++t) {
+            const int ka = my_key[t] + e.dkey;
+            const uint32_t off = f == 2 ? (uint32_t)(e.rowoff8 + my_key8[t] + (e.dkey << 3))
+                                        : (uint32_t)(e.rowoff8 + (med3_i32(ka, key_lo_v, key_hi1_v) << 3));
+            const dpair_u vv = *reinterpret_cast<const dpair_u*>(vbase + off);
+            const double v0 = (f != 2 && ka > k_hi_next - 1) ? vv.y : vv.x;
+            const double v1 = (f != 2 && ka < k_lo_next) ? vv.x : vv.y;
+            acc[2 * t] += pp.x * increment(e, 2 * t);
+            acc[2 * t] += pp.y * v0;
+            acc[2 * t + 1] += pp.x * increment(e, 2 * t + 1);
+            acc[2 * t + 1] += pp.y * v1;
+          }
+          continue;
+        }
+      }
 #pragma unroll
       for (int w = 0; w < NP; ++w) {
         const double inc = increment(e, w);

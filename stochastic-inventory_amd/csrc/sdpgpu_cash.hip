@@ -290,7 +290,7 @@ hipError_t launch_cash_row(sdpgpu_handle* h, const DevParams& P, int period, con
   }
   if (!grid_ok(blocks)) return hipErrorInvalidValue;
   dim3 grid((unsigned)blocks);
-  const size_t smem = (size_t)p.nD * 152 + (size_t)4 * tile_pts * (sizeof(double) + sizeof(int)) + 4 * (((size_t)p.nD + 3) / 4) * sizeof(int);
+  const size_t smem = (size_t)p.nD * 152 + (size_t)4 * tile_pts * (sizeof(double) + sizeof(int)) + 4 * (((size_t)p.nD + 3) / 4 + 3) * sizeof(int);
   // LEAN: `- holdCosts - overheadCost` subtract +0.0 in every cell (holdingCost and the period's overhead are +0.0)
   const bool lean = P.family == sdp::FAM_CASH && P.cash_formula != 1 && P.pi == 0.0 && h->d.holding_cost == 0.0 &&
                     !std::signbit(h->d.holding_cost) && P.overhead == 0.0 && !std::signbit(P.overhead);
