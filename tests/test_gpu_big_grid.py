@@ -77,3 +77,21 @@ def test_cfg3_full_tables_two_periods():
         ov1, oa1, c1 = P.period(1, v2, nthreads=threads)
         assert np.array_equal(eng.values(1), ov1) and np.array_equal(eng.policy(1), oa1)
         assert eng.stats().cells_evaluated == c1 + c2
+
+
+def test_cfg4_full_tables_three_periods():
+    """configs[3] in the reference's (period, x, preQ) shape at its full width (1000 x 200 states, 200 actions, 100 demands),
+    three periods: EVERY state of every period against the oracle (1.2e10 cells) -- the row-window kernel with four states
+    per lane, wave-private row staging and 16-byte LDS reads, as bench.py's cfg4 entry runs it."""
+    import numpy as np
+    import stochastic_inventory_amd as sia
+    from oracle import sdpref
+    from stochastic_inventory_amd import workloads
+    w = workloads.cfg4_leadtime(T=3)
+    threads = min(os.cpu_count() or 1, 16)
+    with sia.SdpEngine(w.desc(), w.pmf, w.overhead()) as eng:
+        eng.solve()
+        V, pol, cells = sdpref.Problem(w.desc(), w.pmf, w.overhead()).solve(nthreads=threads)
+        assert eng.stats().cells_evaluated == cells and eng.stats().kernel_used == 2
+        for period in range(1, 4):
+            assert np.array_equal(eng.values(period), V[period - 1]) and np.array_equal(eng.policy(period), pol[period - 1]), period
