@@ -226,6 +226,33 @@ def test_two_states_per_lane_kernel_on_every_case(sia, staffref, monkeypatch):
                 assert np.array_equal(eng.values(c.T)[lo:hi], V[c.T - 1][lo:hi]) and np.array_equal(eng.policy(c.T), pol[c.T - 1][lo:hi])
 
 
+@pytest.mark.parametrize("win", ["4", "2"], ids=["S4", "S2"])
+def test_window_kernel_on_every_case(sia, staffref, monkeypatch, win):
+    """staff_window_kernel (S adjacent states per lane, one probability per LEVEL from an LDS-staged piece of the table row,
+    immediate costs handed down the diagonal) is chosen by itself on staff ranges of 1024 numbers and more; forced here on
+    every named case and on random ones -- the fold at the table's last row, clamped and unclamped staff ranges, penalties,
+    truncated rows, tiles and action blocks with ragged ends -- and on slabs with odd lengths."""
+    monkeypatch.setenv("SDPGPU_STAFF_PAIR", "1")
+    monkeypatch.setenv("SDPGPU_STAFF_WIN", win)
+    cases = [m() for m in staff_cases.ALL] + [_random_case(s) for s in range(200, 260)]
+    for c in cases:
+        V, pol, cells = c.oracle_problem(staffref).solve()
+        with _engine(sia, c) as eng:
+            eng.solve(sync=True)
+            assert eng.stats().cells_evaluated == cells, c.name
+            for period in range(1, c.T + 1):
+                assert np.array_equal(eng.values(period), V[period - 1]), (c.name, period)
+                assert np.array_equal(eng.policy(period), pol[period - 1]), (c.name, period)
+    c = staff_cases.staff_wide_actions()
+    V, pol, _ = c.oracle_problem(staffref).solve()
+    for world in (2, 3):
+        for rank in range(world):
+            with _engine(sia, c, rank, world) as eng:
+                eng.run_period(c.T)
+                _, lo, hi = eng.slab(c.T)
+                assert np.array_equal(eng.values(c.T)[lo:hi], V[c.T - 1][lo:hi]) and np.array_equal(eng.policy(c.T), pol[c.T - 1][lo:hi])
+
+
 def test_ping_pong_tables(sia, staffref):
     """store_all_values = 0: two value rows reused period after period; V_1 (and the policy of every period) must not
     care."""
