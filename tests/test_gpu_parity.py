@@ -177,6 +177,24 @@ def test_f2_row_window_states_per_lane(sia, oracle, monkeypatch, pipeline, win_s
     eng.close()
 
 
+@pytest.mark.parametrize("env", [{"SDPGPU_WIN_R": "8", "SDPGPU_WIN_S": "2"}, {"SDPGPU_WIN_NCH": "1"},
+                                 {"SDPGPU_WIN_NCH": "2", "SDPGPU_WIN_S": "4"}, {"SDPGPU_WIN_R": "5", "SDPGPU_WIN_S": "4"}],
+                         ids=lambda e: ",".join(f"{k[11:]}={v}" for k, v in e.items()))
+def test_f2_row_window_block_plans(sia, oracle, monkeypatch, env):
+    """The F2 row-window kernel's other plans: eight actions per lane with 120 demand points (the LDS budget then lets only
+    three of a workgroup's four waves take action blocks), one or two chunks per tile (every wave walks several blocks and
+    re-stages its rows between them), five actions per lane."""
+    from stochastic_inventory_amd import workloads
+    for k, v in env.items():
+        monkeypatch.setenv(k, v)
+    w = workloads.cfg4_leadtime(T=2, NX=140, A=43, D=120)
+    eng, P, V, pol, cells = _solve_both(sia, oracle, w)
+    assert eng.stats().cells_evaluated == cells and eng.stats().kernel_used == 2
+    for period in range(1, w.T + 1):
+        _assert_tables(eng.values(period), eng.policy(period), V[period - 1], pol[period - 1], f"{w.name} {env} t={period}")
+    eng.close()
+
+
 @pytest.mark.parametrize("kernel", [0, 1], ids=["auto", "gather"])
 def test_cfg4_pipeline_shape_reduced(sia, oracle, kernel):
     """configs[3] as a two-stage pipeline (x, q1, q2) at 90 x 24 x 24 states (the full shape is 250 x 200 x 200)."""
