@@ -734,6 +734,12 @@ struct RowTiling {
   int32_t n_rows;  // inventory(/preQ) rows launched
   int32_t tps;     // tiles per band; 0 = plain row-major numbering (short rows)
   int32_t nsub;    // bands per XCD
+  // Row order inside a band (nullptr: as numbered).  F5's state is (x, preQ) but its cells read V_{t+1} through the level
+  // y = x + preQ only (SingleProductLeadtime.java:82-119): rows with equal y gather the very same entries.  Walked in order of y
+  // they are in flight together and find each other's lines in L2; in (preQ, x) order the 31 rows of a level are 61 rows apart
+  // and every gather went to the fabric (rocprofv3 on SingleProductLeadtime's size: 59 % L2 misses, 547 GB per launch = 5.7 TB/s,
+  // which was the kernel's time).  Placement only.
+  const int32_t* perm;
 };
 
 // UNI: uniform-key trips are compiled in (F3 without deposit rate, penalty and integer division -- CashConstraint.main,
@@ -782,7 +788,7 @@ __global__ __launch_bounds__(256) void cash_row_kernel(DevParams P, const double
   }
   __syncthreads();
 
-  const int64_t row = row0 + row_i;  // (iq * nx + ix)
+  const int64_t row = row0 + (G.perm ? G.perm[row_i] : row_i);  // (iq * nx + ix)
   const int ic0 = tile * 64;
   const int nc = (int)P.cur.nc;
   const int ic = ic0 + lane;
@@ -1067,7 +1073,7 @@ __global__ __launch_bounds__(256) void cash_row_pair_kernel(DevParams P, const d
   }
   __syncthreads();
 
-  const int64_t row = row0 + row_i;
+  const int64_t row = row0 + (G.perm ? G.perm[row_i] : row_i);
   const int ic0 = tile * TS;
   const int nc = (int)P.cur.nc;
   StateT s[NP];

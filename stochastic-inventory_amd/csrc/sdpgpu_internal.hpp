@@ -105,6 +105,9 @@ struct sdpgpu_handle {
   int n_pending = 0;
   sdp::FinalizeJob* d_jobs = nullptr;
   std::vector<unsigned char> jobs_host;  // upload source of d_jobs: T FinalizeJobs at a fixed address (flush_pending)
+  int32_t* d_rowperm = nullptr;  // cash row kernel, F5: rows of the launch ordered by level x + preQ (RowTiling::perm)
+  std::vector<int32_t> rowperm_host;
+  int64_t rowperm_key[4] = {-1, -1, -1, -1};
   void* d_diag = nullptr;  // cash_diag_kernel: the DiagStep table of the period being run, and its padded p * gamma row
   size_t diag_bytes = 0;
   bool fuse_combine = true;
