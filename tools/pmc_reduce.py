@@ -19,7 +19,13 @@ from kernel_sha import kernel_source_sha  # noqa: E402  (same digest as bench.py
 
 
 def short(name):
+    if name.startswith("(anonymous namespace)::"):  # the reachable-set engine's kernels (sdpgpu_sparse.hip)
+        name = "sparse::" + name[len("(anonymous namespace)::"):]
     return name.split("(")[0].replace("void ", "").strip()
+
+
+def ours(k):
+    return "sdp" in k or k.startswith("sparse::")
 
 
 def main():
@@ -34,14 +40,14 @@ def main():
     for f in glob.glob(os.path.join(out, "pmc*", "**", "*counter_collection.csv"), recursive=True):
         for r in csv.DictReader(open(f)):
             k = short(r["Kernel_Name"])
-            if "sdp" not in k:
+            if not ours(k):
                 continue
             counters[k][r["Counter_Name"]].append(float(r["Counter_Value"]))
     stats = {}
     for f in glob.glob(os.path.join(out, "stats", "**", "*kernel_stats.csv"), recursive=True):
         for r in csv.DictReader(open(f)):
             k = short(r["Name"])
-            if "sdp" in k:
+            if ours(k):
                 stats[k] = {"calls": int(r["Calls"]), "avg_us": float(r["AverageNs"]) / 1e3, "total_ms": float(r["TotalDurationNs"]) / 1e6,
                             "pct": float(r["Percentage"])}
     kernels = {}
