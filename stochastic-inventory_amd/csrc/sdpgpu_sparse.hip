@@ -488,10 +488,18 @@ __global__ __launch_bounds__(256) void backward_kernel(MLParams P, const Tuple* 
     const double before = st.cash - oc - P.overhead;
     const double bi = before - ml_interest(P, before);
     double acc = 0.0;  // thisActionsValue, CashRecursionMultiLead.java:72-80
-    for (int j = 0; j < P.nd; ++j) {
-      const double p = s_p[j];
-      acc += p * cash_increment(st, bi, s_t[j]);
-      if (!P.is_last) acc += p * P.discount * v_next[uid[((int64_t)s * NA + a) * P.nd + j]];
+    // (ids are non-negative 32-bit ranks: zero-extended byte offsets from the table's base instead of sign-extended
+    // 64-bit index arithmetic per cell)
+    const int* urow = uid + ((int64_t)s * NA + a) * P.nd;
+    const char* vb = reinterpret_cast<const char*>(v_next);
+    if (P.is_last) {
+      for (int j = 0; j < P.nd; ++j) acc += s_p[j] * cash_increment(st, bi, s_t[j]);
+    } else {
+      for (int j = 0; j < P.nd; ++j) {
+        const double p = s_p[j];
+        acc += p * cash_increment(st, bi, s_t[j]);
+        acc += p * P.discount * *reinterpret_cast<const double*>(vb + ((uint64_t)(uint32_t)urow[j] << 3));
+      }
     }
     s_q[a] = acc;
   }
