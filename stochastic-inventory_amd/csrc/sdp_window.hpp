@@ -701,9 +701,12 @@ __global__ __launch_bounds__(256) void separable_f1_kernel(SepParams P, const do
 //     Q(x, q1[, q2], a) = c(a) + L(y) + W_{a[,q2]}(y),   L(y) = sum_j p_j M(y - d_j),
 //     W_p(y) = sum_j p_j V_{t+1}[plane p][clamp(y - d_j)],
 // so V_t and the arg-min depend on (y[, q2]) only: a period costs O(A * NY * D [* nq]) for the table
-// G[q2][y] = L(y) + min_a (c(a) + W(y)) instead of O(S * A * D), plus one 12-byte write per state.
-// Same parity statement as the F1 mode: the sum is reassociated, so values agree with the brute-force path and the
-// oracle to rounding (1e-9 relative, tests/test_gpu_separable.py) and the arg-min may differ on near-ties.
+// G[q2][y] = min_a Q(y[, q2], a) instead of O(S * A * D), plus one 12-byte write per state.
+// Unlike the F1 mode this one reassociates nothing: every state of a level evaluates the very same cells (the lambdas read
+// x and preQ only through their sum), so the table kernel forms Q(y, a) with the reference's operations in the reference's
+// order and the expansion copies it -- values and arg-min BIT-IDENTICAL to the brute-force kernels and the oracle
+// (tests/test_gpu_separable.py).  What the mode changes is the number of cells executed, not any result; it stays opt-in
+// because the metric counts executed (state, action, demand) cells.
 // Kernel 1: one workgroup = 64 values of y (lanes) x 4 action slots of one q2; kernel 2 expands G over the slab.
 // ---------------------------------------------------------------------------------------------
 struct SepF2Params {
@@ -736,22 +739,32 @@ __global__ __launch_bounds__(256) void separable_f2_table_kernel(SepF2Params P, 
   int bestk = 0;
   for (int k = as; k < P.n_actions; k += 4) {
     const double a = (double)k * P.step;
-    double w = 0.0;
-    if constexpr (FUTURE) {
-      const double* plane = v_next + (int64_t)(P.lead2 ? k * P.next_nq1 + iq2 : k) * P.next_nx;
+    // Every state (x, preQ) of one level y = x + preQ evaluates the SAME cells -- the reference's lambdas read the two only
+    // through their sum (Leadtime.java:61-81) -- so Q(y, a) formed here with the reference's operations in the reference's
+    // order (imm = fv + hold + pen; acc += p imm; acc += p V, demand ascending) is bit for bit the Q(x, preQ, a) the
+    // brute-force kernels form for each of them: the table is exact, not a reassociation.
+    const double fv = (a > 0 ? P.K : 0.0) + P.v * a;
+    double q = 0.0;
+    {
+      const double* plane = FUTURE ? v_next + (int64_t)(P.lead2 ? k * P.next_nq1 + iq2 : k) * P.next_nx : nullptr;
       for (int j = 0; j < P.n_demand; ++j) {
-        double nx = y - pmf_d[j];
-        if (P.clamp_inventory) {
-          nx = nx > P.max_inventory ? P.max_inventory : nx;
-          nx = nx < P.min_inventory ? P.min_inventory : nx;
+        const double lev = y - pmf_d[j];
+        const double imm = fv + P.h * jmax(lev, 0.0) + P.pi * jmax(-lev, 0.0);
+        const double p = pmf_p[j];
+        q += p * imm;
+        if constexpr (FUTURE) {
+          double nx = lev;
+          if (P.clamp_inventory) {
+            nx = nx > P.max_inventory ? P.max_inventory : nx;
+            nx = nx < P.min_inventory ? P.min_inventory : nx;
+          }
+          int idx = (int)((nx - P.next_x_lo) * P.inv_step);
+          idx = idx > P.next_last ? P.next_last : idx;  // (levels only padded lanes reach)
+          idx = idx < 0 ? 0 : idx;
+          q += p * plane[idx];
         }
-        int idx = (int)((nx - P.next_x_lo) * P.inv_step);
-        idx = idx > P.next_last ? P.next_last : idx;  // (levels only padded lanes reach)
-        idx = idx < 0 ? 0 : idx;
-        w += pmf_p[j] * plane[idx];
       }
     }
-    const double q = ((a > 0 ? P.K : 0.0) + P.v * a) + w;
     if (q < best) {  // LeadtimeRecursion is MIN only (LeadtimeRecursion.java:52,66)
       best = q;
       bestk = k;
@@ -772,12 +785,7 @@ __global__ __launch_bounds__(256) void separable_f2_table_kernel(SepF2Params P, 
         bk = ok;
       }
     }
-    double l = 0.0;  // L(y): expected holding / penalty cost
-    for (int j = 0; j < P.n_demand; ++j) {
-      const double lev = y - pmf_d[j];
-      l += pmf_p[j] * (P.h * jmax(lev, 0.0) + P.pi * jmax(-lev, 0.0));
-    }
-    g_val[(int64_t)iq2 * P.ny + e] = l + bv;
+    g_val[(int64_t)iq2 * P.ny + e] = bv;
     g_idx[(int64_t)iq2 * P.ny + e] = bk;
   }
 }
