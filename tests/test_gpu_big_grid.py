@@ -95,3 +95,24 @@ def test_cfg4_full_tables_three_periods():
         assert eng.stats().cells_evaluated == cells and eng.stats().kernel_used == 2
         for period in range(1, 4):
             assert np.array_equal(eng.values(period), V[period - 1]) and np.array_equal(eng.policy(period), pol[period - 1]), period
+
+
+def test_cfg3t_full_tables_two_periods():
+    """configs[2]'s family at the size and cash quantum of the reference's own CashConstraint.main (501 x 20001 states, cash
+    in tenths, 101 actions, 25 demands): EVERY state of two periods against the oracle -- the cash row pair kernel (two points
+    per lane, two tiles per wave, uniform-key trips, XCD cash bands) as bench.py's cfg3t entry runs it; 5e10 cells."""
+    import numpy as np
+    import stochastic_inventory_amd as sia
+    from oracle import sdpref
+    from stochastic_inventory_amd import workloads
+    w = workloads.cfg3_tenths(T=2)
+    threads = min(os.cpu_count() or 1, 16)
+    with sia.SdpEngine(w.desc(), w.pmf, w.overhead()) as eng:
+        eng.solve()
+        P = sdpref.Problem(w.desc(), w.pmf, w.overhead())
+        v2, p2 = eng.values(2), eng.policy(2)
+        ov2, oa2, c2 = P.period(2, None, nthreads=threads)
+        assert np.array_equal(v2, ov2) and np.array_equal(p2, oa2)
+        ov1, oa1, c1 = P.period(1, v2, nthreads=threads)
+        assert np.array_equal(eng.values(1), ov1) and np.array_equal(eng.policy(1), oa1)
+        assert eng.stats().cells_evaluated == c1 + c2 and eng.stats().kernel_used == 2
