@@ -1,0 +1,45 @@
+"""bench.py's roofline block without a GPU: the binding unit is the one closest to its peak, every fraction is a fraction,
+and a figure outside (0, 1] is withheld with its reason instead of printed (a `frac` of 6.75)."""
+import os
+import sys
+import types
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import bench  # noqa: E402
+
+
+def _stats(fp64_ops=0.0, lds=0.0, l1=0.0, r=0, s=0):
+    return types.SimpleNamespace(fp64_ops_executed=fp64_ops, lds_bytes=lds, l1_bytes=l1, window_r=r, window_s=s)
+
+
+def _workload(name):
+    return types.SimpleNamespace(name=name)
+
+
+def test_fp64_issue_binds_the_window_kernel():
+    cells = 6e11
+    st = _stats(fp64_ops=cells * 3.448, lds=cells * 1.0, r=4, s=4)
+    rf = bench.roofline_block(_workload("no_profile_for_this_name"), st, 6, cells, 6e6, 55.9, [9.3] * 6)
+    assert rf["bound"] == "fp64-valu" and abs(rf["frac"] - cells * 3.448 / 55.9e-3 / bench.VALU_PEAK_LANE_OPS) < 1e-12
+    assert 0.9 < rf["frac"] < 1.0 and rf["units"]["lds"]["frac"] < rf["frac"]
+    assert rf["hbm"] is None and rf["traffic"] is None  # no counter summary for that name
+    assert rf["algorithmic"]["frac_of_hbm_peak"] > 1.0  # the byte MODEL may exceed the HBM peak; it is labelled as such
+
+
+def test_lds_binds_the_diagonal_cash_kernel():
+    cells = 2.6e11
+    st = _stats(fp64_ops=cells * 3.0, lds=cells * 9.5, l1=cells * 1.5)
+    rf = bench.roofline_block(_workload("no_profile_for_this_name"), st, 6, cells, 6e6, 38.9, [6.5] * 6)
+    assert rf["bound"] == "lds" and rf["unit"] == "TB/s" and abs(rf["peak"] - 78.6432) < 1e-9
+    assert set(rf["units"]) == {"lds", "vector-l1", "fp64-valu"}
+    assert all(0.0 < u["frac"] <= rf["frac"] for u in rf["units"].values())
+
+
+def test_a_fraction_above_one_is_withheld(capsys):
+    cells = 1e10
+    st = _stats(fp64_ops=cells * 50.0)  # an op model that cannot be true at this speed
+    rf = bench.roofline_block(_workload("no_profile_for_this_name"), st, 2, cells, 1e4, 0.01, [0.005] * 2)
+    assert rf["frac"] is None and rf["achieved"] is None and "withheld" in rf["error"]
+    assert "withheld" in capsys.readouterr().err
+    assert rf["avg_launch_ms"] == 0.005 and len(rf["per_launch_ms_events"]) == 2  # the measured times stay
