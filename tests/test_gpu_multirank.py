@@ -16,24 +16,22 @@ W2 = ["--workload", "cfg2", "--weak"]
 W5 = ["--workload", "cfg5", "--weak", "--states", "100000"]
 
 
-@pytest.mark.parametrize("extra", [W2 + ["--periods", "6"], W5 + ["--periods", "3"],
-                                   W2 + ["--periods", "6", "--split"],
-                                   W5 + ["--periods", "3", "--split"],
-                                   W2 + ["--periods", "6", "CALIBRATE"],
-                                   W2 + ["--periods", "7", "--schedule", "blocked3"],
-                                   W5 + ["--periods", "4", "--schedule", "blocked2"],
-                                   ["--periods", "2"],
-                                   ["--workload", "cfg2", "--periods", "5"],
-                                   ["--workload", "cfg3", "--periods", "2"],
-                                   ["--workload", "cfg3t", "--periods", "2"],
-                                   ["--workload", "cfg4", "--periods", "3"],
-                                   ["--workload", "cfg4p", "--periods", "2"],
-                                   ["--workload", "cfg5", "--states", "3000000", "--periods", "2"]],
-                         ids=["cfg2_small_slabs_key_rows", "f1_large_slabs", "cfg2_interior_boundary_split",
-                              "f1_large_interior_boundary_split", "cfg2_schedule_calibration",
-                              "cfg2_three_periods_per_exchange", "f1_large_two_periods_per_exchange",
-                              "strong_target_grid", "strong_cfg2", "strong_cfg3", "strong_cfg3_tenths", "strong_cfg4",
-                              "strong_cfg4_pipeline", "strong_cfg5_reduced_width"])
+# (the weak-scaling / K-period schedules of round 1 keep one case each: plain, interior / boundary split, calibration, blocked;
+# SDP_MULTIRANK_ALL=1 runs their large-slab twins too -- every case is a two-process torch.distributed.run of bench.py,
+# ~4 s of start-up each, and the GPU test run should stay within minutes)
+_WEAK = [(W2 + ["--periods", "6"], "cfg2_small_slabs_key_rows"), (W2 + ["--periods", "6", "--split"], "cfg2_interior_boundary_split"),
+         (W2 + ["--periods", "6", "CALIBRATE"], "cfg2_schedule_calibration"),
+         (W5 + ["--periods", "4", "--schedule", "blocked2"], "f1_large_two_periods_per_exchange")]
+if os.environ.get("SDP_MULTIRANK_ALL"):
+    _WEAK += [(W5 + ["--periods", "3"], "f1_large_slabs"), (W5 + ["--periods", "3", "--split"], "f1_large_interior_boundary_split"),
+              (W2 + ["--periods", "7", "--schedule", "blocked3"], "cfg2_three_periods_per_exchange")]
+_STRONG = [(["--periods", "2"], "strong_target_grid"), (["--workload", "cfg2", "--periods", "5"], "strong_cfg2"),
+           (["--workload", "cfg3", "--periods", "2"], "strong_cfg3"), (["--workload", "cfg3t", "--periods", "2"], "strong_cfg3_tenths"),
+           (["--workload", "cfg4", "--periods", "3"], "strong_cfg4"), (["--workload", "cfg4p", "--periods", "2"], "strong_cfg4_pipeline"),
+           (["--workload", "cfg5", "--states", "3000000", "--periods", "2"], "strong_cfg5_reduced_width")]
+
+
+@pytest.mark.parametrize("extra", [e for e, _ in _WEAK + _STRONG], ids=[i for _, i in _WEAK + _STRONG])
 def test_two_ranks_match_single_rank(extra):
     env = dict(os.environ)
     if "CALIBRATE" in extra:  # the N > 1 schedule calibration bench.py runs under RCCL, rehearsed over gloo
