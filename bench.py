@@ -386,6 +386,8 @@ def run_single(sia, torch, dev, name, w, steps, warmup, kernel, gate_cells, no_g
 
 def main():
     args = parse_args()
+    # multi-process GPU work on this image needs dmabuf IPC (RCCL's buffer exchange between the ranks' processes)
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
     import torch
     import torch.distributed as dist
 
@@ -412,6 +414,7 @@ def main():
         dist.init_process_group("gloo", rank=0, world_size=1)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("GLOO_SOCKET_IFNAME", "lo")  # one node: do not depend on the hostname resolving
         # native exchange: the data path is RCCL inside libsdpgpu.so; the process group carries the communicator id,
         # the barriers and the timing reductions, for which gloo is enough
         dist.init_process_group("nccl", device_id=dev) if args.exchange == "torch" else dist.init_process_group("gloo")
