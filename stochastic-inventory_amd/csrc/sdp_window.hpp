@@ -50,6 +50,11 @@ struct WinParams {
   int64_t pol_lo, pol_hi; // states whose action index may be stored (all of them when the rows are chunk rows)
 };
 
+// LDS of one wave of window_f1_kernel: its window (span entries of 16 B) and its copy of the probabilities p_0 .. p_D
+// (the step after the last is requested but not used) -- an even count plus a slot for the staging loop's overshoot.
+__host__ __device__ inline int win_p_slots(int n_demand) { return ((n_demand + 3) & ~1) + 2; }
+__host__ __device__ inline size_t win_wave_lds(int span, int n_demand) { return (size_t)span * 16 + (size_t)win_p_slots(n_demand) * 8; }
+
 // Order-preserving map double -> uint64 (and back): lets a 64-bit atomic min/max reduce fp64 values
 // exactly.  Used for V_t when several tasks share a state tile.
 __device__ __forceinline__ unsigned long long f64_key(double v) {
@@ -130,7 +135,9 @@ __global__ __launch_bounds__(256) void window_f1_kernel(WinParams W, const doubl
   tile = W.tile_first + tile + (tile >= W.tile_gap_at ? W.tile_gap : 0);
   const int chunk_actions = W.chunk_blocks * R;
   const int span = TS + chunk_actions + W.d_pad + S;  // entries [0, span): slot 0 is a spare
-  double2* s_win = reinterpret_cast<double2*>(smem) + (size_t)wave * span;
+  char* my_lds = smem + (size_t)wave * win_wave_lds(span, W.n_demand);
+  double2* s_win = reinterpret_cast<double2*>(my_lds);
+  double* s_p = reinterpret_cast<double*>(my_lds + (size_t)span * 16);
   const int64_t i0 = lo + (int64_t)tile * TS;
   const int kA = chunk * chunk_actions;
 #ifdef SDP_STAMPS  // diagnostic build only (tools/stamp_window.py): per-wave timeline, never in the product
@@ -139,7 +146,30 @@ __global__ __launch_bounds__(256) void window_f1_kernel(WinParams W, const doubl
 
   // stage this wave's window: slot q holds m = m_lo + q, m_lo = i0 + kA - d_pad
   const int m_lo = (int)i0 + kA - W.d_pad;
-  for (int q = lane; q < span; q += 64) s_win[q] = window_entry<FUTURE, KEYED_IN>(W, v_next, k_next, m_lo + q);
+  // (four entries per pass, their loads in flight together: one round trip to L2 per 256 slots instead of four -- on
+  // configs[1] the whole window is one pass, and nothing else runs on the SIMD while its two waves stage.  Slots past
+  // the span are computed from clamped indices and land in the spare slot 0, which no cell reads: stores without a
+  // guard, so that the compiler does not sink a load under its guard and serialise it again.)
+  for (int q0 = lane; q0 < span; q0 += 256) {
+    double2 e[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) e[u] = window_entry<FUTURE, KEYED_IN>(W, v_next, k_next, m_lo + q0 + 64 * u);
+#pragma unroll
+    for (int u = 0; u < 4; ++u) s_win[q0 + 64 * u < span ? q0 + 64 * u : 0] = e[u];
+  }
+  // The probabilities go through LDS as well (one broadcast read per demand step): as scalar loads they shared the
+  // wave's lgkm counter with the window reads, and a scalar load in flight turns every wait for an LDS read into a
+  // wait for everything -- the slide below could not stay in flight across a step.
+  {
+    const int p_cnt = win_p_slots(W.n_demand) - 2;  // (the array ends in kPmfPad = 16 zeros: D + 3 stays inside)
+    for (int q0 = lane; q0 < p_cnt; q0 += 256) {
+      double pv[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) pv[u] = pmf_p[q0 + 64 * u < p_cnt ? q0 + 64 * u : p_cnt - 1];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) s_p[q0 + 64 * u < p_cnt ? q0 + 64 * u : p_cnt] = pv[u];
+    }
+  }
   __builtin_amdgcn_wave_barrier();
 #ifdef SDP_STAMPS
   unsigned long long st_t1 = __builtin_amdgcn_s_memrealtime();
@@ -176,6 +206,7 @@ __global__ __launch_bounds__(256) void window_f1_kernel(WinParams W, const doubl
         immc[s][r] = c0[r] + win[r + s].x;  // (s = 0 unused)
       }
     }
+    double p_cur = s_p[0];  // p_j of the step at hand; every step requests the next one's
 #pragma unroll 1
     for (int jb = 0; jb < W.d_main; jb += NW) {
       if (W.prio_fair) {
@@ -191,17 +222,36 @@ __global__ __launch_bounds__(256) void window_f1_kernel(WinParams W, const doubl
         else __builtin_amdgcn_s_setprio(3);
       }
       const double2* nxt = s_win + (base - jb - NW);  // slots base-jb-NW ... base-jb-1
+      const double* pq = s_p + jb + 1;
 #pragma unroll
       for (int t = 0; t < NW; ++t) {
-        const double p = pmf_p[jb + t];  // wave-uniform -> scalar load
+        const double p = p_cur;
+        // The cell (s = S-1, r = R-1) goes FIRST: it alone reads the window's top entry, so the slide -- the entry for
+        // (s = 0, r = 0, j + 1) replaces that one -- is requested at the start of the step and has the rest of the step
+        // (60 fp64 instructions) to arrive.  (Left to the scheduler the read sat five instructions before its use; a
+        // wave alone on its SIMD then ran at 0.76 of the issue rate.)  Every accumulator still sees its own two adds
+        // per step in the reference's order.
+        if constexpr (S > 1) {
+          acc[S - 1][R - 1] += p * immc[S - 1][R - 1];
+          if constexpr (FUTURE) acc[S - 1][R - 1] += p * win[(R + S - 2 - t + NW) % NW].y;
+        } else {
+          const double2 wt = win[(R - 1 - t + NW) % NW];
+          acc[0][R - 1] += p * (c0[R - 1] + wt.x);
+          if constexpr (FUTURE) acc[0][R - 1] += p * wt.y;
+        }
+        win[(NW - 1 - t) % NW] = nxt[NW - 1 - t];
+        p_cur = pq[t];
+        __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
         for (int r = 0; r < R; ++r) {
+          if (S == 1 && r == R - 1) continue;
           const double2 w0 = win[(r - t + NW) % NW];
           const double imm0 = c0[r] + w0.x;
           acc[0][r] += p * imm0;
           if constexpr (FUTURE) acc[0][r] += p * w0.y;
 #pragma unroll
           for (int s = 1; s < S; ++s) {
+            if (r == R - 1 && s == S - 1) continue;
             acc[s][r] += p * immc[s][r];
             // (cells with the same r + s read the same entry: the product p * V is formed once for them)
             if constexpr (FUTURE) acc[s][r] += p * win[(r + s - t + NW) % NW].y;
@@ -210,8 +260,6 @@ __global__ __launch_bounds__(256) void window_f1_kernel(WinParams W, const doubl
           for (int s = S - 1; s > 1; --s) immc[s][r] = immc[s - 1][r];
           if constexpr (S > 1) immc[1][r] = imm0;
         }
-        // slide: the entry for (s = 0, r = 0, j + 1) replaces the one (s = S-1, r = R-1, j) just used
-        win[(NW - 1 - t) % NW] = nxt[NW - 1 - t];
       }
     }
     // the last D mod NW demand steps: the same unrolled body under wave-uniform guards (the register
@@ -223,7 +271,8 @@ __global__ __launch_bounds__(256) void window_f1_kernel(WinParams W, const doubl
 #pragma unroll
       for (int t = 0; t < NW - 1; ++t) {
         if (t < rem) {
-          const double p = pmf_p[jb + t];
+          const double p = p_cur;
+          p_cur = s_p[jb + t + 1];
 #pragma unroll
           for (int r = 0; r < R; ++r) {
             const double2 w0 = win[(r - t + NW) % NW];
@@ -448,15 +497,24 @@ __global__ __launch_bounds__(256) SDP_F2_WAVES_ATTR void window_f2_kernel(RowPar
         k = k < W.n_actions ? k : W.n_actions - 1;  // padded actions read a valid plane, never selected
         src[r] = v_next + ((int64_t)k * W.plane_stride + row_off);
       }
-      for (int q = lane; q < span; q += 64) {
-        int idx = m_lo + q + W.idx_off;
-        idx = idx > W.next_last ? W.next_last : idx;
-        idx = idx < 0 ? 0 : idx;
-        double tmp[R];
+      // (three passes over q per trip: 3 R loads in flight, two round trips to L2 for the 358 slots of S = 4 instead of six;
+      // slots past the span land in the spare slot 0 -- stores without a guard, see window_f1_kernel)
+      for (int q0 = lane; q0 < span; q0 += 192) {
+        double tmp[3][R];
 #pragma unroll
-        for (int r = 0; r < R; ++r) tmp[r] = src[r][idx];
+        for (int u = 0; u < 3; ++u) {
+          int idx = m_lo + q0 + 64 * u + W.idx_off;
+          idx = idx > W.next_last ? W.next_last : idx;
+          idx = idx < 0 ? 0 : idx;
 #pragma unroll
-        for (int r = 0; r < R; ++r) my_rows[r * span + q] = tmp[r];
+          for (int r = 0; r < R; ++r) tmp[u][r] = src[r][idx];
+        }
+#pragma unroll
+        for (int u = 0; u < 3; ++u) {
+          const int slot = q0 + 64 * u < span ? q0 + 64 * u : 0;
+#pragma unroll
+          for (int r = 0; r < R; ++r) my_rows[r * span + slot] = tmp[u][r];
+        }
       }
       __builtin_amdgcn_wave_barrier();
       __builtin_amdgcn_s_waitcnt(0xC07F);  // lgkmcnt(0): the wave's own LDS writes have landed

@@ -59,7 +59,7 @@ WinPlan plan_window(const sdpgpu_handle* h, int period, int64_t lo, int64_t hi) 
       if ((blocks_total + bpc - 1) / bpc != nch) continue;  // same plan as a smaller nch
       if (nch > 1 && !may_chunk) continue;  // chunk rows need the deferred key/finalize scheme
       const int span = ts + bpc * r + d_pad + sl;
-      const size_t smem = (size_t)4 * span * 16;
+      const size_t smem = 4 * sdp::win_wave_lds(span, D);
       if (smem > 64 * 1024) continue;
       const int64_t tasks = n_tiles * nch;
       const int64_t q = (tasks + 1023) / 1024;  // tasks of the busiest SIMD
@@ -239,15 +239,25 @@ hipError_t launch_row_window(sdpgpu_handle* h, const DevParams& P, int period, c
   auto lds = [&](int wv) { return (size_t)span * 8 * (1 + (future ? wv * R : 0)) + (size_t)(future ? 4 - wv : 4) * TSZ * 12; };
   while (waves > 1 && lds(waves) > 60 * 1024) --waves;
   if (lds(waves) > 64 * 1024) return hipErrorInvalidValue;
-  int bpc = waves;
-  if (h->win_nch) bpc = std::max(1, (blocks_total + h->win_nch - 1) / h->win_nch);
-  W.waves_active = waves;
-  W.chunk_actions = bpc * R;
-  W.n_chunks = (blocks_total + bpc - 1) / bpc;
   // the run of row tiles that covers [lo, hi)
   auto tile_of = [&](int64_t idx) { return (int32_t)((idx / p.g.nx) * W.tiles_per_row + (idx % p.g.nx) / TSZ); };
   W.tile0 = tile_of(lo);
   W.n_tiles = tile_of(hi - 1) - W.tile0 + 1;
+  // Blocks per chunk: a whole number of blocks per wave, as many as still leave about 6.5 rounds of workgroups on the chip
+  // (5000 at three per CU).  What a workgroup pays once -- M staged behind a barrier, the read-out behind another, a
+  // chunk row of (value, action) pairs for the combine pass -- is then shared by several blocks; with ONE chunk there are no
+  // chunk rows and no combine pass at all.  Measured (`profiles/r02_f2_chunk_sweep.txt`): configs[3], 800 tiles per period:
+  // 13 / 7 / 5 / 1 chunks -> 27.3 / 26.7 / 27.2 / 33.8 ms; its pipeline shape, 40,000 tiles: 13 / 4 / 1 -> 93.8 / 89.6 / 88.6 ms.
+  int bpc = waves;
+  for (int m = 2; (m - 1) * waves < blocks_total; ++m) {
+    const int cand_bpc = std::min(m * waves, rup(blocks_total, waves));
+    if ((int64_t)W.n_tiles * ((blocks_total + cand_bpc - 1) / cand_bpc) < 5000) break;
+    bpc = cand_bpc;
+  }
+  if (h->win_nch) bpc = std::max(1, (blocks_total + h->win_nch - 1) / h->win_nch);
+  W.waves_active = waves;
+  W.chunk_actions = bpc * R;
+  W.n_chunks = (blocks_total + bpc - 1) / bpc;
   double* out_val = v_cur;
   int32_t* out_idx = pol;
   if (W.n_chunks > 1) {
@@ -419,7 +429,7 @@ hipError_t launch_window(sdpgpu_handle* h, const DevParams& P, int period, const
         pl.R = fine_r;
         pl.S = 1;
         pl.d_pad = (p.nD_win + fine_r - 1) / fine_r * fine_r;
-        pl.smem = (size_t)4 * (64 + chunk_actions + pl.d_pad + 1) * 16;
+        pl.smem = 4 * sdp::win_wave_lds(64 + chunk_actions + pl.d_pad + 1, p.nD_win);
         W.d_pad = pl.d_pad;
         W.d_main = p.nD_win / fine_r * fine_r;
         W.chunk_blocks = pl.chunk_blocks;
