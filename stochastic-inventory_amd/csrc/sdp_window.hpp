@@ -16,7 +16,8 @@
 // with separate multiplies and adds (no FMA).  Neighbouring cells repeat some of these operations on the
 // very same operands (see window_f1_kernel), and those are executed once: 3 + 1/S + (R+S-1)/(RS) operations
 // per cell instead of 5.  The register window of R + S - 1 entries slides by ONE new ds_read_b128 per demand
-// step: LDS traffic is 16 B per R*S cells.  p_j is wave-uniform and comes through the scalar cache.
+// step: LDS traffic is 16 B per R*S cells, plus 8 B for p_j (wave-uniform: one broadcast read of the wave's LDS copy
+// per step -- not a scalar load, see the staging code).
 // The kernel is bound by fp64 VALU issue (4 cycles per wave64 instruction per SIMD), not by memory.
 //
 // Small grids (configs[1] has only 79 tiles of 128 states) do not fill 1024 SIMDs with whole-action tasks,
@@ -104,7 +105,7 @@ __device__ __forceinline__ double2 window_entry(const WinParams& W, const double
 // two accumulations are per cell.  Operations per cell: (5 + 4*(S-1)) / S = 5, 4.5, 4.25 for S = 1, 2, 4,
 // every one of them an operation the reference performs, in its order.  The register window has
 // R + S - 1 entries (state s, action r reads entry r + s) and still slides by ONE ds_read_b128 per
-// demand step: LDS traffic is 16 B per R*S cells.
+// demand step: LDS traffic is 16 + 8 B per R*S cells.
 //
 // When a tile is shared by several tasks (n_chunks > 1, small grids) a task publishes its best value
 // with a 64-bit atomic min/max on the order-preserving key of V_t (exact), and stores its

@@ -335,7 +335,7 @@ hipError_t launch_window(sdpgpu_handle* h, const DevParams& P, int period, const
   const bool future = period < h->T;
   // c0 + M once per (action, m): 1/S; p * imm: 1; p * V once per window entry: (R + S - 1)/(R S); two accumulations
   p.ops_cell = future ? 3.0 + 1.0 / pl.S + (pl.R + pl.S - 1.0) / (pl.R * pl.S) : 2.0 + 1.0 / pl.S;
-  p.lds_cell = 16.0 / (pl.R * pl.S);  // one {M, V} entry per demand step and lane
+  p.lds_cell = 24.0 / (pl.R * pl.S);  // one {M, V} entry and one probability per demand step and lane
   const bool chunked = pl.n_chunks > 1;
   // a period is never re-run on top of its own pending rows, and a new sweep (period T) first
   // finalizes what the previous one left: the key rows are about to be reset
