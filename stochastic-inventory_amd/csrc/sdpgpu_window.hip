@@ -38,14 +38,18 @@ WinPlan plan_window(const sdpgpu_handle* h, int period, int64_t lo, int64_t hi) 
   struct Cand {
     int r, s, occupancy;  // occupancy: waves a SIMD can hold within the register budget
   };
-  // (84 / 62 / 54 VGPRs for S = 1, R = 8 / 5 / 4; 134 / 116 / 96 for S = 2; 130 for R = 4, S = 4)
+  // (VGPRs: 107 / 62 / 54 for S = 1, R = 8 / 5 / 4; 130 / 116 / 73 for S = 2; 125 for R = 4, S = 4; 244 for R = 4, S = 8)
   const Cand cand[] = {{8, 1, 6}, {5, 1, 8}, {4, 1, 9}, {8, 2, 3}, {4, 2, 5}, {4, 4, 3}, {8, 4, 2}, {4, 8, 2}};
   const bool may_chunk = h->fuse_combine && h->d.store_all_values;
   for (const Cand& c : cand) {
     const int r = c.r, sl = c.s, nw = r + sl - 1, ts = 64 * sl;
     if (h->win_r && r != h->win_r) continue;
     if (h->win_s && sl != h->win_s) continue;
-    if (r * sl >= 32 && !(h->win_r && h->win_s)) continue;  // the 32-cell blocks are opt-in (SDPGPU_WIN_R + SDPGPU_WIN_S): measured, see DESIGN
+    // 32-cell blocks: (4, 8) -- 3.47 operations per cell against (4, 4)'s 3.69, two waves per SIMD -- competes since the
+    // step requests its LDS reads a step ahead (two waves then sustain 0.93 of the issue rate: 53.0 against 55.5 ms on the
+    // target grid, 4 % ahead on slabs down to 125,000 states); (8, 4) measured no gain and stays opt-in (SDPGPU_WIN_R + _S)
+    const bool big_block = r * sl >= 32;
+    if (big_block && !(r == 4 && sl == 8) && !(h->win_r && h->win_s)) continue;
     const int64_t n_tiles = std::max<int64_t>(1, (nominal + ts - 1) / ts);
     const int64_t own_tiles = (hi - lo + ts - 1) / ts;
     const int d_pad = rup(D, nw);
@@ -66,7 +70,7 @@ WinPlan plan_window(const sdpgpu_handle* h, int period, int64_t lo, int64_t hi) 
       // A SIMD holds at most `occupancy` of them at a time and, with priority by progress, resident waves finish
       // together: q tasks run as groups of `occupancy` plus a remainder group, a group of w tasks at the fp64 issue
       // rate w resident waves sustain (per-wave stamps: 0.6 alone, 0.85 two, 0.91 three, 0.94 four, 0.97 eight).
-      auto eff = [](int64_t w) { return w >= 8 ? 0.97 : (w >= 4 ? 0.94 : (w >= 3 ? 0.91 : (w >= 2 ? 0.85 : 0.60))); };
+      auto eff = [big_block](int64_t w) { return w >= 8 ? 0.97 : (w >= 4 ? 0.94 : (w >= 3 ? 0.91 : (w >= 2 ? (big_block ? 0.93 : 0.85) : 0.60))); };
       const int64_t full = q / c.occupancy, rest = q % c.occupancy;
       const double task_units = full * c.occupancy / eff(c.occupancy) + (rest ? rest / eff(rest) : 0.0);
       const double staging = 400.0 + 4.0 * span;

@@ -177,6 +177,32 @@ def test_f2_row_window_states_per_lane(sia, oracle, monkeypatch, pipeline, win_s
     eng.close()
 
 
+@pytest.mark.parametrize("env", [{"SDPGPU_WIN_R": "4", "SDPGPU_WIN_S": "8"}, {"SDPGPU_WIN_R": "4", "SDPGPU_WIN_S": "8", "SDPGPU_WIN_NCH": "3"},
+                                 {"SDPGPU_WIN_R": "8", "SDPGPU_WIN_S": "4"}, {"SDPGPU_WIN_R": "4", "SDPGPU_WIN_S": "4", "SDPGPU_WIN_NCH": "1"},
+                                 {"SDPGPU_WIN_R": "5", "SDPGPU_WIN_S": "1"}, {"SDPGPU_WIN_R": "4", "SDPGPU_WIN_S": "2", "SDPGPU_WIN_NCH": "4"}],
+                         ids=lambda e: ",".join(f"{k[11:]}={v}" for k, v in e.items()))
+@pytest.mark.parametrize("shape", ["min", "max", "gapped", "unclamped"])
+def test_f1_window_register_blocks(sia, oracle, monkeypatch, shape, env):
+    """The F1 window kernel under forced plans -- eight states per lane (the plan of the large grids), eight actions by four
+    states, one task per tile, five actions per lane, several chunks per tile (key rows + deferred read-out): every table
+    against the oracle, on a grid of 1601 states (ragged against the 64- to 512-state tiles) with 38 actions (ragged against
+    every register block) and 23 demand points, under MIN and MAX, with a gapped support and with the unclamped transition."""
+    from stochastic_inventory_amd.functors import BackorderFunctor
+    from stochastic_inventory_amd.states import OptDirection
+    from stochastic_inventory_amd.workloads import Workload
+    for k, v in env.items():
+        monkeypatch.setenv(k, v)
+    f = BackorderFunctor(fixedOrderingCost=30, variOrderingCost=1.5, holdingCost=1, penaltyCost=7, minInventory=-700,
+                         maxInventory=900, maxOrderQuantity=37, iniInventory=5, clampInventory=shape != "unclamped")
+    pmf = cases.discrete_pmf(3, [1, 4, 5, 9, 16, 22], [0.1, 0.2, 0.3, 0.2, 0.15, 0.05]) if shape == "gapped" else cases._pmf([9, 12, 7], 23)
+    w = Workload(f"f1_ragged_{shape}", f, OptDirection.MAX if shape == "max" else OptDirection.MIN, pmf)
+    eng, P, V, pol, cells = _solve_both(sia, oracle, w)
+    assert eng.stats().cells_evaluated == cells
+    for period in range(1, w.T + 1):
+        _assert_tables(eng.values(period), eng.policy(period), V[period - 1], pol[period - 1], f"{w.name} {env} t={period}")
+    eng.close()
+
+
 @pytest.mark.parametrize("env", [{"SDPGPU_WIN_R": "8", "SDPGPU_WIN_S": "2"}, {"SDPGPU_WIN_NCH": "1"},
                                  {"SDPGPU_WIN_NCH": "2", "SDPGPU_WIN_S": "4"}, {"SDPGPU_WIN_R": "5", "SDPGPU_WIN_S": "4"}],
                          ids=lambda e: ",".join(f"{k[11:]}={v}" for k, v in e.items()))
