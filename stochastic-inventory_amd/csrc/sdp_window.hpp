@@ -16,7 +16,7 @@
 // with separate multiplies and adds (no FMA).  Neighbouring cells repeat some of these operations on the
 // very same operands (see window_f1_kernel), and those are executed once: 3 + 1/S + (R+S-1)/(RS) operations
 // per cell instead of 5.  The register window of R + S - 1 entries slides by ONE new ds_read_b128 per demand
-// step: LDS traffic is 16 B per R*S cells, plus 8 B for p_j (wave-uniform: one broadcast read of the wave's LDS copy
+// step: LDS traffic is 16 B per R*S cells, plus 8 B for p_j (wave-uniform: one broadcast read of the workgroup's LDS copy
 // per step -- not a scalar load, see the staging code).
 // The kernel is bound by fp64 VALU issue (4 cycles per wave64 instruction per SIMD), not by memory.
 //
@@ -51,10 +51,13 @@ struct WinParams {
   int64_t pol_lo, pol_hi; // states whose action index may be stored (all of them when the rows are chunk rows)
 };
 
-// LDS of one wave of window_f1_kernel: its window (span entries of 16 B) and its copy of the probabilities p_0 .. p_D
-// (the step after the last is requested but not used) -- an even count plus a slot for the staging loop's overshoot.
+// LDS of a workgroup of window_f1_kernel: one window per wave (span entries of 16 B) and ONE copy of the probabilities
+// p_0 .. p_D (the step after the last is requested but not used) -- an even count plus a slot for the staging loop's
+// overshoot.  Every wave writes the whole copy itself (the same values to the same slots as its neighbours) and reads it
+// after its own writes have landed: no workgroup barrier, and a one-task-per-tile plan of the 500-action, 200-demand
+// grid (R = 4, S = 4: 61.6 KB of windows) still fits the 64 KB a launch may ask for.
 __host__ __device__ inline int win_p_slots(int n_demand) { return ((n_demand + 3) & ~1) + 2; }
-__host__ __device__ inline size_t win_wave_lds(int span, int n_demand) { return (size_t)span * 16 + (size_t)win_p_slots(n_demand) * 8; }
+__host__ __device__ inline size_t win_wg_lds(int span, int n_demand) { return (size_t)4 * span * 16 + (size_t)win_p_slots(n_demand) * 8; }
 
 // Order-preserving map double -> uint64 (and back): lets a 64-bit atomic min/max reduce fp64 values
 // exactly.  Used for V_t when several tasks share a state tile.
@@ -136,9 +139,8 @@ __global__ __launch_bounds__(256) void window_f1_kernel(WinParams W, const doubl
   tile = W.tile_first + tile + (tile >= W.tile_gap_at ? W.tile_gap : 0);
   const int chunk_actions = W.chunk_blocks * R;
   const int span = TS + chunk_actions + W.d_pad + S;  // entries [0, span): slot 0 is a spare
-  char* my_lds = smem + (size_t)wave * win_wave_lds(span, W.n_demand);
-  double2* s_win = reinterpret_cast<double2*>(my_lds);
-  double* s_p = reinterpret_cast<double*>(my_lds + (size_t)span * 16);
+  double2* s_win = reinterpret_cast<double2*>(smem) + (size_t)wave * span;
+  double* s_p = reinterpret_cast<double*>(smem + (size_t)4 * span * 16);  // (shared: see win_wg_lds)
   const int64_t i0 = lo + (int64_t)tile * TS;
   const int kA = chunk * chunk_actions;
 #ifdef SDP_STAMPS  // diagnostic build only (tools/stamp_window.py): per-wave timeline, never in the product

@@ -63,7 +63,7 @@ WinPlan plan_window(const sdpgpu_handle* h, int period, int64_t lo, int64_t hi) 
       if ((blocks_total + bpc - 1) / bpc != nch) continue;  // same plan as a smaller nch
       if (nch > 1 && !may_chunk) continue;  // chunk rows need the deferred key/finalize scheme
       const int span = ts + bpc * r + d_pad + sl;
-      const size_t smem = 4 * sdp::win_wave_lds(span, D);
+      const size_t smem = sdp::win_wg_lds(span, D);
       if (smem > 64 * 1024) continue;
       const int64_t tasks = n_tiles * nch;
       const int64_t q = (tasks + 1023) / 1024;  // tasks of the busiest SIMD
@@ -433,7 +433,7 @@ hipError_t launch_window(sdpgpu_handle* h, const DevParams& P, int period, const
         pl.R = fine_r;
         pl.S = 1;
         pl.d_pad = (p.nD_win + fine_r - 1) / fine_r * fine_r;
-        pl.smem = 4 * sdp::win_wave_lds(64 + chunk_actions + pl.d_pad + 1, p.nD_win);
+        pl.smem = sdp::win_wg_lds(64 + chunk_actions + pl.d_pad + 1, p.nD_win);
         W.d_pad = pl.d_pad;
         W.d_main = p.nD_win / fine_r * fine_r;
         W.chunk_blocks = pl.chunk_blocks;
