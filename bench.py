@@ -452,7 +452,9 @@ def main():
         }
         if args.workload == "target" and not args.no_secondary and not args.weak and not args.states and not args.periods:
             sec = []
-            for name, st_, wu_ in (("cfg2", 20, 5), ("cfg3", 3, 1), ("cfg3t", 3, 1), ("cfg4", 3, 1), ("cfg4p", 2, 1)):
+            # (configs[1]: a sweep is 52 launches of 30 us -- 1.5 ms; 100 of them, so that one hiccup of the host thread that issues
+            # them does not move the entry by a fifth, as it did in one of three runs with 20)
+            for name, st_, wu_ in (("cfg2", 100, 10), ("cfg3", 3, 1), ("cfg3t", 3, 1), ("cfg4", 3, 1), ("cfg4p", 2, 1)):
                 ws = make_workload(name, 1)
                 sec.append(run_single(sia, torch, dev, name, ws, st_, wu_, 0, args.gate_cells / 3, args.no_gate))
             out["secondary"] = sec
