@@ -69,7 +69,7 @@ extern "C" {
 #pragma GCC visibility push(default) /* the library is built with -fvisibility=hidden: only this header is exported */
 #endif
 
-#define SDPGPU_ABI_VERSION 4
+#define SDPGPU_ABI_VERSION 5
 
 /* status codes */
 #define SDPGPU_OK 0
@@ -457,6 +457,24 @@ int sdpgpu_simulate(sdpgpu_handle* h, int64_t n_paths, const double* demand, con
                     double ini_cash, double ini_preq, double* out_sum, uint8_t* out_valid);
 
 int sdpgpu_stats_get(sdpgpu_handle* h, sdpgpu_stats* out);
+
+/* ABI 5: the launch plan of one period of THIS rank's slab, as the launcher would choose it now (descriptor, pmfs,
+ * world size and the SDPGPU_WIN_* overrides read at create time).  Host arithmetic only: no device is touched, so a
+ * caller (or a test without a GPU) can see what a period will cost in LDS before it runs.  Reported for the window
+ * kernels of the backorder family (F1); other kernels return kernel = SDPGPU_KERNEL_GATHER and zeros.  A plan that
+ * cannot run -- a forced register block that does not exist, a forced chunking that exceeds the 160 KiB of LDS of a
+ * compute unit, chunk rows where ping-pong tables forbid them -- returns SDPGPU_ERR_ARG with the reason in
+ * sdpgpu_last_error, which is also what sdpgpu_run_period then returns (before anything is launched). */
+typedef struct sdpgpu_plan {
+  int32_t kernel;            /* SDPGPU_KERNEL_WINDOW or SDPGPU_KERNEL_GATHER */
+  int32_t r, s;              /* register block: actions x adjacent states per lane */
+  int32_t chunks;            /* tasks per state tile (1: no chunk rows, no key atomics, no finalize pass) */
+  int32_t chunk_blocks;      /* register blocks of the action axis per task */
+  int32_t tiles, tasks;      /* state tiles of 64 s states of this slab; tiles x chunks */
+  int32_t workgroups_per_cu; /* workgroups (four tasks each) the LDS lets a compute unit hold at once */
+  int64_t lds_bytes;         /* dynamic LDS per workgroup */
+} sdpgpu_plan;
+int sdpgpu_plan_period(const sdpgpu_handle* h, int32_t period, sdpgpu_plan* out);
 
 /* ---- reachable-set engine for the two-product lead-time family -------------------------------------
  * Replaces `new CashRecursionMultiLead(...).getExpectedValue(iniState)` / getAction

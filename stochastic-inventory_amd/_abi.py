@@ -13,7 +13,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 # SDPGPU_LIB: load another build of the SAME library instead (tests/test_sanitizers.py points it at the host-ASan build)
 LIB_PATH = os.environ.get("SDPGPU_LIB") or os.path.join(_HERE, "libsdpgpu.so")
 
-SDPGPU_ABI_VERSION = 4
+SDPGPU_ABI_VERSION = 5
 
 FAMILY_BACKORDER = 1
 FAMILY_LEADTIME = 2
@@ -105,6 +105,14 @@ class SdpgpuStats(C.Structure):
         ("lds_bytes", C.c_double),
         ("l1_bytes", C.c_double),
     ]
+
+
+class SdpgpuPlan(C.Structure):
+    """struct sdpgpu_plan (include/sdpgpu.h, ABI 5)."""
+
+    _fields_ = [("kernel", C.c_int32), ("r", C.c_int32), ("s", C.c_int32), ("chunks", C.c_int32),
+                ("chunk_blocks", C.c_int32), ("tiles", C.c_int32), ("tasks", C.c_int32),
+                ("workgroups_per_cu", C.c_int32), ("lds_bytes", C.c_int64)]
 
 
 def desc_defaults() -> SdpgpuDesc:
@@ -257,6 +265,7 @@ EXPORTS = {
                                   C.POINTER(C.c_uint8)]),
     "sdpgpu_stats_get": (C.c_int, [_P, C.POINTER(SdpgpuStats)]),
     "sdpgpu_period_ms": (C.c_double, [_P, C.c_int32]),
+    "sdpgpu_plan_period": (C.c_int, [_P, C.c_int32, C.POINTER(SdpgpuPlan)]),
     "sdpgpu_multilead_solve": (C.c_int, [C.POINTER(SdpgpuMultilead), _DP, _IP, _IP, _LP, _LP, _DP]),
     "sdpgpu_multilead_last_error": (C.c_char_p, []),
     "sdpgpu_multi_set_table": (None, [C.POINTER(SdpgpuMultiTable)]),

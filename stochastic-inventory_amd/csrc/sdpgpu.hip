@@ -454,6 +454,7 @@ int run_period_impl(sdpgpu_handle* h, int period, int part, int64_t range_lo, in
   hipError_t e;
   p.ops_cell = 0;
   p.lds_cell = p.l1_cell = 0;
+  h->plan_error.clear();
   if (use_window) {
     e = launch_window(h, P, period, v_next, v_cur, pol, pd, h->d_pmf + p.pmf_win_off, ranged ? range_lo : p.lo,
                       ranged ? range_hi : p.hi, h->stream, part);
@@ -471,6 +472,10 @@ int run_period_impl(sdpgpu_handle* h, int period, int part, int64_t range_lo, in
     if (e == hipSuccess)
       e = launch_gather_grid(P, v_next, v_cur, pol, pd, pp, p.lo, p.hi, h->stream);
     p.kernel_used = SDPGPU_KERNEL_GATHER;
+  }
+  if (e != hipSuccess && !h->plan_error.empty()) {  // the planner said no before anything was launched
+    const std::string why = h->plan_error;
+    return fail(h, SDPGPU_ERR_ARG, "period %d: %s", period, why.c_str());
   }
   if (e != hipSuccess) return fail(h, SDPGPU_ERR_DEVICE, "period %d kernel launch: %s", period, hipGetErrorString(e));
   if (h->profiling) {
@@ -930,6 +935,34 @@ int sdpgpu_set_halo(sdpgpu_handle* h, int64_t halo) {
   if (halo < 0) return fail(h, SDPGPU_ERR_ARG, "set_halo: negative halo");
   if (h->d_chunk_val || h->allocated) return fail(h, SDPGPU_ERR_STATE, "set_halo must precede the first run");
   h->halo = halo;
+  return SDPGPU_OK;
+}
+
+int sdpgpu_plan_period(const sdpgpu_handle* hc, int32_t period, sdpgpu_plan* out) {
+  sdpgpu_handle* h = const_cast<sdpgpu_handle*>(hc);
+  if (!h || !out) return SDPGPU_ERR_ARG;
+  h->err.clear();
+  std::memset(out, 0, sizeof *out);
+  if (period < 1 || period > h->T) return fail(h, SDPGPU_ERR_ARG, "plan: period %d", period);
+  int rc = layout(h);
+  if (rc) return rc;
+  out->kernel = SDPGPU_KERNEL_GATHER;
+  const bool f1_window = !h->custom && h->d.family == SDPGPU_FAMILY_BACKORDER &&
+                         (h->d.kernel == SDPGPU_KERNEL_AUTO || h->d.kernel == SDPGPU_KERNEL_WINDOW) && window_eligible(h, period);
+  if (!f1_window) return SDPGPU_OK;
+  const PeriodInfo& p = h->per[period - 1];
+  std::string why;
+  const WinPlan pl = plan_window(h, period, p.lo, p.hi, &why);
+  if (!pl.R) return fail(h, SDPGPU_ERR_ARG, "period %d: %s", period, why.c_str());
+  out->kernel = SDPGPU_KERNEL_WINDOW;
+  out->r = pl.R;
+  out->s = pl.S;
+  out->chunks = pl.n_chunks;
+  out->chunk_blocks = pl.chunk_blocks;
+  out->tiles = pl.n_tiles;
+  out->tasks = pl.n_tasks;
+  out->workgroups_per_cu = lds_workgroups(pl.smem);
+  out->lds_bytes = (int64_t)pl.smem;
   return SDPGPU_OK;
 }
 

@@ -209,13 +209,21 @@ hipError_t launch_cash_shift(sdpgpu_handle* h, const DevParams& P, int period, c
 }
 
 // ---- cash row kernel (F3-F6 on any cash grid) -------------------------------------------------------
+// LDS of a workgroup of cash_row_kernel / cash_row_pair_kernel: 152 B per demand point (its per-wave entries), the
+// read-out scratch of four waves' tiles, and the per-wave trip flags.
+size_t cash_row_lds(int nD, int tile_pts) {
+  return (size_t)nD * 152 + (size_t)4 * tile_pts * (sizeof(double) + sizeof(int)) + 4 * (((size_t)nD + 3) / 4 + 3) * sizeof(int);
+}
+
 bool cash_row_eligible(const sdpgpu_handle* h, int period) {
   const sdpgpu_desc& d = h->d;
   if (h->custom || !has_cash(d.family) || !d.clamp_inventory || !h->use_cash_row) return false;
   const PeriodInfo& p = h->per[period - 1];
   if (p.g.nc < 32) return false;                       // a wave is 64 consecutive cash points of one row
   if (p.S >= 2147483647LL) return false;               // 32-bit row offsets
-  if ((size_t)p.nD * 156 + 4 * 64 * 12 > 64 * 1024) return false;  // per-wave entries of every demand point in LDS
+  // per-wave entries of every demand point in LDS, plus the read-out scratch of the LARGEST tile a launch may pick (256
+  // points, cash_row_pair_kernel with two tiles per wave): two workgroups of that size still share a compute unit
+  if (cash_row_lds(p.nD, 256) > kLdsPerCU / 2) return false;
   if (period < h->T) {
     // the kernel addresses V_{t+1} by a 32-bit BYTE offset from a scalar base (per pipeline plane for F5) ...
     const PeriodInfo& n = h->per[period];
@@ -235,11 +243,21 @@ bool cash_row_eligible(const sdpgpu_handle* h, int period) {
   return true;
 }
 
+}  // namespace sdpgpu_detail
+namespace sdpgpu_detail {
+
 template <int FAM, bool FORMULA1, bool PEN = false, bool LEAN = false, bool UNI = false>
 hipError_t launch_cash_row_fam(const DevParams& P, bool last, bool intdiv, const double* v_next, double* v_cur,
                                int32_t* pol, const double* pmf_d, const double* pmf_p, int64_t lo, int64_t hi,
                                int64_t row0, sdp::RowTiling G, dim3 grid, size_t smem, hipStream_t st) {
-#define SDP_CR(LS, ID) hipLaunchKernelGGL((sdp::cash_row_kernel<FAM, LS, FORMULA1, ID, PEN, LEAN, UNI && !(ID)>), grid, dim3(256), smem, st, P, v_next, v_cur, pol, pmf_d, pmf_p, lo, hi, row0, G)
+#define SDP_CR(LS, ID)                                                                                                    \
+  do {                                                                                                                    \
+    static LdsMark mark;                                                                                                  \
+    hipError_t ea = lds_allow(sdp::cash_row_kernel<FAM, LS, FORMULA1, ID, PEN, LEAN, UNI && !(ID)>, smem, &mark);         \
+    if (ea != hipSuccess) return ea;                                                                                      \
+    hipLaunchKernelGGL((sdp::cash_row_kernel<FAM, LS, FORMULA1, ID, PEN, LEAN, UNI && !(ID)>), grid, dim3(256), smem, st, \
+                       P, v_next, v_cur, pol, pmf_d, pmf_p, lo, hi, row0, G);                                             \
+  } while (0)
   if (intdiv) {
     if (last) SDP_CR(true, true); else SDP_CR(false, true);
   } else {
@@ -318,7 +336,9 @@ hipError_t launch_cash_row(sdpgpu_handle* h, const DevParams& P, int period, con
   }
   if (!grid_ok(blocks)) return hipErrorInvalidValue;
   dim3 grid((unsigned)blocks);
-  const size_t smem = (size_t)p.nD * 152 + (size_t)4 * tile_pts * (sizeof(double) + sizeof(int)) + 4 * (((size_t)p.nD + 3) / 4 + 3) * sizeof(int);
+  // (the scratch grows with the tile: above 64 KiB -- pmfs of 340 points and more on 128- or 256-point tiles -- the launch
+  // raises the kernel's dynamic-LDS limit; cash_row_eligible has bounded it by half a compute unit's LDS)
+  const size_t smem = cash_row_lds(p.nD, tile_pts);
   // LEAN: `- holdCosts - overheadCost` subtract +0.0 in every cell (holdingCost and the period's overhead are +0.0)
   const bool lean = P.family == sdp::FAM_CASH && P.cash_formula != 1 && P.pi == 0.0 && h->d.holding_cost == 0.0 &&
                     !std::signbit(h->d.holding_cost) && P.overhead == 0.0 && !std::signbit(P.overhead);
@@ -329,6 +349,10 @@ hipError_t launch_cash_row(sdpgpu_handle* h, const DevParams& P, int period, con
       if (pair) {
 #define SDP_PAIR(LS, F1, LN)                                                                                                    \
   do {                                                                                                                        \
+    static LdsMark mark2, mark1;                                                                                              \
+    hipError_t ea = pair_s == 2 ? lds_allow(sdp::cash_row_pair_kernel<LS, F1, LN, 2>, smem, &mark2)                           \
+                                : lds_allow(sdp::cash_row_pair_kernel<LS, F1, LN, 1>, smem, &mark1);                          \
+    if (ea != hipSuccess) return ea;                                                                                          \
     if (pair_s == 2)                                                                                                          \
       hipLaunchKernelGGL((sdp::cash_row_pair_kernel<LS, F1, LN, 2>), grid, dim3(256), smem, st, P, v_next, v_cur, pol, pmf_d, \
                          pmf_p, lo, hi, row_lo, G);                                                                           \

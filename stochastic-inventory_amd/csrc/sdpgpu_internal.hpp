@@ -156,6 +156,7 @@ struct sdpgpu_handle {
   std::vector<sdpgpu_handle*> siblings;  // handles[0..n) of the last sdpgpu_solve_multi (set on every member)
   bool multi_copy = false;               // exchange by device-to-device copies (ranks share a device)
   std::string err;
+  std::string plan_error;  // set by a launcher that rejects a period's plan (run_period_impl reports it as SDPGPU_ERR_ARG)
   int device = -1;
 };
 
@@ -205,6 +206,33 @@ inline bool is_pow2_int(double s) {
 // silently truncated.  Every launcher below sends 256-thread workgroups and refuses a grid over the limit.
 inline bool grid_ok(int64_t blocks) { return blocks > 0 && blocks * 256 < 4294967296LL; }
 
+// LDS of a gfx950 compute unit: 160 KiB, all of which one workgroup may take.  A launch that asks for more than the
+// 64 KiB of earlier parts raises the kernel's dynamic-LDS limit first (lds_allow); planners budget against kLdsPerCU
+// divided by the workgroups they want resident together on a CU.
+constexpr size_t kLdsPerCU = 160 * 1024;
+constexpr size_t kLdsLegacy = 64 * 1024;
+inline int lds_workgroups(size_t smem) { return smem == 0 ? 32 : (int)(kLdsPerCU / smem); }
+
+// Raise a kernel's dynamic-LDS limit to `smem` bytes (a no-op up to 64 KiB).  `raised` is the caller's
+// per-instantiation, per-device high-water mark (the attribute belongs to the function on the current device), so the
+// attribute call is made once per kernel, device and size.
+struct LdsMark {
+  size_t raised[16] = {};
+};
+template <class K>
+inline hipError_t lds_allow(K kernel, size_t smem, LdsMark* mark) {
+  if (smem <= kLdsLegacy) return hipSuccess;
+  if (smem > kLdsPerCU) return hipErrorInvalidValue;
+  int dev = 0;
+  hipError_t e = hipGetDevice(&dev);
+  if (e != hipSuccess) return e;
+  size_t* slot = (dev >= 0 && dev < 16) ? &mark->raised[dev] : nullptr;
+  if (slot && smem <= *slot) return hipSuccess;
+  e = hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+  if (e == hipSuccess && slot) *slot = smem;
+  return e;
+}
+
 // register block / chunking of the F1 window kernel for one period (sdpgpu_window.hip)
 struct WinPlan {
   int R = 0, S = 1, d_pad = 0, n_chunks = 1, chunk_blocks = 0, n_tiles = 0, n_tasks = 0;
@@ -251,12 +279,14 @@ bool cash_shift_eligible(const sdpgpu_handle* h, int period);
 hipError_t launch_cash_shift(sdpgpu_handle* h, const DevParams& P, int period, const double* v_next, double* v_cur,
                              int32_t* pol, const double* pmf_d, const double* pmf_p, int64_t lo, int64_t hi, hipStream_t st);
 bool cash_row_eligible(const sdpgpu_handle* h, int period);
+size_t cash_row_lds(int nD, int tile_pts);
 hipError_t launch_cash_row(sdpgpu_handle* h, const DevParams& P, int period, const double* v_next, double* v_cur,
                            int32_t* pol, const double* pmf_d, const double* pmf_p, int64_t lo, int64_t hi, hipStream_t st);
 
 // ---- sdpgpu_window.hip -------------------------------------------------------------------------------------
 bool window_eligible(const sdpgpu_handle* h, int period);
-WinPlan plan_window(const sdpgpu_handle* h, int period, int64_t lo, int64_t hi);
+// (why: receives the reason when no plan exists -- a forced plan that is infeasible, or a period too big for the LDS)
+WinPlan plan_window(const sdpgpu_handle* h, int period, int64_t lo, int64_t hi, std::string* why = nullptr);
 hipError_t flush_pending(sdpgpu_handle* h);
 bool window_interior_tiles(const sdpgpu_handle* h, int period, int64_t lo, int64_t hi, int* first, int* count);
 hipError_t launch_separable_f2(sdpgpu_handle* h, const DevParams& P, int period, const double* v_next, double* v_cur,

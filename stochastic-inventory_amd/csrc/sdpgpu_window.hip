@@ -25,7 +25,7 @@ bool window_eligible(const sdpgpu_handle* h, int period) {
 // register block R, the states per lane S and the number of chunks per tile that minimise it (fewest chunks
 // on ties: fewer chunk rows, less staging).  More states per lane = fewer fp64 operations per cell
 // ((5 + 4(S-1)) / S, see window_f1_kernel) but bigger, fewer tasks: small grids keep S low.
-WinPlan plan_window(const sdpgpu_handle* h, int period, int64_t lo, int64_t hi) {
+WinPlan plan_window(const sdpgpu_handle* h, int period, int64_t lo, int64_t hi, std::string* why) {
   const PeriodInfo& p = h->per[period - 1];
   const int A = h->n_actions_full, D = p.nD_win;
   WinPlan best;
@@ -41,6 +41,8 @@ WinPlan plan_window(const sdpgpu_handle* h, int period, int64_t lo, int64_t hi) 
   // (VGPRs: 107 / 62 / 54 for S = 1, R = 8 / 5 / 4; 130 / 116 / 73 for S = 2; 125 for R = 4, S = 4; 244 for R = 4, S = 8)
   const Cand cand[] = {{8, 1, 6}, {5, 1, 8}, {4, 1, 9}, {8, 2, 3}, {4, 2, 5}, {4, 4, 3}, {8, 4, 2}, {4, 8, 2}};
   const bool may_chunk = h->fuse_combine && h->d.store_all_values;
+  bool shape_seen = false, lds_rejected = false, chunk_rejected = false;
+  size_t lds_least = 0;
   for (const Cand& c : cand) {
     const int r = c.r, sl = c.s, nw = r + sl - 1, ts = 64 * sl;
     if (h->win_r && r != h->win_r) continue;
@@ -50,6 +52,7 @@ WinPlan plan_window(const sdpgpu_handle* h, int period, int64_t lo, int64_t hi) 
     // target grid, 4 % ahead on slabs down to 125,000 states); (8, 4) measured no gain and stays opt-in (SDPGPU_WIN_R + _S)
     const bool big_block = r * sl >= 32;
     if (big_block && !(r == 4 && sl == 8) && !(h->win_r && h->win_s)) continue;
+    shape_seen = true;
     const int64_t n_tiles = std::max<int64_t>(1, (nominal + ts - 1) / ts);
     const int64_t own_tiles = (hi - lo + ts - 1) / ts;
     const int d_pad = rup(D, nw);
@@ -57,22 +60,40 @@ WinPlan plan_window(const sdpgpu_handle* h, int period, int64_t lo, int64_t hi) 
     // cost of one R-block on one SIMD, in fp64-instruction units per lane: (5 + 4(S-1)) ops per S cells of an
     // action plus a per-step overhead (LDS read, scalar load, waits) that a bigger register block amortises
     const double block_cost = (double)D * ((5.0 + 4.0 * (sl - 1)) * r + 3.0) + 60.0 + 2.0 * (sl - 1) * r;
+    // a forced chunk count is taken as "about that many": the realisable plan with the same blocks per chunk
+    int forced_nch = 0;
+    if (h->win_nch) {
+      const int want = std::max(1, std::min(h->win_nch, blocks_total));
+      const int bpc_w = (blocks_total + want - 1) / want;
+      forced_nch = (blocks_total + bpc_w - 1) / bpc_w;
+    }
     for (int nch = 1; nch <= blocks_total; ++nch) {
-      if (h->win_nch && nch != std::min(h->win_nch, blocks_total)) continue;
+      if (forced_nch && nch != forced_nch) continue;
       const int bpc = (blocks_total + nch - 1) / nch;
       if ((blocks_total + bpc - 1) / bpc != nch) continue;  // same plan as a smaller nch
-      if (nch > 1 && !may_chunk) continue;  // chunk rows need the deferred key/finalize scheme
+      if (nch > 1 && !may_chunk) {  // chunk rows need the deferred key/finalize scheme
+        chunk_rejected = true;
+        continue;
+      }
       const int span = ts + bpc * r + d_pad + sl;
       const size_t smem = sdp::win_wg_lds(span, D);
-      if (smem > 64 * 1024) continue;
+      // A workgroup is four tasks, one per SIMD: `occupancy` workgroups per CU by registers, kLdsPerCU / smem by LDS
+      // (gfx950: 160 KiB per CU -- the one-task-per-tile plan of the 500-action, 200-demand grid on the (4, 8) block is
+      // 78.4 KiB per workgroup, and two of them are resident like any other (4, 8) plan's).
+      const int occ = std::min(c.occupancy, lds_workgroups(smem));
+      if (occ < 1) {
+        lds_rejected = true;
+        lds_least = lds_least ? std::min(lds_least, smem) : smem;
+        continue;
+      }
       const int64_t tasks = n_tiles * nch;
       const int64_t q = (tasks + 1023) / 1024;  // tasks of the busiest SIMD
-      // A SIMD holds at most `occupancy` of them at a time and, with priority by progress, resident waves finish
-      // together: q tasks run as groups of `occupancy` plus a remainder group, a group of w tasks at the fp64 issue
+      // A SIMD holds at most `occ` of them at a time and, with priority by progress, resident waves finish
+      // together: q tasks run as groups of `occ` plus a remainder group, a group of w tasks at the fp64 issue
       // rate w resident waves sustain (per-wave stamps: 0.6 alone, 0.85 two, 0.91 three, 0.94 four, 0.97 eight).
       auto eff = [big_block](int64_t w) { return w >= 8 ? 0.97 : (w >= 4 ? 0.94 : (w >= 3 ? 0.91 : (w >= 2 ? (big_block ? 0.93 : 0.85) : 0.60))); };
-      const int64_t full = q / c.occupancy, rest = q % c.occupancy;
-      const double task_units = full * c.occupancy / eff(c.occupancy) + (rest ? rest / eff(rest) : 0.0);
+      const int64_t full = q / occ, rest = q % occ;
+      const double task_units = full * occ / eff(occ) + (rest ? rest / eff(rest) : 0.0);
       const double staging = 400.0 + 4.0 * span;
       const double cost = task_units * (bpc * block_cost + staging);
       if (best_cost < 0 || cost < best_cost * 0.999) {
@@ -87,6 +108,20 @@ WinPlan plan_window(const sdpgpu_handle* h, int period, int64_t lo, int64_t hi) 
         best.smem = smem;
       }
     }
+  }
+  if (!best.R && why) {
+    char buf[320];
+    if (!shape_seen)
+      std::snprintf(buf, sizeof buf, "window kernel: no instantiation for the forced block SDPGPU_WIN_R=%d SDPGPU_WIN_S=%d "
+                    "(have R x S = 8x1 5x1 4x1 8x2 4x2 4x4 8x4 4x8)", h->win_r, h->win_s);
+    else if (lds_rejected)
+      std::snprintf(buf, sizeof buf, "window kernel: %d actions x %d demand steps need %zu B of LDS per workgroup%s, over the %zu B of a "
+                    "compute unit%s", A, D, lds_least, h->win_nch ? " with the forced chunk count" : "", kLdsPerCU,
+                    chunk_rejected ? " (chunking is off: ping-pong tables or SDPGPU_FUSE_COMBINE=0)" : "");
+    else
+      std::snprintf(buf, sizeof buf, "window kernel: the forced plan (SDPGPU_WIN_R=%d SDPGPU_WIN_S=%d SDPGPU_WIN_NCH=%d) needs chunk rows, "
+                    "which are off (ping-pong tables or SDPGPU_FUSE_COMBINE=0)", h->win_r, h->win_s, h->win_nch);
+    *why = buf;
   }
   return best;
 }
@@ -167,6 +202,10 @@ hipError_t launch_row_r(const sdp::RowParams& W, size_t smem, bool future, const
                         int32_t* out_idx, const double* pmf_p, int64_t lo, int64_t hi, hipStream_t st) {
   if (!grid_ok((int64_t)W.n_tiles * W.n_chunks)) return hipErrorInvalidValue;
   dim3 grid((unsigned)((int64_t)W.n_tiles * W.n_chunks));
+  static LdsMark mark_f, mark_l;
+  hipError_t ea = future ? lds_allow(sdp::window_f2_kernel<R, S, MAXDIR, true>, smem, &mark_f)
+                         : lds_allow(sdp::window_f2_kernel<R, S, MAXDIR, false>, smem, &mark_l);
+  if (ea != hipSuccess) return ea;
   if (future)
     hipLaunchKernelGGL((sdp::window_f2_kernel<R, S, MAXDIR, true>), grid, dim3(256), smem, st, W, v_next, out_val, out_idx, pmf_p, lo, hi);
   else
@@ -241,8 +280,15 @@ hipError_t launch_row_window(sdpgpu_handle* h, const DevParams& P, int period, c
   int waves = std::min(4, blocks_total);
   // (the read-out scratch of a wave that stages rows lies inside its row region)
   auto lds = [&](int wv) { return (size_t)span * 8 * (1 + (future ? wv * R : 0)) + (size_t)(future ? 4 - wv : 4) * TSZ * 12; };
-  while (waves > 1 && lds(waves) > 60 * 1024) --waves;
-  if (lds(waves) > 64 * 1024) return hipErrorInvalidValue;
+  // (two workgroups per compute unit stay resident up to half its 160 KiB each; a single wave's rows may take all of it)
+  while (waves > 1 && lds(waves) > kLdsPerCU / 2) --waves;
+  if (lds(waves) > kLdsPerCU) {
+    char buf[200];
+    std::snprintf(buf, sizeof buf, "row-window kernel: %d demand steps need %zu B of LDS per workgroup, over the %zu B of a compute unit",
+                  D, lds(waves), kLdsPerCU);
+    h->plan_error = buf;
+    return hipErrorInvalidValue;
+  }
   // the run of row tiles that covers [lo, hi)
   auto tile_of = [&](int64_t idx) { return (int32_t)((idx / p.g.nx) * W.tiles_per_row + (idx % p.g.nx) / TSZ); };
   W.tile0 = tile_of(lo);
@@ -331,7 +377,7 @@ hipError_t launch_window(sdpgpu_handle* h, const DevParams& P, int period, const
   }
   // (an empty slab still goes through the bookkeeping below: every rank must treat the row alike)
   PeriodInfo& p = h->per[period - 1];
-  WinPlan pl = plan_window(h, period, lo, hi);
+  WinPlan pl = plan_window(h, period, lo, hi, &h->plan_error);
   if (!pl.R) return hipErrorInvalidValue;
   if (period == h->T && std::getenv("SDPGPU_DEBUG_PLAN"))
     std::fprintf(stderr, "[sdpgpu] window plan: R=%d S=%d chunks=%d blocks/chunk=%d tiles=%d tasks=%d lds=%zu\n", pl.R, pl.S,
@@ -471,9 +517,14 @@ hipError_t launch_window(sdpgpu_handle* h, const DevParams& P, int period, const
 #define SDP_STAMP_ARG
 #endif
   if (W.n_tasks > 0) {
-#define SDP_WIN_GO(RR, SS, FU, KI)                                                                                      \
-  hipLaunchKernelGGL((sdp::window_f1_kernel<RR, SS, FU, KI>), grid, dim3(256), pl.smem, st, W, v_next, k_next, out_val, \
-                     out_idx, k_cur, pmf_p, lo, hi SDP_STAMP_ARG)
+#define SDP_WIN_GO(RR, SS, FU, KI)                                                                                        \
+  do {                                                                                                                    \
+    static LdsMark mark;                                                                                                  \
+    hipError_t ea = lds_allow(sdp::window_f1_kernel<RR, SS, FU, KI>, pl.smem, &mark);                                     \
+    if (ea != hipSuccess) return ea;                                                                                      \
+    hipLaunchKernelGGL((sdp::window_f1_kernel<RR, SS, FU, KI>), grid, dim3(256), pl.smem, st, W, v_next, k_next, out_val, \
+                       out_idx, k_cur, pmf_p, lo, hi SDP_STAMP_ARG);                                                      \
+  } while (0)
 #define SDP_WIN_R(RR, SS)                      \
   if (pl.R == RR && pl.S == SS) {              \
     if (!future)                               \
@@ -551,11 +602,17 @@ hipError_t launch_separable(sdpgpu_handle* h, const DevParams& P, int period, co
       dim3 grid((unsigned)((n + 63) / 64));
       size_t smem = (size_t)(64 + S.n_actions + S.d_range) * 16 + (size_t)(64 + S.n_actions) * 8 +
                     4 * 64 * (sizeof(double) + sizeof(int));
-      if (smem > 64 * 1024) {
+      if (smem > kLdsPerCU) {
         *too_big = true;
         return hipSuccess;
       }
       const bool mx = P.maxdir != 0;
+      {
+        static LdsMark marks[4];
+        hipError_t ea = mx ? (future ? lds_allow(sdp::separable_f1_kernel<true, true>, smem, &marks[0]) : lds_allow(sdp::separable_f1_kernel<true, false>, smem, &marks[1]))
+                           : (future ? lds_allow(sdp::separable_f1_kernel<false, true>, smem, &marks[2]) : lds_allow(sdp::separable_f1_kernel<false, false>, smem, &marks[3]));
+        if (ea != hipSuccess) return ea;
+      }
       if (mx && future) hipLaunchKernelGGL((sdp::separable_f1_kernel<true, true>), grid, dim3(256), smem, h->stream, S, v_next, v_cur, pol, pd, pp, p.lo, p.hi);
       else if (mx) hipLaunchKernelGGL((sdp::separable_f1_kernel<true, false>), grid, dim3(256), smem, h->stream, S, v_next, v_cur, pol, pd, pp, p.lo, p.hi);
       else if (future) hipLaunchKernelGGL((sdp::separable_f1_kernel<false, true>), grid, dim3(256), smem, h->stream, S, v_next, v_cur, pol, pd, pp, p.lo, p.hi);

@@ -180,6 +180,14 @@ class SdpEngine:
         self._check(rc)
         return l.value, r.value
 
+    def plan(self, period: int):
+        """sdpgpu_plan_period: the launch plan of `period` (host arithmetic only; raises SdpgpuError when the plan -- e.g.
+        one forced through SDPGPU_WIN_R / _S / _NCH -- cannot run)."""
+        from ._abi import SdpgpuPlan
+        out = SdpgpuPlan()
+        self._check(self._lib.sdpgpu_plan_period(self._h, period, C.byref(out)))
+        return out
+
     def set_halo(self, halo: int):
         self._check(self._lib.sdpgpu_set_halo(self._h, int(halo)))
 

@@ -109,6 +109,24 @@ def test_cash_row_kernel_variants(sia, oracle, monkeypatch, make, env):
     eng.close()
 
 
+@pytest.mark.parametrize("pair_s", ["2", "1", None], ids=["two-tiles-per-wave", "one-tile", "planned"])
+def test_cash_row_wide_pmf_above_64KiB_of_lds(sia, oracle, monkeypatch, pair_s):
+    """A 345-point pmf on CashConstraint.main's tenths grid: 152 B of per-wave entries per demand point + the read-out
+    scratch of 128- or 256-point tiles = 60-66 KiB of LDS.  The launcher sizes the LDS from the tile it actually picked and
+    raises the kernel's limit above 64 KiB (round 2 budgeted for 64-point tiles and failed the launch at 66,168 B)."""
+    from stochastic_inventory_amd import workloads
+    from stochastic_inventory_amd.workloads import truncated_poisson_tile
+    if pair_s:
+        monkeypatch.setenv("SDPGPU_CASH_PAIR_S", pair_s)
+    w = workloads.cfg3_tenths(T=2, NX=50, maxCash=1100.0, A=8, D=345)
+    w.pmf = [truncated_poisson_tile(170.0, 345), truncated_poisson_tile(150.0, 345)]
+    eng, P, V, pol, cells = _solve_both(sia, oracle, w, nthreads=16)
+    assert eng.stats().cells_evaluated == cells and eng.stats().kernel_used == 2
+    for period in range(1, w.T + 1):
+        _assert_tables(eng.values(period), eng.policy(period), V[period - 1], pol[period - 1], f"{w.name} pair_s={pair_s} t={period}")
+    eng.close()
+
+
 def _cfg3_small():
     from stochastic_inventory_amd import workloads
     return workloads.cfg3_cash(T=3, NX=24, NC=700, A=70, D=30)
@@ -200,6 +218,53 @@ def test_f1_window_register_blocks(sia, oracle, monkeypatch, shape, env):
     assert eng.stats().cells_evaluated == cells
     for period in range(1, w.T + 1):
         _assert_tables(eng.values(period), eng.policy(period), V[period - 1], pol[period - 1], f"{w.name} {env} t={period}")
+    eng.close()
+
+
+@pytest.mark.parametrize("env,store_all", [({"SDPGPU_WIN_R": "4", "SDPGPU_WIN_S": "8", "SDPGPU_WIN_NCH": "1"}, 1),
+                                           ({"SDPGPU_WIN_R": "8", "SDPGPU_WIN_S": "4", "SDPGPU_WIN_NCH": "1"}, 1),
+                                           ({"SDPGPU_WIN_R": "4", "SDPGPU_WIN_S": "8", "SDPGPU_WIN_NCH": "2"}, 1),
+                                           ({}, 0)],
+                         ids=["4x8-one-task-78KiB", "8x4-one-task", "4x8-two-chunks", "ping-pong-planned"])
+def test_f1_window_plans_above_64KiB_of_lds(sia, oracle, monkeypatch, env, store_all):
+    """Workgroups of more than 64 KiB of LDS (gfx950 has 160 KiB per compute unit): the 500-action x 200-demand shape of the
+    target grid with ONE task per tile on the (4, 8) block (78.4 KiB; no chunk rows, no key atomics, no finalize pass), its
+    neighbours, and the plan the library itself takes with ping-pong tables (which cannot keep chunk rows) -- on 1601 states
+    (ragged against the 512-state tile), every table against the oracle."""
+    from stochastic_inventory_amd import workloads
+    for k in ("SDPGPU_WIN_R", "SDPGPU_WIN_S", "SDPGPU_WIN_NCH"):
+        monkeypatch.delenv(k, raising=False)
+    for k, v in env.items():
+        monkeypatch.setenv(k, v)
+    w = workloads.cfg5_scaled(S=1601, T=3)
+    desc = w.desc()
+    desc.store_all_values = store_all
+    eng = sia.SdpEngine(desc, w.pmf, w.overhead())
+    pl = eng.plan(1)
+    assert pl.kernel == 2
+    if env.get("SDPGPU_WIN_S") == "8" and env.get("SDPGPU_WIN_NCH") == "1":
+        assert pl.lds_bytes == 80288 and pl.workgroups_per_cu == 2
+    if not store_all:
+        assert pl.chunks == 1  # (a grid this small takes a finer block than (4, 8); the large ones: test_planner_geometry.py)
+    eng.solve(sync=True)
+    V, pol, cells = oracle.Problem(w.desc(), w.pmf, w.overhead()).solve(nthreads=8)
+    assert eng.stats().cells_evaluated == cells
+    for period in ((1, 2) if not store_all else range(1, w.T + 1)):  # (ping-pong: the last two tables are the ones held)
+        _assert_tables(eng.values(period), eng.policy(period), V[period - 1], pol[period - 1], f"{w.name} {env} t={period}")
+    eng.close()
+
+
+def test_infeasible_forced_plan_is_refused_before_launch(sia, monkeypatch):
+    """3000 actions x 400 demand steps forced into one chunk on the (4, 8) block: 251 KiB of windows.  sdpgpu_run_period
+    returns SDPGPU_ERR_ARG with the planner's reason (was: a launch error from the runtime)."""
+    from stochastic_inventory_amd import workloads
+    for k, v in {"SDPGPU_WIN_R": "4", "SDPGPU_WIN_S": "8", "SDPGPU_WIN_NCH": "1"}.items():
+        monkeypatch.setenv(k, v)
+    w = workloads.cfg5_scaled(S=2000, T=2, A=3000, D=400)
+    eng = sia.SdpEngine(w.desc(), w.pmf, w.overhead())
+    with pytest.raises(sia.SdpgpuError) as ei:
+        eng.solve(sync=True)
+    assert ei.value.code == 1 and "of LDS per workgroup" in ei.value.message
     eng.close()
 
 

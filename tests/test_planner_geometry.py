@@ -87,3 +87,56 @@ def test_baseline_grids_full_size_geometry(sia, make, world):
     finally:
         for e in engs:
             e.close()
+
+
+def _plan(sia, w, monkeypatch, env=None, store_all=1, world=1):
+    for k in ("SDPGPU_WIN_R", "SDPGPU_WIN_S", "SDPGPU_WIN_NCH"):
+        monkeypatch.delenv(k, raising=False)
+    for k, v in (env or {}).items():
+        monkeypatch.setenv(k, v)
+    d = w.desc()
+    d.store_all_values = store_all
+    d.world_size = world
+    with sia.SdpEngine(d, w.pmf, w.overhead()) as eng:
+        return eng.plan(1)
+
+
+def test_window_plans_use_the_whole_lds_of_a_compute_unit(sia, monkeypatch):
+    """gfx950 has 160 KiB of LDS per compute unit: the one-task-per-tile plan of the 500-action x 200-demand grid on the
+    (4, 8) block is 78.4 KiB per workgroup and two of them are resident (sdpgpu_plan_period, host arithmetic only)."""
+    pl = _plan(sia, workloads.target_grid(T=2), monkeypatch, {"SDPGPU_WIN_R": "4", "SDPGPU_WIN_S": "8", "SDPGPU_WIN_NCH": "1"})
+    assert (pl.kernel, pl.r, pl.s, pl.chunks, pl.chunk_blocks) == (2, 4, 8, 1, 125)
+    assert pl.tiles == pl.tasks == 1954 and pl.lds_bytes == 80288 and pl.workgroups_per_cu == 2
+    # ping-pong tables (configs[4] on one GPU) cannot keep chunk rows: the planner now takes the (4, 8) block there as well
+    pl = _plan(sia, workloads.cfg5_scaled(S=12500000, T=3), monkeypatch, store_all=0)
+    assert (pl.r, pl.s, pl.chunks) == (4, 8, 1) and 65536 < pl.lds_bytes <= 81920
+    # with resident tables the 1e6-state grid keeps several chunks per tile (1954 one-chunk tasks would leave 5 % of the
+    # 2048 wave slots idle; measured 56.4 against 53.3 ms per sweep) -- same on every rank of eight
+    pl1 = _plan(sia, workloads.target_grid(), monkeypatch)
+    pl8 = _plan(sia, workloads.target_grid(), monkeypatch, world=8)
+    assert (pl1.r, pl1.s) == (4, 8) and pl1.chunks > 1 and pl1.lds_bytes <= 65536
+    assert pl8.chunks > 1 and pl8.tiles == (125000 + 511) // 512
+
+
+@pytest.mark.parametrize("env,needle", [
+    ({"SDPGPU_WIN_R": "7"}, "no instantiation"),
+    ({"SDPGPU_WIN_R": "4", "SDPGPU_WIN_S": "8", "SDPGPU_WIN_NCH": "1"}, "of LDS per workgroup"),
+])
+def test_infeasible_forced_window_plans_are_refused_with_a_reason(sia, monkeypatch, env, needle):
+    """A forced plan that cannot run is an SDPGPU_ERR_ARG with a message from the planner, not a launch failure:
+    an R the kernel is not instantiated for; 3000 actions x 400 demand steps in ONE chunk (251 KiB of windows)."""
+    w = workloads.cfg5_scaled(S=100000, T=2, A=3000, D=400)
+    with pytest.raises(sia.SdpgpuError) as ei:
+        _plan(sia, w, monkeypatch, env)
+    assert ei.value.code == 1 and needle in ei.value.message
+    # left to itself the planner chunks the same grid
+    pl = _plan(sia, w, monkeypatch)
+    assert pl.kernel == 2 and pl.chunks > 1 and pl.lds_bytes <= 163840
+
+
+def test_forced_chunk_count_rounds_to_a_realisable_plan(sia, monkeypatch):
+    """SDPGPU_WIN_NCH=50 on 125 register blocks: 3 blocks per chunk = 42 chunks (was: no plan, a launch error)."""
+    pl = _plan(sia, workloads.target_grid(T=2), monkeypatch, {"SDPGPU_WIN_R": "4", "SDPGPU_WIN_S": "8", "SDPGPU_WIN_NCH": "50"})
+    assert (pl.chunks, pl.chunk_blocks) == (42, 3)
+    pl = _plan(sia, workloads.target_grid(T=2), monkeypatch, {"SDPGPU_WIN_R": "4", "SDPGPU_WIN_S": "8", "SDPGPU_WIN_NCH": "9999"})
+    assert (pl.chunks, pl.chunk_blocks) == (125, 1)
