@@ -412,14 +412,21 @@ def main():
             os.environ.setdefault("MASTER_PORT", str(sock.getsockname()[1]))
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group("gloo", rank=0, world_size=1)
+    import stochastic_inventory_amd as sia
+    from stochastic_inventory_amd.watchdog import PhaseWatchdog
+
+    # N > 1: every phase of the run has a deadline watched by a thread of this rank; a rank that overruns prints a one-line
+    # JSON error record (phase, rank, times) and exits non-zero -- a stalled peer ends the run with a diagnosis instead of
+    # leaving everybody inside a collective until the launcher's timeout.  Nothing is relaunched or re-executed.
+    wd = PhaseWatchdog(rank, world, context={"metric": "(state,action,demand) cell evals/sec", "n_gpus": world,
+                                               "workload": args.workload, "exchange_requested": args.exchange}) if sharded_path else None
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("GLOO_SOCKET_IFNAME", "lo")  # one node: do not depend on the hostname resolving
         # native exchange: the data path is RCCL inside libsdpgpu.so; the process group carries the communicator id,
         # the barriers and the timing reductions, for which gloo is enough
-        dist.init_process_group("nccl", device_id=dev) if args.exchange == "torch" else dist.init_process_group("gloo")
-
-    import stochastic_inventory_amd as sia
+        with wd.phase("process group", 180):
+            dist.init_process_group("nccl", device_id=dev) if args.exchange == "torch" else dist.init_process_group("gloo")
 
     w = make_workload(args.workload, world, args.states, args.periods, args.weak)
     T = w.T
@@ -491,7 +498,11 @@ def main():
     eng = backend.engine
     exchange = args.exchange
     note = ""
-    if exchange == "native" and not init_native_comm(eng):  # (the ranks agree inside: all or none)
+    t_comm0 = time.perf_counter()
+    with wd.phase("communicator init", 180):
+        native_ok = exchange != "native" or init_native_comm(eng)  # (the ranks agree inside: all or none)
+    comm_init_s = time.perf_counter() - t_comm0
+    if not native_ok:
         exchange = "torch"
         err = init_native_comm.last_error
         note = f" (native communicator failed{': ' + err if err else ' on another rank'}; fell back to torch.distributed nccl)"
@@ -518,6 +529,26 @@ def main():
     blocked_ok = exchange != "native" and not args.split and solver.prepare_blocked(8)
     if sched.startswith("blocked") and not blocked_ok:
         raise SystemExit("blockedK needs --exchange torch|host and a workload with a bounded dependency footprint")
+
+    # PARITY GATE FIRST (every rank on its own slab; all must pass), on the plainest schedule -- a blocking all-gather per
+    # period -- and before any schedule is timed: nothing is calibrated, warmed up or timed on tables that have not been
+    # checked, and the first collectives of the run are issued in a phase with its own deadline.
+    first_runner = make_runner("blocking" if sched == "auto" else sched)
+    t_first0 = time.perf_counter()
+    with wd.phase("first sweep", 300):
+        first_runner()
+        torch.cuda.synchronize(dev)
+        barrier()
+    first_sweep_s = time.perf_counter() - t_first0
+    gate = {"status": "skipped (--no-gate)"}
+    if not args.no_gate:
+        with wd.phase("parity gate", 900):
+            ok, gate = parity_gate(eng, w, args.gate_cells / world, seed=5 + rank)
+            if not all_agree(ok):
+                raise SystemExit(f"PARITY GATE FAILED (rank {rank}: {json.dumps(gate)}) -- no timing accepted")
+        gate["ranks"] = world
+        gate["schedule"] = "blocking" if sched == "auto" else sched
+
     schedule_note = sched
     if sched == "auto":
         candidates = ["blocking", "overlap"]
@@ -526,74 +557,87 @@ def main():
         if exchange == "host" and not os.environ.get("SDP_BENCH_CALIBRATE"):
             candidates = ["overlap"]
         timing = {}
-        for name in candidates:
-            run_c = make_runner(name)
-            took, ok = float("inf"), True
-            try:
+        with wd.phase("schedule calibration", 120 + 40 * first_sweep_s * len(candidates)):
+            for name in candidates:
+                run_c = make_runner(name)
+                took, ok = float("inf"), True
+                try:
+                    run_c()
+                    torch.cuda.synchronize(dev)
+                except Exception as exc:
+                    ok = False
+                    print(f"[bench] schedule {name} failed on rank {rank}: {exc}", file=sys.stderr, flush=True)
+                # agree BEFORE any further collective: a rank that failed must not leave the others inside one
+                if not all_agree(ok):
+                    if name in ("blocking",):
+                        raise SystemExit("the blocking schedule failed: nothing to fall back to")
+                    continue
+                barrier()
+                t0c = time.perf_counter()
                 run_c()
-                torch.cuda.synchronize(dev)
-            except Exception as exc:
-                ok = False
-                print(f"[bench] schedule {name} failed on rank {rank}: {exc}", file=sys.stderr, flush=True)
-            # agree BEFORE any further collective: a rank that failed must not leave the others inside one
-            if not all_agree(ok):
-                if name in ("blocking",):
-                    raise SystemExit("the blocking schedule failed: nothing to fall back to")
-                continue
-            barrier()
-            t0c = time.perf_counter()
-            run_c()
-            run_c()
-            barrier()
-            took = (time.perf_counter() - t0c) / 2
-            timing[name] = max_over_ranks(took)
+                run_c()
+                barrier()
+                took = (time.perf_counter() - t0c) / 2
+                timing[name] = max_over_ranks(took)
         sched = min(timing, key=timing.get)
         schedule_note = sched + " (calibrated, ms per sweep: " + ", ".join(f"{k} {v * 1e3:.3f}" for k, v in timing.items()) + ")"
     run_sweep = make_runner(sched)
+    if sched != gate.get("schedule", sched):
+        # the timed schedule is not the one the gate ran on: its tables must be the gated ones, bit for bit (V_1 on the slab,
+        # V_2 whole, this rank's policy of period 1)
+        import numpy as np
+        with wd.phase("schedule cross-check", 300):
+            ref = (eng.values(1).copy(), eng.values(2 if T > 1 else 1).copy(), eng.policy(1).copy())
+            run_sweep()
+            torch.cuda.synchronize(dev)
+            _, lo1, hi1 = eng.slab(1)
+            same = (np.array_equal(eng.values(1)[lo1:hi1], ref[0][lo1:hi1]) and np.array_equal(eng.policy(1), ref[2])
+                    and (T == 1 or np.array_equal(eng.values(2), ref[1])))
+            if not all_agree(bool(same)):
+                raise SystemExit(f"schedule {sched} does not reproduce the gated tables (rank {rank}) -- no timing accepted")
+        gate["timed_schedule_matches_gated_tables"] = True
 
-    # parity gate on this rank's slab (every rank; all must pass)
-    run_sweep()
-    torch.cuda.synchronize(dev)
-    gate = {"status": "skipped (--no-gate)"}
-    if not args.no_gate:
-        ok, gate = parity_gate(eng, w, args.gate_cells / world, seed=5 + rank)
-        if not all_agree(ok):
-            raise SystemExit(f"PARITY GATE FAILED (rank {rank}: {json.dumps(gate)}) -- no timing accepted")
-        gate["ranks"] = world
-
-    for _ in range(args.warmup):
-        run_sweep()
-    barrier()
+    with wd.phase("warm-up", 120 + 40 * first_sweep_s * max(1, args.warmup)):
+        for _ in range(args.warmup):
+            run_sweep()
+        barrier()
     ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]
-    t0 = time.perf_counter()
-    for k in range(args.steps):
-        ev[k][0].record()
-        run_sweep()
-        ev[k][1].record()
-    barrier()
-    elapsed = max_over_ranks(time.perf_counter() - t0)
+    with wd.phase("timed loop", 120 + 40 * first_sweep_s * max(1, args.steps)):
+        t0 = time.perf_counter()
+        for k in range(args.steps):
+            ev[k][0].record()
+            run_sweep()
+            ev[k][1].record()
+        barrier()
+        elapsed = max_over_ranks(time.perf_counter() - t0)
 
     st = eng.stats()
     cells_step_all = int(st.cells_all_ranks)
     cells_step_rank = int(st.cells_evaluated)
     states_step_rank = sum(backend.slab(p)[2] - backend.slab(p)[1] for p in range(1, T + 1))
     dev_ms = sum(a.elapsed_time(b) for a, b in ev) / args.steps
-    eng.set_profiling(True)
-    run_sweep()
-    torch.cuda.synchronize(dev)
-    per_launch = [eng.period_ms(p) for p in range(T, 0, -1)]
-    eng.set_profiling(False)
+    with wd.phase("per-launch events sweep", 120 + 40 * first_sweep_s):
+        eng.set_profiling(True)
+        run_sweep()
+        torch.cuda.synchronize(dev)
+        per_launch = [eng.period_ms(p) for p in range(T, 0, -1)]
+        eng.set_profiling(False)
     compute_ms = sum(m for m in per_launch if m > 0)
     # load balance: cells per rank (F3's action count depends on the cash balance, CashConstraint.java:96-99)
     cells_t = torch.zeros(world, dtype=torch.float64, device=ctrl)
     cells_t[rank] = float(cells_step_rank)
-    dist.all_reduce(cells_t)
     comp_t = torch.zeros(world, dtype=torch.float64, device=ctrl)
     comp_t[rank] = compute_ms
-    dist.all_reduce(comp_t)
+    sweep_t = torch.zeros(world, dtype=torch.float64, device=ctrl)
+    sweep_t[rank] = dev_ms
+    with wd.phase("reductions", 120):
+        dist.all_reduce(cells_t)
+        dist.all_reduce(comp_t)
+        dist.all_reduce(sweep_t)
 
     check = None
     if args.check:
+      with wd.phase("check vs single rank", 900):
         import numpy as np
         pol_local = eng.policy(1)
         if exchange == "native":
@@ -633,6 +677,13 @@ def main():
                 "schedule": schedule_note,
                 "cells_per_rank": [int(c) for c in cells_t.tolist()],
                 "kernel_ms_per_rank": [round(c, 4) for c in comp_t.tolist()],
+                # device time of a sweep on the rank's launch stream less its period kernels: what the all-gathers (and the
+                # waits for slower peers inside them) cost that rank
+                "sweep_ms_per_rank": [round(c, 4) for c in sweep_t.tolist()],
+                "exchange_ms_per_rank": [round(max(0.0, a - b), 4) for a, b in zip(sweep_t.tolist(), comp_t.tolist())],
+                "communicator_init_s": round(comm_init_s, 3),
+                "first_sweep_s": round(first_sweep_s, 3),
+                "phases_s": {n: round(sec, 3) for n, sec in wd.history},
                 "exchange_bytes_per_rank_per_period": 8 * (backend.slab(1)[0] // world),
                 "kernel": {0: "auto", 1: "gather", 2: "specialised (window / shift / row)", 3: "separable"}[int(st.kernel_used)],
             },
@@ -643,9 +694,11 @@ def main():
             out["check_vs_single_rank"] = check
         # (cpu_baseline is the N = 1 line's: the oracle timed on rank 0 while seven GPUs wait would only lengthen the scaling run)
         print(json.dumps(out), flush=True)
-    dist.barrier()
-    dist.destroy_process_group()
-    backend.close()
+    with wd.phase("teardown", 120):
+        dist.barrier()
+        dist.destroy_process_group()
+        backend.close()
+    wd.close()
 
 
 if __name__ == "__main__":

@@ -393,11 +393,14 @@ int sdpgpu_synchronize(sdpgpu_handle* h);
  *
  *  (1) one process (or thread) per GPU:  every rank creates its handle with desc.rank / desc.world_size /
  *      desc.device, ONE rank calls sdpgpu_comm_unique_id and hands the 128 bytes to the others by whatever channel
- *      the host has (a file, a socket, MPI, torch.distributed's store), every rank calls sdpgpu_comm_init (collective:
+ *      the host has (a file, a socket, MPI, torch.distributed's store), every rank calls sdpgpu_comm_prepare (local:
+ *      device tables, RCCL load) and the ranks agree that all succeeded, every rank calls sdpgpu_comm_init (collective:
  *      ncclCommInitRank), then sdpgpu_solve_sharded.
  *  (2) one process that owns all the GPUs (a JVM calling through JNI): one handle per device, all in this process,
  *      and ONE call sdpgpu_solve_multi(handles, n, ...) -- the library builds the communicators itself
- *      (ncclCommInitAll), drives every device from the calling thread and groups the per-period all-gathers.
+ *      (ncclCommInitAll), drives every device from the calling thread and groups the per-period all-gathers
+ *      (default), or starts one host thread per rank (SDPGPU_SHARDED_THREADS: for slabs whose periods take tens of
+ *      microseconds, where the launches of eight devices issued from one thread would queue up on the host).
  *      Handles that SHARE a device (a rehearsal of N ranks on one GPU) exchange their slabs by device-to-device
  *      copies instead, since RCCL refuses two ranks on one device; the slab arithmetic and results are the same.
  *
@@ -407,6 +410,11 @@ int sdpgpu_synchronize(sdpgpu_handle* h);
  * unless `gather_first` is set. */
 #define SDPGPU_UNIQUE_ID_BYTES 128
 int sdpgpu_comm_unique_id(void* out_id /* SDPGPU_UNIQUE_ID_BYTES */);
+/* ABI 5.  The part of sdpgpu_comm_init that can fail on one rank ALONE (device tables do not fit, no device, RCCL does
+ * not load), without entering a collective.  Call it on every rank, let the ranks agree over the host's channel that
+ * all returned SDPGPU_OK, and only then call sdpgpu_comm_init: a rank that fails here has not left its peers blocked
+ * inside ncclCommInitRank.  (sdpgpu_comm_init does the same work itself when this call was skipped.) */
+int sdpgpu_comm_prepare(sdpgpu_handle* h);
 /* Collective over the `world` ranks; rank / world must equal the handle's desc.rank / desc.world_size.  world = 1 is
  * allowed (a one-rank communicator: the collective path with nobody to talk to -- used by the tests). */
 int sdpgpu_comm_init(sdpgpu_handle* h, const void* unique_id, int32_t rank, int32_t world);
@@ -422,9 +430,11 @@ int sdpgpu_exchange(sdpgpu_handle* h, int32_t period);
 #define SDPGPU_SHARDED_SYNC 1
 #define SDPGPU_SHARDED_OVERLAP 2
 #define SDPGPU_SHARDED_GATHER_FIRST 4
+#define SDPGPU_SHARDED_THREADS 8 /* ABI 5, sdpgpu_solve_multi only: one host thread per rank (see there) */
 int sdpgpu_solve_sharded(sdpgpu_handle* h, int32_t flags);
-/* Way (2): handles[r] is the handle of rank r (desc.rank = r, desc.world_size = n, any devices).  The communicators
- * are created at the first call and kept in the handles.  Errors are reported on handles[0]. */
+/* Way (2): handles[r] is the handle of rank r (desc.rank = r, desc.world_size = n, any devices; all n describing the
+ * same problem -- family, grids, pmf sizes -- else SDPGPU_ERR_ARG).  The communicators are created at the first call
+ * and kept in the handles.  Errors are reported on handles[0].  The calling thread's current device is restored. */
 int sdpgpu_solve_multi(sdpgpu_handle** handles, int32_t n, int32_t flags);
 
 /* ---- results ----------------------------------------------------------------------------- */

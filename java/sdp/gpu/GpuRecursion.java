@@ -93,22 +93,30 @@ public class GpuRecursion {
 		functor.ints[1] = optDirection == OptDirection.MIN ? SdpGpu.MIN : SdpGpu.MAX;
 		functor.ints[2] = pmf.length;
 		this.rankHandles = new long[Math.max(1, nGpus)];
-		for (int r = 0; r < rankHandles.length; r++) {
-			int[] ints = functor.ints.clone();
-			if (rankHandles.length > 1) {
-				ints[8] = r; // device
-				ints[9] = r; // rank
-				ints[10] = rankHandles.length; // world size
-			}
-			rankHandles[r] = SdpGpu.create(ints, functor.doubles);
-			for (int t = 0; t < pmf.length; t++) {
-				double[] d = new double[pmf[t].length], p = new double[pmf[t].length];
-				for (int j = 0; j < d.length; j++) {
-					d[j] = pmf[t][j][0];
-					p[j] = pmf[t][j][1];
+		try {
+			for (int r = 0; r < rankHandles.length; r++) {
+				int[] ints = functor.ints.clone();
+				if (rankHandles.length > 1) {
+					ints[8] = r; // device
+					ints[9] = r; // rank
+					ints[10] = rankHandles.length; // world size
 				}
-				SdpGpu.setPmf(rankHandles[r], t, d, p);
+				rankHandles[r] = SdpGpu.create(ints, functor.doubles);
+				for (int t = 0; t < pmf.length; t++) {
+					double[] d = new double[pmf[t].length], p = new double[pmf[t].length];
+					for (int j = 0; j < d.length; j++) {
+						d[j] = pmf[t][j][0];
+						p[j] = pmf[t][j][1];
+					}
+					SdpGpu.setPmf(rankHandles[r], t, d, p);
+				}
 			}
+		} catch (RuntimeException e) {
+			// a rank that cannot be created (or takes no pmf) must not leak the native handles of the ranks before it
+			for (long h : rankHandles)
+				if (h != 0)
+					SdpGpu.destroy(h);
+			throw e;
 		}
 		this.handle = rankHandles[0];
 		this.values = new double[pmf.length][];

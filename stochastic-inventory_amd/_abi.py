@@ -34,6 +34,7 @@ KERNEL_SEPARABLE = 3  # opt-in, F1 only: reassociated sum, values to 1e-9, arg-o
 SHARDED_SYNC = 1
 SHARDED_OVERLAP = 2
 SHARDED_GATHER_FIRST = 4
+SHARDED_THREADS = 8  # sdpgpu_solve_multi: one host thread per rank
 UNIQUE_ID_BYTES = 128
 
 PART_ALL = 0
@@ -243,6 +244,7 @@ EXPORTS = {
     "sdpgpu_set_halo": (C.c_int, [_P, C.c_int64]),
     "sdpgpu_run_period_range": (C.c_int, [_P, C.c_int32, C.c_int64, C.c_int64]),
     "sdpgpu_comm_unique_id": (C.c_int, [_P]),
+    "sdpgpu_comm_prepare": (C.c_int, [_P]),
     "sdpgpu_comm_init": (C.c_int, [_P, _P, C.c_int32, C.c_int32]),
     "sdpgpu_comm_destroy": (C.c_int, [_P]),
     "sdpgpu_exchange": (C.c_int, [_P, C.c_int32]),

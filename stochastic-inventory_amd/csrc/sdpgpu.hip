@@ -101,6 +101,7 @@ int layout(sdpgpu_handle* h) {
   int64_t s_pad_max = 0;
   for (int t = 0; t < h->T; ++t) {
     PeriodInfo& p = h->per[t];
+    p.cells_counted = false;
     p.g.x_lo = lo;
     p.g.nx = (int64_t)((hi - lo) / d.step) + 1;
     p.g.nc = nc;
@@ -286,6 +287,8 @@ DevParams make_params(const sdpgpu_handle* h, int period) {
 void count_cells(sdpgpu_handle* h, int period) {
   PeriodInfo& p = h->per[period - 1];
   if (h->custom) return;  // counted on the device (sdpgpu_stats_get)
+  if (p.cells_counted) return;  // once per handle and period: the sums below are O(S) host loops for some families
+  p.cells_counted = true;
   const sdpgpu_desc& d = h->d;
   int64_t nD = p.nD;
   auto range_cells = [&](int64_t lo, int64_t hi) -> int64_t {
@@ -735,6 +738,7 @@ int sdpgpu_set_overhead(sdpgpu_handle* h, int32_t t, double overhead_cost) {
   if (t < 0 || t >= h->T) return fail(h, SDPGPU_ERR_ARG, "set_overhead: t=%d", t);
   h->per[t].overhead = overhead_cost;
   h->per[t].overhead_set = true;
+  h->per[t].cells_counted = false;
   return SDPGPU_OK;
 }
 
@@ -751,6 +755,7 @@ int sdpgpu_set_action_counts(sdpgpu_handle* h, int32_t t, const int32_t* counts,
       if (counts[i] < 0 || counts[i] > cap)
         return fail(h, SDPGPU_ERR_ARG, "set_action_counts: state %lld has %d actions, the action grid has %d (max_order_quantity / step + 1)", (long long)i, counts[i], cap);
     h->counts[(size_t)t].assign(counts, counts + n);  // (the length is checked against the grid once it is laid out)
+    h->per[(size_t)t].cells_counted = false;
   } catch (...) {
     return fail(h, SDPGPU_ERR_ARG, "out of host memory");
   }

@@ -14,7 +14,9 @@
 #include <dlfcn.h>
 #include <rccl/rccl.h>
 
+#include <condition_variable>
 #include <mutex>
+#include <thread>
 
 using namespace sdpgpu_detail;
 
@@ -191,6 +193,29 @@ int sdpgpu_comm_unique_id(void* out_id) {
   return SDPGPU_OK;
 }
 
+// Everything of sdpgpu_comm_init that can fail on ONE rank alone -- RCCL does not load, the device tables do not fit, no
+// device -- without entering a collective: a rank that fails here has not left its peers waiting inside
+// ncclCommInitRank.  Idempotent.
+int sdpgpu_comm_prepare(sdpgpu_handle* h) {
+  if (!h) return SDPGPU_ERR_ARG;
+  h->err.clear();
+  try {
+    RcclApi* api = rccl();  // (a load check: no ncclGetUniqueId, which would start a bootstrap thread on every rank)
+    if (!api) return fail(h, SDPGPU_ERR_DEVICE, "%s", g_rccl.err.c_str());
+    int rc = allocate(h);  // needs the device: no CPU path
+    if (rc) return rc;
+    rc = ensure_device(h);
+    if (rc) return rc;
+    if (h->device < 0) HIP_TRY(h, hipGetDevice(&h->device));  // the communicator is bound to a device: pin the handle to it
+    h->comm_prepared = true;
+    return SDPGPU_OK;
+  } catch (const std::exception& e) {
+    return fail(h, SDPGPU_ERR_ARG, "exception: %s", e.what());
+  } catch (...) {
+    return fail(h, SDPGPU_ERR_ARG, "unknown exception");
+  }
+}
+
 int sdpgpu_comm_init(sdpgpu_handle* h, const void* unique_id, int32_t rank, int32_t world) {
   if (!h) return SDPGPU_ERR_ARG;
   h->err.clear();
@@ -199,13 +224,14 @@ int sdpgpu_comm_init(sdpgpu_handle* h, const void* unique_id, int32_t rank, int3
     return fail(h, SDPGPU_ERR_ARG, "comm_init: rank %d of %d, but the handle was created as rank %d of %d", rank, world, h->d.rank, h->d.world_size);
   if (h->comm) return fail(h, SDPGPU_ERR_STATE, "comm_init: the handle already has a communicator");
   try {
+    if (!h->comm_prepared) {  // (a caller that skipped sdpgpu_comm_prepare: same work, but its failure is seen only here)
+      int rc = sdpgpu_comm_prepare(h);
+      if (rc) return rc;
+    }
     RcclApi* api = rccl();
     if (!api) return fail(h, SDPGPU_ERR_DEVICE, "%s", g_rccl.err.c_str());
-    int rc = allocate(h);  // needs the device: no CPU path
+    int rc = ensure_device(h);
     if (rc) return rc;
-    rc = ensure_device(h);
-    if (rc) return rc;
-    if (h->device < 0) HIP_TRY(h, hipGetDevice(&h->device));  // the communicator is bound to a device: pin the handle to it
     ncclUniqueId id;
     std::memcpy(&id, unique_id, sizeof id);
     ncclComm_t comm = nullptr;
@@ -267,13 +293,74 @@ int sdpgpu_solve_sharded(sdpgpu_handle* h, int32_t flags) {
   }
 }
 
-// One host thread drives every rank: per period the kernels of all ranks are enqueued first (each on its own
-// device and stream), then the exchange of that period for all ranks -- one RCCL group, or device-to-device copies
-// when ranks share a device.  Streams are asynchronous, so the devices run concurrently.
+// sdpgpu_solve_multi.  Default: ONE host thread drives every rank -- per period the kernels of all ranks are enqueued
+// first (each on its own device and stream), then the exchange of that period for all ranks: one RCCL group, or
+// device-to-device copies when ranks share a device.  Streams are asynchronous, so the devices run concurrently; the
+// host cost is n x (launch + collective) issued serially per period, which is nothing against periods of milliseconds
+// (the BASELINE grids from configs[2] up) and is the path every one-GPU rehearsal exercises.
+// SDPGPU_SHARDED_THREADS: one host thread per rank instead, each running the very sweep of sdpgpu_solve_sharded on its
+// own device (its own communicator, no RCCL group; with shared devices the copies are ordered by a per-period
+// rendezvous of the threads) -- for periods of tens of microseconds (configs[1]-sized slabs), where eight devices'
+// launches issued from one thread would queue behind each other on the host.
+namespace {
+
+struct Rendezvous {  // a reusable barrier of n threads; `broken` releases everybody once a rank has failed
+  std::mutex m;
+  std::condition_variable cv;
+  int n = 0, waiting = 0;
+  unsigned long generation = 0;
+  bool broken = false;
+  int culprit = -1;  // the rank whose failure broke the rendezvous (the others only report "another rank failed")
+  bool arrive() {
+    std::unique_lock<std::mutex> lk(m);
+    if (broken) return false;
+    const unsigned long g = generation;
+    if (++waiting == n) {
+      waiting = 0;
+      ++generation;
+      cv.notify_all();
+      return true;
+    }
+    cv.wait(lk, [&] { return generation != g || broken; });
+    return !broken;
+  }
+  void abandon(int rank) {
+    std::lock_guard<std::mutex> lk(m);
+    if (!broken) culprit = rank;
+    broken = true;
+    cv.notify_all();
+  }
+};
+
+// rank q pulls slab r of the row of `period` from every other rank r, behind r's kernel (ev_comp of r)
+int enqueue_copies(sdpgpu_handle** hs, int n, int q, int period, sdpgpu_handle* herr) {
+  const size_t cnt = (size_t)(hs[0]->per[period - 1].S_pad / n);
+  if (!cnt) return SDPGPU_OK;
+  HIP_TRY(herr, hipSetDevice(hs[q]->device));
+  char* dst = (char*)exchange_row(hs[q], period);
+  for (int r = 0; r < n; ++r) {
+    if (r == q) continue;
+    const char* src = (const char*)exchange_row(hs[r], period);
+    HIP_TRY(herr, hipStreamWaitEvent(hs[q]->stream, hs[r]->ev_comp, 0));
+    HIP_TRY(herr, hipMemcpyAsync(dst + (size_t)r * cnt * 8, src + (size_t)r * cnt * 8, cnt * 8, hipMemcpyDeviceToDevice, hs[q]->stream));
+  }
+  return SDPGPU_OK;
+}
+
+}  // namespace
+
 int sdpgpu_solve_multi(sdpgpu_handle** hs, int32_t n, int32_t flags) {
   if (!hs || n < 1 || !hs[0]) return SDPGPU_ERR_ARG;
   sdpgpu_handle* h0 = hs[0];
   h0->err.clear();
+  int caller_device = -1;
+  (void)hipGetDevice(&caller_device);  // (no device at all: the calls below report it)
+  struct RestoreDevice {
+    int dev;
+    ~RestoreDevice() {
+      if (dev >= 0) (void)hipSetDevice(dev);
+    }
+  } restore{caller_device};
   try {
     for (int r = 0; r < n; ++r) {
       if (!hs[r]) return fail(h0, SDPGPU_ERR_ARG, "solve_multi: handle %d is null", r);
@@ -296,18 +383,36 @@ int sdpgpu_solve_multi(sdpgpu_handle** hs, int32_t n, int32_t flags) {
       dev[(size_t)r] = h->device;
       for (int q = 0; q < r; ++q) distinct = distinct && dev[(size_t)q] != dev[(size_t)r];
     }
+    // the ranks must describe ONE problem: the same family and, per period, the same grid and padded row (the exchange
+    // moves S_pad / n elements per rank into every handle's row)
+    for (int r = 1; r < n; ++r) {
+      const sdpgpu_handle* h = hs[r];
+      bool same = h->d.family == h0->d.family && h->d.store_all_values == h0->d.store_all_values && h->custom == h0->custom;
+      for (int t = 0; same && t < h0->T; ++t) {
+        const PeriodInfo &a = h0->per[t], &b = h->per[t];
+        same = a.S == b.S && a.S_pad == b.S_pad && a.nD == b.nD && a.g.nx == b.g.nx && a.g.nc == b.g.nc && a.g.nq == b.g.nq &&
+               a.g.x_lo == b.g.x_lo && a.g.k_lo == b.g.k_lo;
+      }
+      if (!same) return fail(h0, SDPGPU_ERR_ARG, "solve_multi: handle %d describes another problem than handle 0 (family, grid or pmf sizes differ)", r);
+    }
     const char* force = std::getenv("SDPGPU_MULTI_EXCHANGE");  // "copy": device-to-device copies even on distinct devices
     const bool want_copy = !distinct || (force && std::strcmp(force, "copy") == 0);
-    bool same_group = true;
-    for (int r = 0; r < n; ++r) same_group = same_group && hs[r]->siblings.size() == (size_t)n && std::equal(hs, hs + n, hs[r]->siblings.begin());
+    bool same_group = true, any_comm = false;
+    for (int r = 0; r < n; ++r) {
+      same_group = same_group && hs[r]->siblings.size() == (size_t)n && std::equal(hs, hs + n, hs[r]->siblings.begin());
+      any_comm = any_comm || hs[r]->comm != nullptr;
+    }
     RcclApi* api = nullptr;
-    if (!want_copy) {
+    if (!want_copy || any_comm) {  // (also when only an earlier communicator has to be destroyed)
       api = rccl();
-      if (!api) return fail(h0, SDPGPU_ERR_DEVICE, "%s", g_rccl.err.c_str());
+      if (!api && !want_copy) return fail(h0, SDPGPU_ERR_DEVICE, "%s", g_rccl.err.c_str());
     }
     if (!same_group || hs[0]->multi_copy != want_copy || (!want_copy && !hs[0]->comm)) {
       for (int r = 0; r < n; ++r) {
-        if (hs[r]->comm && api) (void)api->CommDestroy((ncclComm_t)hs[r]->comm);
+        if (hs[r]->comm && api) {
+          HIP_TRY(h0, hipSetDevice(hs[r]->device));
+          (void)api->CommDestroy((ncclComm_t)hs[r]->comm);
+        }
         hs[r]->comm = nullptr;
       }
       if (!want_copy) {
@@ -327,6 +432,47 @@ int sdpgpu_solve_multi(sdpgpu_handle** hs, int32_t n, int32_t flags) {
         if (rc) return hs[r] == h0 ? rc : fail(h0, rc, "rank %d: %s", r, hs[r]->err.c_str());
       }
     const int last = (flags & SDPGPU_SHARDED_GATHER_FIRST) ? 1 : 2;
+
+    if ((flags & SDPGPU_SHARDED_THREADS) && n > 1) {
+      // one host thread per rank: the sweep of sdpgpu_solve_sharded on its own device
+      Rendezvous meet;
+      meet.n = n;
+      std::vector<int> rcs((size_t)n, SDPGPU_OK);
+      const int inner = flags & ~(SDPGPU_SHARDED_THREADS | (want_copy ? SDPGPU_SHARDED_OVERLAP : 0));
+      auto body = [&](int r) {
+        sdpgpu_handle* h = hs[r];
+        h->err.clear();
+        int rc;
+        try {
+          rc = sweep_rank(h, inner, [&](int period, bool overlapped) -> int {
+            if (!want_copy) return enqueue_allgather(h, api, period, overlapped ? h->comm_stream : h->stream);
+            // shared device: publish "my kernel of this period is enqueued", wait for everybody's, then pull
+            HIP_TRY(h, hipEventRecord(h->ev_comp, h->stream));
+            if (!meet.arrive()) return fail(h, SDPGPU_ERR_STATE, "another rank's sweep failed");
+            int rc2 = enqueue_copies(hs, n, r, period, h);
+            // (nobody re-records its event for the next period before every rank has enqueued its waits on this one)
+            if (!meet.arrive() && !rc2) rc2 = fail(h, SDPGPU_ERR_STATE, "another rank's sweep failed");
+            return rc2;
+          });
+        } catch (...) {
+          rc = fail(h, SDPGPU_ERR_ARG, "exception in the rank's thread");
+        }
+        if (rc) meet.abandon(r);
+        rcs[(size_t)r] = rc;
+      };
+      std::vector<std::thread> th;
+      th.reserve((size_t)n);
+      for (int r = 0; r < n; ++r) th.emplace_back(body, r);
+      for (auto& t : th) t.join();
+      for (int pass = 0; pass < 2; ++pass)  // the rank that failed first, then anybody else
+        for (int r = 0; r < n; ++r) {
+          if (!rcs[(size_t)r] || (pass == 0 && r != meet.culprit)) continue;
+          const std::string why = hs[r]->err;
+          return fail(h0, rcs[(size_t)r], "rank %d: %s", r, why.c_str());
+        }
+      return SDPGPU_OK;
+    }
+
     for (int r = 0; r < n; ++r) {
       sdpgpu_handle* h = hs[r];
       HIP_TRY(h0, hipSetDevice(h->device));
@@ -354,21 +500,13 @@ int sdpgpu_solve_multi(sdpgpu_handle** hs, int32_t n, int32_t flags) {
         }
         NCCL_TRY(h0, api, api->GroupEnd());
       } else {
-        // rank q pulls slab r of the row from rank r once r's kernel has finished
-        const size_t cnt = (size_t)(h0->per[period - 1].S_pad / n);
         for (int r = 0; r < n; ++r) {
           HIP_TRY(h0, hipSetDevice(hs[r]->device));
           HIP_TRY(h0, hipEventRecord(hs[r]->ev_comp, hs[r]->stream));
         }
-        for (int q = 0; q < n && cnt; ++q) {
-          HIP_TRY(h0, hipSetDevice(hs[q]->device));
-          char* dst = (char*)exchange_row(hs[q], period);
-          for (int r = 0; r < n; ++r) {
-            if (r == q) continue;
-            const char* src = (const char*)exchange_row(hs[r], period);
-            HIP_TRY(h0, hipStreamWaitEvent(hs[q]->stream, hs[r]->ev_comp, 0));
-            HIP_TRY(h0, hipMemcpyAsync(dst + (size_t)r * cnt * 8, src + (size_t)r * cnt * 8, cnt * 8, hipMemcpyDeviceToDevice, hs[q]->stream));
-          }
+        for (int q = 0; q < n; ++q) {
+          int rc = enqueue_copies(hs, n, q, period, h0);
+          if (rc) return rc;
         }
       }
     }

@@ -56,6 +56,7 @@ struct PeriodInfo {
   double overhead = 0;
   bool overhead_set = false;
   int64_t cells_rank = 0, cells_all = 0;
+  bool cells_counted = false;  // count_cells has run for this slab, overhead and action counts (reset by whatever changes them)
   hipEvent_t ev0 = nullptr, ev1 = nullptr;
   bool timed = false;
   int32_t kernel_used = 0;
@@ -151,6 +152,7 @@ struct sdpgpu_handle {
   // multi-GPU (sdpgpu_comm.hip): the communicator of this rank, a second stream for the overlapped schedule, and --
   // sdpgpu_solve_multi with several ranks on ONE device -- the sibling handles whose rows are exchanged by copies
   void* comm = nullptr;  // ncclComm_t
+  bool comm_prepared = false;  // sdpgpu_comm_prepare has succeeded (tables allocated, device pinned, RCCL loads)
   hipStream_t comm_stream = nullptr;
   hipEvent_t ev_comp = nullptr, ev_comm = nullptr;
   std::vector<sdpgpu_handle*> siblings;  // handles[0..n) of the last sdpgpu_solve_multi (set on every member)

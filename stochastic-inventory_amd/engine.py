@@ -209,6 +209,12 @@ class SdpEngine:
             raise SdpgpuError(rc, lib.sdpgpu_last_error(None).decode())
         return buf.raw
 
+    def comm_prepare(self):
+        """sdpgpu_comm_prepare: what can fail on this rank ALONE (device tables, RCCL load) -- before the ranks agree to
+        enter the collective comm_init."""
+        _abi.share_rccl_with_torch()
+        self._check(self._lib.sdpgpu_comm_prepare(self._h))
+
     def comm_init(self, unique_id: bytes, rank: int, world: int):
         """Collective over the world's ranks (ncclCommInitRank on this handle's device)."""
         if len(unique_id) != _abi.UNIQUE_ID_BYTES:
@@ -230,12 +236,14 @@ class SdpEngine:
         self._check(self._lib.sdpgpu_solve_sharded(self._h, flags))
 
     @staticmethod
-    def solve_multi(engines, sync: bool = True, gather_first: bool = False):
-        """One process driving every rank: engines[r] is rank r of len(engines) (sdpgpu_solve_multi)."""
+    def solve_multi(engines, sync: bool = True, gather_first: bool = False, threads: bool = False):
+        """One process driving every rank: engines[r] is rank r of len(engines) (sdpgpu_solve_multi).  threads: one host
+        thread per rank inside the library (SDPGPU_SHARDED_THREADS) instead of one thread issuing for all."""
         lib = _abi.load()
         _abi.share_rccl_with_torch()
         arr = (C.c_void_p * len(engines))(*[e._h for e in engines])
-        flags = (_abi.SHARDED_SYNC if sync else 0) | (_abi.SHARDED_GATHER_FIRST if gather_first else 0)
+        flags = (_abi.SHARDED_SYNC if sync else 0) | (_abi.SHARDED_GATHER_FIRST if gather_first else 0) | \
+                (_abi.SHARDED_THREADS if threads else 0)
         rc = lib.sdpgpu_solve_multi(arr, len(engines), flags)
         if rc:
             raise SdpgpuError(rc, lib.sdpgpu_last_error(engines[0]._h).decode())

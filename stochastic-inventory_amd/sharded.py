@@ -46,11 +46,17 @@ def init_native_comm(engine: SdpEngine, group=None) -> bool:
         dist.all_gather_object(flags, bool(ok), group=group)
         return all(flags)
 
-    try:  # phase 1, every rank: does RCCL load here?  (only rank 0's id is used)
-        uid = SdpEngine.comm_unique_id()
+    # phase 1, every rank, nothing collective: the device tables are allocated, the device is pinned and RCCL loads
+    # (sdpgpu_comm_prepare) -- whatever can fail on ONE rank fails here, before anybody is inside ncclCommInitRank; rank 0
+    # alone draws the unique id (ncclGetUniqueId starts a bootstrap thread: no reason to have one on every rank)
+    uid = None
+    try:
+        engine.comm_prepare()
+        if rank == 0:
+            uid = SdpEngine.comm_unique_id()
         ok = True
     except Exception as exc:
-        uid, ok = None, False
+        ok = False
         init_native_comm.last_error = str(exc)
     if not agree(ok):
         return False

@@ -35,7 +35,11 @@ def _check_rank(eng, V, pol, T, first_full, label):
                                         (cases.f3_testing, 5), (cases.f4_overdraft, 2), (cases.f5_cash_leadtime, 2),
                                         (cases.f6_survival, 3), (cases.f3_dyadic_wide, 3), (cases.f3_grid_prices, 4),
                                         (cases.f2_clamped, 5)], ids=lambda v: getattr(v, "__name__", str(v)))
-def test_solve_multi_shared_device(sia, oracle, make, world):
+@pytest.mark.parametrize("threads", [False, True], ids=["one-thread", "thread-per-rank"])
+def test_solve_multi_shared_device(sia, oracle, make, world, threads):
+    """Both ways of driving the ranks from one process: ONE host thread issuing for all (default), and one host thread
+    per rank inside the library (SDPGPU_SHARDED_THREADS: each runs sdpgpu_solve_sharded's sweep; the copies of a shared
+    device are ordered by a per-period rendezvous of the threads)."""
     w = make()
     V, pol = _oracle_tables(oracle, w)
     engs = []
@@ -45,13 +49,13 @@ def test_solve_multi_shared_device(sia, oracle, make, world):
             d.rank, d.world_size, d.device = r, world, 0
             engs.append(sia.SdpEngine(d, w.pmf, w.overhead()))
         for rep in range(2):  # the second call reuses the group
-            sia.SdpEngine.solve_multi(engs, sync=True)
+            sia.SdpEngine.solve_multi(engs, sync=True, threads=threads)
             cells = 0
             for r, e in enumerate(engs):
                 _check_rank(e, V, pol, w.T, 2, f"rank {r}/{world} (call {rep})")
                 cells += int(e.stats().cells_evaluated)
             assert cells == int(engs[0].stats().cells_all_ranks)
-        sia.SdpEngine.solve_multi(engs, sync=True, gather_first=True)
+        sia.SdpEngine.solve_multi(engs, sync=True, gather_first=True, threads=threads)
         for r, e in enumerate(engs):
             _check_rank(e, V, pol, w.T, 1, f"rank {r}/{world} (V_1 gathered)")
     finally:
@@ -68,6 +72,8 @@ def test_solve_sharded_one_rank_communicator(sia, oracle, make, overlap):
     d = w.desc()
     d.device = 0
     with sia.SdpEngine(d, w.pmf, w.overhead()) as eng:
+        eng.comm_prepare()  # (the non-collective half: tables, device, RCCL load -- the ranks agree on it before comm_init)
+        eng.comm_prepare()  # idempotent
         eng.comm_init(sia.SdpEngine.comm_unique_id(), 0, 1)
         eng.solve_sharded(overlap=overlap, sync=True, gather_first=True)
         _check_rank(eng, V, pol, w.T, 1, "one-rank communicator")
@@ -116,3 +122,42 @@ def test_comm_argument_errors(sia):
     with sia.SdpEngine(d2, w.pmf) as e1, sia.SdpEngine(w.desc(), w.pmf) as e0:
         with pytest.raises(sia.SdpgpuError):
             sia.SdpEngine.solve_multi([e0, e1])    # e0 is rank 0 of ONE
+
+
+def test_solve_multi_refuses_handles_of_different_problems(sia):
+    """handles[r] must describe ONE problem: a second handle with another grid (or pmf size) would make the exchange copy
+    S_pad / n elements of handle 0's row into a shorter row.  SDPGPU_ERR_ARG, nothing launched."""
+    w = cases.f1_small()
+    other = cases.f1_clsp_main()
+    other.pmf = other.pmf[:w.T] if len(other.pmf) >= w.T else other.pmf + [other.pmf[-1]] * (w.T - len(other.pmf))
+    d0, d1 = w.desc(), other.desc()
+    d0.rank, d0.world_size, d0.device = 0, 2, 0
+    d1.rank, d1.world_size, d1.device = 1, 2, 0
+    assert d0.periods == d1.periods
+    with sia.SdpEngine(d0, w.pmf) as e0, sia.SdpEngine(d1, other.pmf) as e1:
+        for threads in (False, True):
+            with pytest.raises(sia.SdpgpuError) as ei:
+                sia.SdpEngine.solve_multi([e0, e1], threads=threads)
+            assert ei.value.code == 1 and "another problem" in ei.value.message
+
+
+def test_solve_multi_threads_reports_a_failing_rank(sia, monkeypatch):
+    """One rank's sweep fails (a forced window plan that does not exist): the other ranks' threads are released from the
+    rendezvous and the call returns the failing rank's error instead of hanging."""
+    w = cases.f1_clsp_main()
+    engs = []
+    try:
+        for r in range(3):
+            d = w.desc()
+            d.rank, d.world_size, d.device = r, 3, 0
+            if r == 1:
+                monkeypatch.setenv("SDPGPU_WIN_R", "7")  # (read at create: only rank 1's handle carries it)
+            else:
+                monkeypatch.delenv("SDPGPU_WIN_R", raising=False)
+            engs.append(sia.SdpEngine(d, w.pmf, w.overhead()))
+        with pytest.raises(sia.SdpgpuError) as ei:
+            sia.SdpEngine.solve_multi(engs, sync=True, threads=True)
+        assert "rank 1" in ei.value.message and "no instantiation" in ei.value.message
+    finally:
+        for e in engs:
+            e.close()
