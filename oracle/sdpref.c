@@ -195,20 +195,43 @@ static double action_value(const ctx_t* c, const st_t* s, int32_t k) {
   return (double)k * c->d->step;
 }
 
-/* Piecewise interest, CashOverdraft.java:87-95 == SingleProductLeadtime.java:88-96. */
-static double overdraft_interest(const sdpgpu_desc* d, double cashBalanceBefore) {
+/* ------------------------------------------------------------------------------------------
+ * Statements the overdraft / lost-sales lambdas of the reference share, written ONCE here and used by every family that has
+ * them -- F4 (CashOverdraft.java:80-118), F5 (SingleProductLeadtime.java:82-119) and the two-product KAT family
+ * (MultiProductLeadtime.java:162-223), whose recorded outputs (MultiProductLeadtime.java:30-50, tests/golden/
+ * kat_reference.json) therefore execute the very functions F4 and F5 are checked with.
+ * ---------------------------------------------------------------------------------------- */
+/* Piecewise interest, CashOverdraft.java:87-95 == SingleProductLeadtime.java:88-96 == MultiProductLeadtime.java:184-192
+ * (rates r0 / r2 / r3 there are r0 / r1 / r2 in the two-product file). */
+static double interest_piecewise(double r0, double r_overdraft, double r_beyond, double interest_free, double limit,
+                                 double cashBalanceBefore) {
   double interest = 0;
   if (cashBalanceBefore >= 0)
-    interest = -d->r0 * cashBalanceBefore;
-  else if (cashBalanceBefore >= -d->interest_free_amount)
+    interest = -r0 * cashBalanceBefore;
+  else if (cashBalanceBefore >= -interest_free)
     interest = 0;
-  else if (cashBalanceBefore >= -d->overdraft_limit)
-    interest = d->r2 * (-cashBalanceBefore - d->interest_free_amount);
+  else if (cashBalanceBefore >= -limit)
+    interest = r_overdraft * (-cashBalanceBefore - interest_free);
   else
-    interest = d->r3 * (-cashBalanceBefore - d->overdraft_limit) +
-               d->r2 * (d->overdraft_limit - d->interest_free_amount);
+    interest = r_beyond * (-cashBalanceBefore - limit) + r_overdraft * (limit - interest_free);
   return interest;
 }
+static double overdraft_interest(const sdpgpu_desc* d, double cashBalanceBefore) {
+  return interest_piecewise(d->r0, d->r2, d->r3, d->interest_free_amount, d->overdraft_limit, cashBalanceBefore);
+}
+/* `price * Math.min(stock, demand)`: CashOverdraft.java:81, SingleProductLeadtime.java:83, MultiProductLeadtime.java:170-171 */
+static double lost_sales_revenue(double price, double stock, double demand) { return price * jmin(stock, demand); }
+/* `cash - orderingCosts - overheadCost`: SingleProductLeadtime.java:87, MultiProductLeadtime.java:182 (CashOverdraft.java:86
+ * subtracts the fixed cost first: the caller passes cash - fixedCost) */
+static double balance_before(double cash, double orderingCosts, double overhead) { return cash - orderingCosts - overhead; }
+/* `cashBalanceBefore - interest + revenue`: CashOverdraft.java:96, SingleProductLeadtime.java:97, MultiProductLeadtime.java:193 */
+static double balance_after(double before, double interest, double revenue) { return before - interest + revenue; }
+/* `Math.max(0, level)`: the lost-sales end inventory of every transition (CashOverdraft.java:108, SingleProductLeadtime.java:108,
+ * MultiProductLeadtime.java:205-208) */
+static double end_inventory(double level) { return jmax(0, level); }
+/* the clamp as the reference writes it: upper ternary, then lower ternary (CashOverdraft.java:110-113 etc.) */
+static double clamp_upper(double v, double hi) { return v > hi ? hi : v; }
+static double clamp_lower(double v, double lo) { return v < lo ? lo : v; }
 
 /* immediateValue.apply(state, action, randomDemand) */
 static double imm_value(const ctx_t* c, const st_t* s, double action, double randomDemand) {
@@ -286,25 +309,25 @@ static double imm_value(const ctx_t* c, const st_t* s, double action, double ran
       return cashIncrement;
     }
     case SDPGPU_FAMILY_OVERDRAFT: { /* CashOverdraft.java:80-104 */
-      double revenue = d->price * jmin(s->x + action, randomDemand);
+      double revenue = lost_sales_revenue(d->price, s->x + action, randomDemand);
       double fixedCost = action > 0 ? d->fixed_order_cost : 0;
       double variableCost = d->unit_order_cost * action;
       double inventoryLevel = s->x + action - randomDemand;
-      double cashBalanceBefore = s->cash - fixedCost - variableCost - overhead_at(c, s->period);
+      double cashBalanceBefore = balance_before(s->cash - fixedCost, variableCost, overhead_at(c, s->period));
       double interest = overdraft_interest(d, cashBalanceBefore);
-      double cashBalanceAfter = cashBalanceBefore - interest + revenue;
+      double cashBalanceAfter = balance_after(cashBalanceBefore, interest, revenue);
       double cashIncrement = cashBalanceAfter - s->cash;
       double salValue = s->period == c->T ? d->salvage_value * jmax(inventoryLevel, 0) : 0;
       cashIncrement += salValue;
       return cashIncrement;
     }
     case SDPGPU_FAMILY_CASH_LEADTIME: { /* SingleProductLeadtime.java:82-104 */
-      double revenue = d->price * jmin(s->x + s->preq, randomDemand);
+      double revenue = lost_sales_revenue(d->price, s->x + s->preq, randomDemand);
       double variableCost = d->unit_order_cost * action;
       double inventoryLevel = s->x + s->preq - randomDemand;
-      double cashBalanceBefore = s->cash - variableCost - overhead_at(c, s->period);
+      double cashBalanceBefore = balance_before(s->cash, variableCost, overhead_at(c, s->period));
       double interest = overdraft_interest(d, cashBalanceBefore);
-      double cashBalanceAfter = cashBalanceBefore - interest + revenue;
+      double cashBalanceAfter = balance_after(cashBalanceBefore, interest, revenue);
       double cashIncrement = cashBalanceAfter - s->cash;
       double salValue = s->period == c->T ? d->salvage_value * jmax(inventoryLevel, 0) : 0;
       cashIncrement += salValue;
@@ -379,25 +402,25 @@ static void transition(const ctx_t* c, const st_t* s, double action, double rand
       /* fall through */
     case SDPGPU_FAMILY_SURVIVAL:   /* cashSurvival.java:128-143 (same statements; `Math.round(nextCash * 1) / 1`) */
     case SDPGPU_FAMILY_OVERDRAFT: { /* CashOverdraft.java:107-118 */
-      double nextInventory = jmax(0, s->x + action - randomDemand);
+      double nextInventory = end_inventory(s->x + action - randomDemand);
       double nextCash = s->cash + imm_value(c, s, action, randomDemand);
-      nextCash = nextCash > d->max_cash ? d->max_cash : nextCash;
-      nextCash = nextCash < d->min_cash ? d->min_cash : nextCash;
-      nextInventory = nextInventory > d->max_inventory ? d->max_inventory : nextInventory;
-      nextInventory = nextInventory < d->min_inventory ? d->min_inventory : nextInventory;
+      nextCash = clamp_upper(nextCash, d->max_cash);
+      nextCash = clamp_lower(nextCash, d->min_cash);
+      nextInventory = clamp_upper(nextInventory, d->max_inventory);
+      nextInventory = clamp_lower(nextInventory, d->min_inventory);
       nextCash = round_cash(d, nextCash);
       out->x = nextInventory;
       out->cash = nextCash;
       return;
     }
     case SDPGPU_FAMILY_CASH_LEADTIME: { /* SingleProductLeadtime.java:107-119 */
-      double nextInventory = jmax(0, s->x + s->preq - randomDemand);
+      double nextInventory = end_inventory(s->x + s->preq - randomDemand);
       double nextCash = s->cash + imm_value(c, s, action, randomDemand);
       double nextPreQ = action;
-      nextCash = nextCash > d->max_cash ? d->max_cash : nextCash;
-      nextCash = nextCash < d->min_cash ? d->min_cash : nextCash;
-      nextInventory = nextInventory > d->max_inventory ? d->max_inventory : nextInventory;
-      nextInventory = nextInventory < d->min_inventory ? d->min_inventory : nextInventory;
+      nextCash = clamp_upper(nextCash, d->max_cash);
+      nextCash = clamp_lower(nextCash, d->min_cash);
+      nextInventory = clamp_upper(nextInventory, d->max_inventory);
+      nextInventory = clamp_lower(nextInventory, d->min_inventory);
       nextCash = round_cash(d, nextCash);
       out->x = nextInventory;
       out->cash = nextCash;
@@ -1155,10 +1178,10 @@ static void dump_memo(const mlentry* tab, int64_t cap, int64_t n) {
 static double ml_imm(const sdpref_multilead* k, const mst_t* s, int32_t a1, int32_t a2, int32_t dm1, int32_t dm2) {
   double action1 = a1, action2 = a2, demand1 = dm1, demand2 = dm2;
   double preQ1 = s->q1, preQ2 = s->q2;
-  double endInventory1 = jmax(0, s->i1 + preQ1 - demand1);
-  double endInventory2 = jmax(0, s->i2 + preQ2 - demand2);
-  double revenue1 = k->price[0] * jmin(demand1, s->i1 + preQ1);
-  double revenue2 = k->price[1] * jmin(s->i2 + preQ2, demand2);
+  double endInventory1 = end_inventory(s->i1 + preQ1 - demand1);
+  double endInventory2 = end_inventory(s->i2 + preQ2 - demand2);
+  double revenue1 = lost_sales_revenue(k->price[0], demand1, s->i1 + preQ1); /* :170 writes Math.min(demand1, stock) */
+  double revenue2 = lost_sales_revenue(k->price[1], s->i2 + preQ2, demand2);
   double revenue = revenue1 + revenue2;
   double orderingCost1 = k->vari_cost[0] * action1;
   double orderingCost2 = k->vari_cost[1] * action2;
@@ -1166,17 +1189,9 @@ static double ml_imm(const sdpref_multilead* k, const mst_t* s, int32_t a1, int3
   double salValue = 0;
   if (s->period == k->T) salValue = k->sal_value[0] * endInventory1 + k->sal_value[1] * endInventory2;
   int t = s->period - 1;
-  double cashBalanceBefore = s->cash - orderingCosts - k->overhead[t];
-  double interest = 0;
-  if (cashBalanceBefore >= 0)
-    interest = -k->r0 * cashBalanceBefore;
-  else if (cashBalanceBefore >= -k->interest_free)
-    interest = 0;
-  else if (cashBalanceBefore >= -k->limit)
-    interest = k->r1 * (-cashBalanceBefore - k->interest_free);
-  else
-    interest = k->r2 * (-cashBalanceBefore - k->limit) + k->r1 * (k->limit - k->interest_free);
-  double cashBalanceAfter = cashBalanceBefore - interest + revenue + salValue;
+  double cashBalanceBefore = balance_before(s->cash, orderingCosts, k->overhead[t]);
+  double interest = interest_piecewise(k->r0, k->r1, k->r2, k->interest_free, k->limit, cashBalanceBefore);
+  double cashBalanceAfter = balance_after(cashBalanceBefore, interest, revenue) + salValue;
   double cashIncrement = cashBalanceAfter - s->cash;
   return cashIncrement;
 }
@@ -1186,14 +1201,14 @@ static void ml_trans(const sdpref_multilead* k, const mst_t* s, int32_t a1, int3
                      mst_t* out) {
   double nextPreQ1 = a1, nextPreQ2 = a2;
   double endInventory1 = s->i1 + s->q1 - (double)dm1;
-  endInventory1 = jmax(0, endInventory1);
+  endInventory1 = end_inventory(endInventory1);
   double endInventory2 = s->i2 + s->q2 - (double)dm2;
-  endInventory2 = jmax(0, endInventory2);
+  endInventory2 = end_inventory(endInventory2);
   double nextCash = s->cash + ml_imm(k, s, a1, a2, dm1, dm2);
-  nextCash = nextCash > k->max_cash ? k->max_cash : nextCash;
-  nextCash = nextCash < k->min_cash ? k->min_cash : nextCash;
-  endInventory1 = endInventory1 > k->max_inventory ? k->max_inventory : endInventory1;
-  endInventory2 = endInventory2 < k->min_inventory ? k->min_inventory : endInventory2;
+  nextCash = clamp_upper(nextCash, k->max_cash);
+  nextCash = clamp_lower(nextCash, k->min_cash);
+  endInventory1 = clamp_upper(endInventory1, k->max_inventory);
+  endInventory2 = clamp_lower(endInventory2, k->min_inventory);
   if (k->cash_int_cast) nextCash = (double)jd2i(nextCash); /* :219, commented out in the file as it stands */
   endInventory1 = (double)jd2i(endInventory1);
   endInventory2 = (double)jd2i(endInventory2);
@@ -1209,6 +1224,11 @@ static void ml_trans(const sdpref_multilead* k, const mst_t* s, int32_t a1, int3
  * i = ai * Qbound + aj enumerates buildActionList's double loop (MultiProductLeadtime.java:150-158), demand index
  * j = di * n2 + dj the rows of GetPmfMulti.getPmf (GetPmfMulti.java:157-172), whose third column is the product of the two
  * probabilities. */
+/* `thisActionsValue > val + 0.1` (CashRecursionMultiLead.java:80).  Tests may set the slack to 0 to turn the family's
+ * arg-max into a true one (the bridge to the single-product family, tests/test_oracle_kat.py); NOT thread-safe. */
+static double g_ml_tolerance = 0.1;
+void sdpref_kat_set_tolerance(double tol) { g_ml_tolerance = tol; }
+
 static double ml_value(mlmemo* m, const mst_t* s);
 typedef struct ml_env {
   mlmemo* m;
@@ -1242,7 +1262,7 @@ static double ml_value(mlmemo* m, const mst_t* s) {
   double val;
   int32_t best;
   ml_env ev = {m, s};
-  bellman_loop(k->q_bound * k->q_bound, k->n1 * k->n2, prob, k->discount, s->period < k->T, 1, 0.1, ml_cb_begin, ml_cb_imm,
+  bellman_loop(k->q_bound * k->q_bound, k->n1 * k->n2, prob, k->discount, s->period < k->T, 1, g_ml_tolerance, ml_cb_begin, ml_cb_imm,
                ml_cb_next, &ev, &val, &best);
   int32_t b1 = best / k->q_bound, b2 = best % k->q_bound;
   if ((m->n + 1) * 2 > m->cap) ml_grow(m);

@@ -100,6 +100,8 @@ typedef struct sdpref_multilead {
 
 int sdpref_kat_multilead(const sdpref_multilead* k, double* final_value, int32_t* q1, int32_t* q2,
                          int64_t* states_visited, int64_t* cells);
+/* The `+ 0.1` slack of the family's arg-max (CashRecursionMultiLead.java:80); default 0.1.  Test harness use only. */
+void sdpref_kat_set_tolerance(double tol);
 
 /* CashRecursionMulti.getExpectedValue (CashRecursionMulti.java:82-116) over the lambdas of MultiItemCash.java:66-118:
  * literal memoised recursion.  Same fields as sdpgpu_multicash (include/sdpgpu.h). */

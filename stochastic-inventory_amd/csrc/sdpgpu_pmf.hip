@@ -11,6 +11,7 @@
 // prob(j) indexed by POSITION j not by the demand value (:124), the covered mass as normaliser (:123,:126-129),
 // UniformIntDist taken from distributions[0] for every period (:97-111); CLSP.main: un-truncated quantiles and the
 // cdf-difference branch for Poisson (PoissonDist is not a DiscreteDistribution, CLSP.java:236).
+// tests/test_pmf_reference.py pins the tiles to a 50-digit table (tests/golden/pmf_reference.json, mpmath) at 1e-13;
 // tests/test_pmf_abi.py compares with the Python restatement over scipy (stochastic-inventory_amd/pmf.py) to 1e-12.
 #include "sdpgpu_internal.hpp"
 
@@ -27,9 +28,47 @@ struct Dist {
 };
 
 // ---- Poisson(lambda) ------------------------------------------------------------------------------------------
+// The mass by the saddle-point form (C. Loader, "Fast and accurate computation of binomial probabilities", 2000):
+//     p(k; lam) = exp(-stirlerr(k) - bd0(k, lam)) / sqrt(2 pi k),
+// stirlerr(k) = log k! - log(sqrt(2 pi k) (k/e)^k), bd0(k, lam) = k log(k / lam) + lam - k: both terms are small where the
+// mass is not, so the exponent carries no cancellation.  (exp(-lam + k log lam - lgamma(k + 1)) -- this file's first form --
+// subtracts terms of size ~k log k: 2e-13 relative at lambda = 180, which the 50-digit table of
+// tests/golden/pmf_reference.json showed.)
+double stirlerr(double n) {  // n: a non-negative integer
+  static const double small[16] = {0.0,                        0.08106146679532725821967026, 0.04134069595540929409382208,
+                                   0.02767792568499833914878929, 0.02079067210376509311152277, 0.01664469118982119216319487,
+                                   0.01387612882307074799874573, 0.01189670994589177009505572, 0.01041126526197209649747857,
+                                   0.009255462182712732917728637, 0.008330563433362871256469319, 0.007573675487951840794972024,
+                                   0.006942840107209529865664153, 0.006408994188004207068439631, 0.005951370112758847735624416,
+                                   0.00555473355196280137103869};
+  if (n <= 15.0) return small[(int)n];
+  const double S0 = 1.0 / 12, S1 = 1.0 / 360, S2 = 1.0 / 1260, S3 = 1.0 / 1680, S4 = 1.0 / 1188;
+  const double nn = n * n;
+  if (n > 500) return (S0 - S1 / nn) / n;
+  if (n > 80) return (S0 - (S1 - S2 / nn) / nn) / n;
+  if (n > 35) return (S0 - (S1 - (S2 - S3 / nn) / nn) / nn) / n;
+  return (S0 - (S1 - (S2 - (S3 - S4 / nn) / nn) / nn) / nn) / n;
+}
+double bd0(double x, double np) {  // x log(x / np) + np - x without cancellation near x == np
+  if (std::fabs(x - np) < 0.1 * (x + np)) {
+    double v = (x - np) / (x + np);
+    double s = (x - np) * v;
+    double ej = 2 * x * v;
+    v = v * v;
+    for (int j = 1; j < 1000; ++j) {
+      ej *= v;
+      const double s1 = s + ej / (2 * j + 1);
+      if (s1 == s) return s1;
+      s = s1;
+    }
+  }
+  return x * std::log(x / np) + np - x;
+}
 double poisson_prob(double lam, int64_t k) {
   if (k < 0) return 0.0;
-  return std::exp(-lam + (double)k * std::log(lam) - std::lgamma((double)k + 1.0));
+  if (k == 0) return std::exp(-lam);
+  const double x = (double)k;
+  return std::exp(-stirlerr(x) - bd0(x, lam)) / std::sqrt(2 * kPi * x);
 }
 double poisson_cdf(double lam, double x) {
   if (x < 0) return 0.0;

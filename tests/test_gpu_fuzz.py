@@ -171,3 +171,83 @@ def test_random_wide_cash_rows_bit_exact(sia, oracle, monkeypatch):
             for period in range(1, w.T + 1):
                 assert np.array_equal(eng.policy(period), pol[period - 1]), f"{w.name} t={period}: policy"
                 assert np.array_equal(eng.values(period), V[period - 1]), f"{w.name} t={period}: values"
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# Large magnitudes: the proof-carrying shortcuts of the cash kernels near their admission limit
+# ---------------------------------------------------------------------------------------------------------------
+def make_large_magnitude_cash_instance(seed, past_limit=False):
+    """F3 / F4 on wide cash rows whose BALANCES are large: cash in tenths or hundredths around 2.5e7 .. 4.9e7 (tenths) or
+    2.5e6 .. 4.9e6 (hundredths), i.e. bound * mult within a factor two of the 5e8 up to which cash_row_eligible admits the
+    integer-domain clamp, the uniform-key trips (|mult * inc - delta| < 2^-20 with the balance cancelled) and the LEAN
+    elisions -- the magnitudes at which the chain-error argument behind them (the reference's rounded floating-point chain
+    cash + inc, times mult, stays within +-0.5 of key + delta) has the least room: one ulp of the balance is 7.5e-9 there,
+    against 1.4e-14 at the toy magnitudes of make_instance.  Decimal prices on and off the cash grid.
+    past_limit: the same shapes with bound * mult beyond 5e8 -- the launcher must fall back to the generic kernel."""
+    rng = np.random.default_rng(991000 + seed)
+    T = int(rng.integers(2, 4))
+    hundredths = bool(rng.integers(0, 2))
+    mult = 100.0 if hundredths else 10.0
+    unit = 1.0 / mult
+    on_grid = bool(rng.integers(0, 4))            # three in four: prices and costs on the cash grid (uniform-key trips)
+    money = (lambda lo, hi: float(round(rng.uniform(lo, hi) / unit) * unit)) if on_grid else \
+            (lambda lo, hi: float(round(rng.uniform(lo, hi), 3) + 0.0005))
+    scale = 5.0e8 / mult                          # the balance at which bound * mult reaches the limit
+    base = float(rng.uniform(1.06, 1.6) if past_limit else rng.uniform(0.5, 0.93)) * scale
+    # rows wide enough, and prices small enough, for most successors to land INSIDE the row (not on its clamped ends): a unit
+    # sold moves the balance by 5 .. 60 keys, the row has 1500 .. 5000 of them
+    nc = int(rng.integers(1500, 5000))
+    family4 = bool(rng.integers(0, 4) == 0)
+    if family4:
+        base /= 3.02                              # (the launcher's bound multiplies the balance by 1 + the largest rate, r3 = 2)
+    base = float(np.floor(base * mult) / mult)
+    pscale = 60.0 / mult
+    common = dict(price=money(0.1 * pscale, pscale), variCost=max(unit, money(0.03 * pscale, 0.3 * pscale)),
+                  salvageValue=money(0, 0.1 * pscale),
+                  maxOrderQuantity=float(rng.integers(3, 16)), minInventoryState=0.0, maxInventoryState=float(rng.integers(2, 9)),
+                  minCashState=base, maxCashState=base + (nc - 1) / mult, iniInventory=0.0, iniCash=base + 5.0,
+                  cashRoundMult=mult, cashRoundDiv=mult, cashRoundIntDiv=False)
+    overheads = [money(0, 0.5 * pscale) for _ in range(T)]
+    if family4:
+        f = OverdraftFunctor(fixOrderCost=money(0, 0.5 * pscale), r0=float(rng.choice([0, 0.01])), r2=0.1, r3=2.0,
+                             limit=float(rng.integers(10, 40)), interestFreeAmount=float(rng.integers(0, 10)),
+                             discountFactor=float(rng.choice([1.0, 0.9])), overheadCosts=overheads, **common)
+        return Workload(f"fuzz_big_f4_{seed}", f, OptDirection.MAX, _pmf(rng, T, d_max=12))
+    f = CashFunctor(fixOrderCost=float(rng.choice([0.0, money(0, 0.5 * pscale)])),
+                    holdingCost=float(rng.choice([0.0, money(0, 0.1 * pscale)])),
+                    depositeRate=float(rng.choice([0, 0, 0, 1e-9])), overheadRate=0.0, penaltyCost=float(rng.choice([0, 0, 0, 0.3])),
+                    discountFactor=float(rng.choice([1.0, 0.95])), cashFormula=int(rng.integers(0, 2)),
+                    overheadCosts=[float(rng.choice([0.0, o])) for o in overheads], **common)
+    direction = OptDirection.MAX if rng.integers(0, 4) else OptDirection.MIN
+    return Workload(f"fuzz_big_f3_{seed}", f, direction, _pmf(rng, T, unit_stride=bool(rng.integers(0, 3)), d_max=14))
+
+
+@pytest.mark.parametrize("past_limit", [False, True], ids=["within-2x-of-the-limit", "past-the-limit"])
+def test_large_magnitude_cash_shortcuts_bit_exact(sia, oracle, monkeypatch, past_limit):
+    """Three kernels against the oracle at balances of 2.5e7 .. 8e7 (tenths) / 2.5e6 .. 8e6 (hundredths): the automatically
+    selected one (the cash row kernels with every shortcut, while bound * mult < 5e8 -- the generic kernel beyond), the
+    cash row kernel with pairs and uniform-key trips switched off (the per-point quantiser path), and the generic kernel."""
+    n = int(os.environ.get("SDP_FUZZ_N", "14"))
+    seen = set()
+    for seed in range(n):
+        w = make_large_magnitude_cash_instance(seed, past_limit)
+        V, pol, cells = oracle.Problem(w.desc(), w.pmf, w.overhead()).solve(nthreads=8)
+        for variant in ("auto", "no-shortcuts", "generic"):
+            for k in ("SDPGPU_CASH_PAIR", "SDPGPU_CASH_UNI"):
+                monkeypatch.delenv(k, raising=False)
+            if variant == "no-shortcuts":
+                monkeypatch.setenv("SDPGPU_CASH_PAIR", "0")
+                monkeypatch.setenv("SDPGPU_CASH_UNI", "0")
+            d = w.desc()
+            d.kernel = 1 if variant == "generic" else 0
+            with sia.SdpEngine(d, w.pmf, w.overhead()) as eng:
+                eng.solve()
+                used = eng.stats().kernel_used
+                if variant != "generic":
+                    assert used == (1 if past_limit else 2), f"{w.name} {variant}: kernel {used}"
+                    seen.add(used)
+                assert eng.stats().cells_evaluated == cells, w.name
+                for period in range(1, w.T + 1):
+                    assert np.array_equal(eng.policy(period), pol[period - 1]), f"{w.name} {variant} t={period}: policy"
+                    assert np.array_equal(eng.values(period), V[period - 1]), f"{w.name} {variant} t={period}: values"
+    assert seen == ({1} if past_limit else {2})

@@ -68,3 +68,42 @@ def test_native_sharded_path_with_a_world_of_one(extra):
     assert rec["n_gpus"] == 1 and rec["check_vs_single_rank"] is True and rec["parity_gate"]["status"] == "ok"
     assert "RCCL all-gather issued by libsdpgpu.so" in rec["config"]["exchange"]
     assert rec["config"]["cells_per_rank"] == [rec["config"]["cells_per_step"]]
+
+
+def _device_count():
+    import torch
+    return torch.cuda.device_count()  # (counts devices without initialising the GPU in this process)
+
+
+@pytest.mark.parametrize("extra", [["--periods", "3"], ["--workload", "cfg2", "--periods", "8"]], ids=["target", "cfg2_key_rows"])
+def test_two_processes_native_rccl_between_devices(extra):
+    """The default N > 1 path itself: two processes, two DEVICES, ncclCommInitRank inside libsdpgpu.so and the in-place
+    all-gather between them (--exchange native), checked against a single-rank sweep.  Needs a node with two GPUs: the
+    one-GPU test box skips it (RCCL refuses two ranks on one device), a multi-GPU node runs it."""
+    if _device_count() < 2:
+        pytest.skip("needs two GPUs (RCCL between devices)")
+    port = 29950 + os.getpid() % 40
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr",
+           "127.0.0.1", "--master-port", str(port), os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2",
+           "--warmup", "1", "--exchange", "native", "--check", "--no-cpu-baseline", *extra]
+    out = subprocess.run(cmd, capture_output=True, text=True, timeout=420, cwd=ROOT)
+    assert out.returncode == 0, (out.stdout[-1500:], out.stderr[-2000:])
+    rec = json.loads([l for l in out.stdout.splitlines() if l.startswith("{")][-1])
+    assert rec["n_gpus"] == 2 and rec["check_vs_single_rank"] is True and rec["parity_gate"]["status"] == "ok"
+    assert "RCCL all-gather issued by libsdpgpu.so" in rec["config"]["exchange"] and "fell back" not in rec["config"]["exchange"]
+    assert len(rec["config"]["exchange_ms_per_rank"]) == 2 and rec["config"]["communicator_init_s"] > 0
+
+
+def test_stalled_rank_ends_the_gpu_bench_with_a_record():
+    """bench.py N > 1 on the GPU (two ranks over gloo on one device) with rank 1 stalled before its first sweep: both ranks'
+    watchdogs print the one-line record and the launcher returns non-zero in well under two minutes."""
+    port = 29900 + os.getpid() % 40
+    env = dict(os.environ, SDP_WATCHDOG_INJECT_STALL="first sweep:1", SDP_WATCHDOG_SCALE="0.1")  # 300 s -> 30 s
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr",
+           "127.0.0.1", "--master-port", str(port), os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2",
+           "--warmup", "1", "--backend", "gloo", "--no-cpu-baseline", "--workload", "cfg2", "--periods", "4", "--weak"]
+    out = subprocess.run(cmd, capture_output=True, text=True, timeout=300, cwd=ROOT, env=env)
+    assert out.returncode != 0
+    recs = [json.loads(l) for l in out.stdout.splitlines() if l.startswith("{") and "phase deadline exceeded" in l]
+    assert recs and all(r["phase"] == "first sweep" and r["value"] is None for r in recs)
+    assert {r["rank"] for r in recs} <= {0, 1} and all(r["world"] == 2 for r in recs)
