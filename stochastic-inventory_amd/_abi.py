@@ -105,6 +105,7 @@ class SdpgpuStats(C.Structure):
         ("fp64_ops_executed", C.c_double),
         ("lds_bytes", C.c_double),
         ("l1_bytes", C.c_double),
+        ("graph_replays", C.c_int64),
     ]
 
 

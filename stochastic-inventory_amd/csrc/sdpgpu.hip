@@ -340,9 +340,22 @@ void count_cells(sdpgpu_handle* h, int period) {
 // INTERIOR = the states whose cells read only THIS rank's slab of V_{t+1}, BOUNDARY = the rest.
 // range_lo/range_hi >= 0: sdpgpu_run_period_range -- the states [range_lo, range_hi) instead of this rank's slab
 // (F1 window kernel only: the one family whose dependency footprint is bounded).
+void graph_drop(sdpgpu_handle* h) {
+  if (h->sweep_exec) (void)hipGraphExecDestroy(h->sweep_exec);
+  if (h->sweep_graph) (void)hipGraphDestroy(h->sweep_graph);
+  h->sweep_exec = nullptr;
+  h->sweep_graph = nullptr;
+  // back to "one eager sweep first": a capture must START from the state a complete sweep leaves behind (nothing pending,
+  // key rows to be reset at period T), which only a whole eager sweep re-establishes
+  if (h->graph_state > 0) h->graph_state = 0;
+}
+
 int run_period_impl(sdpgpu_handle* h, int period, int part, int64_t range_lo, int64_t range_hi) {
   int rc = allocate(h);
   if (rc) return rc;
+  // a period run outside sdpgpu_solve (stepwise callers, sharded sweeps) leaves key rows / pending rows in a state the
+  // captured sweep did not start from
+  if (!h->in_solve && h->sweep_exec) graph_drop(h);
   if (period < 1 || period > h->T) return fail(h, SDPGPU_ERR_ARG, "period %d out of 1..%d", period, h->T);
   if (period < h->T && !h->period_done[period]) return fail(h, SDPGPU_ERR_STATE, "V_%d has not been computed yet (periods run T..1)", period + 1);
   rc = ensure_device(h);
@@ -641,6 +654,7 @@ void sdpgpu_destroy(sdpgpu_handle* h) {
     if (h->device >= 0) (void)hipSetDevice(h->device);
     if (h->stream) (void)hipStreamSynchronize(h->stream);
   }
+  graph_drop(h);
   for (auto& p : h->per) {
     if (p.ev0) (void)hipEventDestroy(p.ev0);
     if (p.ev1) (void)hipEventDestroy(p.ev1);
@@ -739,6 +753,7 @@ int sdpgpu_set_overhead(sdpgpu_handle* h, int32_t t, double overhead_cost) {
   h->per[t].overhead = overhead_cost;
   h->per[t].overhead_set = true;
   h->per[t].cells_counted = false;
+  graph_drop(h);  // (the overhead is a kernel argument of the captured launches)
   return SDPGPU_OK;
 }
 
@@ -765,6 +780,7 @@ int sdpgpu_set_action_counts(sdpgpu_handle* h, int32_t t, const int32_t* counts,
 int sdpgpu_set_stream(sdpgpu_handle* h, void* hip_stream) {
   if (!h) return SDPGPU_ERR_ARG;
   h->err.clear();
+  graph_drop(h);  // (captured on the old stream's behalf; the next sweep on the new stream is eager, the one after captures)
   if (h->stream && h->own_stream) {
     (void)hipStreamSynchronize(h->stream);
     (void)hipStreamDestroy(h->stream);
@@ -1012,21 +1028,91 @@ int sdpgpu_run_period_part(sdpgpu_handle* h, int32_t period, int32_t part) {
   }
 }
 
+// The sweep proper: T period launches + the deferred read-out, enqueued on the handle's stream.
+static int enqueue_sweep(sdpgpu_handle* h) {
+  std::fill(h->period_done.begin(), h->period_done.end(), 0);
+  for (int period = h->T; period >= 1; --period) {
+    int rc = run_period_impl(h, period);
+    if (rc) return rc;
+  }
+  return flush_api(h);
+}
+
 int sdpgpu_solve(sdpgpu_handle* h, int32_t sync) {
   if (!h) return SDPGPU_ERR_ARG;
   h->err.clear();
   if (h->d.world_size != 1) return fail(h, SDPGPU_ERR_STATE, "sdpgpu_solve needs world_size 1; sharded handles run period by period with an all-gather in between");
+  struct InSolve {
+    sdpgpu_handle* h;
+    ~InSolve() { h->in_solve = false; }
+  } guard{h};
+  h->in_solve = true;
   try {
     int rc = allocate(h);
     if (rc) return rc;
-    std::fill(h->period_done.begin(), h->period_done.end(), 0);
-    HIP_TRY(h, hipEventRecord(h->ev_solve0, h->stream));
-    for (int period = h->T; period >= 1; --period) {
-      rc = run_period_impl(h, period);
-      if (rc) return rc;
-    }
-    rc = flush_api(h);
+    rc = ensure_device(h);
     if (rc) return rc;
+    HIP_TRY(h, hipEventRecord(h->ev_solve0, h->stream));
+    // Sweep 1 runs eagerly (lazy allocations, LDS attributes, table uploads), sweep 2 is CAPTURED into a HIP graph while it is
+    // enqueued, sweeps 3.. replay it: one hipGraphLaunch instead of T + 2 launches.  Not with per-period profiling events,
+    // user functors (hipModule launches), the legacy NULL stream (it cannot be captured) or the tests' guard-word mode.
+    const bool graphable = h->graph_state >= 1 && !h->profiling && !h->custom && h->stream != nullptr &&
+                           !std::getenv("SDPGPU_CASH_DIAG_CHECK");
+    bool done = false;
+    if (graphable && h->graph_state == 2 && h->sweep_exec) {
+      hipError_t e = hipGraphLaunch(h->sweep_exec, h->stream);
+      if (e == hipSuccess) {
+        h->graph_replays++;
+        done = true;
+      } else {
+        (void)hipGetLastError();
+        graph_drop(h);
+        h->graph_state = -1;  // (eager from here on)
+      }
+    } else if (graphable && h->graph_state == 1) {
+      hipError_t e = hipStreamBeginCapture(h->stream, hipStreamCaptureModeThreadLocal);
+      if (e == hipSuccess) {
+        h->flush_uploads = 0;
+        rc = enqueue_sweep(h);
+        hipGraph_t g = nullptr;
+        e = hipStreamEndCapture(h->stream, &g);
+        // (the job list of the deferred read-out is uploaded from ONE host buffer: a sweep that flushes twice -- window
+        // periods between generic ones -- would replay both uploads with the second list.  Such sweeps stay eager.)
+        if (h->flush_uploads > 1) rc = SDPGPU_ERR_UNSUPPORTED;
+        if (rc == SDPGPU_OK && e == hipSuccess && g) e = hipGraphInstantiate(&h->sweep_exec, g, nullptr, nullptr, 0);
+        if (rc == SDPGPU_OK && e == hipSuccess && g && h->sweep_exec) {
+          h->sweep_graph = g;
+          e = hipGraphLaunch(h->sweep_exec, h->stream);  // (capturing enqueued nothing: this is sweep 2 itself)
+          if (e != hipSuccess) return fail(h, SDPGPU_ERR_DEVICE, "hipGraphLaunch: %s", hipGetErrorString(e));
+          h->graph_state = 2;
+          h->graph_replays++;
+          done = true;
+        } else {
+          // the capture was refused somewhere (a launcher had to allocate or wait): nothing ran.  Forget the graph and the host
+          // bookkeeping of the un-run sweep, and run this sweep eagerly.
+          (void)hipGetLastError();
+          if (g) (void)hipGraphDestroy(g);
+          if (h->sweep_exec) (void)hipGraphExecDestroy(h->sweep_exec);
+          h->sweep_exec = nullptr;
+          h->graph_state = -1;
+          std::fill(h->pending_chunks.begin(), h->pending_chunks.end(), 0);
+          h->n_pending = 0;
+          std::fill(h->key_row_clean.begin(), h->key_row_clean.end(), 0);
+          h->err.clear();
+        }
+      } else {
+        (void)hipGetLastError();
+        h->graph_state = -1;
+      }
+    }
+    if (!done) {
+      rc = enqueue_sweep(h);
+      if (rc) return rc;
+      if (h->graph_state == 0) {
+        const char* env = std::getenv("SDPGPU_GRAPH");
+        h->graph_state = (env && std::atoi(env) == 0) ? -1 : 1;
+      }
+    }
     HIP_TRY(h, hipEventRecord(h->ev_solve1, h->stream));
     h->solve_timed = true;
     for (int period = 1; period <= h->T; ++period)
@@ -1282,6 +1368,7 @@ int sdpgpu_stats_get(sdpgpu_handle* h, sdpgpu_stats* out) {
     if (p.ops_cell == 0 && p.cells_rank > 0) modelled = false;
   }
   if (!modelled) out->fp64_ops_executed = 0;
+  out->graph_replays = h->graph_replays;
   out->kernel_used = h->per[0].kernel_used;
   if (!h->custom && h->d.family == SDPGPU_FAMILY_BACKORDER && h->per[0].kernel_used == SDPGPU_KERNEL_WINDOW &&
       window_eligible(h, 1)) {

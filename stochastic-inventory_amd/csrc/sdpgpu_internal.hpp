@@ -157,6 +157,16 @@ struct sdpgpu_handle {
   hipEvent_t ev_comp = nullptr, ev_comm = nullptr;
   std::vector<sdpgpu_handle*> siblings;  // handles[0..n) of the last sdpgpu_solve_multi (set on every member)
   bool multi_copy = false;               // exchange by device-to-device copies (ranks share a device)
+  // sdpgpu_solve as ONE HIP graph (small grids: a sweep of configs[1] is 52 launches of 30 us -- replayed from a graph the
+  // sweep no longer depends on how promptly the host thread issues them).  0: no eager sweep yet; 1: one eager sweep done
+  // (every lazy allocation, attribute and table upload has happened); 2: graph captured and in use; -1: off (capture refused
+  // or SDPGPU_GRAPH=0).  Dropped by whatever changes what a sweep launches (graph_drop).
+  int graph_state = 0;
+  bool in_solve = false;
+  hipGraph_t sweep_graph = nullptr;
+  hipGraphExec_t sweep_exec = nullptr;
+  int64_t graph_replays = 0;
+  int flush_uploads = 0;  // job-list uploads of flush_pending since the counter was last reset (sdpgpu_solve's capture)
   std::string err;
   std::string plan_error;  // set by a launcher that rejects a period's plan (run_period_impl reports it as SDPGPU_ERR_ARG)
   int device = -1;
@@ -244,6 +254,7 @@ struct WinPlan {
 
 // ---- sdpgpu.hip ----------------------------------------------------------------------------------------
 int run_period_impl(sdpgpu_handle* h, int period, int part = SDPGPU_PART_ALL, int64_t range_lo = -1, int64_t range_hi = -1);
+void graph_drop(sdpgpu_handle* h);  // forget the captured sweep (the next sdpgpu_solve runs eagerly, the one after captures again)
 void count_cells(sdpgpu_handle* h, int period);
 int flush_api(sdpgpu_handle* h);
 int layout(sdpgpu_handle* h);

@@ -191,6 +191,7 @@ hipError_t flush_pending(sdpgpu_handle* h) {
   }
   hipError_t e = hipMemcpyAsync(h->d_jobs, jobs, n_jobs * sizeof(sdp::FinalizeJob), hipMemcpyHostToDevice, h->stream);
   if (e != hipSuccess) return e;
+  h->flush_uploads++;
   hipLaunchKernelGGL(sdp::finalize_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, h->stream, h->d_jobs,
                      (int)n_jobs, total);
   return hipGetLastError();
