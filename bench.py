@@ -349,10 +349,10 @@ def run_single(sia, torch, dev, name, w, steps, warmup, kernel, gate_cells, no_g
     d.device = dev.index
     d.kernel = kernel
     T = w.T
-    # A stream of the run's own (not the legacy NULL stream, which cannot be captured): sdpgpu_solve replays its sweep as ONE HIP
-    # graph from the third call on -- the warm-up covers the eager and the capturing call -- so that a sweep of 52 launches of
-    # 30 us (configs[1]) does not depend on how promptly this Python thread issues them.  The torch events below are recorded
-    # on the same stream.
+    # A stream of the run's own (not the legacy NULL stream, which cannot be captured): with SDPGPU_GRAPH=1 sdpgpu_solve replays
+    # its sweep as ONE HIP graph from the third call on (the warm-up covers the eager and the capturing call).  Off by default:
+    # measured 0.6-1.6 % slower than the eager sweep, whose wall time is within 0.4 % of its device time (`wall_over_device`).
+    # The torch events below are recorded on the same stream.
     side = torch.cuda.Stream(device=dev)
     with sia.SdpEngine(d, w.pmf, w.overhead()) as eng, torch.cuda.stream(side):
         eng.set_stream(side.cuda_stream)
