@@ -734,6 +734,11 @@ struct RowTiling {
   int32_t n_rows;  // inventory(/preQ) rows launched
   int32_t tps;     // tiles per band; 0 = plain row-major numbering (short rows)
   int32_t nsub;    // bands per XCD
+  // colmajor > 0 (the shared-block form, whose workgroup tiles are few and wide -- 20 per row on CashConstraint.main's grid, which
+  // whole-column bands would deal 3, 3, 3, 3, 3, 3, 2, 0 to the eight XCDs): the (tile, row) units in column-major order,
+  // unit u = tile * n_rows + row, are cut into eight equal runs of `colmajor` units, XCD i walks run i.  Still one narrow band
+  // of consecutive rows in flight per XCD, and every XCD gets the same number of workgroups.
+  int32_t colmajor;
   // Row order inside a band (nullptr: as numbered).  F5's state is (x, preQ) but its cells read V_{t+1} through the level
   // y = x + preQ only (SingleProductLeadtime.java:82-119): rows with equal y gather the very same entries.  Walked in order of y
   // they are in flight together and find each other's lines in L2; in (preQ, x) order the 31 rows of a level are 61 rows apart
@@ -1019,6 +1024,114 @@ __global__ __launch_bounds__(256) void cash_row_kernel(DevParams P, const double
 }
 
 // ---------------------------------------------------------------------------------------------
+// The wave-uniform part of a (row, action) of the F3 pair kernel -- one RowEnt per demand point, the uniform-key flag of every
+// trip of four steps, the smallest and largest uniform shift -- as a BLOCK of bytes, laid out the way the kernel's demand loop
+// reads it from LDS:  [RowEnt x D] [int flag x row_tab_flags(D)] (pad to 16) [RowTabHead].
+// cash_row_pair_kernel forms it itself per (tile, action), lanes = demand indices (25 of 64 lanes busy on CashConstraint.main);
+// with TAB it is formed ONCE per (row, action) by cash_row_table_kernel and every tile of the row copies the finished block
+// into its LDS (one 16-byte load and store per lane, requested an action ahead): the ~100 setup instructions per (wave,
+// action) leave the hot kernel.  row_entry() is the one place the entry's arithmetic is written: both paths call it.
+// ---------------------------------------------------------------------------------------------
+struct RowTabHead {
+  int32_t dmin, dmax;  // smallest / largest key shift over the uniform steps of the action (0, 0: none)
+  int32_t pad0, pad1;
+};
+__host__ __device__ inline int row_tab_flags(int D) { return (D + 3) / 4 + 3; }  // whole trips, then the D mod 4 single steps
+__host__ __device__ inline int row_tab_head_off(int D) { return (D * 32 + row_tab_flags(D) * 4 + 15) & ~15; }
+__host__ __device__ inline int row_tab_block(int D) { return row_tab_head_off(D) + 16; }
+
+// off8 = rowoff8 + 8 * dkey (uniform steps; rowoff8 otherwise): what a clamp-free trip adds to the lane's own byte offset.
+// It travels in the `sal` slot of the entry, which only period T reads (and period T gathers nothing).
+__device__ __forceinline__ int row_ent_off8(const RowEnt& e) { return __double2loint(e.sal); }
+
+template <bool LAST, bool FORMULA1, bool LEAN>
+__device__ __forceinline__ RowEnt row_entry(const DevParams& P, double y, double fixed, double var, double d, int k_lo_next,
+                                            bool& is_uni) {
+  const double revenue = P.price * jmin(y, d);
+  const double level = y - d;
+  const double pos = jmax(level, 0.0);
+  RowEnt e;
+  e.hold = P.h * pos;
+  e.sal = LAST ? P.salvage * pos : 0.0;
+  if constexpr (!FORMULA1) {
+    e.u = P.one_minus_overhead_rate * revenue;
+  } else {
+    double inc = revenue - fixed - var - e.hold - P.overhead;
+    inc += e.sal;
+    e.u = inc;
+  }
+  e.rowoff8 = 0;
+  e.dkey = kNoShift;
+  is_uni = false;
+  if constexpr (!LAST) {
+    double ninv = jmax(0.0, level);
+    ninv = ninv > P.max_inventory ? P.max_inventory : ninv;
+    ninv = ninv < P.min_inventory ? P.min_inventory : ninv;
+    e.rowoff8 = (inv_index(P, ninv) * (int)P.next.nc - k_lo_next) * 8;
+    const double inc_u = FORMULA1 ? e.u : (LEAN ? e.u - fixed - var : e.u - fixed - var - e.hold - P.overhead);
+    const double dm = inc_u * P.round_mult;
+    const double dn = rint(dm);
+    is_uni = fabs(dm - dn) < 9.5367431640625e-07 && fabs(dn) < 1.0e9;  // 2^-20, see cash_row_kernel
+    e.dkey = is_uni ? (int)dn : kNoShift;
+    e.sal = __hiloint2double(0, e.rowoff8 + (is_uni ? e.dkey * 8 : 0));
+  }
+  return e;
+}
+
+// One wave per (row, action): the block of that action of that row, written to `tab` (see above).
+template <bool LAST, bool FORMULA1, bool LEAN>
+__global__ __launch_bounds__(256) void cash_row_table_kernel(DevParams P, const double* __restrict__ pmf_d, char* __restrict__ tab,
+                                                             int64_t row0, int n_rows, int n_actions) {
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int64_t g = (int64_t)blockIdx.x * 4 + wave;
+  if (g >= (int64_t)n_rows * n_actions) return;
+  const int row_i = (int)(g / n_actions), k = (int)(g - (int64_t)row_i * n_actions);
+  const int D = P.n_demand;
+  StateT s0;
+  decode_state<FAM_CASH>(P, (row0 + row_i) * P.cur.nc, s0);  // (the row's inventory level: the same in every cash point)
+  const double a = (double)k * P.step;
+  const double y = s0.x + a;
+  const double fixed = a > 0 ? P.K : 0.0;
+  const double var = P.v * a;
+  const int k_lo_next = (int)P.next.k_lo;
+  char* blk = tab + (size_t)g * row_tab_block(D);
+  RowEnt* ent = reinterpret_cast<RowEnt*>(blk);
+  int* uni = reinterpret_cast<int*>(blk + (size_t)D * 32);
+  int dmin = 0x7fffffff, dmax = -0x7fffffff;
+  for (int j0 = 0; j0 < D; j0 += 64) {
+    const int j = j0 + lane;
+    bool is_uni = false;
+    if (j < D) {
+      const RowEnt e = row_entry<LAST, FORMULA1, LEAN>(P, y, fixed, var, pmf_d[j], k_lo_next, is_uni);
+      ent[j] = e;
+      if (is_uni) {
+        dmin = e.dkey < dmin ? e.dkey : dmin;
+        dmax = e.dkey > dmax ? e.dkey : dmax;
+      }
+    }
+    if constexpr (!LAST) {
+      const unsigned long long mu = __ballot(is_uni);
+      if (j < D && (lane & 3) == 0) uni[j / 4] = (((mu >> lane) & 15ull) == 15ull) ? 1 : 0;
+      if (j < D && j >= (D & ~3)) uni[(D + 3) / 4 + (j & 3)] = is_uni ? 1 : 0;
+    }
+  }
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) {
+    const int a0 = __shfl_xor(dmin, off, 64), b0 = __shfl_xor(dmax, off, 64);
+    dmin = a0 < dmin ? a0 : dmin;
+    dmax = b0 > dmax ? b0 : dmax;
+  }
+  if (lane == 0) {
+    RowTabHead hd;
+    hd.dmin = dmax < dmin ? 0 : dmin;
+    hd.dmax = dmax < dmin ? 0 : dmax;
+    hd.pad0 = hd.pad1 = 0;
+    *reinterpret_cast<RowTabHead*>(blk + row_tab_head_off(D)) = hd;
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
 // Cash row kernel, TWO ADJACENT CASH POINTS PER LANE (F3: formulas 0, 1 and 2 without deposit rate, penalty and
 // integer division -- the CashConstraint / CashConstraintTesting / CashConstraintXR drivers).
 //
@@ -1034,29 +1147,54 @@ __global__ __launch_bounds__(256) void cash_row_kernel(DevParams P, const double
 // ---------------------------------------------------------------------------------------------
 // S = 128-point tiles per wave: lane l owns the pairs at ic0 + 128 s + 2 l, s < S.  The per-action setup (lanes = demand
 // indices: with 25 demand points only 25 of 64 lanes work) and the LDS reads of a step's entries are shared by the S pairs.
-template <bool LAST, bool FORMULA1, bool LEAN, int S>
+// SRC: where a (row, action)'s block of wave-uniform operands comes from.
+//  0  every wave forms the blocks of its own actions (k = wave, wave + 4, ...) for its workgroup's ONE tile; the four waves'
+//     results are merged through LDS.  Round 2's form.
+//  2  SHARED (round 3; opt-in SDPGPU_CASH_SHARE=1, measured slower, see the launcher): a workgroup is FOUR tiles of one row, one per wave, and
+//     walks the actions in groups of four: wave w forms the block of action k0 + w, a barrier, then every wave runs the four
+//     actions on its own tile.  The ~100 setup instructions per block are spent once per workgroup instead of once per
+//     wave-action -- a quarter of the setup per cell -- with no memory traffic, and a wave owns its tile's arg-max (no merge).
+//     The blocks carry tile-free flags (uniform trip or not) and the action's smallest / largest shift; a wave decides
+//     "clamp-free" per action from those.
+//  1  TABLE: the blocks come from cash_row_table_kernel's table (`tab`, `tab_actions` blocks per row), copied into two LDS
+//     buffers per wave an action ahead.  Built and measured SLOWER than 0 (42.1 against 38.2 ms per sweep on
+//     CashConstraint.main's grid): vector loads return in order, so every first gather of an action waits behind the block
+//     load, which misses the XCD's L2 on a row's first tile.  Kept behind SDPGPU_CASH_TAB=1.
+template <bool LAST, bool FORMULA1, bool LEAN, int S, int SRC = 0>
 __global__ __launch_bounds__(256) void cash_row_pair_kernel(DevParams P, const double* __restrict__ v_next,
                                                             double* __restrict__ v_cur, int32_t* __restrict__ pol,
                                                             const double* __restrict__ pmf_d,
                                                             const double* __restrict__ pmf_p, int64_t lo, int64_t hi,
-                                                            int64_t row0, RowTiling G) {
+                                                            int64_t row0, RowTiling G, const char* __restrict__ tab,
+                                                            int tab_actions) {
   constexpr int FAM = FAM_CASH;
   constexpr int TS = 128 * S;
   constexpr int NP = 2 * S;  // cash points per lane: point p = 2 s + w is ic0 + 128 s + 2 lane + w
+  constexpr bool TAB = SRC == 1, SHARE = SRC == 2, BLK = SRC != 0;
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int D = P.n_demand;
+  const int BS = row_tab_block(D);
   double2* s_p = reinterpret_cast<double2*>(smem);                  // {p_j, p_j * gamma}
-  RowEnt* s_ent = reinterpret_cast<RowEnt*>(s_p + D);               // [4 waves][D]
-  double* s_d = reinterpret_cast<double*>(s_ent + (size_t)4 * D);   // d_j
-  double* s_val = s_d + D;
+  // SRC 0: [4 waves][D] entries, d_j, scratch, [4 waves] flags.  TAB: [4 waves][2 buffers][BS] bytes, scratch.
+  // SHARE: [4 actions][BS] bytes, d_j, the four waves' action counts.
+  RowEnt* s_ent = reinterpret_cast<RowEnt*>(s_p + D);
+  char* s_blocks = reinterpret_cast<char*>(s_p + D);
+  double* s_d = SHARE ? reinterpret_cast<double*>(s_blocks + (size_t)4 * BS) : reinterpret_cast<double*>(s_ent + (size_t)4 * D);  // d_j
+  int* s_na = reinterpret_cast<int*>(s_d + D);
+  double* s_val = TAB ? reinterpret_cast<double*>(s_blocks + (size_t)8 * BS) : s_d + D;
   int* s_k = reinterpret_cast<int*>(s_val + 4 * TS);
-  int* s_uni = s_k + 4 * TS;  // [4 waves][(D + 3) / 4 trips + 3 single steps]
+  int* s_uni = s_k + 4 * TS;  // (SRC 0) [4 waves][(D + 3) / 4 trips + 3 single steps]
 
   const int tid = threadIdx.x;
   const int lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   int row_i, tile;
-  if (G.tps == 0) {
+  if (G.colmajor > 0) {
+    const int64_t u = (int64_t)(blockIdx.x & 7) * G.colmajor + (blockIdx.x >> 3);
+    if ((blockIdx.x >> 3) >= (unsigned)G.colmajor || u >= (int64_t)G.n_rows * G.tiles_per_row) return;
+    tile = (int)(u / G.n_rows);
+    row_i = (int)(u - (int64_t)tile * G.n_rows);
+  } else if (G.tps == 0) {
     row_i = blockIdx.x / G.tiles_per_row;
     tile = blockIdx.x % G.tiles_per_row;
   } else {
@@ -1068,13 +1206,13 @@ __global__ __launch_bounds__(256) void cash_row_pair_kernel(DevParams P, const d
     if (tile >= G.tiles_per_row) return;
   }
   for (int j = tid; j < D; j += 256) {
-    s_d[j] = pmf_d[j];
+    if constexpr (!TAB) s_d[j] = pmf_d[j];
     s_p[j] = make_double2(pmf_p[j], pmf_p[j] * P.gamma);
   }
   __syncthreads();
 
   const int64_t row = row0 + (G.perm ? G.perm[row_i] : row_i);
-  const int ic0 = tile * TS;
+  const int ic0 = (SHARE ? tile * 4 + wave : tile) * TS;  // (SHARE: G counts workgroup tiles of 4 TS points, one TS per wave)
   const int nc = (int)P.cur.nc;
   StateT s[NP];
   int nA[NP], icc[NP];
@@ -1093,8 +1231,9 @@ __global__ __launch_bounds__(256) void cash_row_pair_kernel(DevParams P, const d
     nA_max = o > nA_max ? o : nA_max;
   }
   nA_max = __builtin_amdgcn_readfirstlane(nA_max);
+  if (SHARE && ic0 >= nc) nA_max = 0;  // (a wave past the row's end: it still forms blocks and meets the barriers)
 
-  RowEnt* ent = s_ent + (size_t)wave * D;
+  RowEnt* ent = s_ent + (size_t)wave * D;        // (in-kernel setup; TAB: re-pointed at the current block every action)
   int* uni = s_uni + wave * ((D + 3) / 4 + 3);
   const bool MAXDIR = P.maxdir != 0;
   double best[NP];
@@ -1121,52 +1260,22 @@ __global__ __launch_bounds__(256) void cash_row_pair_kernel(DevParams P, const d
   // clamp-free trips need every point of the tile to exist and to stay inside the grid under the step's shift
   const bool tile_whole = ic0 + TS <= nc;
   const int key_first = (int)P.cur.k_lo + ic0, key_last = key_first + TS - 1;
-  for (int k = wave; k < nA_max; k += 4) {
-    // ---- wave-uniform part, lanes = demand indices (as cash_row_kernel) ---------------------------------------
-    const double a = (double)k * P.step;
-    const double y = s[0].x + a;
-    const double fixed = a > 0 ? P.K : 0.0;
-    const double var = P.v * a;
-    for (int j = lane; j < D; j += 64) {
-      const double d = s_d[j];
-      const double revenue = P.price * jmin(y, d);
-      const double level = y - d;
-      const double pos = jmax(level, 0.0);
-      RowEnt e;
-      e.hold = P.h * pos;
-      e.sal = LAST ? P.salvage * pos : 0.0;
-      if constexpr (!FORMULA1) {
-        e.u = P.one_minus_overhead_rate * revenue;
-      } else {
-        double inc = revenue - fixed - var - e.hold - P.overhead;
-        inc += e.sal;
-        e.u = inc;
-      }
-      e.rowoff8 = 0;
-      e.dkey = kNoShift;
-      if constexpr (!LAST) {
-        double ninv = jmax(0.0, level);
-        ninv = ninv > P.max_inventory ? P.max_inventory : ninv;
-        ninv = ninv < P.min_inventory ? P.min_inventory : ninv;
-        e.rowoff8 = (inv_index(P, ninv) * (int)P.next.nc - k_lo_next) * 8;
-        const double inc_u = FORMULA1 ? e.u : (LEAN ? e.u - fixed - var : e.u - fixed - var - e.hold - overhead);
-        const double dm = inc_u * round_mult;
-        const double dn = rint(dm);
-        const bool is_uni = fabs(dm - dn) < 9.5367431640625e-07 && fabs(dn) < 1.0e9;  // 2^-20, see cash_row_kernel
-        e.dkey = is_uni ? (int)dn : kNoShift;
-        const bool free_ = is_uni && tile_whole && (double)key_first + dn >= (double)k_lo_next &&
-                           (double)key_last + dn <= (double)k_hi_next;
-        const unsigned long long mu = __ballot(is_uni), mf = __ballot(free_);
-        if ((lane & 3) == 0)
-          uni[j / 4] = (((mf >> lane) & 15ull) == 15ull) ? 2 : ((((mu >> lane) & 15ull) == 15ull) ? 1 : 0);
-        // the D mod 4 steps behind the last whole trip carry a flag each (they run one at a time)
-        if (j >= (D & ~3)) uni[(D + 3) / 4 + (j & 3)] = free_ ? 2 : (is_uni ? 1 : 0);
-      }
-      ent[j] = e;
-    }
+  // TAB: this wave's two block buffers, the row's blocks in the table, and the synchronous part of a block copy
+  char* my_blocks = s_blocks + (size_t)wave * 2 * BS;
+  const char* row_tab = TAB ? tab + ((size_t)row_i * tab_actions) * (size_t)BS : nullptr;
+  [[maybe_unused]] auto copy_block = [&](int kk, int b, int from) {  // bytes [from, BS) of block kk -> buffer b
+    const char* src = row_tab + (size_t)kk * BS;
+    for (int o = from + lane * 16; o < BS; o += 1024)
+      *reinterpret_cast<uint4*>(my_blocks + (size_t)b * BS + o) = *reinterpret_cast<const uint4*>(src + o);
+  };
+  int buf = 0;
+  if constexpr (TAB) {
+    if (wave < nA_max) copy_block(wave, 0, 0);
     __builtin_amdgcn_wave_barrier();
-    __builtin_amdgcn_s_waitcnt(0xC07F);  // lgkmcnt(0): the wave's own LDS writes have landed
-
+    __builtin_amdgcn_s_waitcnt(0xC07F);
+  }
+  // One action on this wave's points: the demand loop in the reference's order, then the strict-compare update of the arg-opt.
+  auto consume = [&](const int k, const double fixed, const double var, [[maybe_unused]] const bool free_action) {
     double dep[NP];
 #pragma unroll
     for (int w = 0; w < NP; ++w) dep[w] = (s[w].cash - fixed - var) * P.one_plus_deposit;
@@ -1192,7 +1301,8 @@ __global__ __launch_bounds__(256) void cash_row_pair_kernel(DevParams P, const d
     for (; j + U <= D; j += U) {
       double add1[U][NP], pg[U];
       if constexpr (!LAST) {
-        const int f = __builtin_amdgcn_readfirstlane(uni[j / U]);
+        const int f_raw = __builtin_amdgcn_readfirstlane(uni[j / U]);
+        const int f = BLK ? (f_raw ? (free_action ? 2 : 1) : 0) : f_raw;  // (a block's flag knows no tile)
         // one uniform-key trip; FREE: no point of the wave's tiles clamps (decided for the whole trip, so that the four
         // steps are straight-line code: the compiler turned a per-step choice into mask arithmetic on every step)
         auto uni_trip = [&](auto free_tag) {
@@ -1209,8 +1319,8 @@ __global__ __launch_bounds__(256) void cash_row_pair_kernel(DevParams P, const d
 #pragma unroll
             for (int t = 0; t < S; ++t) {
               uint32_t off;
-              if constexpr (FREE) {  // the pair sits at the lane's own offset plus the shift
-                off = (uint32_t)(e.rowoff8 + my_key8[t] + (e.dkey << 3));
+              if constexpr (FREE) {  // the pair sits at the lane's own offset plus the step's (row offset + shift)
+                off = (uint32_t)(my_key8[t] + row_ent_off8(e));
               } else {  // {V[c], V[c + 1]}, c = clamp(key, lo, hi - 1): at the ends both points may fold onto one entry
                 const int ka = my_key[t] + e.dkey;
                 off = (uint32_t)(e.rowoff8 + (med3_i32(ka, key_lo_v, key_hi1_v) << 3));
@@ -1275,12 +1385,13 @@ __global__ __launch_bounds__(256) void cash_row_pair_kernel(DevParams P, const d
       if constexpr (!LAST) {
         // a uniform-key step on its own (D is not a multiple of four: D = 25 in CashConstraint.main): the pair gather at the
         // shifted key instead of the quantiser and one gather per point
-        const int f = __builtin_amdgcn_readfirstlane(uni[(D + 3) / 4 + (j & 3)]);
+        const int f_raw = __builtin_amdgcn_readfirstlane(uni[(D + 3) / 4 + (j & 3)]);
+        const int f = BLK ? (f_raw ? (free_action ? 2 : 1) : 0) : f_raw;
         if (f != 0) {
 #pragma unroll
           for (int t = 0; t < S; ++t) {
             const int ka = my_key[t] + e.dkey;
-            const uint32_t off = f == 2 ? (uint32_t)(e.rowoff8 + my_key8[t] + (e.dkey << 3))
+            const uint32_t off = f == 2 ? (uint32_t)(my_key8[t] + row_ent_off8(e))
                                         : (uint32_t)(e.rowoff8 + (med3_i32(ka, key_lo_v, key_hi1_v) << 3));
             const dpair_u vv = *reinterpret_cast<const dpair_u*>(vbase + off);
             const double v0 = (f != 2 && ka > k_hi_next - 1) ? vv.y : vv.x;
@@ -1310,6 +1421,144 @@ __global__ __launch_bounds__(256) void cash_row_pair_kernel(DevParams P, const d
         best[w] = acc[w];
         bestk[w] = k;
       }
+  };
+  if constexpr (SHARE) {
+    // the block of (row, k) into `dst`, lanes = demand indices (cash_row_table_kernel's body, writing LDS)
+    auto form_block = [&](const int k, char* dst) {
+      const double a = (double)k * P.step;
+      const double y = s[0].x + a;
+      const double fixed = a > 0 ? P.K : 0.0;
+      const double var = P.v * a;
+      RowEnt* e_out = reinterpret_cast<RowEnt*>(dst);
+      int* u_out = reinterpret_cast<int*>(dst + (size_t)D * 32);
+      int dmin = 0x7fffffff, dmax = -0x7fffffff;
+      for (int j0 = 0; j0 < D; j0 += 64) {
+        const int j = j0 + lane;
+        bool is_uni = false;
+        if (j < D) {
+          const RowEnt e = row_entry<LAST, FORMULA1, LEAN>(P, y, fixed, var, s_d[j], k_lo_next, is_uni);
+          e_out[j] = e;
+          if (is_uni) {
+            dmin = e.dkey < dmin ? e.dkey : dmin;
+            dmax = e.dkey > dmax ? e.dkey : dmax;
+          }
+        }
+        if constexpr (!LAST) {
+          const unsigned long long mu = __ballot(is_uni);
+          if (j < D && (lane & 3) == 0) u_out[j / 4] = (((mu >> lane) & 15ull) == 15ull) ? 1 : 0;
+          if (j < D && j >= (D & ~3)) u_out[(D + 3) / 4 + (j & 3)] = is_uni ? 1 : 0;
+        }
+      }
+#pragma unroll
+      for (int off = 32; off > 0; off >>= 1) {
+        const int a0 = __shfl_xor(dmin, off, 64), b0 = __shfl_xor(dmax, off, 64);
+        dmin = a0 < dmin ? a0 : dmin;
+        dmax = b0 > dmax ? b0 : dmax;
+      }
+      if (lane == 0) {
+        RowTabHead hd;
+        hd.dmin = dmax < dmin ? 0 : dmin;
+        hd.dmax = dmax < dmin ? 0 : dmax;
+        hd.pad0 = hd.pad1 = 0;
+        *reinterpret_cast<RowTabHead*>(dst + row_tab_head_off(D)) = hd;
+      }
+    };
+    if (lane == 0) s_na[wave] = nA_max;
+    __syncthreads();
+    int nA_wg = s_na[0];
+#pragma unroll
+    for (int w = 1; w < 4; ++w) nA_wg = s_na[w] > nA_wg ? s_na[w] : nA_wg;
+    nA_wg = __builtin_amdgcn_readfirstlane(nA_wg);
+    for (int k0 = 0; k0 < nA_wg; k0 += 4) {
+      if (k0 + wave < nA_wg) form_block(k0 + wave, s_blocks + (size_t)wave * BS);
+      __syncthreads();
+#pragma unroll 1
+      for (int i = 0; i < 4; ++i) {
+        const int k = k0 + i;
+        if (k >= nA_max) break;
+        const char* blk = s_blocks + (size_t)i * BS;
+        ent = reinterpret_cast<RowEnt*>(const_cast<char*>(blk));
+        uni = reinterpret_cast<int*>(const_cast<char*>(blk) + (size_t)D * 32);
+        const RowTabHead hd = *reinterpret_cast<const RowTabHead*>(blk + row_tab_head_off(D));
+        const int dmin = __builtin_amdgcn_readfirstlane(hd.dmin), dmax = __builtin_amdgcn_readfirstlane(hd.dmax);
+        const bool free_action = tile_whole && (int64_t)key_first + dmin >= (int64_t)k_lo_next && (int64_t)key_last + dmax <= (int64_t)k_hi_next;
+        const double a = (double)k * P.step;
+        consume(k, a > 0 ? P.K : 0.0, P.v * a, free_action);
+      }
+      __syncthreads();  // (the blocks are rewritten by the next group)
+    }
+    // a wave owns its tile: results go straight out (lane l holds the adjacent points 2 l, 2 l + 1 of each 128-point piece)
+#pragma unroll
+    for (int w = 0; w < NP; ++w) {
+      const int ic = ic0 + 128 * (w >> 1) + 2 * lane + (w & 1);
+      const int64_t idx = row * nc + ic;
+      if (ic < nc && idx >= lo && idx < hi) {
+        v_cur[idx] = best[w];
+        pol[idx] = bestk[w];
+      }
+    }
+    return;
+  }
+  for (int k = wave; k < nA_max; k += 4) {
+    const double a = (double)k * P.step;
+    const double fixed = a > 0 ? P.K : 0.0;
+    const double var = P.v * a;
+    [[maybe_unused]] bool free_action = false, has_next = false;
+    [[maybe_unused]] uint4 pf[2];
+    if constexpr (TAB) {
+      // ---- the finished block of (row, k) is in buffer `buf`; request the first 2 KB of the block of k + 4 ---------------
+      ent = reinterpret_cast<RowEnt*>(my_blocks + (size_t)buf * BS);
+      uni = reinterpret_cast<int*>(my_blocks + (size_t)buf * BS + (size_t)D * 32);
+      const RowTabHead hd = *reinterpret_cast<const RowTabHead*>(my_blocks + (size_t)buf * BS + row_tab_head_off(D));
+      const int dmin = __builtin_amdgcn_readfirstlane(hd.dmin), dmax = __builtin_amdgcn_readfirstlane(hd.dmax);
+      // clamp-free: every point of the tile exists and stays inside the next grid under every uniform shift of the action
+      free_action = tile_whole && (int64_t)key_first + dmin >= (int64_t)k_lo_next && (int64_t)key_last + dmax <= (int64_t)k_hi_next;
+      has_next = k + 4 < nA_max;
+      if (has_next) {
+        const char* src = row_tab + (size_t)(k + 4) * BS;
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+          const int o = u * 1024 + lane * 16;
+          if (o < BS) pf[u] = *reinterpret_cast<const uint4*>(src + o);
+        }
+      }
+    } else {
+      // ---- wave-uniform part, lanes = demand indices (as cash_row_kernel) ---------------------------------------
+      const double y = s[0].x + a;
+      for (int j = lane; j < D; j += 64) {
+        bool is_uni;
+        const RowEnt e = row_entry<LAST, FORMULA1, LEAN>(P, y, fixed, var, s_d[j], k_lo_next, is_uni);
+        if constexpr (!LAST) {
+          const double dn = (double)e.dkey;
+          const bool free_ = is_uni && tile_whole && (double)key_first + dn >= (double)k_lo_next &&
+                             (double)key_last + dn <= (double)k_hi_next;
+          const unsigned long long mu = __ballot(is_uni), mf = __ballot(free_);
+          if ((lane & 3) == 0)
+            uni[j / 4] = (((mf >> lane) & 15ull) == 15ull) ? 2 : ((((mu >> lane) & 15ull) == 15ull) ? 1 : 0);
+          // the D mod 4 steps behind the last whole trip carry a flag each (they run one at a time)
+          if (j >= (D & ~3)) uni[(D + 3) / 4 + (j & 3)] = free_ ? 2 : (is_uni ? 1 : 0);
+        }
+        ent[j] = e;
+      }
+      __builtin_amdgcn_wave_barrier();
+      __builtin_amdgcn_s_waitcnt(0xC07F);  // lgkmcnt(0): the wave's own LDS writes have landed
+    }
+
+    consume(k, fixed, var, free_action);
+    if constexpr (TAB) {
+      // the block of this wave's next action goes into the other buffer (nobody reads that one any more)
+      if (has_next) {
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+          const int o = u * 1024 + lane * 16;
+          if (o < BS) *reinterpret_cast<uint4*>(my_blocks + (size_t)(buf ^ 1) * BS + o) = pf[u];
+        }
+        if (BS > 2048) copy_block(k + 4, buf ^ 1, 2048);
+      }
+      buf ^= 1;
+      __builtin_amdgcn_wave_barrier();
+      __builtin_amdgcn_s_waitcnt(0xC07F);
+    }
   }
 
 #pragma unroll

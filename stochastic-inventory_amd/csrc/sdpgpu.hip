@@ -674,6 +674,7 @@ void sdpgpu_destroy(sdpgpu_handle* h) {
   if (h->d_chunk_idx) (void)hipFree(h->d_chunk_idx);
   if (h->d_jobs) (void)hipFree(h->d_jobs);
   if (h->d_diag) (void)hipFree(h->d_diag);
+  if (h->d_rowtab) (void)hipFree(h->d_rowtab);
   if (h->d_rowperm) (void)hipFree(h->d_rowperm);
   for (void* q : h->staff_owned) (void)hipFree(q);
   if (h->d_staff_val) (void)hipFree(h->d_staff_val);

@@ -290,11 +290,23 @@ hipError_t launch_cash_row(sdpgpu_handle* h, const DevParams& P, int period, con
     pair_s = std::atoi(e) == 2 ? 2 : 1;
   }
   const int tile_pts = pair ? 128 * pair_s : 64;
+  // OPT-IN (SDPGPU_CASH_SHARE=1): SHARED blocks (cash_row_pair_kernel, SRC 2) -- a workgroup is four tiles of one row, one per
+  // wave, and forms every action's block of wave-uniform operands once for the four (rows of four tiles and more).  Built to
+  // take the per-action setup (12 % of the kernel's instructions) out of the hot loop; measured SLOWER on CashConstraint.main's
+  // grid, 49-50 against 39-40 ms per sweep: with one tile per workgroup the four waves run CONSECUTIVE actions on the same
+  // cash window, whose gathers land on the same next-inventory rows 90 keys apart and share the compute unit's vector-L1 lines;
+  // four different tiles share nothing (profiles/r03_cash_share_l1.txt).  The default stays one tile per workgroup.
+  const bool share_off = !(std::getenv("SDPGPU_CASH_SHARE") && std::atoi(std::getenv("SDPGPU_CASH_SHARE")) == 1);
+  const bool tab_on = std::getenv("SDPGPU_CASH_TAB") && std::atoi(std::getenv("SDPGPU_CASH_TAB")) == 1;
+  const size_t blk_bytes = (size_t)sdp::row_tab_block(p.nD);
+  const size_t smem_share = (size_t)p.nD * 16 + 4 * blk_bytes + (size_t)p.nD * 8 + 16;
+  const bool share = pair && !share_off && !tab_on && p.g.nc > 3 * (int64_t)tile_pts && smem_share <= kLdsPerCU / 2;
+  const int wg_pts = share ? 4 * tile_pts : tile_pts;  // cash points per workgroup
   // F5: rows in order of the level x + preQ (RowTiling::perm); SDPGPU_CASH_ROWPERM=0 keeps the (preQ, x) order
   const bool level_order = P.family == sdp::FAM_CASH_LEADTIME && p.g.nq > 1 &&
                            !(std::getenv("SDPGPU_CASH_ROWPERM") && std::atoi(std::getenv("SDPGPU_CASH_ROWPERM")) == 0);
   sdp::RowTiling G{};
-  G.tiles_per_row = (int32_t)((p.g.nc + tile_pts - 1) / tile_pts);
+  G.tiles_per_row = (int32_t)((p.g.nc + wg_pts - 1) / wg_pts);
   G.n_rows = (int32_t)(row_hi - row_lo + 1);
   int64_t blocks = (int64_t)G.n_rows * G.tiles_per_row;
   // cash bands per XCD (see RowTiling): rows of 16 tiles and more; ~1280 cash points per band (CashConstraint.main, 313
@@ -302,12 +314,17 @@ hipError_t launch_cash_row(sdpgpu_handle* h, const DevParams& P, int period, con
   // SDPGPU_CASH_BANDS=0 keeps the plain row-major numbering, =n forces n bands per XCD.
   int nsub = -1;
   if (const char* e = std::getenv("SDPGPU_CASH_BANDS")) nsub = std::atoi(e);
-  if (nsub != 0 && G.tiles_per_row >= 16 && row_hi - row_lo + 1 < (1LL << 24)) {
+  if (share && nsub != 0 && (int64_t)G.n_rows * G.tiles_per_row >= 64) {
+    // few, wide workgroup tiles: equal runs of the column-major (tile, row) order per XCD (RowTiling::colmajor)
+    const int64_t units = (int64_t)G.n_rows * G.tiles_per_row;
+    G.colmajor = (int32_t)((units + 7) / 8);
+    blocks = 8LL * G.colmajor;
+  } else if (nsub != 0 && G.tiles_per_row >= 16 && row_hi - row_lo + 1 < (1LL << 24)) {
     const int tpb = (G.tiles_per_row + 7) / 8;  // tiles per XCD and row
     // (F5 walks its rows in order of the level x + preQ, below: the rows of a level gather the same entries, and with bands of
     // two tiles ~130 rows are in flight on an XCD -- four levels, whose windows fit its L2.  SingleProductLeadtime's size:
     // 20 / 5 / 2 / 1 tiles per band = 293 / 220 / 185 / 185 ms per sweep; without the level order 291 / 416 / 374 / 375.)
-    const int per_band = level_order ? 2 : 1280 / tile_pts;  // tiles per band
+    const int per_band = level_order ? 2 : std::max(1, 1280 / wg_pts);  // tiles per band
     G.nsub = nsub > 0 ? std::min(nsub, tpb) : std::max(1, (tpb + per_band / 2) / per_band);
     G.tps = (tpb + G.nsub - 1) / G.nsub;
     blocks = 8LL * G.nsub * G.tps * G.n_rows;
@@ -347,19 +364,54 @@ hipError_t launch_cash_row(sdpgpu_handle* h, const DevParams& P, int period, con
     case sdp::FAM_CASH: {
       // (cash_formula 2, the (x, R) state of CashConstraintXR: formula 0's increment on initCash = R - variCost * x)
       if (pair) {
-#define SDP_PAIR(LS, F1, LN)                                                                                                    \
-  do {                                                                                                                        \
-    static LdsMark mark2, mark1;                                                                                              \
-    hipError_t ea = pair_s == 2 ? lds_allow(sdp::cash_row_pair_kernel<LS, F1, LN, 2>, smem, &mark2)                           \
-                                : lds_allow(sdp::cash_row_pair_kernel<LS, F1, LN, 1>, smem, &mark1);                          \
-    if (ea != hipSuccess) return ea;                                                                                          \
-    if (pair_s == 2)                                                                                                          \
-      hipLaunchKernelGGL((sdp::cash_row_pair_kernel<LS, F1, LN, 2>), grid, dim3(256), smem, st, P, v_next, v_cur, pol, pmf_d, \
-                         pmf_p, lo, hi, row_lo, G);                                                                           \
-    else                                                                                                                      \
-      hipLaunchKernelGGL((sdp::cash_row_pair_kernel<LS, F1, LN, 1>), grid, dim3(256), smem, st, P, v_next, v_cur, pol, pmf_d, \
-                         pmf_p, lo, hi, row_lo, G);                                                                           \
+#define SDP_PAIR_GO(LS, F1, LN, SS, SRC)                                                                                        \
+  do {                                                                                                                         \
+    static LdsMark mark;                                                                                                       \
+    hipError_t ea = lds_allow(sdp::cash_row_pair_kernel<LS, F1, LN, SS, SRC>, smem_pair, &mark);                               \
+    if (ea != hipSuccess) return ea;                                                                                           \
+    hipLaunchKernelGGL((sdp::cash_row_pair_kernel<LS, F1, LN, SS, SRC>), grid, dim3(256), smem_pair, st, P, v_next, v_cur, pol, \
+                       pmf_d, pmf_p, lo, hi, row_lo, G, tab_ptr, tab_actions);                                                 \
   } while (0)
+#define SDP_PAIR(LS, F1, LN)                                                                                                  \
+  do {                                                                                                                        \
+    if (use_tab) {                                                                                                            \
+      const int64_t waves = (int64_t)G.n_rows * tab_actions;                                                                  \
+      hipLaunchKernelGGL((sdp::cash_row_table_kernel<LS, F1, LN>), dim3((unsigned)((waves + 3) / 4)), dim3(256), 0, st, P,    \
+                         pmf_d, h->d_rowtab, row_lo, G.n_rows, tab_actions);                                                  \
+      hipError_t et = hipGetLastError();                                                                                      \
+      if (et != hipSuccess) return et;                                                                                        \
+      if (pair_s == 2) SDP_PAIR_GO(LS, F1, LN, 2, 1); else SDP_PAIR_GO(LS, F1, LN, 1, 1);                                     \
+    } else if (share) {                                                                                                       \
+      if (pair_s == 2) SDP_PAIR_GO(LS, F1, LN, 2, 2); else SDP_PAIR_GO(LS, F1, LN, 1, 2);                                     \
+    } else {                                                                                                                  \
+      if (pair_s == 2) SDP_PAIR_GO(LS, F1, LN, 2, 0); else SDP_PAIR_GO(LS, F1, LN, 1, 0);                                     \
+    }                                                                                                                         \
+  } while (0)
+        // OPT-IN (SDPGPU_CASH_TAB=1; measured slower, see cash_row_pair_kernel): the (row, action) blocks from a table formed
+        // once per row by cash_row_table_kernel -- rows of two tiles and more, formulas 0 and 1 (the (x, R) state has its own
+        // action range), while the two block buffers per wave still leave two workgroups per compute unit and the table
+        // stays under 1 GiB.
+        const int tab_actions = h->n_actions_full;
+        const size_t blk = blk_bytes;
+        const size_t smem_tab = (size_t)p.nD * 16 + 8 * blk + (size_t)4 * tile_pts * (sizeof(double) + sizeof(int));
+        const size_t tab_bytes = (size_t)G.n_rows * (size_t)tab_actions * blk;
+        bool use_tab = tab_on && P.cash_formula != 2 && G.tiles_per_row >= 2 && smem_tab <= kLdsPerCU / 2 &&
+                       tab_bytes <= ((size_t)1 << 30) && grid_ok(((int64_t)G.n_rows * tab_actions + 3) / 4);
+        if (use_tab && h->rowtab_bytes < tab_bytes) {
+          hipError_t e = hipStreamSynchronize(st);  // (an earlier launch may still read the old table)
+          if (e != hipSuccess) return e;
+          if (h->d_rowtab) (void)hipFree(h->d_rowtab);
+          h->d_rowtab = nullptr;
+          h->rowtab_bytes = 0;
+          if (hipMalloc((void**)&h->d_rowtab, tab_bytes) == hipSuccess) {
+            h->rowtab_bytes = tab_bytes;
+          } else {  // no room: the in-kernel setup needs no table
+            (void)hipGetLastError();
+            use_tab = false;
+          }
+        }
+        const char* tab_ptr = use_tab ? h->d_rowtab : nullptr;
+        const size_t smem_pair = use_tab ? smem_tab : (share ? smem_share : smem);
         if (P.cash_formula == 1) {
           if (last) SDP_PAIR(true, true, false); else SDP_PAIR(false, true, false);
         } else if (lean) {
@@ -368,6 +420,7 @@ hipError_t launch_cash_row(sdpgpu_handle* h, const DevParams& P, int period, con
           if (last) SDP_PAIR(true, false, false); else SDP_PAIR(false, false, false);
         }
 #undef SDP_PAIR
+#undef SDP_PAIR_GO
         return hipGetLastError();
       }
       if (uni) {

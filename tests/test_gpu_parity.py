@@ -90,13 +90,16 @@ def test_cfg2_full_horizon_full_tables(sia, oracle):
 
 @pytest.mark.parametrize("env", [{"SDPGPU_CASH_PAIR_S": "2"}, {"SDPGPU_CASH_PAIR_S": "1"}, {"SDPGPU_CASH_PAIR": "0"},
                                  {"SDPGPU_CASH_PAIR": "0", "SDPGPU_CASH_UNI": "0"}, {"SDPGPU_CASH_BANDS": "0"},
-                                 {"SDPGPU_CASH_BANDS": "3", "SDPGPU_CASH_PAIR_S": "2"}],
+                                 {"SDPGPU_CASH_BANDS": "3", "SDPGPU_CASH_PAIR_S": "2"}, {"SDPGPU_CASH_SHARE": "1"},
+                                 {"SDPGPU_CASH_SHARE": "1", "SDPGPU_CASH_PAIR_S": "1"}, {"SDPGPU_CASH_TAB": "1"},
+                                 {"SDPGPU_CASH_TAB": "1", "SDPGPU_CASH_PAIR_S": "1"}],
                          ids=lambda e: ",".join(f"{k[12:]}={v}" for k, v in e.items()))
 @pytest.mark.parametrize("make", [cases.f3_grid_prices, cases.f3_half_grid_prices, cases.f3_testing, cases.f3_xr],
                          ids=lambda f: f.__name__)
 def test_cash_row_kernel_variants(sia, oracle, monkeypatch, make, env):
     """Every variant of the cash row kernels (one / two points per lane, one / two tiles per wave, with and without the
-    uniform-key trips, banded and row-major block order) gives the oracle's tables bit for bit -- on grids with on-grid
+    uniform-key trips, banded and row-major block order, the (row, action) operand blocks formed per wave (default), shared
+    by the four tiles of a workgroup (SHARE=1) or copied from cash_row_table_kernel's table (TAB=1)) gives the oracle's tables bit for bit -- on grids with on-grid
     prices (all trips uniform), half-grid prices (uniform and tie steps mixed), integer cash and the (x, R) state."""
     for k, v in env.items():
         monkeypatch.setenv(k, v)
