@@ -350,6 +350,8 @@ struct DiagParams {
   int32_t n_steps;   // D + DIAG_R - 1 rounded up to an even number (the kernel's step loop is unrolled by two)
   int32_t n_rows;    // inventory rows launched
   int32_t cap;       // largest shift spread of a step the launch stages for (64 or DIAG_CAP: one 64-entry piece less)
+  int32_t band_tiles;  // > 0: XCD i owns the cash band of tiles [i * band_tiles, (i + 1) * band_tiles) of EVERY row (see the kernel)
+  int32_t pad0;
 };
 
 // shift, row and t1 of one (action, demand): the operations of cash_shift_kernel's per-action setup, in its order
@@ -584,11 +586,23 @@ __global__ __launch_bounds__(256) void cash_diag_kernel(DiagParams Q, const Diag
   // the other, all tiles of a row in a run.  The workgroups of one row stream the same DiagStep records: kept on one XCD
   // and close in time they find them in its L2 (numbered row-major, the tiles of a row sat on eight XCDs and ~25 rows were in
   // flight: 9 GB per launch came through the fabric and every scalar load waited for it).  Placement only.
+  // Q.band_tiles > 0 (round 3): XCD i owns a BAND of the cash axis for every row and walks the rows in order.  Its working set
+  // of V_{t+1} is then one band (plus the shifts' reach) of every row -- configs[2]: 200 rows x ~1000 points = 1.6 MB, inside
+  // its 4 MB L2 -- where "rows i, i + 8, ..." makes every XCD read the whole 8 MB table per row it walks; the price is that
+  // every XCD streams all rows' DiagStep records instead of an eighth of them.
   const int xcd = blockIdx.x & 7, seq = blockIdx.x >> 3;
-  const int rowi = (seq / P.tiles_per_row) * 8 + xcd;
+  int rowi, tile;
+  if (Q.band_tiles > 0) {
+    rowi = seq / Q.band_tiles;
+    tile = xcd * Q.band_tiles + (seq - rowi * Q.band_tiles);
+    if (tile >= P.tiles_per_row) return;
+  } else {
+    rowi = (seq / P.tiles_per_row) * 8 + xcd;
+    tile = seq % P.tiles_per_row;
+  }
   if (rowi >= Q.n_rows) return;
   const int row = P.row0 + rowi;
-  const int ic0 = (seq % P.tiles_per_row) * TS;
+  const int ic0 = tile * TS;
   const int nc1 = P.nc - 1;
 
   // feasible action count per point (CashConstraint.java:96-99) and the wave's maximum

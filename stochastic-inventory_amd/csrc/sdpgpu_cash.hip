@@ -131,7 +131,14 @@ hipError_t launch_cash_shift(sdpgpu_handle* h, const DevParams& P, int period, c
                          table, pmf_d, pmf_p, overflow, bounds);
       hipError_t e = hipGetLastError();
       if (e != hipSuccess) return e;
-      const dim3 grid((unsigned)(8 * ((rows + 7) / 8) * C.tiles_per_row));  // (XCD i: rows i, i + 8, ...)
+      // block -> (row, tile): rows i, i + 8, ... per XCD.  OPT-IN SDPGPU_CASH_DIAG_BANDS=1: cash bands per XCD (rows of 16 tiles
+      // and more) -- measured on configs[2] (profiles/r03_diag_bands.txt): the fabric traffic falls from 12.6 to 4.4 GB per
+      // launch and the L2 hit rate rises from 77 to 95 %, and the sweep takes 39.4 instead of 38.1 ms: the kernel is bound by
+      // its LDS reads, not by the fabric, and with bands every XCD streams every row's step records.
+      const bool bands_off = !(std::getenv("SDPGPU_CASH_DIAG_BANDS") && std::atoi(std::getenv("SDPGPU_CASH_DIAG_BANDS")) == 1);
+      Q.band_tiles = (!bands_off && C.tiles_per_row >= 16) ? (C.tiles_per_row + 7) / 8 : 0;
+      if (Q.band_tiles > 0 && !grid_ok(8LL * rows * Q.band_tiles)) return hipErrorInvalidValue;
+      const dim3 grid(Q.band_tiles > 0 ? (unsigned)(8LL * rows * Q.band_tiles) : (unsigned)(8 * ((rows + 7) / 8) * C.tiles_per_row));
       const size_t smem = (size_t)4 * 2 * (TSZ + sdp::DIAG_CAP) * 8 + (size_t)4 * TSZ * (sizeof(double) + sizeof(int));
       h->per[period - 1].ops_cell = 3.0;  // acc += T1; acc += (p gamma) * V
       {  // one 8-byte LDS read per cell; per step and wave NU pieces of 64 entries are loaded (L1) and stored (LDS) for DIAG_R * TSZ cells

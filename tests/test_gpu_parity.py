@@ -144,7 +144,8 @@ def _dyadic_wide_min():
     return w
 
 
-@pytest.mark.parametrize("env", [{}, {"SDPGPU_CASH_DIAG_S": "2"}, {"SDPGPU_CASH_DIAG_S": "1"}, {"SDPGPU_CASH_DIAG": "0"}],
+@pytest.mark.parametrize("env", [{}, {"SDPGPU_CASH_DIAG_S": "2"}, {"SDPGPU_CASH_DIAG_S": "1"}, {"SDPGPU_CASH_DIAG": "0"},
+                                 {"SDPGPU_CASH_DIAG_BANDS": "1"}],
                          ids=lambda e: ",".join(f"{k[12:]}={v}" for k, v in e.items()) or "default")
 @pytest.mark.parametrize("make", [_cfg3_small, cases.f3_dyadic_wide, _dyadic_wide_min, cases.f3_dyadic_big_fixed], ids=lambda f: f.__name__)
 def test_cash_diag_kernel_variants(sia, oracle, monkeypatch, make, env):
