@@ -252,6 +252,15 @@ void sdpgpu_destroy(sdpgpu_handle* h);
  *       result must be a grid point of the next period, otherwise the next read of results fails with
  *       SDPGPU_ERR_ARG.
  *
+ * ABI 5, optional: a text that also says `#define SDP_USER_CELL 1` and defines
+ *   __device__ void   sdp_cell(const sdp_ctx& c, double x, double cash, double preq, double action, double demand,
+ *                              double& imm, double& next_x, double& next_cash, double& next_preq);
+ * gives the period kernel ONE callback per cell: imm = immediateValue.apply(...) and the successor of the same cell.  The
+ * reference's cash-type transitions call immediateValue again (CashConstraint.java:125 `nextCash = cash +
+ * immediateValue.apply(...)`); as two functions the increment is spelled out twice per cell.  sdp_immediate and
+ * sdp_transition are still required (the reachable-set pass and sdpgpu_eval_states' host twins use them); the
+ * natural way to write them is as calls of sdp_cell.
+ *
  * with `struct sdp_ctx { int period; int T; double step; const double* params; }` (period = state.getPeriod(),
  * params = the n_params doubles given here: the constants the Java lambdas close over) and the helpers
  * sdp_max / sdp_min / sdp_round / sdp_trunc (java.lang.Math.max / min / round and the (int) cast).

@@ -351,12 +351,25 @@ _HOST_WRAPPERS = r"""
 extern "C" int sdpref_user_count(const sdp_ctx* c, double x, double cash, double preq) {
   return sdp_feasible_count(*c, x, cash, preq);
 }
+// (a text with the fused callback -- #define SDP_USER_CELL 1 + sdp_cell -- is run through THAT function here as well, so that the
+// oracle executes the very text the period kernel calls)
 extern "C" double sdpref_user_imm(const sdp_ctx* c, double x, double cash, double preq, double a, double d) {
+#ifdef SDP_USER_CELL
+  double imm, nx, nc, nq;
+  sdp_cell(*c, x, cash, preq, a, d, imm, nx, nc, nq);
+  return imm;
+#else
   return sdp_immediate(*c, x, cash, preq, a, d);
+#endif
 }
 extern "C" void sdpref_user_trans(const sdp_ctx* c, double x, double cash, double preq, double a, double d, double* nx,
                                   double* nc, double* nq) {
+#ifdef SDP_USER_CELL
+  double imm;
+  sdp_cell(*c, x, cash, preq, a, d, imm, *nx, *nc, *nq);
+#else
   sdp_transition(*c, x, cash, preq, a, d, *nx, *nc, *nq);
+#endif
 }
 """
 

@@ -177,22 +177,25 @@ __device__ inline void custom_period_body(
     double acc = 0.0;
     for (int j = 0; j < nD; ++j) {
       const double2 dp = s_pmf[j];
+#ifdef SDP_USER_CELL
+      // the user's fused callback: immediate value AND successor of the cell in one evaluation (a cash-type transition is
+      // `cash + immediateValue(...)`, CashConstraint.java:125: written as two functions the increment is spelled out twice)
+      double imm, nx, nc, nq;
+      sdp_cell(U, s.x, s.cash, s.preq, a, dp.x, imm, nx, nc, nq);
+#else
       const double imm = sdp_immediate(U, s.x, s.cash, s.preq, a, dp.x);
+      double nx = 0, nc = 0, nq = 0;
+      if (!LAST) sdp_transition(U, s.x, s.cash, s.preq, a, dp.x, nx, nc, nq);
+#endif
       if (SDP_SURVIVAL) {  // RiskRecursion.java:78-98
         if (LAST) {
           acc += dp.y * ((s.cash + imm) >= 0 ? 1.0 : 0.0);
         } else {
-          double nx, nc, nq;
-          sdp_transition(U, s.x, s.cash, s.preq, a, dp.x, nx, nc, nq);
           acc += (dp.y * P.gamma) * (nc < 0 ? 0.0 : v_next[c_next_index(P, nx, nc, nq, bad)]);
         }
       } else {
         acc += dp.y * imm;
-        if (!LAST) {
-          double nx, nc, nq;
-          sdp_transition(U, s.x, s.cash, s.preq, a, dp.x, nx, nc, nq);
-          acc += (dp.y * P.gamma) * v_next[c_next_index(P, nx, nc, nq, bad)];
-        }
+        if (!LAST) acc += (dp.y * P.gamma) * v_next[c_next_index(P, nx, nc, nq, bad)];
       }
     }
     if (SDP_MAXDIR ? (acc > best) : (acc < best)) {

@@ -93,5 +93,53 @@ __device__ void sdp_transition(const sdp_ctx& c, double x, double cash, double p
 }
 """
 
+# the same lambdas with the FUSED callback (ABI 5): the increment is formed once per cell and both the immediate value and the
+# successor are read off it; sdp_immediate / sdp_transition are calls of sdp_cell
+OVERDRAFT_LIMIT_FUSED = r"""
+#define SDP_USER_CELL 1
+__device__ int sdp_feasible_count(const sdp_ctx& c, double x, double cash, double preq) {
+  double maxQ = c.params[7];
+  return (int)maxQ + 1;
+}
+__device__ void sdp_cell(const sdp_ctx& c, double x, double cash, double preq, double action, double randomDemand,
+                         double& imm, double& nx, double& ncash, double& npreq) {
+  const double price = c.params[0], fixOrderCost = c.params[1], variCost = c.params[2], holdingCost = c.params[3];
+  const double interestRate = c.params[4], depositeRate = c.params[5], salvageValue = c.params[6];
+  double revenue = price * sdp_min(x + action, randomDemand);
+  double fixedCost = action > 0 ? fixOrderCost : 0;
+  double variableCost = variCost * action;
+  double inventoryLevel = x + action - randomDemand;
+  double holdCosts = holdingCost * sdp_max(inventoryLevel, 0);
+  double cashBalanceBeforeRevenue = cash - fixedCost - variableCost - holdCosts - c.params[12 + c.period - 1];
+  double interest = interestRate * sdp_max(-cashBalanceBeforeRevenue, 0);
+  double deposite = depositeRate * sdp_max(cashBalanceBeforeRevenue, 0);
+  double cashBalanceAfter = cashBalanceBeforeRevenue - interest + deposite + revenue;
+  double cashIncrement = cashBalanceAfter - cash;
+  double salValue = c.period == c.T ? salvageValue * sdp_max(inventoryLevel, 0) : 0;
+  cashIncrement += salValue;
+  imm = cashIncrement;
+  double nextInventory = sdp_max(0, inventoryLevel);
+  double nextCash = cash + cashIncrement;
+  nextCash = nextCash > c.params[11] ? c.params[11] : nextCash;
+  nextCash = nextCash < c.params[10] ? c.params[10] : nextCash;
+  nextInventory = nextInventory > c.params[9] ? c.params[9] : nextInventory;
+  nextInventory = nextInventory < c.params[8] ? c.params[8] : nextInventory;
+  nextCash = sdp_trunc(sdp_round(nextCash * 10) / 10);
+  nx = nextInventory;
+  ncash = nextCash;
+  npreq = 0;
+}
+__device__ double sdp_immediate(const sdp_ctx& c, double x, double cash, double preq, double action, double randomDemand) {
+  double imm, nx, nc, nq;
+  sdp_cell(c, x, cash, preq, action, randomDemand, imm, nx, nc, nq);
+  return imm;
+}
+__device__ void sdp_transition(const sdp_ctx& c, double x, double cash, double preq, double action, double randomDemand,
+                               double& nx, double& ncash, double& npreq) {
+  double imm;
+  sdp_cell(c, x, cash, preq, action, randomDemand, imm, nx, ncash, npreq);
+}
+"""
+
 # a transition that forgets to clamp: leaves the grid
 BROKEN_TRANSITION = BACKORDER.replace("nextInventory = nextInventory < c.params[4] ? c.params[4] : nextInventory;", "")

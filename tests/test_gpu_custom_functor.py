@@ -53,15 +53,20 @@ def _overdraft_limit_case(sia, T=4):
     return shape, params, pmf
 
 
-def test_driver_outside_the_builtin_families(sia, oracle):
+@pytest.mark.parametrize("source", ["OVERDRAFT_LIMIT", "OVERDRAFT_LIMIT_FUSED"], ids=["three-functions", "fused-sdp_cell"])
+def test_driver_outside_the_builtin_families(sia, oracle, source):
+    """CashOverdraftLimit's lambdas as user text, written as the reference's three lambdas and with the fused per-cell callback
+    (ABI 5: `#define SDP_USER_CELL 1` + sdp_cell, one evaluation of the increment per cell): tables, reachable sets, off-grid
+    evaluations and the memoised recursion's root value all match the oracle running the SAME text compiled for the host."""
     shape, params, pmf = _overdraft_limit_case(sia)
     T = len(pmf)
     desc = shape.to_desc(T, sia.OptDirection.MAX)
     desc.discount_factor = 0.98
-    eng = sia.SdpEngine(desc, pmf, custom_source=cs.OVERDRAFT_LIMIT, custom_params=params)
+    text = getattr(cs, source)
+    eng = sia.SdpEngine(desc, pmf, custom_source=text, custom_params=params)
     eng.solve()
     P = oracle.Problem(desc, pmf)
-    with oracle.custom_functor(cs.OVERDRAFT_LIMIT, params):
+    with oracle.custom_functor(text, params):
         V, pol, cells = P.solve(nthreads=4)
         m = P.memo()
         reach = P.reachable()
@@ -76,6 +81,11 @@ def test_driver_outside_the_builtin_families(sia, oracle):
     assert np.array_equal(gv, ov) and np.array_equal(ga, oa)
     i0 = eng.state_index(1, 0.0, 10.0)
     assert eng.values(1)[i0] == m["value"] and eng.policy(1)[i0] == m["action"]
+    if source.endswith("FUSED"):  # ... and the fused text gives the three-function text's tables
+        with sia.SdpEngine(desc, pmf, custom_source=cs.OVERDRAFT_LIMIT, custom_params=params) as plain:
+            plain.solve()
+            for period in range(1, T + 1):
+                assert np.array_equal(plain.values(period), eng.values(period)) and np.array_equal(plain.policy(period), eng.policy(period))
     # the built-in OVERDRAFT family (CashOverdraft.java's piecewise schedule) is a different model
     other = sia.SdpEngine(desc, pmf, [9.0, 12.0, 7.0, 10.0])
     other.solve()
