@@ -64,7 +64,7 @@ def parse_args():
     ap.add_argument("--periods", type=int, default=0, help="override the horizon")
     ap.add_argument("--weak", action="store_true",
                     help="weak scaling instead of strong: every rank keeps --states states (default 1e4 for cfg2, 1e6 otherwise)")
-    ap.add_argument("--kernel", type=int, default=0, help="0 auto, 1 gather, 2 window, 3 separable (opt-in, F1)")
+    ap.add_argument("--kernel", type=int, default=0, help="0 auto, 1 gather, 2 window, 3 separable (opt-in: F1 to 1e-9, F2 exact)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-secondary", action="store_true", help="skip the other BASELINE configs (N = 1, default workload)")
     ap.add_argument("--no-gate", action="store_true", help="skip the parity gate (profiling runs only: the line says so)")

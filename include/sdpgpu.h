@@ -123,11 +123,13 @@ typedef enum sdpgpu_direction { SDPGPU_MIN = 0, SDPGPU_MAX = 1 } sdpgpu_directio
 #define SDPGPU_KERNEL_AUTO 0
 #define SDPGPU_KERNEL_GATHER 1 /* generic per-cell functor + gather from V_{t+1} in HBM/L2 */
 #define SDPGPU_KERNEL_WINDOW 2 /* F1/F2: LDS-staged {L(l), V(clamp l)} window, register sliding */
-#define SDPGPU_KERNEL_SEPARABLE 3 /* OPT-IN, never chosen automatically.  F1: Q(x,a) = c(a) + G(x+a), O((S+A)D + SA) per
-                                     period.  F2 (lead time 1 or 2): V_t and the arg-min depend on (x + preQ[, q2])
-                                     only, O(A (nx+nq) D [nq]) for that table + one write per state.  Reassociates the
-                                     reference's sum: values agree to rounding (1e-9 relative), the arg-opt may differ
-                                     on near-ties. */
+#define SDPGPU_KERNEL_SEPARABLE 3 /* OPT-IN, never chosen automatically.
+                                     F1: Q(x,a) = c(a) + G(x+a), O((S+A)D + SA) per period.  REASSOCIATES the reference's
+                                     sum: values agree to rounding (1e-9 relative), the arg-opt may differ on near-ties.
+                                     F2 (lead time 1 or 2): V_t and the arg-min depend on (x + preQ[, q2]) only: one
+                                     evaluation per level in the reference's operation order, O(A (nx+nq) D [nq]) for
+                                     that table + one write per state.  EXACT: values and policy bit-identical to the
+                                     cell-by-cell kernels (tests/test_gpu_separable.py). */
 
 /*
  * Problem descriptor: everything the reference's lambdas close over.  Field names
@@ -322,7 +324,9 @@ int sdpgpu_set_overhead(sdpgpu_handle* h, int32_t t, double overhead_cost);
  * counts[i] = getFeasibleAction.apply(state i of period t+1).length for every grid state i (flat index order,
  * n = sdpgpu_num_states), 0 <= counts[i] <= (int)(max_order_quantity / step) + 1; 0 = no feasible action (the value is
  * then +-Double.MAX_VALUE and the action 0, Recursion.java:132-134).  Such a period runs on the generic kernel (the
- * specialised kernels build on the family's rule); off-grid states (sdpgpu_eval_states) keep the family's rule.
+ * specialised kernels build on the family's rule).  sdpgpu_eval_states ALWAYS applies the family's rule -- to off-grid
+ * states (the caller's list is defined on grid states only) and to on-grid states alike, so for a grid state whose count was
+ * overridden here its answer may differ from sdpgpu_values / sdpgpu_policy of the same state: read those for grid states.
  * Before the first run.  Lists that are not prefixes of the action grid need sdpgpu_create_custom. */
 int sdpgpu_set_action_counts(sdpgpu_handle* h, int32_t t, const int32_t* counts, int64_t n);
 

@@ -29,7 +29,7 @@ MAX = 1
 KERNEL_AUTO = 0
 KERNEL_GATHER = 1
 KERNEL_WINDOW = 2
-KERNEL_SEPARABLE = 3  # opt-in, F1 only: reassociated sum, values to 1e-9, arg-opt may differ on near-ties
+KERNEL_SEPARABLE = 3  # opt-in.  F1: reassociated sum, values to 1e-9, arg-opt may differ on near-ties; F2: exact
 
 SHARDED_SYNC = 1
 SHARDED_OVERLAP = 2
