@@ -161,3 +161,39 @@ def test_solve_multi_threads_reports_a_failing_rank(sia, monkeypatch):
     finally:
         for e in engs:
             e.close()
+
+
+@pytest.mark.parametrize("threads", [False, True], ids=["one-thread", "thread-per-rank"])
+@pytest.mark.parametrize("name,world", [("target_8_slabs", 8), ("cfg4_4_slabs", 4), ("cfg3t_8_slabs", 8)])
+def test_baseline_shardings_rehearsed_on_one_device(sia, name, world, threads):
+    """The shardings BASELINE.json names -- 8 slabs of the F1 target shape (500 actions x 200 demands: the (4, 8) block, chunk
+    rows and key rows per slab), 4 slabs of configs[3]'s lead-time shape, 8 slabs of CashConstraint.main's shape (ragged action
+    counts along the cash axis) -- at reduced width, all ranks on ONE device (slabs exchanged by copies inside
+    sdpgpu_solve_multi), against the single-rank sweep of the same library, every table bit for bit.  (The single-rank sweep
+    is what the oracle tests pin; what one device cannot show is RCCL's transport between devices.)"""
+    from stochastic_inventory_amd import workloads
+    w = {"target_8_slabs": lambda: workloads.target_grid(T=3, S=400000),
+         "cfg4_4_slabs": lambda: workloads.cfg4_leadtime(T=3, NX=600, A=120, D=100),
+         "cfg3t_8_slabs": lambda: workloads.cfg3_tenths(T=3, NX=40, maxCash=400.0, A=60, D=25)}[name]()
+    d1 = w.desc()
+    d1.device = 0
+    engs = []
+    with sia.SdpEngine(d1, w.pmf, w.overhead()) as ref:
+        ref.solve(sync=True)
+        try:
+            for r in range(world):
+                d = w.desc()
+                d.rank, d.world_size, d.device = r, world, 0
+                engs.append(sia.SdpEngine(d, w.pmf, w.overhead()))
+            sia.SdpEngine.solve_multi(engs, sync=True, gather_first=True, threads=threads)
+            cells = 0
+            for r, e in enumerate(engs):
+                for period in range(1, w.T + 1):
+                    _, lo, hi = e.slab(period)
+                    assert np.array_equal(e.values(period), ref.values(period)), f"{name} rank {r}: V_{period}"
+                    assert np.array_equal(e.policy(period), ref.policy(period)[lo:hi]), f"{name} rank {r}: policy {period}"
+                cells += int(e.stats().cells_evaluated)
+            assert cells == int(ref.stats().cells_evaluated)
+        finally:
+            for e in engs:
+                e.close()
