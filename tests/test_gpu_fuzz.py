@@ -213,9 +213,13 @@ def make_large_magnitude_cash_instance(seed, past_limit=False):
                              limit=float(rng.integers(10, 40)), interestFreeAmount=float(rng.integers(0, 10)),
                              discountFactor=float(rng.choice([1.0, 0.9])), overheadCosts=overheads, **common)
         return Workload(f"fuzz_big_f4_{seed}", f, OptDirection.MAX, _pmf(rng, T, d_max=12))
+    penalty = float(rng.choice([0, 0, 0, 0.3]))
+    if penalty:  # (the launcher's bound multiplies by 1 + the end-cash penalty rate)
+        base = float(np.floor(base / 1.31 * mult) / mult)
+        common.update(minCashState=base, maxCashState=base + (nc - 1) / mult, iniCash=base + 5.0)
     f = CashFunctor(fixOrderCost=float(rng.choice([0.0, money(0, 0.5 * pscale)])),
                     holdingCost=float(rng.choice([0.0, money(0, 0.1 * pscale)])),
-                    depositeRate=float(rng.choice([0, 0, 0, 1e-9])), overheadRate=0.0, penaltyCost=float(rng.choice([0, 0, 0, 0.3])),
+                    depositeRate=float(rng.choice([0, 0, 0, 1e-9])), overheadRate=0.0, penaltyCost=penalty,
                     discountFactor=float(rng.choice([1.0, 0.95])), cashFormula=int(rng.integers(0, 2)),
                     overheadCosts=[float(rng.choice([0.0, o])) for o in overheads], **common)
     direction = OptDirection.MAX if rng.integers(0, 4) else OptDirection.MIN
