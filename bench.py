@@ -439,6 +439,11 @@ def main():
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("GLOO_SOCKET_IFNAME", "lo")  # one node: do not depend on the hostname resolving
+        # RCCL's bootstrap (the rendezvous behind ncclCommInitRank; the data itself travels over xGMI) on the loopback interface
+        # as well -- a GPU box without network may have no other -- and its warnings on stderr, so that a failed communicator
+        # says why
+        os.environ.setdefault("NCCL_SOCKET_IFNAME", "lo")
+        os.environ.setdefault("NCCL_DEBUG", "WARN")
         # native exchange: the data path is RCCL inside libsdpgpu.so; the process group carries the communicator id,
         # the barriers and the timing reductions, for which gloo is enough
         with wd.phase("process group", 180):
