@@ -290,6 +290,20 @@ def test_f2_row_window_block_plans(sia, oracle, monkeypatch, env):
     eng.close()
 
 
+@pytest.mark.parametrize("win_s", ["4", "2"], ids=["S4", "S2"])
+def test_f2_row_window_above_64KiB_of_lds(sia, oracle, monkeypatch, win_s):
+    """400 demand points: a wave's four row segments are 21 KiB, a workgroup's 69-86 KiB -- above the 64 KiB a launch could ask
+    for before the launcher raised the kernel's dynamic-LDS limit (three of the four waves take action blocks at S = 4)."""
+    from stochastic_inventory_amd import workloads
+    monkeypatch.setenv("SDPGPU_WIN_S", win_s)
+    w = workloads.cfg4_leadtime(T=2, NX=300, A=22, D=400)
+    eng, P, V, pol, cells = _solve_both(sia, oracle, w)
+    assert eng.stats().cells_evaluated == cells and eng.stats().kernel_used == 2
+    for period in range(1, w.T + 1):
+        _assert_tables(eng.values(period), eng.policy(period), V[period - 1], pol[period - 1], f"{w.name} S={win_s} t={period}")
+    eng.close()
+
+
 @pytest.mark.parametrize("kernel", [0, 1], ids=["auto", "gather"])
 def test_cfg4_pipeline_shape_reduced(sia, oracle, kernel):
     """configs[3] as a two-stage pipeline (x, q1, q2) at 90 x 24 x 24 states (the full shape is 250 x 200 x 200)."""

@@ -96,3 +96,12 @@ def test_separable_refuses_other_families(sia):
         with pytest.raises(sia.SdpgpuError) as e:
             eng.solve()
         assert e.value.code == 4
+
+
+def test_separable_f1_above_64KiB_of_lds(sia, oracle):
+    """3000 actions x 400 demand steps: the separable F1 kernel's window + cost rows take 80 KiB of LDS per workgroup (round 2
+    refused anything above 64 KiB as "too big"; gfx950 has 160 KiB per compute unit)."""
+    from stochastic_inventory_amd import workloads
+    w = workloads.cfg5_scaled(S=1500, T=2, A=3000, D=400)
+    worst, mismatches, states = _compare_with_oracle(sia, oracle, w)
+    assert worst <= REL_TOL and mismatches <= 0.02 * states
