@@ -416,7 +416,7 @@ def main():
         raise SystemExit(f"WORLD_SIZE={world} but --gpus {args.gpus}")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the engine has no CPU path")
-    if args.exchange == "host":
+    if args.exchange == "host" or local_rank >= torch.cuda.device_count():
         local_rank = local_rank % torch.cuda.device_count()  # rehearsal: several ranks share a GPU
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
@@ -519,6 +519,8 @@ def main():
     eng = backend.engine
     exchange = args.exchange
     note = ""
+    if os.environ.get("SDP_TEST_BREAK_RCCL_ON_RANK") == str(rank):  # (tests: this rank's collective library does not load)
+        os.environ["SDPGPU_RCCL_LIB"] = "/nonexistent/librccl.so"
     t_comm0 = time.perf_counter()
     with wd.phase("communicator init", 180):
         native_ok = exchange != "native" or init_native_comm(eng)  # (the ranks agree inside: all or none)
@@ -527,9 +529,9 @@ def main():
         exchange = "torch"
         err = init_native_comm.last_error
         note = f" (native communicator failed{': ' + err if err else ' on another rank'}; fell back to torch.distributed nccl)"
-        if rank == 0:
-            print(f"[bench] native RCCL communicator unavailable{': ' + err if err else ''}; using torch.distributed",
-                  file=sys.stderr, flush=True)
+        if rank == 0 or err:  # (rank 0 announces the fallback; a rank whose own preparation failed says why)
+            print(f"[bench] rank {rank}: native RCCL communicator unavailable{': ' + err if err else ' (another rank could not prepare)'}; "
+                  "using torch.distributed", file=sys.stderr, flush=True)
     group = dist.new_group(backend="nccl") if (exchange == "torch" and args.exchange != "torch") else None
     solver = ShardedSolver(backend, group=group, stage_through_host=(exchange == "host"))
     solver.force_split = args.split

@@ -43,9 +43,19 @@ RcclApi* rccl() {
   std::call_once(g_rccl_once, [] {
     static_assert(SDPGPU_UNIQUE_ID_BYTES == NCCL_UNIQUE_ID_BYTES, "unique id size");
     const char* names[] = {"librccl.so.1", "librccl.so"};
+    // SDPGPU_RCCL_LIB: the collective library to open instead (a site's own RCCL build; tests/mock_rccl.c -- a stand-in that
+    // moves the slabs through host shared memory, so that the multi-PROCESS path can run with several ranks on one GPU)
+    if (const char* path = std::getenv("SDPGPU_RCCL_LIB")) {
+      g_rccl.lib = dlopen(path, RTLD_NOW | RTLD_LOCAL);
+      if (!g_rccl.lib) {
+        const char* e = dlerror();
+        g_rccl.err = std::string("cannot load SDPGPU_RCCL_LIB=") + path + ": " + (e ? e : "?");
+        return;
+      }
+    }
     for (const char* n : names) {
-      g_rccl.lib = dlopen(n, RTLD_NOW | RTLD_GLOBAL | RTLD_NOLOAD);  // a copy the process already holds (e.g. PyTorch's)
       if (g_rccl.lib) break;
+      g_rccl.lib = dlopen(n, RTLD_NOW | RTLD_GLOBAL | RTLD_NOLOAD);  // a copy the process already holds (e.g. PyTorch's)
     }
     for (int i = 0; !g_rccl.lib && i < 2; ++i) g_rccl.lib = dlopen(names[i], RTLD_NOW | RTLD_GLOBAL);
     if (!g_rccl.lib) {

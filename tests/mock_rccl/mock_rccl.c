@@ -1,0 +1,148 @@
+/*
+ * mock_rccl.c -- TEST DOUBLE for librccl.so.1 (never shipped, never linked by the product): the eight RCCL entry points
+ * libsdpgpu.so resolves with dlsym (csrc/sdpgpu_comm.hip), implemented over POSIX shared memory and blocking HIP copies, so
+ * that the multi-PROCESS path of the library -- sdpgpu_comm_prepare / sdpgpu_comm_init with world > 1 in separate processes,
+ * sdpgpu_solve_sharded, bench.py --exchange native -- can run with several ranks on ONE GPU (RCCL itself refuses two ranks on
+ * one device).  What it does not stand in for is RCCL's transport between devices.
+ *
+ * Loaded through SDPGPU_RCCL_LIB.  An all-gather: wait for the stream, copy this rank's slab to its slot of the shared
+ * segment, barrier, copy the other ranks' slabs into place, barrier.  Synchronous where RCCL is asynchronous -- the
+ * ordering the library relies on (the collective behind the kernel that produced the slab, ahead of whatever is enqueued
+ * next on that stream) is kept.
+ *
+ * Build: hipcc -shared -fPIC -o libmock_rccl.so mock_rccl.c   (tests/test_gpu_native_mock_rccl.py does it)
+ */
+#define _GNU_SOURCE
+#include <fcntl.h>
+#include <hip/hip_runtime_api.h>
+#include <sched.h>
+#include <stdatomic.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+#include <sys/mman.h>
+#include <sys/stat.h>
+#include <time.h>
+#include <unistd.h>
+
+typedef enum { ncclSuccess = 0, ncclUnhandledCudaError = 1, ncclSystemError = 2, ncclInternalError = 3, ncclInvalidArgument = 4 } ncclResult_t;
+typedef struct { char internal[128]; } ncclUniqueId;
+typedef int ncclDataType_t;
+
+typedef struct {
+  _Atomic int arrived;
+  _Atomic int generation;
+  _Atomic int attached;
+  int world;
+  size_t slot_bytes;
+} header_t;
+
+typedef struct mock_comm {
+  int rank, world;
+  char name[64];
+  header_t* hd;
+  char* slots;
+  size_t map_bytes;
+} mock_comm;
+
+static size_t slot_bytes_env(void) {
+  const char* e = getenv("MOCK_RCCL_SLOT_MB");
+  size_t mb = e ? (size_t)atol(e) : 64;
+  return mb << 20;
+}
+
+ncclResult_t ncclGetUniqueId(ncclUniqueId* id) {
+  memset(id, 0, sizeof *id);
+  struct timespec ts;
+  clock_gettime(CLOCK_REALTIME, &ts);
+  snprintf(id->internal, sizeof id->internal, "/sdpmock_%d_%ld", (int)getpid(), (long)(ts.tv_nsec ^ ts.tv_sec));
+  return ncclSuccess;
+}
+
+ncclResult_t ncclCommInitRank(void** out, int world, ncclUniqueId id, int rank) {
+  if (!out || world < 1 || rank < 0 || rank >= world) return ncclInvalidArgument;
+  mock_comm* c = (mock_comm*)calloc(1, sizeof *c);
+  c->rank = rank;
+  c->world = world;
+  memcpy(c->name, id.internal, sizeof c->name - 1);
+  const size_t slot = slot_bytes_env();
+  c->map_bytes = 4096 + slot * (size_t)world;
+  int fd = shm_open(c->name, O_CREAT | O_RDWR, 0600);
+  if (fd < 0) return ncclSystemError;
+  if (ftruncate(fd, (off_t)c->map_bytes) != 0) return ncclSystemError;  /* (every rank sets the same size) */
+  void* p = mmap(NULL, c->map_bytes, PROT_READ | PROT_WRITE, MAP_SHARED, fd, 0);
+  close(fd);
+  if (p == MAP_FAILED) return ncclSystemError;
+  c->hd = (header_t*)p;
+  c->slots = (char*)p + 4096;
+  c->hd->world = world;
+  c->hd->slot_bytes = slot;
+  atomic_fetch_add(&c->hd->attached, 1);
+  /* collective: wait until every rank has attached (RCCL's ncclCommInitRank blocks the same way) */
+  for (long spins = 0; atomic_load(&c->hd->attached) < world; ++spins) {
+    sched_yield();
+    if (spins > 2000000000L) return ncclInternalError;
+  }
+  *out = c;
+  return ncclSuccess;
+}
+
+ncclResult_t ncclCommInitAll(void** comms, int n, const int* devs) {
+  (void)comms; (void)n; (void)devs;
+  return ncclInvalidArgument;  /* one process owning distinct devices: not what this double is for */
+}
+
+ncclResult_t ncclCommDestroy(void* comm) {
+  mock_comm* c = (mock_comm*)comm;
+  if (!c) return ncclSuccess;
+  if (atomic_fetch_sub(&c->hd->attached, 1) == 1) shm_unlink(c->name);
+  munmap((void*)c->hd, c->map_bytes);
+  free(c);
+  return ncclSuccess;
+}
+
+static void barrier(mock_comm* c) {
+  const int gen = atomic_load(&c->hd->generation);
+  if (atomic_fetch_add(&c->hd->arrived, 1) == c->world - 1) {
+    atomic_store(&c->hd->arrived, 0);
+    atomic_fetch_add(&c->hd->generation, 1);
+  } else {
+    while (atomic_load(&c->hd->generation) == gen) sched_yield();
+  }
+}
+
+ncclResult_t ncclAllGather(const void* send, void* recv, size_t count, ncclDataType_t type, void* comm, hipStream_t stream) {
+  (void)type;  /* the library sends 8-byte elements (ncclUint64) */
+  mock_comm* c = (mock_comm*)comm;
+  const size_t bytes = count * 8;
+  if (bytes > c->hd->slot_bytes) {
+    fprintf(stderr, "[mock_rccl] slab of %zu bytes exceeds the slot (MOCK_RCCL_SLOT_MB)\n", bytes);
+    return ncclInvalidArgument;
+  }
+  if (hipStreamSynchronize(stream) != hipSuccess) return ncclUnhandledCudaError;
+  if (hipMemcpy(c->slots + (size_t)c->rank * c->hd->slot_bytes, send, bytes, hipMemcpyDeviceToHost) != hipSuccess) return ncclUnhandledCudaError;
+  barrier(c);
+  for (int r = 0; r < c->world; ++r) {
+    char* dst = (char*)recv + (size_t)r * bytes;
+    if (r == c->rank) {
+      if (dst != (const char*)send && hipMemcpy(dst, send, bytes, hipMemcpyDeviceToDevice) != hipSuccess) return ncclUnhandledCudaError;
+      continue;
+    }
+    if (hipMemcpy(dst, c->slots + (size_t)r * c->hd->slot_bytes, bytes, hipMemcpyHostToDevice) != hipSuccess) return ncclUnhandledCudaError;
+  }
+  barrier(c);  /* nobody overwrites its slot before everybody has read it */
+  return ncclSuccess;
+}
+
+ncclResult_t ncclGroupStart(void) { return ncclSuccess; }
+ncclResult_t ncclGroupEnd(void) { return ncclSuccess; }
+const char* ncclGetErrorString(ncclResult_t r) {
+  switch (r) {
+    case ncclSuccess: return "no error (mock_rccl)";
+    case ncclUnhandledCudaError: return "HIP error inside mock_rccl";
+    case ncclSystemError: return "shared memory error inside mock_rccl";
+    case ncclInvalidArgument: return "invalid argument (mock_rccl)";
+    default: return "internal error (mock_rccl)";
+  }
+}

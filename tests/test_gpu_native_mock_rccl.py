@@ -1,0 +1,66 @@
+"""The multi-PROCESS native path -- sdpgpu_comm_prepare / sdpgpu_comm_init with world > 1 in separate processes,
+sdpgpu_solve_sharded's kernels and in-place all-gathers issued by libsdpgpu.so, bench.py's default `--exchange native` flow with
+its watchdog phases -- run with 2 and 3 ranks on ONE GPU against a test double of RCCL (tests/mock_rccl/mock_rccl.c, loaded
+through SDPGPU_RCCL_LIB: slabs travel through host shared memory).  RCCL itself refuses two ranks on one device, so until a
+multi-GPU node runs tests/test_gpu_multirank.py::test_two_processes_native_rccl_between_devices this is as close as the
+world > 1 branch of csrc/sdpgpu_comm.hip gets to being executed; what the double does not stand in for is RCCL's transport.
+bench.py --check compares the sharded tables with a single-rank sweep, bit for bit."""
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+SRC = os.path.join(ROOT, "tests", "mock_rccl", "mock_rccl.c")
+LIB = os.path.join(ROOT, "tests", "mock_rccl", "libmock_rccl.so")
+
+
+@pytest.fixture(scope="module")
+def mock_rccl():
+    if not os.path.exists(LIB) or os.path.getmtime(LIB) < os.path.getmtime(SRC):
+        subprocess.run(["gcc", "-O2", "-shared", "-fPIC", "-D__HIP_PLATFORM_AMD__", "-I/opt/rocm/include", "-o", LIB, SRC,
+                        "-L/opt/rocm/lib", "-lamdhip64", "-lrt", "-lpthread"], check=True)
+    return LIB
+
+
+CASES = [(2, ["--periods", "3"], "target_2_ranks"),
+         (3, ["--workload", "cfg2", "--periods", "8"], "cfg2_key_rows_3_ranks"),
+         (2, ["--workload", "cfg2", "--periods", "6", "--schedule", "overlap"], "cfg2_overlapped_second_stream"),
+         (2, ["--workload", "cfg3t", "--periods", "2"], "cfg3t_ragged_action_counts"),
+         (4, ["--workload", "cfg4", "--periods", "3"], "cfg4_4_ranks"),
+         (3, ["--workload", "cfg5", "--states", "3000000", "--periods", "2"], "cfg5_reduced_width_3_ranks")]
+
+
+@pytest.mark.parametrize("world,extra", [(w, e) for w, e, _ in CASES], ids=[i for _, _, i in CASES])
+def test_native_exchange_between_processes(mock_rccl, world, extra):
+    port = 29700 + (os.getpid() + world * 7 + len(extra)) % 200
+    env = dict(os.environ, SDPGPU_RCCL_LIB=mock_rccl, MOCK_RCCL_SLOT_MB="64")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(world), "--master-addr",
+           "127.0.0.1", "--master-port", str(port), os.path.join(ROOT, "bench.py"), "--gpus", str(world), "--steps", "2",
+           "--warmup", "1", "--exchange", "native", "--check", "--no-cpu-baseline", *extra]
+    out = subprocess.run(cmd, capture_output=True, text=True, timeout=420, cwd=ROOT, env=env)
+    assert out.returncode == 0, (out.stdout[-1500:], out.stderr[-2500:])
+    rec = json.loads([l for l in out.stdout.splitlines() if l.startswith("{")][-1])
+    assert rec["n_gpus"] == world and rec["check_vs_single_rank"] is True
+    assert rec["parity_gate"]["status"] == "ok" and rec["parity_gate"]["ranks"] == world
+    assert "RCCL all-gather issued by libsdpgpu.so" in rec["config"]["exchange"] and "fell back" not in rec["config"]["exchange"]
+    assert len(rec["config"]["cells_per_rank"]) == world and sum(rec["config"]["cells_per_rank"]) == rec["config"]["cells_per_step"]
+    assert len(rec["config"]["exchange_ms_per_rank"]) == world and rec["config"]["communicator_init_s"] > 0
+    assert "communicator init" in rec["config"]["phases_s"] and "timed loop" in rec["config"]["phases_s"]
+
+
+def test_a_rank_that_cannot_prepare_does_not_strand_its_peers(mock_rccl):
+    """Rank 1's collective library does not load (SDPGPU_RCCL_LIB points nowhere on that rank): sdpgpu_comm_prepare fails
+    THERE, the ranks agree before anybody enters ncclCommInitRank, and the run ends -- here with a non-zero exit, since the
+    torch fallback cannot put two ranks on one GPU either -- instead of hanging rank 0 inside the collective."""
+    port = 29980 + os.getpid() % 15
+    env = dict(os.environ, SDPGPU_RCCL_LIB=mock_rccl, SDP_TEST_BREAK_RCCL_ON_RANK="1", SDP_WATCHDOG_SCALE="0.5")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr",
+           "127.0.0.1", "--master-port", str(port), os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "1",
+           "--warmup", "0", "--exchange", "native", "--no-cpu-baseline", "--workload", "cfg2", "--periods", "3"]
+    out = subprocess.run(cmd, capture_output=True, text=True, timeout=300, cwd=ROOT, env=env)
+    assert "native RCCL communicator unavailable" in out.stderr and "cannot load SDPGPU_RCCL_LIB" in out.stderr
+    assert "phase deadline exceeded" not in out.stdout  # nobody waited in a collective: the ranks agreed and moved on
