@@ -405,8 +405,12 @@ int sdpgpu_solve_multi(sdpgpu_handle** hs, int32_t n, int32_t flags) {
       }
       if (!same) return fail(h0, SDPGPU_ERR_ARG, "solve_multi: handle %d describes another problem than handle 0 (family, grid or pmf sizes differ)", r);
     }
-    const char* force = std::getenv("SDPGPU_MULTI_EXCHANGE");  // "copy": device-to-device copies even on distinct devices
-    const bool want_copy = !distinct || (force && std::strcmp(force, "copy") == 0);
+    // SDPGPU_MULTI_EXCHANGE = "copy": device-to-device copies even on distinct devices; "rccl": the communicator branch
+    // (ncclCommInitAll + one group of all-gathers per period) even when ranks share a device -- RCCL itself refuses that, the
+    // tests' stand-in (SDPGPU_RCCL_LIB=tests/mock_rccl) does not, which is how this branch runs on a one-GPU box
+    const char* force = std::getenv("SDPGPU_MULTI_EXCHANGE");
+    const bool force_rccl = force && std::strcmp(force, "rccl") == 0;
+    const bool want_copy = (!distinct && !force_rccl) || (force && std::strcmp(force, "copy") == 0);
     bool same_group = true, any_comm = false;
     for (int r = 0; r < n; ++r) {
       same_group = same_group && hs[r]->siblings.size() == (size_t)n && std::equal(hs, hs + n, hs[r]->siblings.begin());

@@ -40,11 +40,18 @@ typedef struct {
 
 typedef struct mock_comm {
   int rank, world;
-  char name[64];
+  char name[64];  /* "" = a process-local segment (ncclCommInitAll) */
   header_t* hd;
   char* slots;
   size_t map_bytes;
 } mock_comm;
+
+/* ncclGroupStart / ncclGroupEnd: ONE thread issuing the all-gathers of several ranks (sdpgpu_solve_multi's default) cannot
+ * block in the first of them; the calls of a group are queued and carried out together at the closing ncclGroupEnd. */
+typedef struct { const void* send; void* recv; size_t bytes; mock_comm* c; hipStream_t stream; } queued_t;
+static __thread int g_depth = 0;
+static __thread int g_n = 0;
+static __thread queued_t g_q[64];
 
 static size_t slot_bytes_env(void) {
   const char* e = getenv("MOCK_RCCL_SLOT_MB");
@@ -89,15 +96,38 @@ ncclResult_t ncclCommInitRank(void** out, int world, ncclUniqueId id, int rank) 
 }
 
 ncclResult_t ncclCommInitAll(void** comms, int n, const int* devs) {
-  (void)comms; (void)n; (void)devs;
-  return ncclInvalidArgument;  /* one process owning distinct devices: not what this double is for */
+  (void)devs;  /* one process owning every rank: the segment is ordinary memory of this process */
+  if (!comms || n < 1 || n > 64) return ncclInvalidArgument;
+  const size_t slot = slot_bytes_env();
+  const size_t bytes = 4096 + slot * (size_t)n;
+  char* p = (char*)calloc(1, bytes);
+  if (!p) return ncclSystemError;
+  header_t* hd = (header_t*)p;
+  hd->world = n;
+  hd->slot_bytes = slot;
+  atomic_store(&hd->attached, n);
+  for (int r = 0; r < n; ++r) {
+    mock_comm* c = (mock_comm*)calloc(1, sizeof *c);
+    c->rank = r;
+    c->world = n;
+    c->hd = hd;
+    c->slots = p + 4096;
+    c->map_bytes = bytes;
+    comms[r] = c;
+  }
+  return ncclSuccess;
 }
 
 ncclResult_t ncclCommDestroy(void* comm) {
   mock_comm* c = (mock_comm*)comm;
   if (!c) return ncclSuccess;
-  if (atomic_fetch_sub(&c->hd->attached, 1) == 1) shm_unlink(c->name);
-  munmap((void*)c->hd, c->map_bytes);
+  const int last = atomic_fetch_sub(&c->hd->attached, 1) == 1;
+  if (c->name[0]) {
+    if (last) shm_unlink(c->name);
+    munmap((void*)c->hd, c->map_bytes);
+  } else if (last) {
+    free((void*)c->hd);
+  }
   free(c);
   return ncclSuccess;
 }
@@ -120,6 +150,11 @@ ncclResult_t ncclAllGather(const void* send, void* recv, size_t count, ncclDataT
     fprintf(stderr, "[mock_rccl] slab of %zu bytes exceeds the slot (MOCK_RCCL_SLOT_MB)\n", bytes);
     return ncclInvalidArgument;
   }
+  if (g_depth > 0) {  /* inside a group: carried out at ncclGroupEnd */
+    if (g_n >= 64) return ncclInternalError;
+    g_q[g_n++] = (queued_t){send, recv, bytes, c, stream};
+    return ncclSuccess;
+  }
   if (hipStreamSynchronize(stream) != hipSuccess) return ncclUnhandledCudaError;
   if (hipMemcpy(c->slots + (size_t)c->rank * c->hd->slot_bytes, send, bytes, hipMemcpyDeviceToHost) != hipSuccess) return ncclUnhandledCudaError;
   barrier(c);
@@ -135,8 +170,35 @@ ncclResult_t ncclAllGather(const void* send, void* recv, size_t count, ncclDataT
   return ncclSuccess;
 }
 
-ncclResult_t ncclGroupStart(void) { return ncclSuccess; }
-ncclResult_t ncclGroupEnd(void) { return ncclSuccess; }
+ncclResult_t ncclGroupStart(void) {
+  ++g_depth;
+  return ncclSuccess;
+}
+ncclResult_t ncclGroupEnd(void) {
+  if (g_depth <= 0) return ncclInvalidArgument;
+  if (--g_depth > 0) return ncclSuccess;
+  /* every rank of the communicator is in the group (sdpgpu_solve_multi): all slabs out, then all slabs in */
+  ncclResult_t rc = ncclSuccess;
+  for (int i = 0; i < g_n && rc == ncclSuccess; ++i) {
+    const queued_t* q = &g_q[i];
+    if (hipStreamSynchronize(q->stream) != hipSuccess ||
+        hipMemcpy(q->c->slots + (size_t)q->c->rank * q->c->hd->slot_bytes, q->send, q->bytes, hipMemcpyDeviceToHost) != hipSuccess)
+      rc = ncclUnhandledCudaError;
+  }
+  for (int i = 0; i < g_n && rc == ncclSuccess; ++i) {
+    const queued_t* q = &g_q[i];
+    for (int r = 0; r < q->c->world; ++r) {
+      char* dst = (char*)q->recv + (size_t)r * q->bytes;
+      if (r == q->c->rank) {
+        if (dst != (const char*)q->send && hipMemcpy(dst, q->send, q->bytes, hipMemcpyDeviceToDevice) != hipSuccess) rc = ncclUnhandledCudaError;
+      } else if (hipMemcpy(dst, q->c->slots + (size_t)r * q->c->hd->slot_bytes, q->bytes, hipMemcpyHostToDevice) != hipSuccess) {
+        rc = ncclUnhandledCudaError;
+      }
+    }
+  }
+  g_n = 0;
+  return rc;
+}
 const char* ncclGetErrorString(ncclResult_t r) {
   switch (r) {
     case ncclSuccess: return "no error (mock_rccl)";

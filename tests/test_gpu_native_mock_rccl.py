@@ -64,3 +64,44 @@ def test_a_rank_that_cannot_prepare_does_not_strand_its_peers(mock_rccl):
     out = subprocess.run(cmd, capture_output=True, text=True, timeout=300, cwd=ROOT, env=env)
     assert "native RCCL communicator unavailable" in out.stderr and "cannot load SDPGPU_RCCL_LIB" in out.stderr
     assert "phase deadline exceeded" not in out.stdout  # nobody waited in a collective: the ranks agreed and moved on
+
+
+_MULTI_DRIVER = r"""
+import os, sys
+sys.path.insert(0, os.environ["SDP_ROOT"]); sys.path.insert(0, os.path.join(os.environ["SDP_ROOT"], "tests"))
+import numpy as np
+import stochastic_inventory_amd as sia
+from stochastic_inventory_amd import workloads
+import cases
+world, threads, name = int(sys.argv[1]), sys.argv[2] == "1", sys.argv[3]
+w = {"cfg2": lambda: workloads.cfg2_clsp(T=6), "target": lambda: workloads.target_grid(T=3, S=300000),
+     "cfg3t": lambda: workloads.cfg3_tenths(T=3, NX=40, maxCash=400.0, A=60, D=25), "f5": cases.f5_cash_leadtime}[name]()
+d1 = w.desc(); d1.device = 0
+ref = sia.SdpEngine(d1, w.pmf, w.overhead()); ref.solve(sync=True)
+engs = []
+for r in range(world):
+    d = w.desc(); d.rank, d.world_size, d.device = r, world, 0
+    engs.append(sia.SdpEngine(d, w.pmf, w.overhead()))
+for rep in range(2):
+    sia.SdpEngine.solve_multi(engs, sync=True, gather_first=True, threads=threads)
+    for r, e in enumerate(engs):
+        for period in range(1, w.T + 1):
+            _, lo, hi = e.slab(period)
+            assert np.array_equal(e.values(period), ref.values(period)), (name, r, period)
+            assert np.array_equal(e.policy(period), ref.policy(period)[lo:hi]), (name, r, period)
+print("MULTI_OK", world, threads, name)
+"""
+
+
+@pytest.mark.parametrize("threads", ["0", "1"], ids=["one-thread-grouped", "thread-per-rank"])
+@pytest.mark.parametrize("world,name", [(4, "cfg2"), (8, "target"), (3, "cfg3t"), (2, "f5")])
+def test_solve_multi_communicator_branch(mock_rccl, world, name, threads):
+    """sdpgpu_solve_multi's COMMUNICATOR branch -- ncclCommInitAll, then per period every rank's kernel and one ncclGroupStart /
+    ncclAllGather x n / ncclGroupEnd (default), or one host thread per rank each issuing its own all-gather
+    (SDPGPU_SHARDED_THREADS) -- which on real hardware needs one device per rank: here all ranks on one GPU against the test
+    double (SDPGPU_MULTI_EXCHANGE=rccl forces the branch), every table against the single-rank sweep, twice (the second
+    call reuses the communicators)."""
+    env = dict(os.environ, SDPGPU_RCCL_LIB=mock_rccl, SDPGPU_MULTI_EXCHANGE="rccl", MOCK_RCCL_SLOT_MB="16", SDP_ROOT=ROOT)
+    out = subprocess.run([sys.executable, "-c", _MULTI_DRIVER, str(world), threads, name], capture_output=True, text=True,
+                         timeout=300, cwd=ROOT, env=env)
+    assert out.returncode == 0 and "MULTI_OK" in out.stdout, (out.stdout[-800:], out.stderr[-2500:])
