@@ -98,7 +98,7 @@ def test_stalled_rank_ends_the_gpu_bench_with_a_record():
     """bench.py N > 1 on the GPU (two ranks over gloo on one device) with rank 1 stalled before its first sweep: both ranks'
     watchdogs print the one-line record and the launcher returns non-zero in well under two minutes."""
     port = 29900 + os.getpid() % 40
-    env = dict(os.environ, SDP_WATCHDOG_INJECT_STALL="first sweep:1", SDP_WATCHDOG_SCALE="0.1")  # 300 s -> 30 s
+    env = dict(os.environ, SDP_WATCHDOG_INJECT_STALL="first sweep:1", SDP_WATCHDOG_SCALE="0.05")  # 300 s -> 15 s
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr",
            "127.0.0.1", "--master-port", str(port), os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2",
            "--warmup", "1", "--backend", "gloo", "--no-cpu-baseline", "--workload", "cfg2", "--periods", "4", "--weak"]
