@@ -459,6 +459,11 @@ int run_period_impl(sdpgpu_handle* h, int period, int part, int64_t range_lo, in
   } else if (h->d.kernel == SDPGPU_KERNEL_AUTO) {
     use_window = !own_counts && window_eligible(h, period);
   }
+  // automatic choice, nothing forced, and no window plan fits (a pmf of thousands of points: the window of even the smallest
+  // block would take more than a compute unit's LDS): the generic kernel evaluates any period
+  if (use_window && h->d.kernel == SDPGPU_KERNEL_AUTO && h->d.family == SDPGPU_FAMILY_BACKORDER && !ranged &&
+      !(h->win_r || h->win_s || h->win_nch) && !plan_window(h, period, p.lo, p.hi).R)
+    use_window = false;
   if (part != SDPGPU_PART_ALL) {
     // only the F1 window kernel has a bounded dependency footprint; everything else is "all boundary"
     const bool splittable = use_window && window_interior_tiles(h, period, p.lo, p.hi, nullptr, nullptr);
@@ -490,8 +495,20 @@ int run_period_impl(sdpgpu_handle* h, int period, int part, int64_t range_lo, in
     p.kernel_used = SDPGPU_KERNEL_GATHER;
   }
   if (e != hipSuccess && !h->plan_error.empty()) {  // the planner said no before anything was launched
-    const std::string why = h->plan_error;
-    return fail(h, SDPGPU_ERR_ARG, "period %d: %s", period, why.c_str());
+    const bool forced = h->win_r || h->win_s || h->win_nch;
+    if (use_window && h->d.kernel == SDPGPU_KERNEL_AUTO && !forced && part == SDPGPU_PART_ALL && !ranged) {
+      // nobody asked for the window kernel and the period does not fit it (a pmf of thousands of points: its window would take
+      // more than a compute unit's LDS): the generic kernel evaluates any period
+      h->plan_error.clear();
+      e = flush_pending(h);
+      if (e == hipSuccess) e = launch_gather_grid(P, v_next, v_cur, pol, pd, pp, p.lo, p.hi, h->stream);
+      p.kernel_used = SDPGPU_KERNEL_GATHER;
+      p.ops_cell = 0;
+      p.lds_cell = p.l1_cell = 0;
+    } else {
+      const std::string why = h->plan_error;
+      return fail(h, SDPGPU_ERR_ARG, "period %d: %s", period, why.c_str());
+    }
   }
   if (e != hipSuccess) return fail(h, SDPGPU_ERR_DEVICE, "period %d kernel launch: %s", period, hipGetErrorString(e));
   if (h->profiling) {
@@ -975,7 +992,11 @@ int sdpgpu_plan_period(const sdpgpu_handle* hc, int32_t period, sdpgpu_plan* out
   const PeriodInfo& p = h->per[period - 1];
   std::string why;
   const WinPlan pl = plan_window(h, period, p.lo, p.hi, &why);
-  if (!pl.R) return fail(h, SDPGPU_ERR_ARG, "period %d: %s", period, why.c_str());
+  if (!pl.R) {
+    // (automatic kernel choice, nothing forced: such a period runs on the generic kernel, see run_period_impl)
+    if (h->d.kernel == SDPGPU_KERNEL_AUTO && !(h->win_r || h->win_s || h->win_nch)) return SDPGPU_OK;
+    return fail(h, SDPGPU_ERR_ARG, "period %d: %s", period, why.c_str());
+  }
   out->kernel = SDPGPU_KERNEL_WINDOW;
   out->r = pl.R;
   out->s = pl.S;

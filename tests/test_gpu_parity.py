@@ -780,3 +780,28 @@ def test_graph_is_off_by_default(sia, oracle, monkeypatch):
         for _ in range(4):
             eng.solve(sync=True)
         assert eng.stats().graph_replays == 0
+
+
+@pytest.mark.parametrize("family", ["f1", "f2"])
+def test_pmf_too_wide_for_any_window_falls_back_to_the_generic_kernel(sia, oracle, family):
+    """A pmf of 2300 (F1) / 3900 (F2) points: the window of even the smallest register block would need more than the 160 KiB
+    of LDS of a compute unit.  With the automatic kernel choice such a period runs on the generic kernel (round 2: a launch
+    error); asked for explicitly (kernel = WINDOW) it is SDPGPU_ERR_ARG with the planner's reason."""
+    from stochastic_inventory_amd import workloads
+    w = workloads.cfg5_scaled(S=600, T=2, A=6, D=2300) if family == "f1" else workloads.cfg4_leadtime(T=2, NX=80, A=4, D=3900)
+    eng, P, V, pol, cells = _solve_both(sia, oracle, w)
+    assert eng.stats().kernel_used == 1 and eng.stats().cells_evaluated == cells
+    for period in range(1, w.T + 1):
+        _assert_tables(eng.values(period), eng.policy(period), V[period - 1], pol[period - 1], f"{w.name} t={period}")
+    if family == "f1":
+        assert eng.plan(1).kernel == 1
+    eng.close()
+    d = w.desc()
+    d.kernel = 2
+    with sia.SdpEngine(d, w.pmf, w.overhead()) as forced:
+        with pytest.raises(sia.SdpgpuError) as ei:
+            forced.solve(sync=True)
+        if family == "f1":
+            assert ei.value.code == 1 and "of LDS per workgroup" in ei.value.message
+        else:  # (actions + demand steps beyond 3500: not a window-kernel shape at all)
+            assert ei.value.code == 4
