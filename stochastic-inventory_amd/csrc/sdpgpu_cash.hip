@@ -5,6 +5,11 @@
 namespace sdpgpu_detail {
 
 // ---- uniform-shift kernel (F3 on dyadic grids) ---------------------------------------------------
+// LDS of a workgroup of cash_shift_kernel with tiles of tile_pts cash points
+static size_t cash_shift_lds(int nD, int tile_pts) {
+  const size_t dp8 = ((size_t)nD + 7) & ~(size_t)7;
+  return (size_t)nD * 16 + dp8 * 16 * 8 + (size_t)4 * tile_pts * (sizeof(double) + sizeof(int)) + 4 * (dp8 / 2) * sizeof(int);
+}
 static inline int narrow_pieces(int cap, int S) { return 2 * S + (cap == 64 ? 1 : 2); }  // 64-entry pieces of a staged segment
 bool dyadic(double x, double scale, double max_abs) { return std::fabs(x) <= max_abs && x * scale == std::floor(x * scale); }
 
@@ -43,6 +48,9 @@ bool cash_shift_eligible(const sdpgpu_handle* h, int period) {
   if (incmax * q > 1.0e9) return false;
   // (byte offsets into V_{t+1} are formed and clamped in signed 32-bit arithmetic)
   if ((p.S + 2 * p.g.nc) * 8 >= 2147483647LL || p.nD > 2000) return false;
+  // cash_shift_kernel (period T, short rows, shifts too far apart for the diagonal form) keeps 144 B per demand point in LDS:
+  // with its largest tile two workgroups must still fit a compute unit, else the cash row / generic kernels take the period
+  if (cash_shift_lds(p.nD, 512) > kLdsPerCU / 2) return false;
   return true;
 }
 
@@ -186,12 +194,18 @@ hipError_t launch_cash_shift(sdpgpu_handle* h, const DevParams& P, int period, c
   C.row0 = (int32_t)row_lo;
   if (!grid_ok((row_hi - row_lo + 1) * (int64_t)C.tiles_per_row)) return hipErrorInvalidValue;
   dim3 grid((unsigned)((row_hi - row_lo + 1) * C.tiles_per_row));
-  const size_t dp8 = ((size_t)p.nD + 7) & ~(size_t)7;
-  size_t smem = (size_t)p.nD * 16 + dp8 * 16 * 8 + (size_t)4 * TSZ * (sizeof(double) + sizeof(int)) + 4 * (dp8 / 2) * sizeof(int);
+  const size_t smem = cash_shift_lds(p.nD, TSZ);  // (above 64 KiB -- pmfs of ~450 points and more -- the launch raises the kernel's limit)
   const bool last = period == h->T;
   h->per[period - 1].ops_cell = last ? 1.0 : 3.0;  // acc += T1; acc += (p gamma) * V
   h->per[period - 1].l1_cell = last ? 0.0 : 8.0;      // one 8-byte entry per cell through the vector L1 (16-byte gathers of pairs)
-#define SDP_CS(MX, LS, SS, WW) hipLaunchKernelGGL((sdp::cash_shift_kernel<MX, LS, SS, WW>), grid, dim3(256), smem, st, C, v_next, v_cur, pol, pmf_d, pmf_p, lo, hi)
+#define SDP_CS(MX, LS, SS, WW)                                                                                              \
+  do {                                                                                                                     \
+    static LdsMark mark;                                                                                                   \
+    hipError_t ea = lds_allow(sdp::cash_shift_kernel<MX, LS, SS, WW>, smem, &mark);                                        \
+    if (ea != hipSuccess) return ea;                                                                                       \
+    hipLaunchKernelGGL((sdp::cash_shift_kernel<MX, LS, SS, WW>), grid, dim3(256), smem, st, C, v_next, v_cur, pol, pmf_d,  \
+                       pmf_p, lo, hi);                                                                                     \
+  } while (0)
 #define SDP_CS_S(MX, LS)      \
   if (S == 4 && W == 2)       \
     SDP_CS(MX, LS, 4, 2);     \

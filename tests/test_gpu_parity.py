@@ -805,3 +805,20 @@ def test_pmf_too_wide_for_any_window_falls_back_to_the_generic_kernel(sia, oracl
             assert ei.value.code == 1 and "of LDS per workgroup" in ei.value.message
         else:  # (actions + demand steps beyond 3500: not a window-kernel shape at all)
             assert ei.value.code == 4
+
+
+@pytest.mark.parametrize("shape", [(6, 300, 5, 900), (64, 16500, 5, 370)], ids=["D900-generic-fallback", "D370-82KiB-tiles-of-512"])
+def test_uniform_shift_kernel_wide_pmfs(sia, oracle, shape):
+    """cash_shift_kernel keeps 144 B of LDS per demand point: 370 points on its 512-point tiles are 82 KiB per workgroup (the
+    launch raises the kernel's limit: gfx950 has 160 KiB per compute unit), 900 points are over the budget of two workgroups
+    per compute unit and the period goes to the next more general kernel (round 2 launched either with more than 64 KiB and
+    failed)."""
+    from stochastic_inventory_amd import workloads
+    NX, NC, A, D = shape
+    w = workloads.cfg3_cash(T=2, NX=NX, NC=NC, A=A, D=D)
+    eng, P, V, pol, cells = _solve_both(sia, oracle, w, nthreads=16)
+    assert eng.stats().cells_evaluated == cells
+    assert eng.stats().kernel_used == (1 if D == 900 else 2)
+    for period in range(1, w.T + 1):
+        _assert_tables(eng.values(period), eng.policy(period), V[period - 1], pol[period - 1], f"{w.name} t={period}")
+    eng.close()
