@@ -403,6 +403,8 @@ int run_period_impl(sdpgpu_handle* h, int period, int part, int64_t range_lo, in
   }
   if (h->custom) {
     if (part == SDPGPU_PART_INTERIOR) return SDPGPU_OK;  // no bounded footprint is known for user lambdas
+    if ((size_t)p.nD * 16 + 4 * 64 * 12 > kLdsLegacy)  // (a hipRTC module function keeps the 64 KiB launch limit)
+      return fail(h, SDPGPU_ERR_UNSUPPORTED, "a user functor takes pmfs of at most 3900 points (period %d has %d)", period, p.nD);
     hipError_t ec = launch_custom_period(h, period, v_next, v_cur, pol, p.lo, p.hi, nullptr, nullptr, nullptr, true);
     if (ec != hipSuccess) return fail(h, SDPGPU_ERR_DEVICE, "period %d user-functor kernel: %s", period, hipGetErrorString(ec));
     p.kernel_used = SDPGPU_KERNEL_GATHER;

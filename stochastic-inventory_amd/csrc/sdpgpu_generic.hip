@@ -100,6 +100,9 @@ hipError_t launch_gather_sx(const DevParams& P, const double* v_next, double* v_
   int64_t blocks = (n + SX - 1) / SX;
   if (!grid_ok(blocks)) return hipErrorInvalidValue;
   size_t smem = (size_t)P.n_demand * 16 + 4 * 64 * (sizeof(double) + sizeof(int));
+  static LdsMark mark;  // (a pmf of 3905 .. 4000 points is 65-67 KiB: above the legacy limit of a launch)
+  hipError_t ea = lds_allow(sdp::gather_period_kernel<FAM, MAXDIR, SX, QUERY>, smem, &mark);
+  if (ea != hipSuccess) return ea;
   hipLaunchKernelGGL((sdp::gather_period_kernel<FAM, MAXDIR, SX, QUERY>), dim3((unsigned)blocks), dim3(256), smem, st, P,
                      v_next, v_cur, pol, pmf_d, pmf_p, lo, hi, q);
   return hipGetLastError();

@@ -742,6 +742,18 @@ int sparse_solve(const SparseProblem& sp, double* final_value, int32_t* q1, int3
       d_act = nullptr;
       ML_TRY(hipMalloc((void**)&d_act, (size_t)n_states[t] * 4));
       const size_t smem = (size_t)NA * 8 + (size_t)nd * (sizeof(DemandTerms) + 8) + (size_t)(P.qb + 1) * 4;
+      // (Q(s, a) of every action pair of a state sits in LDS: Qbound up to ~140 within the 160 KiB of a compute unit)
+      constexpr size_t kLdsPerCU = 160 * 1024;  // (gfx950; sdpgpu_internal.hpp has the same figure for the grid kernels)
+      if (smem > kLdsPerCU) {
+        char buf[200];
+        std::snprintf(buf, sizeof buf, "two-product solver: Qbound %d with %d demand pairs needs %zu B of LDS per state, over the %zu B of a compute unit",
+                      (int)P.qb, nd, smem, kLdsPerCU);
+        g_ml_error = buf;
+        rc = SDPGPU_ERR_UNSUPPORTED;
+        goto fail;
+      }
+      if (smem > 64 * 1024)  // above the legacy limit of a launch: raise the kernel's dynamic-LDS limit
+        ML_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(backward_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
       // a dispatch carries at most 2^32 work-items: batches of 4M workgroups (2^30 lanes)
       for (int64_t first = 0; first < n_states[t]; first += (int64_t)1 << 22) {
         const int64_t nb = std::min<int64_t>((int64_t)1 << 22, n_states[t] - first);

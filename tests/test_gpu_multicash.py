@@ -190,3 +190,13 @@ def test_soak_whole_memo_both_paths(sia, oracle, monkeypatch):
             r = sia.multixr_solve(dep, table=True, **kw)
             (fv, y1, y2, states, cells), want = oracle.memo_table("multixr", dep, **kw)
             assert r.finalValue == fv and r.statesPerPeriod == states and r.cells == cells and (r.table == want).all(), (seed, path)
+
+
+def test_action_box_beyond_the_lds_is_refused_with_a_reason(sia):
+    """Q(s, a) of every action pair of a state sits in LDS (8 B x Qbound^2): Qbound 200 would need 320 KB, over the 160 KiB of a
+    compute unit -- SDPGPU_ERR_UNSUPPORTED with the arithmetic, not a launch error."""
+    kw = multicash_cases.main_instance()
+    kw["q_bound"] = 200
+    with pytest.raises(sia.SdpgpuError) as ei:
+        sia.multicash_solve(**kw)
+    assert ei.value.code == 4 and "of LDS per state" in ei.value.message

@@ -822,3 +822,14 @@ def test_uniform_shift_kernel_wide_pmfs(sia, oracle, shape):
     for period in range(1, w.T + 1):
         _assert_tables(eng.values(period), eng.policy(period), V[period - 1], pol[period - 1], f"{w.name} t={period}")
     eng.close()
+
+
+def test_generic_kernel_takes_the_longest_pmf(sia, oracle):
+    """3950 demand points (the ABI's limit is 4000): 63 KiB of {d, p} pairs + the scratch = 66 KiB of LDS in the generic kernel."""
+    from stochastic_inventory_amd import workloads
+    w = workloads.cfg5_scaled(S=300, T=2, A=3, D=3950)
+    eng, P, V, pol, cells = _solve_both(sia, oracle, w, kernel=1)
+    assert eng.stats().kernel_used == 1 and eng.stats().cells_evaluated == cells
+    for period in range(1, w.T + 1):
+        _assert_tables(eng.values(period), eng.policy(period), V[period - 1], pol[period - 1], f"{w.name} t={period}")
+    eng.close()
