@@ -197,3 +197,45 @@ def test_baseline_shardings_rehearsed_on_one_device(sia, name, world, threads):
         finally:
             for e in engs:
                 e.close()
+
+
+@pytest.mark.parametrize("name,world", [("configs3_pipeline_4_slabs", 4), ("configs4_1e8_states_8_slabs", 8)])
+def test_full_size_baseline_shardings_on_one_device(sia, name, world):
+    """BASELINE.json's two sharded configs at FULL width, all ranks on one device (slabs exchanged by copies inside
+    sdpgpu_solve_multi): configs[3] -- the 250 x 200 x 200 pipeline state, 1e7 states, 200 actions, 100 demands, cut into 4
+    slabs -- and configs[4] -- 1e8 states x 500 x 200 on ping-pong tables, cut into 8 slabs, three periods (3e13 cells) --
+    against the single-rank sweep of the same library: the last two value tables and this rank's policy slabs, bit for
+    bit.  What one device cannot show is RCCL's transport (tests/test_gpu_multirank.py has the two-device test)."""
+    from stochastic_inventory_amd import workloads
+    if name.startswith("configs3"):
+        w, store_all = workloads.cfg4_pipeline(T=2), 1
+    else:
+        w, store_all = workloads.cfg5_scaled(S=100_000_000, T=3), 0
+
+    def desc(rank, n):
+        d = w.desc()
+        d.rank, d.world_size, d.device, d.store_all_values = rank, n, 0, store_all
+        return d
+
+    periods = (1, 2)
+    with sia.SdpEngine(desc(0, 1), w.pmf, w.overhead()) as ref:
+        ref.solve(sync=True)
+        want_v = {p: ref.values(p) for p in periods}
+        want_pol = {p: ref.policy(p) for p in periods}
+        cells = int(ref.stats().cells_evaluated)
+    engs = []
+    try:
+        for r in range(world):
+            engs.append(sia.SdpEngine(desc(r, world), w.pmf, w.overhead()))
+        sia.SdpEngine.solve_multi(engs, sync=True, gather_first=True)
+        total = 0
+        for r, e in enumerate(engs):
+            for p in periods:
+                _, lo, hi = e.slab(p)
+                assert np.array_equal(e.values(p), want_v[p]), f"{name} rank {r}: V_{p}"
+                assert np.array_equal(e.policy(p), want_pol[p][lo:hi]), f"{name} rank {r}: policy of period {p}"
+            total += int(e.stats().cells_evaluated)
+        assert total == cells
+    finally:
+        for e in engs:
+            e.close()
