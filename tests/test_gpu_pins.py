@@ -10,7 +10,8 @@ Seconds in total."""
 import numpy as np
 import pytest
 
-from test_oracle_kat import (bridge_f5_workload, bridge_instance, _initial_index,  # noqa: F401
+from test_oracle_kat import (bridge_f3_f4_workloads, bridge_f5_workload, bridge_instance, _initial_index,  # noqa: F401
+                             test_bridge_f3_equals_f4_when_no_interest_accrues,
                              test_bridge_kat_family_equals_f5_with_a_null_second_product, test_kat1_bit_exact)
 from test_pmf_abi import test_clsp_variant_matches, test_getpmf_matches_the_scipy_restatement  # noqa: F401
 from test_pmf_reference import (test_native_clsp_variant_against_the_50_digit_table,  # noqa: F401
@@ -44,3 +45,21 @@ def test_gpu_f5_sweep_reproduces_the_reference_pinned_family(sia, oracle, kernel
             assert np.array_equal(eng.values(period), V[period - 1]) and np.array_equal(eng.policy(period), pol[period - 1])
         i0 = _initial_index(P, ml)
         assert ml["ini_cash"] + eng.values(1)[i0] == final and (int(eng.policy(1)[i0]), 0) == (q1, q2)
+
+
+@pytest.mark.parametrize("kernel", [0, 1], ids=["auto", "gather"])
+def test_gpu_f3_and_f4_agree_when_no_interest_accrues(sia, oracle, kernel):
+    """Product side of the second bridge: the HIP path's F3 (CashConstraint's lambdas) and F4 (CashOverdraft's, whose
+    statements the KATs execute) tables on the exact, interest-free instance -- against each other and against the oracle's."""
+    w3, w4 = bridge_f3_f4_workloads()
+    V, pol, _ = oracle.Problem(w4.desc(), w4.pmf, w4.overhead()).solve()
+    tables = []
+    for w in (w3, w4):
+        d = w.desc()
+        d.kernel = kernel
+        with sia.SdpEngine(d, w.pmf, w.overhead()) as eng:
+            eng.solve(sync=True)
+            tables.append([(eng.values(p), eng.policy(p)) for p in range(1, w.T + 1)])
+    for t in range(w3.T):
+        for fam in (0, 1):
+            assert np.array_equal(tables[fam][t][0], V[t]) and np.array_equal(tables[fam][t][1], pol[t]), (fam, t)

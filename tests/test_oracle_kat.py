@@ -123,3 +123,38 @@ def test_bridge_kat_family_equals_f5_with_a_null_second_product(oracle):
     # within 0.1 of each other at the root -- record which it is, so a change of the instance is noticed
     final_slack, q1s, _, _, _ = oracle.kat_multilead(**ml)
     assert (final_slack == final) == (q1s == q1)
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# Bridge 2: F3 (CashConstraint's lambdas) == F4 (CashOverdraft's, whose statements the KATs execute) when no interest accrues
+# ---------------------------------------------------------------------------------------------------------------
+def bridge_f3_f4_workloads(T=4):
+    """One problem, two families.  F4 with all three rates zero pays no interest: cashIncrement = (cash - fixed - var -
+    overhead) + revenue - cash (CashOverdraft.java:86-97); F3's formula 0 with no deposit, overhead rate, holding cost or
+    penalty: revenue + (cash - fixed - var) - 0 - overhead - cash (CashConstraint.java:103-119).  The same number in real
+    arithmetic, associated differently in fp64 -- on integer data (prices, costs, overheads, demands, cash quantum 1) every
+    operation of both chains is exact, so the tables must agree to the last bit.  The cash axis starts above the cost of the
+    largest order, so that F3's cash-constrained action list (CashConstraint.java:96-99) is the full list everywhere, as F4's
+    always is.  Both quantise with Math.round(c * 1) / 1 (long / int)."""
+    import numpy as np
+    from stochastic_inventory_amd.functors import CashFunctor, OverdraftFunctor
+    from stochastic_inventory_amd.states import OptDirection
+    from stochastic_inventory_amd.workloads import Workload
+    common = dict(price=7.0, fixOrderCost=5.0, variCost=2.0, salvageValue=1.0, maxOrderQuantity=9, minInventoryState=0,
+                  maxInventoryState=14, minCashState=40.0, maxCashState=400.0, cashRoundMult=1.0, cashRoundDiv=1.0,
+                  cashRoundIntDiv=True, iniInventory=1, iniCash=60.0, overheadCosts=[3.0, 6.0, 2.0, 4.0][:T], discountFactor=1.0)
+    pmf = [np.array([[float(v), p] for v, p in zip(vals, (0.125, 0.25, 0.5, 0.125))]) for vals in ([0, 2, 3, 7], [1, 2, 5, 6], [0, 1, 4, 8], [2, 3, 4, 5])][:T]
+    f3 = CashFunctor(holdingCost=0.0, depositeRate=0.0, overheadRate=0.0, penaltyCost=0.0, cashFormula=0, **common)
+    f4 = OverdraftFunctor(r0=0.0, r2=0.0, r3=0.0, limit=1000.0, interestFreeAmount=0.0, **common)
+    return (Workload("bridge_f3", f3, OptDirection.MAX, pmf), Workload("bridge_f4_no_interest", f4, OptDirection.MAX, pmf))
+
+
+def test_bridge_f3_equals_f4_when_no_interest_accrues(oracle):
+    import numpy as np
+    w3, w4 = bridge_f3_f4_workloads()
+    V3, pol3, cells3 = oracle.Problem(w3.desc(), w3.pmf, w3.overhead()).solve()
+    V4, pol4, cells4 = oracle.Problem(w4.desc(), w4.pmf, w4.overhead()).solve()
+    assert cells3 == cells4  # (F3's action list is the full list on this cash axis)
+    for t in range(w3.T):
+        assert np.array_equal(V3[t], V4[t]) and np.array_equal(pol3[t], pol4[t]), f"period {t + 1}"
+    assert len(np.unique(V3[0])) >= 10 and len(np.unique(pol3[0])) > 2  # (values vary with the inventory level, orders too)
