@@ -97,7 +97,17 @@ hipError_t launch_cash_shift(sdpgpu_handle* h, const DevParams& P, int period, c
                        whole(d.fixed_order_cost) && whole(p.overhead) && whole(d.price * h->pmf_d[period - 1][0]) &&
                        whole(d.price * p.g.x_lo) && whole(d.holding_cost * p.g.x_lo) && whole(d.holding_cost * h->pmf_d[period - 1][0]);
     const double spread_bound = brk + slide * (sdp::DIAG_R - 1) + (exact ? 0 : 2);
-    bool table_ok = diag_on && period < h->T && p.g.nc >= 256 && spread_bound <= sdp::DIAG_CAP && table_bytes <= ((size_t)2 << 30);
+    // The diagonal form pairs action k + i with demand j + i and relies on all of them leaving the SAME inventory behind
+    // (one staged row per step): that needs consecutive demand values one `step` apart.  A support with gaps ({0, 2, 3, 7})
+    // breaks it -- round 2 took the diagonal kernel there and produced wrong tables (found by round 3's F3 / F4 bridge
+    // instance, tests/test_oracle_kat.py); such periods run on the uniform-shift kernel below.
+    bool unit_stride = true;
+    {
+      const std::vector<double>& dv = h->pmf_d[period - 1];
+      for (size_t j = 1; j < dv.size(); ++j) unit_stride = unit_stride && dv[j] - dv[j - 1] == d.step;
+    }
+    bool table_ok = diag_on && unit_stride && period < h->T && p.g.nc >= 256 && spread_bound <= sdp::DIAG_CAP &&
+                    table_bytes <= ((size_t)2 << 30);
     if (table_ok && h->diag_bytes < table_bytes) {
       hipError_t e = hipStreamSynchronize(st);  // (an earlier launch may still read the old table)
       if (e != hipSuccess) return e;

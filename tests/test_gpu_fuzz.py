@@ -156,7 +156,10 @@ def make_wide_cash_instance(seed):
                     minInventoryState=0.0, maxInventoryState=float(rng.integers(3, 25)), minCashState=min_cash,
                     maxCashState=min_cash + (nc - 1) / q, iniInventory=0.0, iniCash=float(rng.integers(0, 15)))
     direction = OptDirection.MAX if rng.integers(0, 4) else OptDirection.MIN
-    return Workload(f"fuzz_wide_cash_{seed}", f, direction, _pmf(rng, T, unit_stride=True, d_max=int(rng.integers(3, 40))))
+    # (one instance in three has a demand support with gaps: the diagonal kernel pairs action k + i with demand j + i and must
+    # leave such periods to the uniform-shift kernel -- round 2 did not, and no test had a gapped support on a wide dyadic row)
+    return Workload(f"fuzz_wide_cash_{seed}", f, direction,
+                    _pmf(rng, T, unit_stride=bool(rng.integers(0, 3)), d_max=int(rng.integers(3, 40))))
 
 
 def test_random_wide_cash_rows_bit_exact(sia, oracle, monkeypatch):

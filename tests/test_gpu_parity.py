@@ -833,3 +833,20 @@ def test_generic_kernel_takes_the_longest_pmf(sia, oracle):
     for period in range(1, w.T + 1):
         _assert_tables(eng.values(period), eng.policy(period), V[period - 1], pol[period - 1], f"{w.name} t={period}")
     eng.close()
+
+
+@pytest.mark.parametrize("env", [{}, {"SDPGPU_CASH_DIAG": "0"}, {"SDPGPU_CASH_SHIFT": "0"}], ids=["auto", "no-diag", "cash-row"])
+def test_dyadic_cash_grid_with_gapped_demand_support(sia, oracle, monkeypatch, env):
+    """Demand supports {0, 2, 3, 7}, {1, 2, 5, 6}, ... on a dyadic cash row of 361 points: the diagonal form of the
+    uniform-shift kernel (action k + i paired with demand j + i, ONE staged row per step) is only valid on consecutive
+    demand values.  Round 2 took it here and got every table before period T wrong; the F3 / F4 bridge instance of round 3
+    found it.  Such periods now run on the uniform-shift kernel."""
+    import test_oracle_kat
+    for k, v in env.items():
+        monkeypatch.setenv(k, v)
+    w, _ = test_oracle_kat.bridge_f3_f4_workloads()
+    eng, P, V, pol, cells = _solve_both(sia, oracle, w)
+    assert eng.stats().kernel_used == 2 and eng.stats().cells_evaluated == cells
+    for period in range(1, w.T + 1):
+        _assert_tables(eng.values(period), eng.policy(period), V[period - 1], pol[period - 1], f"{w.name} {env} t={period}")
+    eng.close()
