@@ -67,6 +67,8 @@ int validate(const sdpgpu_desc& d) {
     if (d.clamp_inventory ? (d.min_inventory < 0 || d.max_inventory > 1e9) : (d.ini_inventory < 0 || d.ini_inventory > 1e9)) return fail(nullptr, SDPGPU_ERR_ARG, "staff numbers must lie in 0 .. 1e9");
     if (d.clamp_inventory && (d.ini_inventory < d.min_inventory || d.ini_inventory > d.max_inventory || d.ini_inventory != std::floor(d.ini_inventory))) return fail(nullptr, SDPGPU_ERR_ARG, "iniStaffNum must be an integer inside [minX, maxX]");
   }
+  if (d.family == SDPGPU_FAMILY_CASH_LEADTIME && d.step != 1)  // (orders k * step, k <= (int)maxQ, would leave the pipeline axis of (int)(maxQ / step) + 1 planes)
+    return fail(nullptr, SDPGPU_ERR_UNSUPPORTED, "SingleProductLeadtime's action list has (int)maxOrderQuantity + 1 entries whatever the step (SingleProductLeadtime.java:74-78): step must be 1");
   if ((d.family == SDPGPU_FAMILY_LEADTIME) && d.direction != SDPGPU_MIN) return fail(nullptr, SDPGPU_ERR_ARG, "LeadtimeRecursion is MIN only (LeadtimeRecursion.java:52,66)");
   if ((d.family == SDPGPU_FAMILY_SURVIVAL) && d.direction != SDPGPU_MAX) return fail(nullptr, SDPGPU_ERR_ARG, "getSurvProb maximises (RiskRecursion.java:70,101)");
   if ((d.family == SDPGPU_FAMILY_CASH_LEADTIME) && d.direction != SDPGPU_MAX) return fail(nullptr, SDPGPU_ERR_ARG, "CashLeadtimeRecursion is MAX only (CashLeadtimeRecursion.java:53,70)");
@@ -74,7 +76,11 @@ int validate(const sdpgpu_desc& d) {
 }
 
 int32_t full_action_count(const sdpgpu_desc& d) {
-  if (d.family == SDPGPU_FAMILY_OVERDRAFT || d.family == SDPGPU_FAMILY_CASH_LEADTIME) return java_d2i(d.max_order_quantity) + 1;
+  // `DoubleStream.iterate(0, i -> i + stepSize).limit((int) maxQ + 1)` -- the cash drivers' lists have (int)maxQ + 1 entries whatever the
+  // step (CashConstraint.java:99, cashSurvival.java:108, CashOverdraft.java:74, SingleProductLeadtime.java:76); for CASH / SURVIVAL
+  // this is the longest list any state has.  F1 / F2: `new double[(int)(maxOrderQuantity / stepSize) + 1]` (CLSPTesting.java:79).
+  if (d.family == SDPGPU_FAMILY_OVERDRAFT || d.family == SDPGPU_FAMILY_CASH_LEADTIME || d.family == SDPGPU_FAMILY_CASH || d.family == SDPGPU_FAMILY_SURVIVAL)
+    return java_d2i(d.max_order_quantity) + 1;
   return java_d2i(d.max_order_quantity / d.step) + 1;
 }
 
@@ -788,7 +794,7 @@ int sdpgpu_set_action_counts(sdpgpu_handle* h, int32_t t, const int32_t* counts,
   try {
     for (int64_t i = 0; i < n; ++i)
       if (counts[i] < 0 || counts[i] > cap)
-        return fail(h, SDPGPU_ERR_ARG, "set_action_counts: state %lld has %d actions, the action grid has %d (max_order_quantity / step + 1)", (long long)i, counts[i], cap);
+        return fail(h, SDPGPU_ERR_ARG, "set_action_counts: state %lld has %d actions, the family's action list has at most %d", (long long)i, counts[i], cap);
     h->counts[(size_t)t].assign(counts, counts + n);  // (the length is checked against the grid once it is laid out)
     h->per[(size_t)t].cells_counted = false;
   } catch (...) {

@@ -258,3 +258,53 @@ def test_large_magnitude_cash_shortcuts_bit_exact(sia, oracle, monkeypatch, past
                     assert np.array_equal(eng.policy(period), pol[period - 1]), f"{w.name} {variant} t={period}: policy"
                     assert np.array_equal(eng.values(period), V[period - 1]), f"{w.name} {variant} t={period}: values"
     assert seen == ({1} if past_limit else {2})
+
+
+def make_stepped_instance(family, seed, step):
+    """make_instance(family, seed) on a COARSER inventory grid: stepSize = 2 or 4 (the ABI takes any power-of-two integer; every
+    in-scope driver, and until round 3 every test, uses 1).  Inventory bounds, initial inventory and demands are multiplied by
+    the step, so every level stays a multiple of it; costs and the cash axis are as they were.  The order bound is multiplied
+    too for F1 / F2, whose action list has (int)(maxQ / step) + 1 entries; the cash families' lists have (int)maxQ + 1 entries
+    WHATEVER the step (`limit((int) maxQ + 1)`, CashConstraint.java:99 ...), so there the bound stays and the largest order is
+    maxQ * step."""
+    w = make_instance(family, seed)
+    f = w.functor
+    f.stepSize = float(step)
+    names = ["minInventory", "maxInventory", "minInventoryState", "maxInventoryState", "iniInventory", "iniPreQ", "iniPreQ2"]
+    if family in (1, 2):
+        names.append("maxOrderQuantity")
+    for name in names:
+        if hasattr(f, name) and getattr(f, name) is not None:
+            setattr(f, name, float(getattr(f, name)) * step)
+    w.pmf = [np.stack([t[:, 0] * step, t[:, 1]], axis=1) for t in w.pmf]
+    w.name = f"{w.name}_step{step}"
+    return w
+
+
+@pytest.mark.parametrize("step", [2, 4])
+@pytest.mark.parametrize("family", [1, 2, 3, 4, 6])
+def test_random_instances_on_coarser_inventory_grids(sia, oracle, family, step):
+    kernels_seen = set()
+    for seed in range(24):
+        w = make_stepped_instance(family, 300 + seed, step)
+        V, pol, cells = oracle.Problem(w.desc(), w.pmf, w.overhead()).solve(nthreads=4)
+        for kernel in (0, 1):
+            d = w.desc()
+            d.kernel = kernel
+            with sia.SdpEngine(d, w.pmf, w.overhead()) as eng:
+                eng.solve()
+                kernels_seen.add(eng.stats().kernel_used)
+                assert eng.stats().cells_evaluated == cells, w.name
+                for period in range(1, w.T + 1):
+                    assert np.array_equal(eng.policy(period), pol[period - 1]), f"{w.name} kernel {kernel} t={period}: policy"
+                    assert np.array_equal(eng.values(period), V[period - 1]), f"{w.name} kernel {kernel} t={period}: values"
+    assert len(kernels_seen) >= 2, kernels_seen  # (the family's fast kernel took some of the instances, the gather kernel the rest)
+
+
+def test_pipeline_cash_family_refuses_a_coarser_grid(sia):
+    """F5's orders are k * step for k <= (int)maxQ (SingleProductLeadtime.java:76) and become the next state's preQ: with step != 1
+    they leave the pipeline axis of (int)(maxQ / step) + 1 planes.  No in-scope driver does that; the engine says so at create."""
+    w = make_stepped_instance(5, 300, 2)
+    with pytest.raises(sia.SdpgpuError) as e:
+        sia.SdpEngine(w.desc(), w.pmf, w.overhead())
+    assert e.value.code == 4 and "step must be 1" in e.value.message  # SDPGPU_ERR_UNSUPPORTED
