@@ -308,3 +308,107 @@ def test_pipeline_cash_family_refuses_a_coarser_grid(sia):
     with pytest.raises(sia.SdpgpuError) as e:
         sia.SdpEngine(w.desc(), w.pmf, w.overhead())
     assert e.value.code == 4 and "step must be 1" in e.value.message  # SDPGPU_ERR_UNSUPPORTED
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# Degenerate and boundary SHAPES: the axis lengths and pmf widths at which tiles, waves and LDS segments are ragged or empty
+# ---------------------------------------------------------------------------------------------------------------
+def _set(f, **kw):
+    for name, v in kw.items():
+        if hasattr(f, name):
+            setattr(f, name, v)
+
+
+def _one_inventory_level(w, rng):
+    f = w.functor
+    _set(f, clampInventory=True)
+    for lo, hi, ini in (("minInventory", "maxInventory", "iniInventory"), ("minInventoryState", "maxInventoryState", "iniInventory")):
+        if hasattr(f, lo):
+            v = float(rng.integers(0, 3))
+            _set(f, **{lo: v, hi: v, ini: v})
+
+
+def _one_cash_point(w, rng):
+    f = w.functor
+    if hasattr(f, "minCashState"):
+        c = float(rng.integers(0, 20))
+        _set(f, minCashState=c, maxCashState=c, iniCash=c)
+    else:  # (no cash axis: a two-level inventory grid instead)
+        _set(f, clampInventory=True, minInventory=0.0, maxInventory=1.0, iniInventory=0.0)
+
+
+def _no_orders(w, rng):
+    _set(w.functor, maxOrderQuantity=0.0)
+
+
+def _one_demand(w, rng):
+    w.pmf = [np.array([[float(rng.integers(0, 6)), 1.0]]) for _ in w.pmf]
+
+
+def _negative_demands(w, rng):
+    w.pmf = [np.stack([t[:, 0] - float(rng.integers(1, 8)), t[:, 1]], axis=1) for t in w.pmf]
+
+
+def _demands_beyond_grid(w, rng):
+    w.pmf = [np.stack([t[:, 0] * float(rng.integers(20, 60)), t[:, 1]], axis=1) for t in w.pmf]
+
+
+def _zero_probabilities(w, rng):
+    out = []
+    for t in w.pmf:
+        p = t[:, 1].copy()
+        p[rng.random(len(p)) < 0.4] = 0.0
+        p[0] = 0.0
+        p[-1] = 0.0
+        out.append(np.stack([t[:, 0], p], axis=1))
+    w.pmf = out
+
+
+def _wide_pmf(n):
+    def mutate(w, rng):
+        p = rng.random(n) + 0.01
+        w.pmf = [np.stack([np.arange(n, dtype=np.float64) + float(rng.integers(0, 2)), p / p.sum()], axis=1) for _ in w.pmf]
+        if hasattr(w.functor, "maxCashState"):  # (keep the cash families' cell counts modest)
+            _set(w.functor, maxCashState=min(w.functor.maxCashState, 30.0))
+    return mutate
+
+
+def _one_period(w, rng):
+    w.pmf = w.pmf[:1]
+    f = w.functor
+    if getattr(f, "overheadCosts", None) is not None:
+        f.overheadCosts = list(f.overheadCosts)[:1]
+
+
+SHAPES = {"one_inventory_level": _one_inventory_level, "one_cash_point": _one_cash_point, "no_orders": _no_orders, "one_demand": _one_demand,
+          "negative_demands": _negative_demands, "demands_beyond_grid": _demands_beyond_grid, "zero_probabilities": _zero_probabilities,
+          "one_period": _one_period, **{f"pmf_{n}_points": _wide_pmf(n) for n in (63, 64, 65, 127, 128, 129, 255, 256, 257)}}
+
+
+def make_shaped_instance(family, seed, shape):
+    w = make_instance(family, seed)
+    SHAPES[shape](w, np.random.default_rng(5150 + 100 * family + seed))
+    w.name = f"{w.name}_{shape}"
+    return w
+
+
+@pytest.mark.parametrize("shape", list(SHAPES))
+def test_degenerate_and_boundary_shapes_bit_exact(sia, oracle, shape):
+    """Every family on grids with ONE inventory level, ONE cash point, no orders, one demand point, negative demands, demands
+    far beyond the grid (every successor clamps), zero probabilities at both ends of the support, one period, and pmf widths
+    around the wave (64), the window kernels' LDS segments (128) and the workgroup (256): automatically selected kernel and the
+    generic kernel against the oracle."""
+    wide = shape.startswith("pmf_")
+    for family in (1, 2, 3, 4, 5, 6):
+        for seed in range(3 if wide else 6):
+            w = make_shaped_instance(family, 40 + seed, shape)
+            V, pol, cells = oracle.Problem(w.desc(), w.pmf, w.overhead()).solve(nthreads=8)
+            for kernel in (0, 1):
+                d = w.desc()
+                d.kernel = kernel
+                with sia.SdpEngine(d, w.pmf, w.overhead()) as eng:
+                    eng.solve()
+                    assert eng.stats().cells_evaluated == cells, w.name
+                    for period in range(1, w.T + 1):
+                        assert np.array_equal(eng.policy(period), pol[period - 1]), f"{w.name} kernel {kernel} t={period}: policy"
+                        assert np.array_equal(eng.values(period), V[period - 1]), f"{w.name} kernel {kernel} t={period}: values"
