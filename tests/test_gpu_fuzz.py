@@ -412,3 +412,61 @@ def test_degenerate_and_boundary_shapes_bit_exact(sia, oracle, shape):
                     for period in range(1, w.T + 1):
                         assert np.array_equal(eng.policy(period), pol[period - 1]), f"{w.name} kernel {kernel} t={period}: policy"
                         assert np.array_equal(eng.values(period), V[period - 1]), f"{w.name} kernel {kernel} t={period}: values"
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# The read-out side on the same random instances: reachable set, device rollout, off-grid evaluation
+# ---------------------------------------------------------------------------------------------------------------
+def _readout_instances(family):
+    for seed in range(8):
+        yield make_instance(family, 500 + seed)
+    if family != 5:
+        for seed in range(4):
+            yield make_stepped_instance(family, 520 + seed, 2)
+    for shape in ("one_inventory_level", "no_orders", "negative_demands", "demands_beyond_grid", "zero_probabilities", "pmf_65_points"):
+        yield make_shaped_instance(family, 540, shape)
+
+
+@pytest.mark.parametrize("family", [1, 2, 3, 4, 5, 6])
+def test_random_instances_read_out_bit_exact(sia, oracle, family):
+    """getOptTable's reachable-set filter (Recursion.java:177-186), the simulators' table-lookup rollout (Simulation.java:53-107) and
+    the evaluation of states that are not grid points (what getExpectedValue answers for an arbitrary State) on the random,
+    coarser-grid and degenerate instances of this file: sdpgpu_reachable / sdpgpu_simulate / sdpgpu_eval_states against the
+    oracle's literal loops, bit for bit."""
+    import math
+    import zlib
+    for w in _readout_instances(family):
+        f = w.functor
+        rng = np.random.default_rng(zlib.crc32(w.name.encode()))
+        P = oracle.Problem(w.desc(), w.pmf, w.overhead())
+        V, pol, _ = P.solve(nthreads=4)
+        with sia.SdpEngine(w.desc(), w.pmf, w.overhead()) as eng:
+            eng.solve()
+            reach = P.reachable()
+            for period in range(1, w.T + 1):
+                assert np.array_equal(eng.reachable(period), reach[period - 1]), f"{w.name} t={period}: reachable"
+            # rollout: demands drawn from each period's support (zero-probability points included: the table still answers)
+            n = 64
+            dem = np.stack([rng.choice(np.asarray(w.pmf[t])[:, 0], size=n) for t in range(w.T)], axis=1)
+            gamma = getattr(f, "discountFactor", 1.0) if w.desc().family in (3, 4) else 1.0
+            disc = np.array([math.pow(gamma, t) for t in range(w.T)])
+            ini = (getattr(f, "iniInventory", 0.0), getattr(f, "iniCash", 0.0) or 0.0, getattr(f, "iniPreQ", 0.0) or 0.0)
+            gs, gv = eng.simulate(dem, disc, *ini)
+            os_, ov = P.simulate(V, pol, dem, disc, *ini)
+            assert np.array_equal(gv, ov), f"{w.name}: rollout validity"
+            assert np.array_equal(gs[gv.astype(bool)], os_[ov.astype(bool)]), f"{w.name}: rollout sums"
+            # states between grid points (and on them) of a middle period
+            period = max(1, w.T - 1)
+            x, cash, preq = P.state_arrays(period)
+            pick = rng.choice(len(x), size=min(40, len(x)), replace=False)
+            step = float(f.stepSize) if hasattr(f, "stepSize") and f.stepSize else 1.0
+            qx = x[pick]
+            qc = cash[pick] + (rng.integers(0, 3, size=len(pick)) * 0.013 if family in (3, 4, 5, 6) else 0.0)
+            qp = preq[pick]
+            v_next = V[period] if period < w.T else None
+            kw = dict(cash=qc if family in (3, 4, 5, 6) else None, preq=qp if family in (2, 5) else None)
+            if family == 2 and w.desc().lead_time == 2:
+                kw["preq2"] = P.preq2_array(period)[pick]
+            ov_, oa_ = P.eval_states(period, v_next, qx, **kw)
+            gv_, ga_ = eng.eval_states(period, qx, **kw)
+            assert np.array_equal(ga_, oa_) and np.array_equal(gv_, ov_), f"{w.name}: eval_states t={period}"
