@@ -470,3 +470,42 @@ def test_random_instances_read_out_bit_exact(sia, oracle, family):
             ov_, oa_ = P.eval_states(period, v_next, qx, **kw)
             gv_, ga_ = eng.eval_states(period, qx, **kw)
             assert np.array_equal(ga_, oa_) and np.array_equal(gv_, ov_), f"{w.name}: eval_states t={period}"
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# sdp.cash.CashRecursionXR (family CASH, cash_formula 2): state (x, R), order-up-to actions bounded by R / variCost
+# ---------------------------------------------------------------------------------------------------------------
+def make_xr_instance(seed):
+    from stochastic_inventory_amd.functors import CashXRFunctor
+    rng = np.random.default_rng(424200 + seed)
+    T = int(rng.integers(1, 5))
+    kind = ["int", "dyadic", "decimal"][int(rng.integers(0, 3))]
+    vari = max(0.25, _money(rng, 0.5, 3, kind))
+    max_inv = float(rng.integers(2, 16))
+    f = CashXRFunctor(price=_money(rng, 2, 9, kind), fixOrderCost=float(rng.choice([0.0, _money(rng, 0, 4, kind)])), variCost=vari,
+                      holdingCost=float(rng.choice([0.0, _money(rng, 0, 1, kind)])), depositeRate=float(rng.choice([0, 0, 0.02])),
+                      overheadCost=float(rng.choice([0.0, _money(rng, 0, 2, kind)])), overheadRate=float(rng.choice([0, 0, 0.05])),
+                      salvageValue=_money(rng, 0, 1, kind), discountFactor=float(rng.choice([1.0, 0.96])),
+                      maxOrderQuantity=float(rng.integers(5, 200)), minInventoryState=0, maxInventoryState=max_inv,
+                      minCashState=-float(rng.integers(0, 12)), maxCashState=float(rng.integers(15, 70)),
+                      iniInventory=float(rng.integers(0, 3)), iniCash=float(rng.integers(5, 30)), **_rounding(rng))
+    return Workload(f"fuzz_xr_{seed}", f, OptDirection.MAX if rng.integers(0, 4) else OptDirection.MIN,
+                    _pmf(rng, T, unit_stride=bool(rng.integers(0, 3)), d_max=int(rng.integers(2, 12))))
+
+
+def test_random_xr_instances_bit_exact(sia, oracle):
+    seen = set()
+    for seed in range(int(os.environ.get("SDP_FUZZ_N", "40"))):
+        w = make_xr_instance(seed)
+        V, pol, cells = oracle.Problem(w.desc(), w.pmf, w.overhead()).solve(nthreads=4)
+        for kernel in (0, 1):
+            d = w.desc()
+            d.kernel = kernel
+            with sia.SdpEngine(d, w.pmf, w.overhead()) as eng:
+                eng.solve()
+                seen.add(eng.stats().kernel_used)
+                assert eng.stats().cells_evaluated == cells, w.name
+                for period in range(1, w.T + 1):
+                    assert np.array_equal(eng.policy(period), pol[period - 1]), f"{w.name} kernel {kernel} t={period}: policy"
+                    assert np.array_equal(eng.values(period), V[period - 1]), f"{w.name} kernel {kernel} t={period}: values"
+    assert seen == {1, 2}
