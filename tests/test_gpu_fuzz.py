@@ -509,3 +509,38 @@ def test_random_xr_instances_bit_exact(sia, oracle):
                     assert np.array_equal(eng.policy(period), pol[period - 1]), f"{w.name} kernel {kernel} t={period}: policy"
                     assert np.array_equal(eng.values(period), V[period - 1]), f"{w.name} kernel {kernel} t={period}: values"
     assert seen == {1, 2}
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# The same random instances cut into slabs: N rank-handles on one device through sdpgpu_solve_multi
+# ---------------------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("family", [1, 2, 3, 4, 5, 6])
+def test_random_instances_sharded_bit_exact(sia, oracle, family):
+    """Slabs of 2, 3, 5 and 7 ranks (ragged against every grid: more ranks than states happens too) of the random, coarser-grid and
+    degenerate instances, the slabs exchanged inside the library (value rows or key rows, whichever the period's plan makes
+    travel): every rank's tables against the oracle's."""
+    instances = [make_instance(family, 700 + s) for s in range(6)]
+    if family != 5:
+        instances += [make_stepped_instance(family, 720 + s, 2) for s in range(2)]
+    instances += [make_shaped_instance(family, 730, shape) for shape in ("one_inventory_level", "one_demand", "pmf_129_points")]
+    for i, w in enumerate(instances):
+        world = (2, 3, 5, 7)[i % 4]
+        V, pol, cells = oracle.Problem(w.desc(), w.pmf, w.overhead()).solve(nthreads=4)
+        engs = []
+        try:
+            for r in range(world):
+                d = w.desc()
+                d.rank, d.world_size, d.device = r, world, 0
+                engs.append(sia.SdpEngine(d, w.pmf, w.overhead()))
+            sia.SdpEngine.solve_multi(engs, sync=True, gather_first=True, threads=bool(i % 2))
+            total = 0
+            for r, e in enumerate(engs):
+                total += int(e.stats().cells_evaluated)
+                for period in range(1, w.T + 1):
+                    _, lo, hi = e.slab(period)
+                    assert np.array_equal(e.values(period), V[period - 1]), f"{w.name} rank {r}/{world}: V_{period}"
+                    assert np.array_equal(e.policy(period), pol[period - 1][lo:hi]), f"{w.name} rank {r}/{world}: policy of period {period}"
+            assert total == cells, w.name
+        finally:
+            for e in engs:
+                e.close()
