@@ -147,7 +147,11 @@ typedef struct sdpgpu_desc {
   double step;               /* stepSize */
   double min_inventory;      /* minState / minInventory / minInventoryState */
   double max_inventory;      /* maxState / maxInventory / maxInventoryState */
-  double max_order_quantity; /* maxOrderQuantity: actions 0, step, ... (count (int)(Q/step)+1) */
+  double max_order_quantity; /* maxOrderQuantity: actions 0, step, ...; count (int)(Q/step)+1 for BACKORDER / LEADTIME
+                                (`new double[(int)(maxOrderQuantity/stepSize)+1]`, CLSPTesting.java:79), (int)Q+1 WHATEVER the
+                                step for the cash families (`iterate(0, i -> i + stepSize).limit((int) maxQ + 1)`,
+                                CashConstraint.java:99).  CASH_LEADTIME, whose order becomes the next state's preQ, therefore
+                                needs step = 1 (SDPGPU_ERR_UNSUPPORTED otherwise), like cash_formula 2 and STAFF. */
   int32_t clamp_inventory;   /* 1: clamp as CLSP.java:257-258; 0: no clamp (Leadtime.java:65-66
                                 has the clamp commented out) -> per-period boxes grown from ini_* */
   int32_t zero_order_last_period; /* SingleProductLeadtime.java:74-75: maxQ = 0 when period == T */
@@ -322,7 +326,7 @@ int sdpgpu_set_overhead(sdpgpu_handle* h, int32_t t, double overhead_cost);
  * action grid whose length follows one of the families' closed forms.  A driver whose list is still such a prefix but
  * with a length of its own (a storage capacity Q <= cap - x, a budget table, ...) hands the lengths over here:
  * counts[i] = getFeasibleAction.apply(state i of period t+1).length for every grid state i (flat index order,
- * n = sdpgpu_num_states), 0 <= counts[i] <= (int)(max_order_quantity / step) + 1; 0 = no feasible action (the value is
+ * n = sdpgpu_num_states), 0 <= counts[i] <= the family's longest list (see max_order_quantity); 0 = no feasible action (the value is
  * then +-Double.MAX_VALUE and the action 0, Recursion.java:132-134).  Such a period runs on the generic kernel (the
  * specialised kernels build on the family's rule).  sdpgpu_eval_states ALWAYS applies the family's rule -- to off-grid
  * states (the caller's list is defined on grid states only) and to on-grid states alike, so for a grid state whose count was
