@@ -25,6 +25,31 @@
 
 namespace sdp {
 
+// The same state from its coordinates: a cash family's row r = iq * nx + ix (inventory level, pipeline plane) and cash index ic.
+// The row kernels know both; decode_state's four 64-bit divisions (emulated: ~130 instructions each) cost the pair kernel a
+// thousand instructions per tile.  Every value is formed by the statements of decode_state above.
+template <int FAM>
+__device__ __forceinline__ void decode_state_row(const DevParams& P, int64_t row, int ic, StateT& s) {
+  static_assert(FAM != FAM_BACKORDER && FAM != FAM_LEADTIME, "cash families only");
+#ifdef SDP_DECODE_DIV  // (A/B builds only, tools/build_variant.sh: the round-2 form)
+  decode_state<FAM>(P, row * P.cur.nc + ic, s);
+  return;
+#endif
+  s.cash = 0;
+  s.preq = 0;
+  int64_t ix = row, iq = 0;
+  if constexpr (FAM == FAM_CASH_LEADTIME) {  // (the one cash family with planes: one division per wave, not four per point)
+    iq = row / P.cur.nx;
+    ix = row - iq * P.cur.nx;
+  }
+  s.x = P.cur.x_lo + (double)ix * P.step;
+  double k = (double)(P.cur.k_lo + (int64_t)ic);
+  s.cash = P.cash_round_int_div ? k : k / P.round_div;
+  if constexpr (FAM == FAM_CASH_LEADTIME) s.preq = (double)iq * P.step;
+  xr_state<FAM>(P, s, true);
+}
+
+
 struct CashShiftParams {
   double price, K, v, h, overhead, salvage, gamma, step;
   double x_lo;          // inventory value of ix = 0 (same grid every period: clamped family)
@@ -753,6 +778,7 @@ struct RowTiling {
   // unit u = tile * n_rows + row, are cut into eight equal runs of `colmajor` units, XCD i walks run i.  Still one narrow band
   // of consecutive rows in flight per XCD, and every XCD gets the same number of workgroups.
   int32_t colmajor;
+  int32_t slots;  // cash_row_pair_kernel, in-kernel setup: entry slots per wave (cash_row_slots(D); 1 = one action per setup pass)
   // Row order inside a band (nullptr: as numbered).  F5's state is (x, preQ) but its cells read V_{t+1} through the level
   // y = x + preQ only (SingleProductLeadtime.java:82-119): rows with equal y gather the very same entries.  Walked in order of y
   // they are in flight together and find each other's lines in L2; in (preQ, x) order the 31 rows of a level are 61 rows apart
@@ -816,7 +842,7 @@ __global__ __launch_bounds__(256) void cash_row_kernel(DevParams P, const double
   const bool live = ic < nc && idx >= lo && idx < hi;
 
   StateT s;
-  decode_state<FAM>(P, row * nc + ic_c, s);  // x (and preQ) are the same in every lane
+  decode_state_row<FAM>(P, row, ic_c, s);  // x (and preQ) are the same in every lane
   const double base = (FAM == FAM_CASH_LEADTIME) ? s.x + s.preq : s.x;  // + action below for F3/F4/F6
 
   // feasible actions: per lane, and the tile's maximum (non-decreasing in cash where it varies at all)
@@ -1046,6 +1072,9 @@ __global__ __launch_bounds__(256) void cash_row_kernel(DevParams P, const double
 // into its LDS (one 16-byte load and store per lane, requested an action ahead): the ~100 setup instructions per (wave,
 // action) leave the hot kernel.  row_entry() is the one place the entry's arithmetic is written: both paths call it.
 // ---------------------------------------------------------------------------------------------
+// Entry slots per wave of cash_row_pair_kernel's in-kernel setup: two when a pmf fits half a wave.
+__host__ __device__ inline int cash_row_slots(int D) { return D <= 32 ? 2 : 1; }
+
 struct RowTabHead {
   int32_t dmin, dmax;  // smallest / largest key shift over the uniform steps of the action (0, 0: none)
   int32_t pad0, pad1;
@@ -1103,7 +1132,7 @@ __global__ __launch_bounds__(256) void cash_row_table_kernel(DevParams P, const 
   const int row_i = (int)(g / n_actions), k = (int)(g - (int64_t)row_i * n_actions);
   const int D = P.n_demand;
   StateT s0;
-  decode_state<FAM_CASH>(P, (row0 + row_i) * P.cur.nc, s0);  // (the row's inventory level: the same in every cash point)
+  decode_state_row<FAM_CASH>(P, row0 + row_i, 0, s0);  // (the row's inventory level: the same in every cash point)
   const double a = (double)k * P.step;
   const double y = s0.x + a;
   const double fixed = a > 0 ? P.K : 0.0;
@@ -1193,7 +1222,10 @@ __global__ __launch_bounds__(256) void cash_row_pair_kernel(DevParams P, const d
   // SHARE: [4 actions][BS] bytes, d_j, the four waves' action counts.
   RowEnt* s_ent = reinterpret_cast<RowEnt*>(s_p + D);
   char* s_blocks = reinterpret_cast<char*>(s_p + D);
-  double* s_d = SHARE ? reinterpret_cast<double*>(s_blocks + (size_t)4 * BS) : reinterpret_cast<double*>(s_ent + (size_t)4 * D);  // d_j
+  // SRC 0, pmfs of at most 32 points: TWO entry slots per wave -- one setup pass forms the entries of two of the wave's actions,
+  // lanes 0-31 those of action k, lanes 32-63 those of action k + 4 (cash_row_slots; the launcher sizes the LDS with it)
+  const int SLOTS = (SRC == 0 && G.slots == 2) ? 2 : 1;
+  double* s_d = SHARE ? reinterpret_cast<double*>(s_blocks + (size_t)4 * BS) : reinterpret_cast<double*>(s_ent + (size_t)4 * SLOTS * D);  // d_j
   int* s_na = reinterpret_cast<int*>(s_d + D);
   double* s_val = TAB ? reinterpret_cast<double*>(s_blocks + (size_t)8 * BS) : s_d + D;
   int* s_k = reinterpret_cast<int*>(s_val + 4 * TS);
@@ -1235,7 +1267,7 @@ __global__ __launch_bounds__(256) void cash_row_pair_kernel(DevParams P, const d
   for (int w = 0; w < NP; ++w) {
     const int ic = ic0 + 128 * (w >> 1) + 2 * lane + (w & 1);
     icc[w] = ic < nc ? ic : nc - 1;
-    decode_state<FAM>(P, row * nc + icc[w], s[w]);  // x is the same in every lane and for both points
+    decode_state_row<FAM>(P, row, icc[w], s[w]);  // x is the same in every lane and for both points
     nA[w] = n_actions<FAM>(P, s[w]);
     nA_max = nA[w] > nA_max ? nA[w] : nA_max;
   }
@@ -1247,8 +1279,11 @@ __global__ __launch_bounds__(256) void cash_row_pair_kernel(DevParams P, const d
   nA_max = __builtin_amdgcn_readfirstlane(nA_max);
   if (SHARE && ic0 >= nc) nA_max = 0;  // (a wave past the row's end: it still forms blocks and meets the barriers)
 
-  RowEnt* ent = s_ent + (size_t)wave * D;        // (in-kernel setup; TAB: re-pointed at the current block every action)
-  int* uni = s_uni + wave * ((D + 3) / 4 + 3);
+  const int NF = (D + 3) / 4 + 3;                // trip flags of one action
+  RowEnt* const ent0 = s_ent + (size_t)wave * SLOTS * D;
+  int* const uni0 = s_uni + wave * SLOTS * NF;
+  RowEnt* ent = ent0;                            // (in-kernel setup; TAB: re-pointed at the current block every action)
+  int* uni = uni0;
   const bool MAXDIR = P.maxdir != 0;
   double best[NP];
   int bestk[NP];
@@ -1401,15 +1436,27 @@ __global__ __launch_bounds__(256) void cash_row_pair_kernel(DevParams P, const d
         // shifted key instead of the quantiser and one gather per point
         const int f_raw = __builtin_amdgcn_readfirstlane(uni[(D + 3) / 4 + (j & 3)]);
         const int f = BLK ? (f_raw ? (free_action ? 2 : 1) : 0) : f_raw;
+        if (f == 2) {  // clamp-free: straight-line, as in the trips (the step's two forms under one flag cost 14 instructions per cell)
+          dpair_u vv[S];
+#pragma unroll
+          for (int t = 0; t < S; ++t) vv[t] = *reinterpret_cast<const dpair_u*>(vbase + (uint32_t)(my_key8[t] + row_ent_off8(e)));
+#pragma unroll
+          for (int t = 0; t < S; ++t) {
+            acc[2 * t] += pp.x * increment(e, 2 * t);
+            acc[2 * t] += pp.y * vv[t].x;
+            acc[2 * t + 1] += pp.x * increment(e, 2 * t + 1);
+            acc[2 * t + 1] += pp.y * vv[t].y;
+          }
+          continue;
+        }
         if (f != 0) {
 #pragma unroll
           for (int t = 0; t < S; ++t) {
             const int ka = my_key[t] + e.dkey;
-            const uint32_t off = f == 2 ? (uint32_t)(my_key8[t] + row_ent_off8(e))
-                                        : (uint32_t)(e.rowoff8 + (med3_i32(ka, key_lo_v, key_hi1_v) << 3));
+            const uint32_t off = (uint32_t)(e.rowoff8 + (med3_i32(ka, key_lo_v, key_hi1_v) << 3));
             const dpair_u vv = *reinterpret_cast<const dpair_u*>(vbase + off);
-            const double v0 = (f != 2 && ka > k_hi_next - 1) ? vv.y : vv.x;
-            const double v1 = (f != 2 && ka < k_lo_next) ? vv.x : vv.y;
+            const double v0 = ka > k_hi_next - 1 ? vv.y : vv.x;
+            const double v1 = ka < k_lo_next ? vv.x : vv.y;
             acc[2 * t] += pp.x * increment(e, 2 * t);
             acc[2 * t] += pp.y * v0;
             acc[2 * t + 1] += pp.x * increment(e, 2 * t + 1);
@@ -1513,6 +1560,7 @@ __global__ __launch_bounds__(256) void cash_row_pair_kernel(DevParams P, const d
     }
     return;
   }
+  [[maybe_unused]] bool next_ready = false;  // (two slots) the entries of this action were formed by the previous pass
   for (int k = wave; k < nA_max; k += 4) {
     const double a = (double)k * P.step;
     const double fixed = a > 0 ? P.K : 0.0;
@@ -1535,6 +1583,44 @@ __global__ __launch_bounds__(256) void cash_row_pair_kernel(DevParams P, const d
           const int o = u * 1024 + lane * 16;
           if (o < BS) pf[u] = *reinterpret_cast<const uint4*>(src + o);
         }
+      }
+    } else if (SLOTS == 2) {
+      // ---- two actions per setup pass: lanes 0-31 form the entries of action k (slot 0), lanes 32-63 those of action k + 4
+      // (slot 1), which the NEXT trip of this loop consumes without a setup of its own.  Per lane the same row_entry()
+      // on the same operands as the one-action pass below.
+      if (next_ready) {
+        next_ready = false;
+        ent = ent0 + D;
+        uni = uni0 + NF;
+      } else {
+        const int half = lane >> 5, j = lane & 31;
+        const bool second = k + 4 < nA_max;
+        const double a_l = (double)(k + 4 * half) * P.step;
+        const double fixed_l = a_l > 0 ? P.K : 0.0;
+        const double var_l = P.v * a_l;
+        const bool act = j < D && (half == 0 || second);
+        bool is_uni = false, free_ = false;
+        RowEnt e{};
+        if (act) {
+          e = row_entry<LAST, FORMULA1, LEAN>(P, s[0].x + a_l, fixed_l, var_l, s_d[j], k_lo_next, is_uni);
+          if constexpr (!LAST) {
+            const double dn = (double)e.dkey;
+            free_ = is_uni && tile_whole && (double)key_first + dn >= (double)k_lo_next && (double)key_last + dn <= (double)k_hi_next;
+          }
+        }
+        if constexpr (!LAST) {
+          const unsigned long long mu = __ballot(is_uni), mf = __ballot(free_);
+          int* un = uni0 + half * NF;
+          if (act && (lane & 3) == 0)
+            un[j / 4] = (((mf >> lane) & 15ull) == 15ull) ? 2 : ((((mu >> lane) & 15ull) == 15ull) ? 1 : 0);
+          if (act && j >= (D & ~3)) un[(D + 3) / 4 + (j & 3)] = free_ ? 2 : (is_uni ? 1 : 0);
+        }
+        if (act) ent0[half * D + j] = e;
+        next_ready = second;
+        ent = ent0;
+        uni = uni0;
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_s_waitcnt(0xC07F);  // lgkmcnt(0): the wave's own LDS writes have landed
       }
     } else {
       // ---- wave-uniform part, lanes = demand indices (as cash_row_kernel) ---------------------------------------

@@ -243,7 +243,9 @@ hipError_t launch_cash_shift(sdpgpu_handle* h, const DevParams& P, int period, c
 // LDS of a workgroup of cash_row_kernel / cash_row_pair_kernel: 152 B per demand point (its per-wave entries), the
 // read-out scratch of four waves' tiles, and the per-wave trip flags.
 size_t cash_row_lds(int nD, int tile_pts) {
-  return (size_t)nD * 152 + (size_t)4 * tile_pts * (sizeof(double) + sizeof(int)) + 4 * (((size_t)nD + 3) / 4 + 3) * sizeof(int);
+  const size_t slots = (size_t)sdp::cash_row_slots(nD);  // (entries and flags of a second action per wave: the pair kernel's setup)
+  return (size_t)nD * (24 + 128 * slots) + (size_t)4 * tile_pts * (sizeof(double) + sizeof(int)) +
+         4 * slots * (((size_t)nD + 3) / 4 + 3) * sizeof(int);
 }
 
 bool cash_row_eligible(const sdpgpu_handle* h, int period) {
@@ -337,6 +339,9 @@ hipError_t launch_cash_row(sdpgpu_handle* h, const DevParams& P, int period, con
   const bool level_order = P.family == sdp::FAM_CASH_LEADTIME && p.g.nq > 1 &&
                            !(std::getenv("SDPGPU_CASH_ROWPERM") && std::atoi(std::getenv("SDPGPU_CASH_ROWPERM")) == 0);
   sdp::RowTiling G{};
+  // two actions per setup pass of the pair kernel when a pmf fits half a wave (SDPGPU_CASH_SLOTS=1: one, as in round 2)
+  static const bool one_slot = std::getenv("SDPGPU_CASH_SLOTS") && std::atoi(std::getenv("SDPGPU_CASH_SLOTS")) == 1;
+  G.slots = one_slot ? 1 : sdp::cash_row_slots(p.nD);
   G.tiles_per_row = (int32_t)((p.g.nc + wg_pts - 1) / wg_pts);
   G.n_rows = (int32_t)(row_hi - row_lo + 1);
   int64_t blocks = (int64_t)G.n_rows * G.tiles_per_row;
