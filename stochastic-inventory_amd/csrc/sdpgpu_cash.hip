@@ -340,8 +340,8 @@ hipError_t launch_cash_row(sdpgpu_handle* h, const DevParams& P, int period, con
                            !(std::getenv("SDPGPU_CASH_ROWPERM") && std::atoi(std::getenv("SDPGPU_CASH_ROWPERM")) == 0);
   sdp::RowTiling G{};
   // two actions per setup pass of the pair kernel when a pmf fits half a wave (SDPGPU_CASH_SLOTS=1: one, as in round 2)
-  static const bool one_slot = std::getenv("SDPGPU_CASH_SLOTS") && std::atoi(std::getenv("SDPGPU_CASH_SLOTS")) == 1;
-  G.slots = one_slot ? 1 : sdp::cash_row_slots(p.nD);
+  const char* slots_env = std::getenv("SDPGPU_CASH_SLOTS");
+  G.slots = (slots_env && std::atoi(slots_env) == 1) ? 1 : sdp::cash_row_slots(p.nD);
   G.tiles_per_row = (int32_t)((p.g.nc + wg_pts - 1) / wg_pts);
   G.n_rows = (int32_t)(row_hi - row_lo + 1);
   int64_t blocks = (int64_t)G.n_rows * G.tiles_per_row;

@@ -92,7 +92,8 @@ def test_cfg2_full_horizon_full_tables(sia, oracle):
                                  {"SDPGPU_CASH_PAIR": "0", "SDPGPU_CASH_UNI": "0"}, {"SDPGPU_CASH_BANDS": "0"},
                                  {"SDPGPU_CASH_BANDS": "3", "SDPGPU_CASH_PAIR_S": "2"}, {"SDPGPU_CASH_SHARE": "1"},
                                  {"SDPGPU_CASH_SHARE": "1", "SDPGPU_CASH_PAIR_S": "1"}, {"SDPGPU_CASH_TAB": "1"},
-                                 {"SDPGPU_CASH_TAB": "1", "SDPGPU_CASH_PAIR_S": "1"}],
+                                 {"SDPGPU_CASH_TAB": "1", "SDPGPU_CASH_PAIR_S": "1"}, {"SDPGPU_CASH_SLOTS": "1"},
+                                 {"SDPGPU_CASH_SLOTS": "1", "SDPGPU_CASH_PAIR_S": "1"}],
                          ids=lambda e: ",".join(f"{k[12:]}={v}" for k, v in e.items()))
 @pytest.mark.parametrize("make", [cases.f3_grid_prices, cases.f3_half_grid_prices, cases.f3_testing, cases.f3_xr],
                          ids=lambda f: f.__name__)
@@ -127,6 +128,22 @@ def test_cash_row_wide_pmf_above_64KiB_of_lds(sia, oracle, monkeypatch, pair_s):
     assert eng.stats().cells_evaluated == cells and eng.stats().kernel_used == 2
     for period in range(1, w.T + 1):
         _assert_tables(eng.values(period), eng.policy(period), V[period - 1], pol[period - 1], f"{w.name} pair_s={pair_s} t={period}")
+    eng.close()
+
+
+@pytest.mark.parametrize("D", [3, 4, 5, 31, 32, 33, 64])
+def test_cash_row_pair_setup_slots_around_half_a_wave(sia, oracle, D):
+    """The pair kernel forms the entries of TWO actions per setup pass when a pmf fits half a wave (lanes 0-31 / 32-63): pmfs of
+    3 .. 5 points (trips of four and single tail steps), 31, 32 (the last width with two slots), 33 and 64 points (one slot), on
+    CashConstraint.main's tenths grid with an odd number of actions (the last pass has no second action) -- every table against the oracle."""
+    from stochastic_inventory_amd import workloads
+    from stochastic_inventory_amd.workloads import truncated_poisson_tile
+    w = workloads.cfg3_tenths(T=3, NX=40, maxCash=300.0, A=23, D=D)
+    w.pmf = [truncated_poisson_tile(m, D) for m in (max(1.0, D / 3.0), max(1.0, D / 2.5), max(1.0, D / 4.0))]
+    eng, P, V, pol, cells = _solve_both(sia, oracle, w, nthreads=8)
+    assert eng.stats().cells_evaluated == cells and eng.stats().kernel_used == 2
+    for period in range(1, w.T + 1):
+        _assert_tables(eng.values(period), eng.policy(period), V[period - 1], pol[period - 1], f"{w.name} D={D} t={period}")
     eng.close()
 
 
