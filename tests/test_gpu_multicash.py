@@ -200,3 +200,24 @@ def test_action_box_beyond_the_lds_is_refused_with_a_reason(sia):
     with pytest.raises(sia.SdpgpuError) as ei:
         sia.multicash_solve(**kw)
     assert ei.value.code == 4 and "of LDS per state" in ei.value.message
+
+
+@pytest.mark.parametrize("seed", [3, 7, 11])
+@pytest.mark.parametrize("q_bound,T", [(1, None), (2, 1), (1, 1)], ids=["one-action", "one-period", "one-action-one-period"])
+def test_degenerate_action_boxes_and_horizons(sia, oracle, seed, q_bound, T):
+    """Qbound 1 (the only action pair is (0, 0)) and a horizon of one period, both two-product cash recursions."""
+    kw = multicash_cases.random_instance(seed)
+    dep, kx = multicash_cases.xr_random_instance(seed)
+    for k in (kw, kx):
+        k["q_bound"] = q_bound
+        if T:
+            k["T"] = T
+            k["pmf"] = k["pmf"][:T]
+    r = sia.multicash_solve(**kw)
+    fv, q1, q2, states, cells = oracle.multicash_memo(**kw)
+    assert r.finalValue == fv and (r.firstAction, r.secondAction) == (q1, q2)
+    assert r.statesPerPeriod == states and r.cells == cells
+    r = sia.multixr_solve(dep, **kx)
+    fv, y1, y2, states, cells = oracle.multixr_memo(dep, **kx)
+    assert r.finalValue == fv and (r.firstAction, r.secondAction) == (y1, y2)
+    assert r.statesPerPeriod == states and r.cells == cells

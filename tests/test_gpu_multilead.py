@@ -53,17 +53,17 @@ def test_kat3_to_kat6_three_point_demands(sia, name):
     print(f"{name}: {r.finalValue!r} in {r.gpu_ms:.0f} ms, states {r.statesPerPeriod}")
 
 
-@pytest.mark.parametrize("seed", [1, 2, 3, 4])
+@pytest.mark.parametrize("seed", list(range(1, 17)) + [101, 102, 103])
 def test_random_instances_match_the_oracle(sia, oracle, seed):
     from stochastic_inventory_amd.multiitem import multilead_solve
     rng = np.random.default_rng(seed)
-    T = int(rng.integers(2, 4))
+    T = int(rng.integers(2, 4)) if seed < 100 else 1 + seed % 100  # (101 .. 103: horizons 2 .. 4 with the smallest action boxes)
     n1, n2 = int(rng.integers(1, 4)), int(rng.integers(1, 4))
     v1 = sorted(rng.choice(np.arange(1, 12), size=n1, replace=False).tolist())
     v2 = sorted(rng.choice(np.arange(1, 9), size=n2, replace=False).tolist())
     p1 = rng.dirichlet(np.ones(n1)).tolist()
     p2 = rng.dirichlet(np.ones(n2)).tolist()
-    kw = dict(T=T, q_bound=int(rng.integers(3, 8)), price=(float(rng.integers(3, 9)), float(rng.integers(5, 14))),
+    kw = dict(T=T, q_bound=int(rng.integers(3, 8)) if seed < 100 else 1 + seed % 2, price=(float(rng.integers(3, 9)), float(rng.integers(5, 14))),
               vari_cost=(1.0, 2.5), sal_value=(0.5, 1.25), ini_cash=float(rng.integers(-5, 30)), ini_i1=float(rng.integers(0, 4)),
               ini_i2=0.0, r0=0.01, r1=0.1, r2=1.5, limit=40.0, interest_free=3.0, min_inventory=0.0, max_inventory=9.0,
               min_cash=-120.0, max_cash=400.0, discount=float(rng.choice([1.0, 0.95])),
