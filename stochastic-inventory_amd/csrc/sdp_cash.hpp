@@ -25,6 +25,12 @@
 
 namespace sdp {
 
+// A demand trip of the cash row kernels has two phases: (1) offsets formed, gathers issued, increments multiplied; (2) the
+// gathered values consumed.  A scheduling barrier between them keeps the compiler from sinking phase-1 work under the waits of
+// phase 2 (+1 % on CashConstraint.main's grid; s_setprio at the same two places -- any level, 0 included -- measured the same:
+// it is the instruction order that matters, not the priority).
+#define SDP_TRIP_PHASE(hi) __builtin_amdgcn_sched_barrier(0)
+
 // The same state from its coordinates: a cash family's row r = iq * nx + ix (inventory level, pipeline plane) and cash index ic.
 // The row kernels know both; decode_state's four 64-bit divisions (emulated: ~130 instructions each) cost the pair kernel a
 // thousand instructions per tile.  Every value is formed by the statements of decode_state above.
@@ -1011,6 +1017,7 @@ __global__ __launch_bounds__(256) void cash_row_kernel(DevParams P, const double
           continue;
         }
       }
+      if constexpr (!LAST) SDP_TRIP_PHASE(1);  // (two phases per trip, see cash_row_pair_kernel)
 #pragma unroll
       for (int u = 0; u < U; ++u) {
         const double2 pp = s_p[j + u];
@@ -1020,6 +1027,7 @@ __global__ __launch_bounds__(256) void cash_row_kernel(DevParams P, const double
       if constexpr (!LAST) {
 #pragma unroll
         for (int u = 0; u < U; ++u) v[u] = *reinterpret_cast<const double*>(vbase + off[u]);
+        SDP_TRIP_PHASE(0);
       }
 #pragma unroll
       for (int u = 0; u < U; ++u) {
@@ -1358,6 +1366,7 @@ __global__ __launch_bounds__(256) void cash_row_pair_kernel(DevParams P, const d
           constexpr bool FREE = decltype(free_tag)::value;
           dpair_u v[U][S];
           [[maybe_unused]] bool hi_fold[U][S], lo_fold[U][S];
+          SDP_TRIP_PHASE(1);
 #pragma unroll
           for (int u = 0; u < U; ++u) {
             const RowEnt e = ent[j + u];
@@ -1379,6 +1388,7 @@ __global__ __launch_bounds__(256) void cash_row_pair_kernel(DevParams P, const d
               v[u][t] = *reinterpret_cast<const dpair_u*>(vbase + off);
             }
           }
+          SDP_TRIP_PHASE(0);
 #pragma unroll
           for (int u = 0; u < U; ++u)
 #pragma unroll
