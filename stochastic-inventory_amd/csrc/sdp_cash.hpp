@@ -1350,15 +1350,24 @@ __global__ __launch_bounds__(256) void cash_row_pair_kernel(DevParams P, const d
       if constexpr (LAST && !FORMULA1) inc += e.sal;
       return inc;
     };
-    constexpr int U = 4;
+#ifndef SDP_PAIR_U
+#define SDP_PAIR_U 2
+#endif
+    constexpr int G = 4;           // demand steps per trip FLAG (the setup's granularity)
+    // Demand steps per trip of the loop.  Trips of TWO steps keep half the gathered pairs and products in registers: 114 VGPRs
+    // instead of 153, i.e. FOUR waves per SIMD instead of three -- on a kernel that loads the VALU issue port and the vector L1
+    // to three quarters each, the extra wave is worth more than the trip overhead it doubles (CashConstraint.main's grid:
+    // 35.6 against 37.3 ms per sweep, same box, back to back; -DSDP_PAIR_U=4 rebuilds the four-step form).
+    constexpr int U = SDP_PAIR_U;
     double acc[NP];
 #pragma unroll
     for (int w = 0; w < NP; ++w) acc[w] = 0.0;
     int j = 0;
-    for (; j + U <= D; j += U) {
+    for (int jg = 0; jg + G <= D; jg += G)
+    for (j = jg; j < jg + G; j += U) {
       double add1[U][NP], pg[U];
       if constexpr (!LAST) {
-        const int f_raw = __builtin_amdgcn_readfirstlane(uni[j / U]);
+        const int f_raw = __builtin_amdgcn_readfirstlane(uni[jg / G]);
         const int f = BLK ? (f_raw ? (free_action ? 2 : 1) : 0) : f_raw;  // (a block's flag knows no tile)
         // one uniform-key trip; FREE: no point of the wave's tiles clamps (decided for the whole trip, so that the four
         // steps are straight-line code: the compiler turned a per-step choice into mask arithmetic on every step)
@@ -1438,7 +1447,7 @@ __global__ __launch_bounds__(256) void cash_row_pair_kernel(DevParams P, const d
           if constexpr (!LAST) acc[w] += pg[u] * v[u][w];
         }
     }
-    for (; j < D; ++j) {
+    for (j = D & ~(G - 1); j < D; ++j) {
       const RowEnt e = ent[j];
       const double2 pp = s_p[j];
       if constexpr (!LAST) {
