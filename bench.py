@@ -1,8 +1,9 @@
 #!/usr/bin/env python3
 """bench.py -- the hot path (backward Bellman sweep t = T..1) on N MI355X GPUs of one node.
 
-    python bench.py --gpus 1 --steps K --warmup W
-    python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+    python bench.py --gpus N --steps K --warmup W              (any N: for N > 1 and no WORLD_SIZE in the environment the
+                                                                process starts its own N ranks, see `self_launch`)
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...   (the driver's form)
 
 A "step" is one full backward sweep of the workload with every input (PMF tiles, descriptor) already resident
 in HBM.  Default workload: the grid BASELINE.json's target is quoted on -- 1e6 states x 500 actions x 200
@@ -83,6 +84,9 @@ def parse_args():
                     help="N = 1 only: take the N > 1 code path with a world of one (gloo group of one, one-rank RCCL communicator "
                          "inside libsdpgpu.so, sdpgpu_solve_sharded, per-rank gate) -- what one rank of eight executes")
     ap.add_argument("--cpu-seconds", type=float, default=15.0, help="target CPU time of the oracle sample")
+    ap.add_argument("--launch-timeout", type=float, default=float(os.environ.get("SDP_BENCH_LAUNCH_TIMEOUT", "1500")),
+                    help="bare `bench.py --gpus N` (N > 1, not under torchrun): seconds the N ranks this process starts may "
+                         "take before they are ended with an error record")
     a = ap.parse_args()
     if a.backend == "gloo":
         a.exchange = "host"
@@ -400,8 +404,116 @@ def run_single(sia, torch, dev, name, w, steps, warmup, kernel, gate_cells, no_g
             "kernel": {0: "auto", 1: "gather", 2: "specialised (window / shift / row)", 3: "separable"}[int(st.kernel_used)]}
 
 
+# ---------------------------------------------------------------------------------------------------------------
+# bare `python bench.py --gpus N`, N > 1: start the N ranks ourselves
+# ---------------------------------------------------------------------------------------------------------------
+def self_launch(args, argv) -> int:
+    """`python bench.py --gpus N` with N > 1 and no WORLD_SIZE in the environment: this process becomes the PARENT of a
+    `python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py <same arguments>` CHILD process (one rank
+    per GPU underneath it) -- a child, never an exec, started before anything here has imported torch or touched HIP --
+    and relays rank 0's ONE JSON line on its own stdout (the ranks' stderr is passed through).  The reference's contract
+    is one call that solves everything (Recursion.java:89); so is this.
+
+    A non-zero exit of the ranks, no bench line, or an overrun of --launch-timeout ends with ONE JSON error record on
+    stdout (phase = the last phase a rank announced, the ranks' own watchdog record if one fired, the tail of stderr)
+    and a non-zero exit code; on an overrun the process group this parent started (and only that) is ended first."""
+    import collections
+    import signal
+    import socket
+    import subprocess
+    import threading
+
+    with socket.socket() as sock:
+        sock.bind(("127.0.0.1", 0))
+        port = sock.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__), *argv]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    env["SDP_BENCH_PHASE_TRACE"] = "1"  # the ranks announce every phase on stderr: the record of a failure names the last one
+    t0 = time.monotonic()
+    proc = subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, env=env, cwd=ROOT,
+                            start_new_session=True)  # its own process group: what an overrun ends, by id
+    out_lines, err_tail, fatal = [], collections.deque(maxlen=40), []
+    last_phase = {}
+
+    def pump_out():
+        for line in proc.stdout:
+            out_lines.append(line.rstrip("\n"))
+
+    def pump_err():
+        for line in proc.stderr:
+            sys.stderr.write(line)
+            sys.stderr.flush()
+            text = line.rstrip("\n")
+            if text.startswith("[bench phase] "):  # "[bench phase] rank R: NAME"
+                try:
+                    head, name = text[len("[bench phase] "):].split(": ", 1)
+                    last_phase[int(head.split()[1])] = name
+                except (ValueError, IndexError):
+                    pass
+            elif text.startswith("[bench fatal] "):  # a rank's own reason for ending (see __main__)
+                fatal.append(text[len("[bench fatal] "):])
+            elif text.strip():
+                err_tail.append(text)
+
+    pumps = [threading.Thread(target=pump_out, daemon=True), threading.Thread(target=pump_err, daemon=True)]
+    for t in pumps:
+        t.start()
+    timed_out = False
+    try:
+        rc = proc.wait(timeout=args.launch_timeout)
+    except subprocess.TimeoutExpired:
+        timed_out = True
+        for sig, grace in ((signal.SIGTERM, 10.0), (signal.SIGKILL, 10.0)):
+            try:
+                os.killpg(proc.pid, sig)  # exactly the group started above (start_new_session: pgid == proc.pid)
+            except ProcessLookupError:
+                break
+            try:
+                proc.wait(timeout=grace)
+                break
+            except subprocess.TimeoutExpired:
+                continue
+        rc = proc.returncode if proc.returncode is not None else -9
+    for t in pumps:
+        t.join(timeout=5.0)
+
+    records = []
+    for line in out_lines:
+        if line.startswith("{"):
+            try:
+                records.append(json.loads(line))
+                continue
+            except ValueError:
+                pass
+        if line.strip():
+            print(line, file=sys.stderr, flush=True)  # anything else a rank printed is not the bench line
+    bench = [r for r in records if r.get("metric") and r.get("value") is not None and "error" not in r]
+    if rc == 0 and not timed_out and len(bench) == 1:
+        print(json.dumps(bench[0]), flush=True)
+        return 0
+    fired = [r for r in records if "error" in r]  # the ranks' own watchdog records (phase, rank, times)
+    phase = (fired[0].get("phase") if fired else None) or (last_phase.get(0) or next(iter(last_phase.values()), None)) or "launch"
+    rec = {"error": ("launch timeout exceeded" if timed_out else
+                     "ranks exited with a non-zero code" if rc != 0 else
+                     f"{len(bench)} bench lines on the ranks' stdout (expected exactly one)"),
+           "phase": phase, "returncode": rc, "elapsed_s": round(time.monotonic() - t0, 2),
+           "launch_timeout_s": args.launch_timeout, "n_gpus": args.gpus, "workload": args.workload,
+           "metric": "(state,action,demand) cell evals/sec", "value": None,
+           "last_phase_per_rank": {str(k): v for k, v in sorted(last_phase.items())},
+           "rank_records": fired[:8], "fatal": fatal[:8], "stderr_tail": list(err_tail)[-12:]}
+    print(json.dumps(rec), flush=True)
+    return rc if rc not in (0, None) else 1
+
+
 def main():
     args = parse_args()
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # not under a launcher: start the N ranks as a child process (before torch or HIP are touched) and relay their line
+        sys.exit(self_launch(args, sys.argv[1:]))
+    if os.environ.get("SDP_BENCH_TEST_STALL_AT_START"):  # (tests: a rank that never gets as far as the process group)
+        time.sleep(float(os.environ["SDP_BENCH_TEST_STALL_AT_START"]))
     # multi-process GPU work on this image needs dmabuf IPC (RCCL's buffer exchange between the ranks' processes)
     os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
     import torch
@@ -411,8 +523,6 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            raise SystemExit("--gpus N > 1 must be launched with torch.distributed.run (one rank per GPU)")
         raise SystemExit(f"WORLD_SIZE={world} but --gpus {args.gpus}")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the engine has no CPU path")
@@ -725,4 +835,13 @@ def main():
 
 
 if __name__ == "__main__":
-    main()
+    try:
+        main()
+    except SystemExit as exc:
+        if isinstance(exc.code, str):  # a refusal with a reason: tagged, so that a self-launching parent can quote it in its record
+            print(f"[bench fatal] rank {os.environ.get('RANK', '0')}: {exc.code}", file=sys.stderr, flush=True)
+            sys.exit(1)
+        raise
+    except Exception as exc:
+        print(f"[bench fatal] rank {os.environ.get('RANK', '0')}: {type(exc).__name__}: {exc}", file=sys.stderr, flush=True)
+        raise

@@ -33,6 +33,7 @@ class PhaseWatchdog:
         self.context = dict(context or {})
         self.scale = float(os.environ.get("SDP_WATCHDOG_SCALE", "1") or 1)
         self._inject = os.environ.get("SDP_WATCHDOG_INJECT_STALL", "")
+        self._trace = os.environ.get("SDP_BENCH_PHASE_TRACE", "") == "1"  # announce phases (bench.py's self-launching parent reads them)
         self._lock = threading.Lock()
         self._phase = None       # (name, t_start, deadline_s)
         self._closed = False
@@ -48,6 +49,8 @@ class PhaseWatchdog:
         t0 = time.monotonic()
         with self._lock:
             self._phase = (name, t0, limit)
+        if self._trace:
+            print(f"[bench phase] rank {self.rank}: {name}", file=sys.stderr, flush=True)
         try:
             if self._inject == f"{name}:{self.rank}":
                 time.sleep(1e6)  # a stalled rank (tests)

@@ -70,6 +70,23 @@ def test_native_sharded_path_with_a_world_of_one(extra):
     assert rec["config"]["cells_per_rank"] == [rec["config"]["cells_per_step"]]
 
 
+def test_bare_command_starts_its_own_ranks_host_exchange():
+    """`python3 bench.py --gpus 2 --exchange host` with no launcher: bench.py starts its two ranks itself (self_launch: a child
+    torch.distributed.run, never an exec) and relays exactly one JSON line with n_gpus = 2."""
+    env = dict(os.environ)
+    for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1", "--exchange", "host",
+           "--check", "--no-cpu-baseline", "--periods", "2"]
+    out = subprocess.run(cmd, capture_output=True, text=True, timeout=420, cwd=ROOT, env=env)
+    assert out.returncode == 0, (out.stdout[-1500:], out.stderr[-2500:])
+    lines = [l for l in out.stdout.splitlines() if l.strip()]
+    assert len(lines) == 1, "exactly one line on stdout"
+    rec = json.loads(lines[0])
+    assert rec["n_gpus"] == 2 and rec["check_vs_single_rank"] is True and rec["parity_gate"]["status"] == "ok"
+    assert "host-staged" in rec["config"]["exchange"]
+
+
 def _device_count():
     import torch
     return torch.cuda.device_count()  # (counts devices without initialising the GPU in this process)

@@ -52,6 +52,45 @@ def test_native_exchange_between_processes(mock_rccl, world, extra):
     assert "communicator init" in rec["config"]["phases_s"] and "timed loop" in rec["config"]["phases_s"]
 
 
+def _bare_env(**extra):
+    env = dict(os.environ, **extra)
+    for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    return env
+
+
+@pytest.mark.parametrize("world,extra", [(2, ["--periods", "3"]), (4, ["--workload", "cfg2", "--periods", "6"])], ids=["target_2", "cfg2_4"])
+def test_bare_command_starts_its_own_ranks_native(mock_rccl, world, extra):
+    """`python3 bench.py --gpus N` with NO launcher (bench.py: self_launch): the process starts N ranks as a child, the default
+    --exchange native path runs between them (mock transport), and exactly ONE JSON line comes back with n_gpus = N."""
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", str(world), "--steps", "2", "--warmup", "1", "--check",
+           "--no-cpu-baseline", *extra]
+    out = subprocess.run(cmd, capture_output=True, text=True, timeout=420, cwd=ROOT,
+                         env=_bare_env(SDPGPU_RCCL_LIB=mock_rccl, MOCK_RCCL_SLOT_MB="64"))
+    assert out.returncode == 0, (out.stdout[-1500:], out.stderr[-2500:])
+    lines = [l for l in out.stdout.splitlines() if l.strip()]
+    assert len(lines) == 1, "exactly one line on stdout"
+    rec = json.loads(lines[0])
+    assert rec["n_gpus"] == world and rec["check_vs_single_rank"] is True and rec["parity_gate"]["status"] == "ok"
+    assert "RCCL all-gather issued by libsdpgpu.so" in rec["config"]["exchange"] and "fell back" not in rec["config"]["exchange"]
+    assert "[bench phase] rank 0: timed loop" in out.stderr  # the ranks announced their phases to the parent
+
+
+def test_bare_command_relays_a_stalled_rank_as_one_record(mock_rccl):
+    """The bare command with rank 1 stalled before its first sweep: the ranks' watchdogs fire, the launcher ends, and the
+    parent prints ONE record naming the phase and exits non-zero."""
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "0", "--no-cpu-baseline",
+           "--workload", "cfg2", "--periods", "4"]
+    out = subprocess.run(cmd, capture_output=True, text=True, timeout=300, cwd=ROOT,
+                         env=_bare_env(SDPGPU_RCCL_LIB=mock_rccl, SDP_WATCHDOG_INJECT_STALL="first sweep:1", SDP_WATCHDOG_SCALE="0.05"))
+    assert out.returncode != 0
+    lines = [l for l in out.stdout.splitlines() if l.strip()]
+    assert len(lines) == 1
+    rec = json.loads(lines[0])
+    assert rec["value"] is None and rec["phase"] == "first sweep" and rec["n_gpus"] == 2
+    assert rec["rank_records"] and all(r["error"] == "phase deadline exceeded" for r in rec["rank_records"])
+
+
 def test_a_rank_that_cannot_prepare_does_not_strand_its_peers(mock_rccl):
     """Rank 1's collective library does not load (SDPGPU_RCCL_LIB points nowhere on that rank): sdpgpu_comm_prepare fails
     THERE, the ranks agree before anybody enters ncclCommInitRank, and the run ends -- here with a non-zero exit, since the
