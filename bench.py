@@ -109,6 +109,15 @@ def make_workload(name: str, world: int, states: int = 0, periods: int = 0, weak
     return workloads.by_name(name, **kw)
 
 
+def build_identity():
+    """The loaded library's sdpgpu_build_id against the digest of the tree's sources (tools/kernel_sha.py: build_source_sha):
+    every bench line says which binary produced it and whether that binary is this tree's."""
+    import stochastic_inventory_amd as sia
+    from tools.kernel_sha import build_source_sha
+    have, want = sia._abi.load().sdpgpu_build_id().decode(), build_source_sha(ROOT)
+    return {"build_id": have, "source_digest": want, "match": have == want}
+
+
 def algorithmic_bytes(cells: float, states_periods: float) -> float:
     """SURVEY.md section 8(d)'s byte MODEL: 8 B per cell (one fp64 gather of V_{t+1}) + 12 B per state-period."""
     return 8.0 * cells + 12.0 * states_periods
@@ -576,6 +585,7 @@ def main():
                        "kernel": head["kernel"]},
             "parity_gate": head["parity_gate"],
             "roofline": head["roofline"],
+            "build": build_identity(),
         }
         flops = REFERENCE_FLOPS_PER_CELL.get(args.workload, 14)
         out["side_by_side"] = {
@@ -822,6 +832,7 @@ def main():
             },
             "parity_gate": gate,
             "roofline": rf,
+            "build": build_identity(),
         }
         if check is not None:
             out["check_vs_single_rank"] = check

@@ -69,7 +69,7 @@ extern "C" {
 #pragma GCC visibility push(default) /* the library is built with -fvisibility=hidden: only this header is exported */
 #endif
 
-#define SDPGPU_ABI_VERSION 5
+#define SDPGPU_ABI_VERSION 6
 
 /* status codes */
 #define SDPGPU_OK 0
@@ -77,6 +77,8 @@ extern "C" {
 #define SDPGPU_ERR_STATE 2    /* call out of order (e.g. values before solve) */
 #define SDPGPU_ERR_DEVICE 3   /* HIP runtime error (message carries hipGetErrorString) */
 #define SDPGPU_ERR_UNSUPPORTED 4
+#define SDPGPU_ERR_ALLOC 5    /* ABI 6: a host allocation failed (std::bad_alloc caught at the boundary) */
+#define SDPGPU_ERR_INTERNAL 6 /* ABI 6: any other C++ exception caught at the boundary -- none crosses it */
 
 /* Functor families = the closed-form lambda families of the in-scope drivers. */
 typedef enum sdpgpu_family {
@@ -229,6 +231,14 @@ typedef struct sdpgpu_handle sdpgpu_handle;
 
 /* Library identity: returns SDPGPU_ABI_VERSION. */
 int sdpgpu_abi_version(void);
+
+/* ABI 6.  Identity of the BINARY: the 16-hex-digit digest of the sources it was built from (every file of csrc/, this
+ * header and build.py with its flags -- tools/kernel_sha.py: build_source_sha), baked in at build time by build.py.  The
+ * shipped libsdpgpu.so is a prebuilt artefact (git-ignored, carried to the GPU box with the tree): __graft_entry__.smoke()
+ * and every bench line compare this string with the digest of the tree they run from, and a mismatch fails smoke.
+ * "unknown" when the library was compiled by hand without -DSDPGPU_BUILD_ID.  The reference has no counterpart (a JVM
+ * runs the classes it was given: Recursion.java has no native half). */
+const char* sdpgpu_build_id(void);
 
 /* Fill a descriptor with the defaults the reference drivers use (discount 1,
  * rounding 10/10.0, clamp on, world 1, store all values, kernel auto). */

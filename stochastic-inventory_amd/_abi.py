@@ -13,7 +13,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 # SDPGPU_LIB: load another build of the SAME library instead (tests/test_sanitizers.py points it at the host-ASan build)
 LIB_PATH = os.environ.get("SDPGPU_LIB") or os.path.join(_HERE, "libsdpgpu.so")
 
-SDPGPU_ABI_VERSION = 5
+SDPGPU_ABI_VERSION = 6
 
 FAMILY_BACKORDER = 1
 FAMILY_LEADTIME = 2
@@ -218,6 +218,7 @@ _IP = C.POINTER(C.c_int32)
 _LP = C.POINTER(C.c_int64)
 EXPORTS = {
     "sdpgpu_abi_version": (C.c_int, []),
+    "sdpgpu_build_id": (C.c_char_p, []),
     "sdpgpu_desc_init": (None, [C.POINTER(SdpgpuDesc)]),
     "sdpgpu_create": (C.c_int, [C.POINTER(SdpgpuDesc), C.POINTER(_P)]),
     "sdpgpu_create_custom": (C.c_int, [C.POINTER(SdpgpuDesc), C.c_char_p, _DP, C.c_int32, C.POINTER(_P)]),

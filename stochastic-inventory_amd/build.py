@@ -40,11 +40,33 @@ def deps():
     return out
 
 
+def source_sha() -> str:
+    """Digest of everything the library is built from (tools/kernel_sha.py: build_source_sha)."""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("_kernel_sha", os.path.join(HERE, "..", "tools", "kernel_sha.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    return mod.build_source_sha(os.path.join(HERE, ".."))
+
+
+def baked_build_id(path: str = OUT):
+    """The identity a built library carries (what sdpgpu_build_id returns), read from the file without loading it."""
+    marker = b"sdpgpu-build-id:"
+    try:
+        blob = open(path, "rb").read()
+    except OSError:
+        return None
+    at = blob.find(marker)
+    if at < 0:
+        return None
+    end = blob.find(b"\0", at)
+    return blob[at + len(marker):end].decode("ascii", "replace")
+
+
 def up_to_date() -> bool:
-    if not os.path.exists(OUT):
-        return False
-    t = os.path.getmtime(OUT)
-    return all(os.path.getmtime(f) <= t for f in deps())
+    """The library exists and was built from exactly these sources (by content, not by modification time: the .so is a
+    git-ignored artefact that travels with the tree)."""
+    return os.path.exists(OUT) and baked_build_id() == source_sha()
 
 
 def build(force: bool = False, extra_flags=(), verbose: bool = True) -> str:
@@ -56,7 +78,8 @@ def build(force: bool = False, extra_flags=(), verbose: bool = True) -> str:
     hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
     objdir = os.path.join(HERE, "_build")
     os.makedirs(objdir, exist_ok=True)
-    compile_flags = [f for f in HIPCC_FLAGS if f != "-shared"] + ["-fvisibility=hidden", *extra_flags]
+    compile_flags = [f for f in HIPCC_FLAGS if f != "-shared"] + ["-fvisibility=hidden", f'-DSDPGPU_BUILD_ID="{source_sha()}"',
+                                                                   *extra_flags]
 
     def compile_one(src):
         obj = os.path.join(objdir, os.path.basename(src) + ".o")

@@ -564,6 +564,13 @@ extern "C" {
 
 int sdpgpu_abi_version(void) { return SDPGPU_ABI_VERSION; }
 
+#ifndef SDPGPU_BUILD_ID
+#define SDPGPU_BUILD_ID "unknown"
+#endif
+// (the marker in front lets build.py read the identity out of the file without loading it)
+static const char g_build_id[] = "sdpgpu-build-id:" SDPGPU_BUILD_ID;
+const char* sdpgpu_build_id(void) { return g_build_id + sizeof("sdpgpu-build-id:") - 1; }
+
 void sdpgpu_desc_init(sdpgpu_desc* d) {
   if (!d) return;
   std::memset(d, 0, sizeof *d);

@@ -28,6 +28,7 @@ struct RcclApi {
   decltype(&ncclCommInitRank) CommInitRank = nullptr;
   decltype(&ncclCommInitAll) CommInitAll = nullptr;
   decltype(&ncclCommDestroy) CommDestroy = nullptr;
+  decltype(&ncclCommAbort) CommAbort = nullptr;  // optional: the failure path of the thread-per-rank sweep
   decltype(&ncclAllGather) AllGather = nullptr;
   decltype(&ncclGroupStart) GroupStart = nullptr;
   decltype(&ncclGroupEnd) GroupEnd = nullptr;
@@ -80,6 +81,7 @@ RcclApi* rccl() {
     g_rccl.GroupStart = (decltype(g_rccl.GroupStart))sym("ncclGroupStart");
     g_rccl.GroupEnd = (decltype(g_rccl.GroupEnd))sym("ncclGroupEnd");
     g_rccl.GetErrorString = (decltype(g_rccl.GetErrorString))sym("ncclGetErrorString");
+    g_rccl.CommAbort = (decltype(g_rccl.CommAbort))dlsym(g_rccl.lib, "ncclCommAbort");  // (absent: peers are not released early)
     if (!ok) g_rccl.lib = nullptr;
   });
   return g_rccl.lib ? &g_rccl : nullptr;
@@ -453,13 +455,45 @@ int sdpgpu_solve_multi(sdpgpu_handle** hs, int32_t n, int32_t flags) {
       meet.n = n;
       std::vector<int> rcs((size_t)n, SDPGPU_OK);
       const int inner = flags & ~(SDPGPU_SHARDED_THREADS | (want_copy ? SDPGPU_SHARDED_OVERLAP : 0));
+      // (tests: "kernel:R:P" = rank R fails where its kernel of period P would be launched, "collective:R:P" = where its
+      // all-gather of that period would be enqueued -- neither may leave the other ranks inside a collective)
+      int inject_kind = 0, inject_rank = -1, inject_period = -1;
+      if (const char* inj = std::getenv("SDPGPU_TEST_FAIL_RANK")) {
+        char kind[16] = {0};
+        if (std::sscanf(inj, "%15[a-z]:%d:%d", kind, &inject_rank, &inject_period) == 3)
+          inject_kind = std::strcmp(kind, "kernel") == 0 ? 1 : std::strcmp(kind, "collective") == 0 ? 2 : 0;
+      }
+      // A rank that fails after its peers have enqueued the all-gather of a period would leave them waiting for a
+      // participant that never comes (for ever under SDPGPU_SHARDED_SYNC): the failing thread then aborts EVERY
+      // communicator of the call (ncclCommAbort, which is what releases a blocked collective), once; the communicators
+      // are gone afterwards and the next call builds new ones.
+      std::once_flag abort_once;
+      bool aborted = false;
+      auto abort_all = [&] {
+        std::call_once(abort_once, [&] {
+          aborted = true;
+          if (!api || !api->CommAbort) return;
+          for (int q = 0; q < n; ++q)
+            if (hs[q]->comm) (void)api->CommAbort((ncclComm_t)hs[q]->comm);
+        });
+      };
       auto body = [&](int r) {
         sdpgpu_handle* h = hs[r];
         h->err.clear();
         int rc;
         try {
           rc = sweep_rank(h, inner, [&](int period, bool overlapped) -> int {
-            if (!want_copy) return enqueue_allgather(h, api, period, overlapped ? h->comm_stream : h->stream);
+            if (inject_kind == 1 && inject_rank == r && inject_period == period)
+              return fail(h, SDPGPU_ERR_DEVICE, "injected failure of the kernel launch of period %d (SDPGPU_TEST_FAIL_RANK)", period);
+            if (!want_copy) {
+              // every rank confirms that its kernel of this period is launched BEFORE any rank enters the collective: a
+              // rank that failed in run_period_impl has abandoned the rendezvous and nobody enqueues an all-gather it
+              // would never join
+              if (!meet.arrive()) return fail(h, SDPGPU_ERR_STATE, "another rank's sweep failed");
+              if (inject_kind == 2 && inject_rank == r && inject_period == period)
+                return fail(h, SDPGPU_ERR_DEVICE, "injected failure of the all-gather of period %d (SDPGPU_TEST_FAIL_RANK)", period);
+              return enqueue_allgather(h, api, period, overlapped ? h->comm_stream : h->stream);
+            }
             // shared device: publish "my kernel of this period is enqueued", wait for everybody's, then pull
             HIP_TRY(h, hipEventRecord(h->ev_comp, h->stream));
             if (!meet.arrive()) return fail(h, SDPGPU_ERR_STATE, "another rank's sweep failed");
@@ -471,13 +505,20 @@ int sdpgpu_solve_multi(sdpgpu_handle** hs, int32_t n, int32_t flags) {
         } catch (...) {
           rc = fail(h, SDPGPU_ERR_ARG, "exception in the rank's thread");
         }
-        if (rc) meet.abandon(r);
+        if (rc) {
+          const std::string why = h->err;  // (kept: the abort below must not replace the reason)
+          meet.abandon(r);
+          if (!want_copy) abort_all();
+          h->err = why;
+        }
         rcs[(size_t)r] = rc;
       };
       std::vector<std::thread> th;
       th.reserve((size_t)n);
       for (int r = 0; r < n; ++r) th.emplace_back(body, r);
       for (auto& t : th) t.join();
+      if (aborted)  // (ncclCommAbort frees a communicator as ncclCommDestroy does; without it the handles keep theirs)
+        for (int r = 0; r < n && api && api->CommAbort; ++r) hs[r]->comm = nullptr;
       for (int pass = 0; pass < 2; ++pass)  // the rank that failed first, then anybody else
         for (int r = 0; r < n; ++r) {
           if (!rcs[(size_t)r] || (pass == 0 && r != meet.culprit)) continue;

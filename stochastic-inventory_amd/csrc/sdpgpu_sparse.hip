@@ -27,7 +27,10 @@
 #include <algorithm>
 #include <cmath>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
+#include <new>
+#include <stdexcept>
 #include <string>
 #include <vector>
 
@@ -543,6 +546,43 @@ __global__ __launch_bounds__(256) void backward_kernel(MLParams P, const Tuple* 
     }                                                                                    \
   } while (0)
 
+// No C++ exception crosses the C ABI: the entry points of this file build host vectors of up to ~1.8e7
+// tuples (the memo read-out) and a std::bad_alloc there must come back as a status code.  ML_GUARD wraps an entry point's
+// body; sparse_solve catches inside itself as well, so that its device buffers are released on that path too.
+//   SDPGPU_TEST_THROW = bad_alloc | runtime | other : thrown at the top of the guarded region (tests, no device needed)
+//   SDPGPU_TEST_HOST_ALLOC_CAP = BYTES              : a host vector of the read-out larger than this throws bad_alloc
+void test_throw_hook() {
+  const char* e = std::getenv("SDPGPU_TEST_THROW");
+  if (!e) return;
+  if (std::strcmp(e, "bad_alloc") == 0) throw std::bad_alloc();
+  if (std::strcmp(e, "runtime") == 0) throw std::runtime_error("injected (SDPGPU_TEST_THROW)");
+  if (std::strcmp(e, "other") == 0) throw 42;
+}
+
+template <class V>
+void checked_resize(V& v, size_t n) {
+  if (const char* cap = std::getenv("SDPGPU_TEST_HOST_ALLOC_CAP"))
+    if ((double)n * sizeof(typename V::value_type) > std::atof(cap)) throw std::bad_alloc();
+  v.resize(n);
+}
+
+template <class Body>
+int ml_guard(const char* who, Body&& body) {
+  try {
+    test_throw_hook();
+    return body();
+  } catch (const std::bad_alloc&) {
+    g_ml_error = std::string(who) + ": host allocation failed (std::bad_alloc)";
+    return SDPGPU_ERR_ALLOC;
+  } catch (const std::exception& e) {
+    g_ml_error = std::string(who) + ": internal error: " + e.what();
+    return SDPGPU_ERR_INTERNAL;
+  } catch (...) {
+    g_ml_error = std::string(who) + ": internal error (unknown exception)";
+    return SDPGPU_ERR_INTERNAL;
+  }
+}
+
 struct SparseProblem {
   int T = 0;
   MLParams P{};
@@ -594,7 +634,7 @@ int sparse_solve(const SparseProblem& sp, double* final_value, int32_t* q1, int3
   std::vector<int64_t> table_off((size_t)T, 0);
   std::vector<Tuple> h_tuples;
   std::vector<int> h_acts;
-  {
+  try {
     ML_TRY(hipEventCreate(&ev0));
     ML_TRY(hipEventCreate(&ev1));
     ML_TRY(hipMalloc((void**)&d_dem, (size_t)nd_all * sizeof(double2)));
@@ -766,8 +806,8 @@ int sparse_solve(const SparseProblem& sp, double* final_value, int32_t* q1, int3
       if (table_rows_ok) {  // the memo of this period: states, values, actions (hash order; sorted on the host below)
         const size_t n = (size_t)n_states[t];
         const size_t at = (size_t)table_off[(size_t)t];
-        h_tuples.resize(n);
-        h_acts.resize(n);
+        checked_resize(h_tuples, n);
+        checked_resize(h_acts, n);
         ML_TRY(hipMemcpy(h_tuples.data(), d_states[t], n * sizeof(Tuple), hipMemcpyDeviceToHost));
         ML_TRY(hipMemcpy(g_ml_table->value + at, d_vcur, n * 8, hipMemcpyDeviceToHost));
         ML_TRY(hipMemcpy(h_acts.data(), d_act, n * 4, hipMemcpyDeviceToHost));
@@ -811,6 +851,15 @@ int sparse_solve(const SparseProblem& sp, double* final_value, int32_t* q1, int3
       *gpu_ms = ms;
     }
     rc = SDPGPU_OK;
+  } catch (const std::bad_alloc&) {  // (the device buffers are released below on this path too)
+    g_ml_error = "two-product solver: host allocation failed (std::bad_alloc)";
+    rc = SDPGPU_ERR_ALLOC;
+  } catch (const std::exception& e) {
+    g_ml_error = std::string("two-product solver: internal error: ") + e.what();
+    rc = SDPGPU_ERR_INTERNAL;
+  } catch (...) {
+    g_ml_error = "two-product solver: internal error (unknown exception)";
+    rc = SDPGPU_ERR_INTERNAL;
   }
 fail:
   for (Tuple* p : d_states) if (p) (void)hipFree(p);
@@ -846,9 +895,8 @@ const char* sdpgpu_multilead_last_error(void) { return g_ml_error.c_str(); }
 
 void sdpgpu_multi_set_table(sdpgpu_multi_table* table) { g_ml_table = table; }
 
-int sdpgpu_multilead_solve(const sdpgpu_multilead* k, double* final_value, int32_t* q1, int32_t* q2,
-                           int64_t* states_per_period, int64_t* cells, double* gpu_ms) {
-  g_ml_error.clear();
+static int multilead_body(const sdpgpu_multilead* k, double* final_value, int32_t* q1, int32_t* q2,
+                          int64_t* states_per_period, int64_t* cells, double* gpu_ms) {
   if (!k || k->T < 1 || k->T > 16 || k->n1 < 1 || k->n1 > 16 || k->n2 < 1 || k->n2 > 16 || k->q_bound < 1 ||
       k->q_bound > 256) {
     g_ml_error = "multilead: bad descriptor";
@@ -882,9 +930,14 @@ int sdpgpu_multilead_solve(const sdpgpu_multilead* k, double* final_value, int32
   return sparse_solve(sp, final_value, q1, q2, states_per_period, cells, gpu_ms);
 }
 
-static int multicash_common(const sdpgpu_multicash* k, int model, double deposit_rate, double* final_value, int32_t* q1,
-                            int32_t* q2, int64_t* states_per_period, int64_t* cells, double* gpu_ms) {
+int sdpgpu_multilead_solve(const sdpgpu_multilead* k, double* final_value, int32_t* q1, int32_t* q2,
+                           int64_t* states_per_period, int64_t* cells, double* gpu_ms) {
   g_ml_error.clear();
+  return ml_guard("multilead", [&] { return multilead_body(k, final_value, q1, q2, states_per_period, cells, gpu_ms); });
+}
+
+static int multicash_body(const sdpgpu_multicash* k, int model, double deposit_rate, double* final_value, int32_t* q1,
+                          int32_t* q2, int64_t* states_per_period, int64_t* cells, double* gpu_ms) {
   if (!k || k->T < 1 || k->T > 16 || k->q_bound < 1 || k->q_bound > 256 || !k->pmf_off || !k->d1 || !k->d2 || !k->p) {
     g_ml_error = "multicash: bad descriptor";
     return SDPGPU_ERR_ARG;
@@ -965,6 +1018,13 @@ static int multicash_common(const sdpgpu_multicash* k, int model, double deposit
     if (q2) *q2 = model == 2 ? (int)k->ini_i2 + a2 : a2;
   }
   return rc;
+}
+
+static int multicash_common(const sdpgpu_multicash* k, int model, double deposit_rate, double* final_value, int32_t* q1,
+                            int32_t* q2, int64_t* states_per_period, int64_t* cells, double* gpu_ms) {
+  g_ml_error.clear();
+  return ml_guard(model == 2 ? "multixr" : "multicash",
+                  [&] { return multicash_body(k, model, deposit_rate, final_value, q1, q2, states_per_period, cells, gpu_ms); });
 }
 
 int sdpgpu_multicash_solve(const sdpgpu_multicash* k, double* final_value, int32_t* q1, int32_t* q2,

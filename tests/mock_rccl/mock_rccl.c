@@ -1,5 +1,5 @@
 /*
- * mock_rccl.c -- TEST DOUBLE for librccl.so.1 (never shipped, never linked by the product): the eight RCCL entry points
+ * mock_rccl.c -- TEST DOUBLE for librccl.so.1 (never shipped, never linked by the product): the RCCL entry points
  * libsdpgpu.so resolves with dlsym (csrc/sdpgpu_comm.hip), implemented over POSIX shared memory and blocking HIP copies, so
  * that the multi-PROCESS path of the library -- sdpgpu_comm_prepare / sdpgpu_comm_init with world > 1 in separate processes,
  * sdpgpu_solve_sharded, bench.py --exchange native -- can run with several ranks on ONE GPU (RCCL itself refuses two ranks on
@@ -34,6 +34,7 @@ typedef struct {
   _Atomic int arrived;
   _Atomic int generation;
   _Atomic int attached;
+  _Atomic int aborted;  /* ncclCommAbort on any rank: everybody waiting in a barrier of this communicator leaves it with an error */
   int world;
   size_t slot_bytes;
 } header_t;
@@ -132,14 +133,29 @@ ncclResult_t ncclCommDestroy(void* comm) {
   return ncclSuccess;
 }
 
-static void barrier(mock_comm* c) {
+/* 0 = everybody arrived; 1 = the communicator was aborted while waiting */
+static int barrier(mock_comm* c) {
   const int gen = atomic_load(&c->hd->generation);
+  if (atomic_load(&c->hd->aborted)) return 1;
   if (atomic_fetch_add(&c->hd->arrived, 1) == c->world - 1) {
     atomic_store(&c->hd->arrived, 0);
     atomic_fetch_add(&c->hd->generation, 1);
   } else {
-    while (atomic_load(&c->hd->generation) == gen) sched_yield();
+    while (atomic_load(&c->hd->generation) == gen) {
+      if (atomic_load(&c->hd->aborted)) return 1;
+      sched_yield();
+    }
   }
+  return 0;
+}
+
+/* releases every rank blocked in a collective of this communicator (they return an error) and frees the handle, as
+ * ncclCommAbort does; the shared header stays until its last holder is gone */
+ncclResult_t ncclCommAbort(void* comm) {
+  mock_comm* c = (mock_comm*)comm;
+  if (!c) return ncclSuccess;
+  atomic_store(&c->hd->aborted, 1);
+  return ncclSuccess;  /* (the handle itself is leaked on purpose: a peer thread may still be inside a call on it) */
 }
 
 ncclResult_t ncclAllGather(const void* send, void* recv, size_t count, ncclDataType_t type, void* comm, hipStream_t stream) {
@@ -157,7 +173,7 @@ ncclResult_t ncclAllGather(const void* send, void* recv, size_t count, ncclDataT
   }
   if (hipStreamSynchronize(stream) != hipSuccess) return ncclUnhandledCudaError;
   if (hipMemcpy(c->slots + (size_t)c->rank * c->hd->slot_bytes, send, bytes, hipMemcpyDeviceToHost) != hipSuccess) return ncclUnhandledCudaError;
-  barrier(c);
+  if (barrier(c)) return ncclSystemError;
   for (int r = 0; r < c->world; ++r) {
     char* dst = (char*)recv + (size_t)r * bytes;
     if (r == c->rank) {
@@ -166,7 +182,7 @@ ncclResult_t ncclAllGather(const void* send, void* recv, size_t count, ncclDataT
     }
     if (hipMemcpy(dst, c->slots + (size_t)r * c->hd->slot_bytes, bytes, hipMemcpyHostToDevice) != hipSuccess) return ncclUnhandledCudaError;
   }
-  barrier(c);  /* nobody overwrites its slot before everybody has read it */
+  if (barrier(c)) return ncclSystemError;  /* nobody overwrites its slot before everybody has read it */
   return ncclSuccess;
 }
 

@@ -45,7 +45,7 @@ def test_struct_layout_matches_the_header(sia, lib):
     assert int(out[0]) == C.sizeof(sia.SdpgpuDesc)
     assert [int(v) for v in out[1:-1]] == [getattr(sia.SdpgpuDesc, f).offset for f in fields]
     assert int(out[-1]) == C.sizeof(sia.SdpgpuStats)
-    assert d.abi_version == 5 and d.discount_factor == 1.0 and d.cash_round_div == 10.0 and d.world_size == 1
+    assert d.abi_version == 6 and d.discount_factor == 1.0 and d.cash_round_div == 10.0 and d.world_size == 1
 
 
 def test_two_product_struct_layouts_match_the_header(sia):

@@ -86,3 +86,18 @@ def test_kat1_whole_memo_matches_the_oracle(sia, oracle):
     assert r.table.shape == want.shape == (2501, 9)
     assert (r.table == want).all()
     assert r.table[0, 0] == 1 and r.table[0, 6] + k["ini_cash"] == k["expected_final_cash"]
+
+
+def test_read_out_allocation_failure_is_a_status_code(sia, monkeypatch):
+    """SURVEY 8(b): no C++ exception crosses the ABI.  The memo read-out builds host vectors of one entry per visited state;
+    with the allocation capped (SDPGPU_TEST_HOST_ALLOC_CAP: larger vectors throw std::bad_alloc inside the library) the solve
+    returns SDPGPU_ERR_ALLOC with a message -- the process lives, the device buffers are released, the next solve is right."""
+    from stochastic_inventory_amd.multiitem import multilead_solve
+    k = KATS["kat1"]
+    monkeypatch.setenv("SDPGPU_TEST_HOST_ALLOC_CAP", "1000")
+    with pytest.raises(sia.SdpgpuError) as e:
+        multilead_solve(table=True, **{n: k[n] for n in KEYS})
+    assert e.value.code == 5 and "host allocation failed" in str(e.value)
+    monkeypatch.delenv("SDPGPU_TEST_HOST_ALLOC_CAP")
+    r = multilead_solve(table=True, **{n: k[n] for n in KEYS})
+    assert r.finalValue == k["expected_final_cash"] and len(r.table) == 2501

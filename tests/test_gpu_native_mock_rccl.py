@@ -144,3 +144,50 @@ def test_solve_multi_communicator_branch(mock_rccl, world, name, threads):
     out = subprocess.run([sys.executable, "-c", _MULTI_DRIVER, str(world), threads, name], capture_output=True, text=True,
                          timeout=300, cwd=ROOT, env=env)
     assert out.returncode == 0 and "MULTI_OK" in out.stdout, (out.stdout[-800:], out.stderr[-2500:])
+
+
+_FAIL_DRIVER = r"""
+import os, sys
+sys.path.insert(0, os.environ["SDP_ROOT"])
+import numpy as np
+import stochastic_inventory_amd as sia
+from stochastic_inventory_amd import workloads
+world, inject = int(sys.argv[1]), sys.argv[2]
+w = workloads.cfg2_clsp(T=6)
+d1 = w.desc(); d1.device = 0
+ref = sia.SdpEngine(d1, w.pmf, w.overhead()); ref.solve(sync=True)
+engs = []
+for r in range(world):
+    d = w.desc(); d.rank, d.world_size, d.device = r, world, 0
+    engs.append(sia.SdpEngine(d, w.pmf, w.overhead()))
+os.environ["SDPGPU_TEST_FAIL_RANK"] = inject
+try:
+    sia.SdpEngine.solve_multi(engs, sync=True, gather_first=True, threads=True)
+    print("NO_ERROR")
+except Exception as exc:
+    print("FAILED_AS_EXPECTED:", exc)
+del os.environ["SDPGPU_TEST_FAIL_RANK"]
+# the call after the failure: new communicators, the right tables
+sia.SdpEngine.solve_multi(engs, sync=True, gather_first=True, threads=True)
+for r, e in enumerate(engs):
+    for period in range(1, w.T + 1):
+        _, lo, hi = e.slab(period)
+        assert np.array_equal(e.values(period), ref.values(period)), (r, period)
+        assert np.array_equal(e.policy(period), ref.policy(period)[lo:hi]), (r, period)
+print("RECOVERED_OK")
+"""
+
+
+@pytest.mark.parametrize("inject", ["kernel:1:4", "collective:2:3", "kernel:0:6", "collective:0:1"])
+def test_thread_per_rank_failure_does_not_strand_the_peers(mock_rccl, inject):
+    """in sdpgpu_solve_multi's thread-per-rank communicator branch a rank that fails must not leave its peers inside
+    an all-gather it never joins.  One rank is made to fail where its kernel of a period would be launched (the peers must not
+    enqueue that period's collective: rendezvous before the all-gather) or where its all-gather would be enqueued (the peers ARE
+    inside the collective -- the double blocks there as RCCL's kernel would -- and are released by ncclCommAbort): the call
+    returns the failing rank's error, nobody hangs, and the next call solves the problem on fresh communicators."""
+    env = dict(os.environ, SDPGPU_RCCL_LIB=mock_rccl, SDPGPU_MULTI_EXCHANGE="rccl", MOCK_RCCL_SLOT_MB="16", SDP_ROOT=ROOT)
+    out = subprocess.run([sys.executable, "-c", _FAIL_DRIVER, "3", inject], capture_output=True, text=True, timeout=120, cwd=ROOT, env=env)
+    assert out.returncode == 0, (out.stdout[-800:], out.stderr[-2500:])
+    rank = inject.split(":")[1]
+    assert "FAILED_AS_EXPECTED" in out.stdout and f"rank {rank}: injected failure" in out.stdout, out.stdout
+    assert "RECOVERED_OK" in out.stdout

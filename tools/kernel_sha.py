@@ -20,3 +20,20 @@ def kernel_source_sha(root: str, workload_name: str) -> str:
         h.update(name.encode())
         h.update(open(os.path.join(d, name), "rb").read())
     return h.hexdigest()[:16]
+
+
+def build_source_files(root: str):
+    """Everything libsdpgpu.so is built from: every file of csrc/, the public header, and build.py (its compiler flags)."""
+    d = os.path.join(root, "stochastic-inventory_amd", "csrc")
+    files = [os.path.join(d, f) for f in sorted(os.listdir(d)) if os.path.isfile(os.path.join(d, f))]
+    return files + [os.path.join(root, "include", "sdpgpu.h"), os.path.join(root, "stochastic-inventory_amd", "build.py")]
+
+
+def build_source_sha(root: str) -> str:
+    """Identity of a build of libsdpgpu.so (sdpgpu_build_id returns it; build.py bakes it in): smoke() and bench.py compare
+    the binary's with the tree's, so that a stale prebuilt library cannot pass for HEAD's."""
+    h = hashlib.sha256()
+    for path in build_source_files(root):
+        h.update(os.path.basename(path).encode())
+        h.update(open(path, "rb").read())
+    return h.hexdigest()[:16]
