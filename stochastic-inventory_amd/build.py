@@ -117,14 +117,14 @@ def build_host_asan(force: bool = False, verbose: bool = False) -> str:
     descriptor validation, per-period layout, slab and halo arithmetic, the window planner, footprints, state
     indexing -- which tests/test_sanitizers.py drives through the C ABI without a GPU.  Not shipped, not loaded by
     the product."""
-    if not force and os.path.exists(ASAN_OUT) and all(os.path.getmtime(f) <= os.path.getmtime(ASAN_OUT) for f in deps()):
+    if not force and os.path.exists(ASAN_OUT) and baked_build_id(ASAN_OUT) == source_sha():
         return ASAN_OUT
     from concurrent.futures import ThreadPoolExecutor
     hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
     os.makedirs(ASAN_DIR, exist_ok=True)
     san = ["-fsanitize=address,undefined", "-fno-gpu-sanitize", "-fno-sanitize-recover=undefined", "-shared-libasan"]
     flags = ["--offload-arch=gfx950", "-O1", "-g", "-std=c++17", "-ffp-contract=off", "-fno-fast-math", "-fPIC",
-             "-fvisibility=hidden", "-Wno-unused-function", *san]
+             "-fvisibility=hidden", "-Wno-unused-function", f'-DSDPGPU_BUILD_ID="{source_sha()}"', *san]
 
     def compile_one(src):
         obj = os.path.join(ASAN_DIR, os.path.basename(src) + ".o")

@@ -168,6 +168,7 @@ int layout(sdpgpu_handle* h) {
   }
   h->values_elems = v_off;
   h->policy_elems = pol_off;
+  for (PeriodInfo& q : h->per) q.win_plan.valid = false;  // (slabs and pmf widths may have changed)
   h->laid_out = true;
   return SDPGPU_OK;
 }
@@ -1001,8 +1002,10 @@ int sdpgpu_plan_period(const sdpgpu_handle* hc, int32_t period, sdpgpu_plan* out
   int rc = layout(h);
   if (rc) return rc;
   out->kernel = SDPGPU_KERNEL_GATHER;
-  const bool f1_window = !h->custom && h->d.family == SDPGPU_FAMILY_BACKORDER &&
-                         (h->d.kernel == SDPGPU_KERNEL_AUTO || h->d.kernel == SDPGPU_KERNEL_WINDOW) && window_eligible(h, period);
+  // (the launcher's own predicate: an AUTO handle with action counts of the caller's for this period runs the generic kernel)
+  const bool own_counts = !h->counts[(size_t)period - 1].empty();
+  const bool f1_window = !h->custom && h->d.family == SDPGPU_FAMILY_BACKORDER && window_eligible(h, period) &&
+                         (h->d.kernel == SDPGPU_KERNEL_WINDOW || (h->d.kernel == SDPGPU_KERNEL_AUTO && !own_counts));
   if (!f1_window) return SDPGPU_OK;
   const PeriodInfo& p = h->per[period - 1];
   std::string why;
@@ -1120,10 +1123,23 @@ int sdpgpu_solve(sdpgpu_handle* h, int32_t sync) {
         if (rc == SDPGPU_OK && e == hipSuccess && g && h->sweep_exec) {
           h->sweep_graph = g;
           e = hipGraphLaunch(h->sweep_exec, h->stream);  // (capturing enqueued nothing: this is sweep 2 itself)
-          if (e != hipSuccess) return fail(h, SDPGPU_ERR_DEVICE, "hipGraphLaunch: %s", hipGetErrorString(e));
-          h->graph_state = 2;
-          h->graph_replays++;
-          done = true;
+          if (e == hipSuccess) {
+            h->graph_state = 2;
+            h->graph_replays++;
+            done = true;
+          } else {
+            // the first launch of the new graph failed: nothing of this sweep ran on the device.  Drop the graph and its
+            // executable (graph_drop destroys both: a later capture must not overwrite a live exec), rewind the host
+            // bookkeeping the un-run sweep advanced, stay eager from here on, and run this sweep eagerly below.
+            (void)hipGetLastError();
+            graph_drop(h);
+            h->graph_state = -1;
+            std::fill(h->pending_chunks.begin(), h->pending_chunks.end(), 0);
+            h->n_pending = 0;
+            std::fill(h->key_row_clean.begin(), h->key_row_clean.end(), 0);
+            std::fill(h->period_done.begin(), h->period_done.end(), 0);
+            h->err.clear();
+          }
         } else {
           // the capture was refused somewhere (a launcher had to allocate or wait): nothing ran.  Forget the graph and the host
           // bookkeeping of the un-run sweep, and run this sweep eagerly.

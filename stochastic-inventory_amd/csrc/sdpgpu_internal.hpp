@@ -21,6 +21,7 @@
 #include <cstring>
 #include <algorithm>
 #include <new>
+#include <mutex>
 #include <string>
 #include <vector>
 
@@ -38,6 +39,25 @@ using sdp::Grid;
 
 
 constexpr size_t kPmfPad = 16;  // zero-probability tail: demand loop in blocks of R <= 8, one block of prefetch
+
+// register block / chunking of the F1 window kernel for one period (sdpgpu_window.hip)
+struct WinPlan {
+  int R = 0, S = 1, d_pad = 0, n_chunks = 1, chunk_blocks = 0, n_tiles = 0, n_tasks = 0;
+  size_t smem = 0;
+  int tile_states() const { return 64 * S; }
+};
+
+// plan_window's answer for one period, kept per (slab, forced block): the search walks 8 block shapes x up to blocks_total
+// chunk counts on the issuing thread, and launch_window, run_period_impl's pre-check and sdpgpu_plan_period all ask for it
+// (at 30 us per period the second search sat on the critical path).  Dropped by layout().
+struct WinPlanCache {
+  bool valid = false;
+  int64_t lo = 0, hi = 0;
+  int win_r = 0, win_s = 0, win_nch = 0;
+  bool may_chunk = false;
+  WinPlan plan;
+  std::string why;
+};
 
 struct PeriodInfo {
   Grid g{};
@@ -64,6 +84,7 @@ struct PeriodInfo {
   // neighbouring cells are formed once, see sdp_window.hpp / sdp_cash.hpp); 0 = the kernel has no such model
   double ops_cell = 0;
   double lds_cell = 0, l1_cell = 0;  // bytes per cell through the LDS / the vector L1 of the kernel that ran the period (0: no model)
+  mutable WinPlanCache win_plan;     // (a cache: filled through const handles by plan_window)
 };
 
 struct sdpgpu_handle {
@@ -227,11 +248,13 @@ constexpr size_t kLdsPerCU = 160 * 1024;
 constexpr size_t kLdsLegacy = 64 * 1024;
 inline int lds_workgroups(size_t smem) { return smem == 0 ? 32 : (int)(kLdsPerCU / smem); }
 
-// Raise a kernel's dynamic-LDS limit to `smem` bytes (a no-op up to 64 KiB).  `raised` is the caller's
-// per-instantiation, per-device high-water mark (the attribute belongs to the function on the current device), so the
-// attribute call is made once per kernel, device and size.
+// Allow a kernel more than 64 KiB of dynamic LDS.  The attribute belongs to the function on the current device: it is
+// raised ONCE per kernel instantiation and device, straight to the whole 160 KiB of the CU, under a lock -- so the limit never
+// decreases and two host threads (SDPGPU_SHARDED_THREADS with ranks sharing a device, slabs planning different sizes) cannot
+// lower it under each other's launch.  `mark` is the caller's per-instantiation record.
 struct LdsMark {
-  size_t raised[16] = {};
+  std::mutex m;
+  bool raised[64] = {};
 };
 template <class K>
 inline hipError_t lds_allow(K kernel, size_t smem, LdsMark* mark) {
@@ -240,19 +263,13 @@ inline hipError_t lds_allow(K kernel, size_t smem, LdsMark* mark) {
   int dev = 0;
   hipError_t e = hipGetDevice(&dev);
   if (e != hipSuccess) return e;
-  size_t* slot = (dev >= 0 && dev < 16) ? &mark->raised[dev] : nullptr;
-  if (slot && smem <= *slot) return hipSuccess;
-  e = hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
-  if (e == hipSuccess && slot) *slot = smem;
+  std::lock_guard<std::mutex> lk(mark->m);
+  bool* slot = (dev >= 0 && dev < 64) ? &mark->raised[dev] : nullptr;
+  if (slot && *slot) return hipSuccess;
+  e = hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)kLdsPerCU);
+  if (e == hipSuccess && slot) *slot = true;
   return e;
 }
-
-// register block / chunking of the F1 window kernel for one period (sdpgpu_window.hip)
-struct WinPlan {
-  int R = 0, S = 1, d_pad = 0, n_chunks = 1, chunk_blocks = 0, n_tiles = 0, n_tasks = 0;
-  size_t smem = 0;
-  int tile_states() const { return 64 * S; }
-};
 
 // ---- sdpgpu.hip ----------------------------------------------------------------------------------------
 int run_period_impl(sdpgpu_handle* h, int period, int part = SDPGPU_PART_ALL, int64_t range_lo = -1, int64_t range_hi = -1);

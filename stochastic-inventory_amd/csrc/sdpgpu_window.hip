@@ -25,7 +25,28 @@ bool window_eligible(const sdpgpu_handle* h, int period) {
 // register block R, the states per lane S and the number of chunks per tile that minimise it (fewest chunks
 // on ties: fewer chunk rows, less staging).  More states per lane = fewer fp64 operations per cell
 // ((5 + 4(S-1)) / S, see window_f1_kernel) but bigger, fewer tasks: small grids keep S low.
+static WinPlan plan_window_search(const sdpgpu_handle* h, int period, int64_t lo, int64_t hi, std::string* why);
+
 WinPlan plan_window(const sdpgpu_handle* h, int period, int64_t lo, int64_t hi, std::string* why) {
+  WinPlanCache& c = h->per[period - 1].win_plan;
+  const bool may_chunk = h->fuse_combine && h->d.store_all_values;
+  if (!(c.valid && c.lo == lo && c.hi == hi && c.win_r == h->win_r && c.win_s == h->win_s && c.win_nch == h->win_nch &&
+        c.may_chunk == may_chunk)) {
+    c.why.clear();
+    c.plan = plan_window_search(h, period, lo, hi, &c.why);
+    c.lo = lo;
+    c.hi = hi;
+    c.win_r = h->win_r;
+    c.win_s = h->win_s;
+    c.win_nch = h->win_nch;
+    c.may_chunk = may_chunk;
+    c.valid = true;
+  }
+  if (why && !c.plan.R) *why = c.why;
+  return c.plan;
+}
+
+static WinPlan plan_window_search(const sdpgpu_handle* h, int period, int64_t lo, int64_t hi, std::string* why) {
   const PeriodInfo& p = h->per[period - 1];
   const int A = h->n_actions_full, D = p.nD_win;
   WinPlan best;
