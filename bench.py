@@ -50,8 +50,15 @@ L1_PEAK_BPS = 64 * 256 * 2.4e9    # vector L1: 64 B/clk/CU
 FAMILY_NAME = {"target": "F1 backorder (capacitated.CLSP.f lambdas)", "cfg2": "F1 backorder (capacitated.CLSP.f)",
                "cfg5": "F1 backorder (capacitated.CLSP.f lambdas)", "cfg3": "F3 cash (CashRecursion, quantum 1)",
                "cfg3t": "F3 cash (CashConstraint.main, quantum 0.1)", "cfg4": "F2 lead time (LeadtimeRecursion)",
-               "cfg4p": "F2 lead time 2 (pipeline state)"}
+               "cfg4p": "F2 lead time 2 (pipeline state)",
+               "f5_spl": "F5 cash + lead time (SingleProductLeadtime.main via CashLeadtimeRecursion)",
+               "staff": "F7 workforce (WorkforceTesting.main[0] via StaffRecursion, level-dependent pmf)",
+               "custom_clsp": "user lambdas as HIP text (CLSP's, through sdpgpu_create_custom / hipRTC)",
+               "separable_target": "F1 backorder, OPT-IN separable mode (values to 1e-9, not the bit-exact path)",
+               "multilead_kat2": "two-product overdraft with lead time (MultiProductLeadtime via CashRecursionMultiLead)"}
 REFERENCE_FLOPS_PER_CELL = {"target": 14, "cfg2": 14, "cfg5": 14, "cfg4": 14, "cfg4p": 14, "cfg3": 25, "cfg3t": 25}
+# the entries of `secondary` beyond the BASELINE configs: configs[4] at full width and the SURVEY 8(f)-3 / 8(f)-4 rows
+FAMILY_WORKLOADS = ("f5_spl", "staff", "custom_clsp", "separable_target", "multilead_kat2")
 
 
 def parse_args():
@@ -60,7 +67,8 @@ def parse_args():
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--workload", default="target",
-                    help="target (default: 1e6 x 500 x 200, T = 6) | cfg2 | cfg3 | cfg3t | cfg4 | cfg4p | cfg5 (1e8 states)")
+                    help="target (default: 1e6 x 500 x 200, T = 6) | cfg2 | cfg3 | cfg3t | cfg4 | cfg4p | cfg5 (1e8 states) | "
+                         "f5_spl | staff | custom_clsp | separable_target | multilead_kat2 (N = 1 only)")
     ap.add_argument("--states", type=int, default=0, help="override the state count of the F1 grids (target/cfg2/cfg5)")
     ap.add_argument("--periods", type=int, default=0, help="override the horizon")
     ap.add_argument("--weak", action="store_true",
@@ -106,7 +114,20 @@ def make_workload(name: str, world: int, states: int = 0, periods: int = 0, weak
         return workloads.target_grid(S=S, **kw)
     if weak:
         raise SystemExit(f"--weak is defined for the F1 grids only (target/cfg2/cfg5), not {name}")
+    if name == "separable_target":
+        w = workloads.target_grid(**kw)
+        w.name = "separable_" + w.name
+        return w
     return workloads.by_name(name, **kw)
+
+
+def make_engine(sia, w, d):
+    """The engine of a workload: built-in family, level-dependent pmf (staff) or the caller's lambdas as HIP text."""
+    if getattr(w, "level_pmf", None) is not None:
+        return sia.SdpEngine(d, None, w.overhead(), level_pmf=w.level_pmf)
+    if getattr(w, "custom_source", None):
+        return sia.SdpEngine(d, w.pmf, w.overhead(), custom_source=w.custom_source, custom_params=w.custom_params)
+    return sia.SdpEngine(d, w.pmf, w.overhead())
 
 
 def build_identity():
@@ -126,14 +147,18 @@ def algorithmic_bytes(cells: float, states_periods: float) -> float:
 # ---------------------------------------------------------------------------------------------------------------
 # parity gate
 # ---------------------------------------------------------------------------------------------------------------
-def parity_gate(eng, w, budget_cells: float, seed: int = 5):
+def parity_gate(eng, w, budget_cells: float, seed: int = 5, periods=None, rel_tol=None):
     """Sampled states of this rank's slab, every checked period, against the oracle (oracle/sdpref.c eval_state) fed
-    the GPU's own V_{t+1}.  Bit-exact on values and policy indices.  Returns (ok, record)."""
+    the GPU's own V_{t+1}.  Bit-exact on values and policy indices.  Returns (ok, record).
+    `periods`: the periods to check (ping-pong tables keep only V_1 and V_2: [1]).  `rel_tol` (the OPT-IN separable mode
+    only, whose parity statement is its own: include/sdpgpu.h): values within that relative tolerance, and an action that
+    differs must be a near-tie -- which the value tolerance implies, V_sep(s) = Q_sep(s, a')."""
     import numpy as np
     from oracle import sdpref
     T = w.T
     P = sdpref.Problem(w.desc(), w.pmf, w.overhead())
-    periods = list(range(T, 0, -1)) if T <= 8 else sorted({T, T - 1, T // 2, 2, 1}, reverse=True)
+    if periods is None:
+        periods = list(range(T, 0, -1)) if T <= 8 else sorted({T, T - 1, T // 2, 2, 1}, reverse=True)
     st = eng.stats()
     cells_per_state = max(1.0, float(st.cells_all_ranks) / max(1, int(st.states_total)))
     n_samples = int(max(64, min(20000, budget_cells / len(periods) / cells_per_state)))
@@ -141,6 +166,7 @@ def parity_gate(eng, w, budget_cells: float, seed: int = 5):
     rng = np.random.default_rng(seed)
     step = w.desc().step
     checked, bad = 0, []
+    worst_rel, action_diffs = 0.0, 0
     t0 = time.perf_counter()
     for period in periods:
         x_lo, nx, nc, nq1, nq2 = eng.grid2(period)
@@ -163,15 +189,117 @@ def parity_gate(eng, w, budget_cells: float, seed: int = 5):
         ov, oa = P.eval_states(period, v_next, x, cash, q1, q2, nthreads=threads)
         gv = eng.values(period)[pick]
         gp = eng.policy(period)[pick - lo]
-        if not (np.array_equal(gv, ov) and np.array_equal(gp, oa)):
-            bad.append(period)
+        if rel_tol is None:
+            if not (np.array_equal(gv, ov) and np.array_equal(gp, oa)):
+                bad.append(period)
+        else:
+            rel = np.abs(gv - ov) / np.maximum(np.abs(ov), 1e-300)
+            worst_rel = max(worst_rel, float(rel.max()))
+            action_diffs += int((gp != oa).sum())
+            if not (rel.max() <= rel_tol):
+                bad.append(period)
         checked += len(pick)
     rec = {"status": "ok" if not bad else "FAILED", "states_checked": checked, "periods_checked": periods,
            "seconds": round(time.perf_counter() - t0, 2),
            "against": "oracle/sdpref.c eval_state fed the GPU's own V_{t+1}; values and policy indices bit-identical"}
+    if rel_tol is not None:
+        rec.update({"against": f"oracle/sdpref.c eval_state fed the GPU's own V_{{t+1}}; values within {rel_tol:g} relative (the "
+                               "separable mode's own parity statement; arg-opt may differ on near-ties)",
+                    "worst_relative_difference": worst_rel, "actions_differing": action_diffs})
     if bad:
         rec["periods_failed"] = bad
     return not bad, rec
+
+
+def staff_gate(eng, w, budget_cells: float, seed: int = 5):
+    """workforce.StaffRecursion's gate: runs of states of every period against oracle/staffref.c (staffref_period) fed the
+    GPU's own V_{t+1}; values and policy (hire counts) bit-identical."""
+    import numpy as np
+    from oracle import staffref
+    f, T = w.functor, w.T
+    P = staffref.Problem(T=T, min_x=f.minX, max_x=f.maxX, clamp=f.clampStaff, ini_x=f.iniStaffNum, max_hire=f.maxHireNum,
+                         fix_cost=f.fixCost, unit_vari_cost=f.unitVariCost, salary=f.salary, unit_penalty=f.unitPenalty,
+                         min_staff=list(f.minStaffNum), prob=w.level_pmf)
+    st = eng.stats()
+    cells_per_state = max(1.0, float(st.cells_all_ranks) / max(1, int(st.states_total)))
+    run = int(max(8, min(512, budget_cells / T / cells_per_state / 3)))  # three runs of states per period: both ends and a random one
+    threads = min(os.cpu_count() or 1, 16)
+    rng = np.random.default_rng(seed)
+    checked, bad = 0, []
+    t0 = time.perf_counter()
+    for period in range(T, 0, -1):
+        n = int(P.nx[period - 1])
+        assert n == eng.num_states(period), "the oracle and the engine lay the period out differently"
+        v_next = eng.values(period + 1) if period < T else None
+        gv, gp = eng.values(period), eng.policy(period)
+        starts = sorted({0, max(0, n - run), int(rng.integers(0, max(1, n - run + 1)))})
+        for lo in starts:
+            hi = min(n, lo + run)
+            ov, oa = np.zeros(n), np.zeros(n, dtype=np.int32)
+            P.period(period, v_next, lo, hi, threads, ov, oa)
+            if not (np.array_equal(gv[lo:hi], ov[lo:hi]) and np.array_equal(gp[lo:hi], oa[lo:hi])):
+                bad.append(period)
+            checked += hi - lo
+    rec = {"status": "ok" if not bad else "FAILED", "states_checked": checked, "periods_checked": list(range(T, 0, -1)),
+           "seconds": round(time.perf_counter() - t0, 2),
+           "against": "oracle/staffref.c staffref_period fed the GPU's own V_{t+1}; values and hire counts bit-identical"}
+    if bad:
+        rec["periods_failed"] = sorted(set(bad))
+    return not bad, rec
+
+
+def run_multilead(steps: int, no_gate: bool):
+    """The two-product overdraft recursion on its reachable set (sdpgpu_multilead_solve; csrc/sdpgpu_sparse.hip) at the size of
+    the reference's slowest RECORDED run: "3 periods ... final optimal cash is -76.56 ... Q1 = 30, Q2 = 15, running time is
+    1568.0s" (MultiProductLeadtime.java:45-50).  The gate is that recorded output itself (tests/golden/kat_reference.json holds
+    the parameters and the number): the value must be THE double nearest -76.56 and the first order (30, 15).  A step = one whole
+    solve (forward expansion of the reachable set + backward recursion), device buffers allocated and freed inside the call."""
+    from stochastic_inventory_amd.multiitem import multilead_solve
+    k = json.load(open(os.path.join(ROOT, "tests", "golden", "kat_reference.json")))["kat2_slow"]
+    keys = ("T", "q_bound", "price", "vari_cost", "sal_value", "ini_cash", "ini_i1", "ini_i2", "r0", "r1", "r2", "limit",
+            "interest_free", "min_inventory", "max_inventory", "min_cash", "max_cash", "discount", "overhead", "values", "probs")
+    kw = {n: k[n] for n in keys}
+    r = multilead_solve(**kw)
+    ok = r.finalValue == k["expected_final_cash"] and (r.firstAction, r.secondAction) == (k["expected_q1"], k["expected_q2"])
+    gate = {"status": "ok" if ok else "FAILED", "states_checked": int(sum(r.statesPerPeriod)),
+            "final_cash": r.finalValue, "first_order": [r.firstAction, r.secondAction],
+            "against": "the output the reference itself recorded (MultiProductLeadtime.java:45-50): final optimal cash -76.56, "
+                       "Q1 = 30, Q2 = 15 -- all 17 digits of the value, both quantities"}
+    if no_gate:
+        gate = {"status": "skipped (--no-gate)"}
+    elif not ok:
+        raise SystemExit(f"PARITY GATE FAILED on multilead_kat2: {json.dumps(gate)} -- no timing accepted")
+    walls, gpus = [], []
+    for _ in range(steps):
+        t0 = time.perf_counter()
+        r = multilead_solve(**kw)
+        walls.append(time.perf_counter() - t0)
+        gpus.append(r.gpu_ms)
+    wall = sum(walls) / len(walls)
+    name = f"multilead_kat2_T{k['T']}_Q{k['q_bound']}"
+    rf = {"bound": "valu-issue", "achieved": None, "peak": VALU_PEAK_LANE_OPS / 1e12, "unit": "T lane-op/s", "frac": None,
+          "device_ms_per_solve": sum(gpus) / len(gpus), "traffic": None, "hbm": None,
+          "note": "no counter summary in profiles/ for this build of csrc/sdpgpu_sparse.hip"}
+    pmc = load_pmc(name)
+    if pmc and pmc.get("valu_insts_per_launch") and pmc.get("kernels", {}).get(pmc.get("dominant_kernel"), {}).get("rocprof"):
+        dom = pmc["kernels"][pmc["dominant_kernel"]]
+        n_launch = dom["rocprof"]["calls"] / max(1, pmc.get("solves_profiled", 1))
+        # the recursion kernel is launched once per period on reachable sets of very different sizes: totals per SOLVE
+        insts = float(pmc["valu_insts_per_launch"]) * n_launch
+        kern_ms = dom["rocprof"]["avg_us"] * n_launch / 1e3
+        lane_ops = insts * 64.0 / (kern_ms * 1e-3)
+        rf.update({"achieved": lane_ops / 1e12, "frac": lane_ops / VALU_PEAK_LANE_OPS, "kernel": pmc["dominant_kernel"],
+                   "kernel_ms_per_solve_rocprof": kern_ms, "valu_insts_per_cell": insts * 64.0 / max(r.cells, 1),
+                   "traffic": pmc.get("hbm_bytes_per_launch"),
+                   "counters": {kk: pmc.get(kk) for kk in ("valu_busy_frac", "lds_busy_frac", "ta_busy_frac")},
+                   "note": f"SQ_INSTS_VALU x 64 lanes of the recursion kernel's launches of one solve / their rocprofv3 duration ({pmc['_file']})"})
+        if not (0.0 < rf["frac"] <= 1.0):
+            rf.update({"frac": None, "achieved": None})
+    return {"workload": name, "family": FAMILY_NAME["multilead_kat2"], "value": r.cells / wall, "unit": "cells/s",
+            "ms_per_step": wall * 1e3, "steps": steps, "periods": k["T"], "states": int(sum(r.statesPerPeriod)),
+            "states_per_period": [int(v) for v in r.statesPerPeriod], "cells_per_step": int(r.cells), "parity_gate": gate,
+            "roofline": rf, "kernel": "reachable-set engine (expand, sort, rank, backward)",
+            "reference_remark": "1568 s (the reference author's own comment; hardware and JVM unstated)"}
 
 
 # ---------------------------------------------------------------------------------------------------------------
@@ -357,31 +485,44 @@ def roofline_block(w, st, T, cells_rank, states_rank, dev_ms_per_sweep, per_laun
 # ---------------------------------------------------------------------------------------------------------------
 # one workload on one GPU (the headline at N = 1 and every secondary entry)
 # ---------------------------------------------------------------------------------------------------------------
-def run_single(sia, torch, dev, name, w, steps, warmup, kernel, gate_cells, no_gate):
+def run_single(sia, torch, dev, name, w, steps, warmup, kernel, gate_cells, no_gate, ping_pong=False, min_warmup=2):
+    """`ping_pong`: two value tables instead of one per period (store_all_values = 0; what configs[4]'s full horizon runs
+    on) -- only V_1 and V_2 outlive the sweep, so the gate checks period 1."""
+    if name == "multilead_kat2":
+        return run_multilead(steps, no_gate)
     d = w.desc()
     d.device = dev.index
-    d.kernel = kernel
+    d.kernel = 3 if name == "separable_target" else kernel
+    if ping_pong:
+        d.store_all_values = 0
     T = w.T
+
+    def gate_of(eng, budget, seed=5):
+        if no_gate:
+            return True, {"status": "skipped (--no-gate)"}
+        if getattr(w, "level_pmf", None) is not None:
+            return staff_gate(eng, w, budget, seed=seed)
+        return parity_gate(eng, w, budget, seed=seed, periods=[1] if ping_pong else None,
+                           rel_tol=1e-9 if name == "separable_target" else None)
+
     # A stream of the run's own (not the legacy NULL stream, which cannot be captured): with SDPGPU_GRAPH=1 sdpgpu_solve replays
     # its sweep as ONE HIP graph from the third call on (the warm-up covers the eager and the capturing call).  Off by default:
     # measured 0.6-1.6 % slower than the eager sweep, whose wall time is within 0.4 % of its device time (`wall_over_device`).
     # The torch events below are recorded on the same stream.
     side = torch.cuda.Stream(device=dev)
-    with sia.SdpEngine(d, w.pmf, w.overhead()) as eng, torch.cuda.stream(side):
+    with make_engine(sia, w, d) as eng, torch.cuda.stream(side):
         eng.set_stream(side.cuda_stream)
         eng.solve(sync=True)
-        gate = {"status": "skipped (--no-gate)"}
-        if not no_gate:
-            ok, gate = parity_gate(eng, w, gate_cells)
-            if not ok:
-                raise SystemExit(f"PARITY GATE FAILED on {w.name}: {json.dumps(gate)} -- no timing accepted")
-        for _ in range(max(warmup, 2)):
+        ok, gate = gate_of(eng, gate_cells)
+        if not ok:
+            raise SystemExit(f"PARITY GATE FAILED on {w.name}: {json.dumps(gate)} -- no timing accepted")
+        for _ in range(max(warmup, min_warmup)):
             eng.solve(sync=False)
         torch.cuda.synchronize(dev)
         if not no_gate and eng.stats().graph_replays > 0:
             # the timed sweeps are graph replays: their tables must be the gated (eager) sweep's, bit for bit
             import numpy as np
-            ok2, gate2 = parity_gate(eng, w, gate_cells / 4, seed=11)
+            ok2, gate2 = gate_of(eng, gate_cells / 4, seed=11)
             if not ok2:
                 raise SystemExit(f"PARITY GATE FAILED on the graph-replayed sweep of {w.name}: {json.dumps(gate2)}")
             gate["graph_replay_gate"] = {"status": gate2["status"], "states_checked": gate2["states_checked"]}
@@ -406,11 +547,19 @@ def run_single(sia, torch, dev, name, w, steps, warmup, kernel, gate_cells, no_g
         rf["sweep_issue"] = ("one hipGraphLaunch per sweep (captured inside sdpgpu_solve)" if replays >= steps
                              else "eager: one launch per period")
         rf["wall_over_device"] = (elapsed / steps * 1e3) / dev_ms if dev_ms > 0 else None
-        x_lo, nx, nc, nq1, nq2 = eng.grid2(1)
-    return {"workload": w.name, "family": FAMILY_NAME.get(name, name), "value": cells * steps / elapsed, "unit": "cells/s",
-            "ms_per_step": elapsed / steps * 1e3, "steps": steps, "periods": T, "states": nx * nc * nq1 * nq2,
-            "cells_per_step": cells, "parity_gate": gate, "roofline": rf,
-            "kernel": {0: "auto", 1: "gather", 2: "specialised (window / shift / row)", 3: "separable"}[int(st.kernel_used)]}
+        n_states = max(eng.num_states(p) for p in range(1, T + 1))  # (unclamped families grow with the period: the widest)
+    out = {"workload": w.name, "family": FAMILY_NAME.get(name, name), "value": cells * steps / elapsed, "unit": "cells/s",
+           "ms_per_step": elapsed / steps * 1e3, "steps": steps, "periods": T, "states": n_states,
+           "cells_per_step": cells, "parity_gate": gate, "roofline": rf,
+           "kernel": {0: "auto", 1: "gather", 2: "specialised (window / shift / row)", 3: "separable"}[int(st.kernel_used)]}
+    if ping_pong:
+        out["tables"] = "two ping-pong value tables (store_all_values = 0), as the full 100-period horizon runs"
+    if getattr(w, "custom_source", None):
+        out["kernel"] = "user lambdas compiled with hipRTC around the generic period loop"
+    if name == "separable_target":
+        out["value_is"] = ("brute-force-equivalent cells/s: the cells of the (state x action x demand) grid / time -- the mode "
+                           "evaluates O((S + A) D + S A) terms instead; compare `ms_per_step` with the headline's")
+    return out
 
 
 # ---------------------------------------------------------------------------------------------------------------
@@ -568,19 +717,23 @@ def main():
         with wd.phase("process group", 180):
             dist.init_process_group("nccl", device_id=dev) if args.exchange == "torch" else dist.init_process_group("gloo")
 
-    w = make_workload(args.workload, world, args.states, args.periods, args.weak)
-    T = w.T
+    if args.workload in FAMILY_WORKLOADS and sharded_path:
+        raise SystemExit(f"--workload {args.workload} is a single-GPU entry (the N > 1 path shards the grid families)")
+    w = None if args.workload == "multilead_kat2" else make_workload(args.workload, world, args.states, args.periods, args.weak)
+    T = w.T if w is not None else 3
 
     if not sharded_path:
         head = run_single(sia, torch, dev, args.workload, w, args.steps, args.warmup, args.kernel, args.gate_cells,
-                          args.no_gate)
+                          args.no_gate, ping_pong=(args.workload == "cfg5" and not args.states))
+        f = getattr(w, "functor", None)
         out = {
             "metric": "(state,action,demand) cell evals/sec",
             "value": head["value"], "unit": "cells/s", "n_gpus": 1, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": head["ms_per_step"], "higher_is_better": True,
             "scaling": "weak" if args.weak else "strong", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
-            "config": {"workload": w.name, "family": head["family"], "states": head["states"],
-                       "actions": int(w.functor.maxOrderQuantity) + 1, "demands": len(w.pmf[0]), "periods": T,
+            "config": {"workload": head["workload"], "family": head["family"], "states": head["states"],
+                       "actions": (int(getattr(f, "maxOrderQuantity", getattr(f, "maxHireNum", 0))) + 1) if f is not None else None,
+                       "demands": len(w.pmf[0]) if getattr(w, "pmf", None) is not None else None, "periods": head["periods"],
                        "cells_per_step": head["cells_per_step"], "parallelism": "single GPU", "exchange": "single rank",
                        "kernel": head["kernel"]},
             "parity_gate": head["parity_gate"],
@@ -588,16 +741,17 @@ def main():
             "build": build_identity(),
         }
         flops = REFERENCE_FLOPS_PER_CELL.get(args.workload, 14)
-        out["side_by_side"] = {
-            "cells_per_s": out["value"],
-            "algorithmic_GBps": head["roofline"]["algorithmic"]["GBps"],
-            "hbm_measured_GBps": head["roofline"]["hbm"]["GBps"] if head["roofline"]["hbm"] else None,
-            "fp64_TFLOPs_at_reference_op_count": out["value"] * flops / 1e12,
-            "reference_fp64_ops_per_cell": flops,
-            "compulsory_bytes_per_launch": 20.0 * head["states"],
-            "note": "the reference's formulas spend 14 (F1/F2) / 25 (F3) fp64 operations per cell; the kernels execute fewer "
-                    "(identical operations are formed once): roofline.ops_per_cell",
-        }
+        if "algorithmic" in head["roofline"]:
+            out["side_by_side"] = {
+                "cells_per_s": out["value"],
+                "algorithmic_GBps": head["roofline"]["algorithmic"]["GBps"],
+                "hbm_measured_GBps": head["roofline"]["hbm"]["GBps"] if head["roofline"]["hbm"] else None,
+                "fp64_TFLOPs_at_reference_op_count": out["value"] * flops / 1e12,
+                "reference_fp64_ops_per_cell": flops,
+                "compulsory_bytes_per_launch": 20.0 * head["states"],
+                "note": "the reference's formulas spend 14 (F1/F2) / 25 (F3) fp64 operations per cell; the kernels execute fewer "
+                        "(identical operations are formed once): roofline.ops_per_cell",
+            }
         if args.workload == "target" and not args.no_secondary and not args.weak and not args.states and not args.periods:
             sec = []
             # (configs[1]: a sweep is 52 launches of 30 us -- 1.5 ms; 100 of them, so that one hiccup of the host thread that issues
@@ -605,8 +759,22 @@ def main():
             for name, st_, wu_ in (("cfg2", 100, 10), ("cfg3", 3, 1), ("cfg3t", 3, 1), ("cfg4", 3, 1), ("cfg4p", 2, 1)):
                 ws = make_workload(name, 1)
                 sec.append(run_single(sia, torch, dev, name, ws, st_, wu_, 0, args.gate_cells / 3, args.no_gate))
+            # configs[4] at its full width (1e8 states, the largest single-GPU configuration; three periods of its hundred, on
+            # the two ping-pong tables the full horizon runs on: tools/cfg5_full_horizon.py), then the SURVEY 8(f)-3 families at
+            # the sizes of the reference's slowest drivers and the 8(f)-4 mode -- each gated like the rest
+            sec.append(run_single(sia, torch, dev, "cfg5", make_workload("cfg5", 1, periods=3), 1, 1, 0, args.gate_cells / 8,
+                                  args.no_gate, ping_pong=True, min_warmup=1))
+            for name, st_, wu_ in (("f5_spl", 3, 1), ("staff", 20, 2), ("custom_clsp", 10, 2), ("multilead_kat2", 3, 0)):
+                ws = None if name == "multilead_kat2" else make_workload(name, 1)
+                sec.append(run_single(sia, torch, dev, name, ws, st_, wu_, 0, args.gate_cells / 6, args.no_gate))
+            sep = run_single(sia, torch, dev, "separable_target", make_workload("separable_target", 1), 5, 1, 0,
+                             args.gate_cells / 6, args.no_gate)
+            sep["ms_per_sweep"] = sep["ms_per_step"]
+            sep["speedup_over_brute_force"] = head["ms_per_step"] / sep["ms_per_step"]
+            sep["brute_force_ms_per_sweep"] = head["ms_per_step"]
+            sec.append(sep)
             out["secondary"] = sec
-        if not args.no_cpu_baseline:
+        if not args.no_cpu_baseline and args.workload not in FAMILY_WORKLOADS:
             out["cpu_baseline"] = cpu_baseline(w, args.cpu_seconds)
         print(json.dumps(out), flush=True)
         return

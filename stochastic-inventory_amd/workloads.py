@@ -131,9 +131,103 @@ def cfg3_tenths(T: int = 6, NX: int = 501, maxCash: float = 2000.0, A: int = 101
                     "CashConstraint.main: cash quantum 0.1")
 
 
+def f5_single_product_leadtime(T: int = 4, mean: float = 20.0) -> Workload:
+    """cash.overdraft.SingleProductLeadtime at the size its header calls the limit of the Java code -- "4 periods, mean
+    demand 20 ... 50 s ... maximum computational capacity for java, otherwise memory errors" (SingleProductLeadtime.java:22-24):
+    F5 (CashLeadtimeRecursion), state (inventory 0..60, cash -200..300 in HUNDREDTHS, preQ 0..30) = 9.5e7 states per period,
+    orders 0..30, Poisson(20) truncated at 0.9999 (GetPmf.java:82-134)."""
+    from .functors import CashLeadtimeFunctor
+    from .pmf import GetPmf, PoissonDist
+    f = CashLeadtimeFunctor(price=5, variCost=1, salvageValue=0.5, maxOrderQuantity=30, minInventoryState=0,
+                            maxInventoryState=60, minCashState=-200, maxCashState=300, r0=0, r2=0.1, r3=2, limit=500,
+                            interestFreeAmount=0, iniInventory=0, iniCash=0, iniPreQ=0, overheadCosts=[0.0] * T)
+    pmf = [np.asarray(t, dtype=np.float64) for t in GetPmf([PoissonDist(mean)] * T, 0.9999, 1).getpmf()]
+    return Workload(f"f5_spl_61x50001x31q_31x{len(pmf[0])}x{T}", f, OptDirection.MAX, pmf,
+                    "SingleProductLeadtime.main via CashLeadtimeRecursion, cash quantum 0.01")
+
+
+@dataclass
+class StaffWorkload:
+    """workforce.StaffRecursion: the pmf depends on the hire-up-to level (StaffRecursion.java:93-95), so the workload carries a
+    (T, levels, stride) table instead of per-period tiles; `overhead()` hands the engine minStaffNum[t]."""
+    name: str
+    functor: object
+    level_pmf: np.ndarray
+    note: str = ""
+    pmf = None
+    direction = OptDirection.MIN
+
+    @property
+    def T(self) -> int:
+        return int(self.level_pmf.shape[0])
+
+    def desc(self):
+        return self.functor.to_desc(self.T)
+
+    def overhead(self):
+        return [float(m) for m in self.functor.minStaffNum]
+
+
+def staff_testing(T: int = 8, maxHire: int = 1000, rate: float = 0.1) -> StaffWorkload:
+    """The first of WorkforceTesting.main's 216 instances (WorkforceTesting.java:45-107): T = 8, hires 0..1000, no clamp
+    (staff 0..7000 by period 8), binomial turnover at rate turnoverRates[0] tabulated for 1001 hire-up-to levels."""
+    from .pmf import staff_level_pmf
+    from .workforce import StaffFunctor
+    f = StaffFunctor(fixCost=50, unitVariCost=20, salary=30, unitPenalty=50, minStaffNum=[40] * T, maxHireNum=maxHire,
+                     clampStaff=False, iniStaffNum=0)
+    one = staff_level_pmf([rate], maxHire + 1)
+    return StaffWorkload(f"staff_testing0_{maxHire + 1}hires_x{T}", f, np.repeat(one, T, axis=0), "WorkforceTesting.main[0] via StaffRecursion")
+
+
+# capacitated.CLSP's three lambdas (CLSP.java:251-272) as the HIP device text a driver hands to sdpgpu_create_custom when its
+# lambdas are its own: params = {K, v, h, pi, minInventory, maxInventory, maxOrderQuantity}.  bench.py's `custom_clsp` entry
+# runs configs[1] through this text, i.e. through the reference's actual plugin API (arbitrary closures) instead of the
+# built-in family.
+CLSP_LAMBDAS_HIP = r"""
+__device__ int sdp_feasible_count(const sdp_ctx& c, double x, double cash, double preq) {
+  return (int)(c.params[6] / c.step) + 1;
+}
+__device__ double sdp_immediate(const sdp_ctx& c, double x, double cash, double preq, double action, double randomDemand) {
+  double fixedCost = action > 0 ? c.params[0] : 0;
+  double variableCost = c.params[1] * action;
+  double inventoryLevel = x + action - randomDemand;
+  double holdingCosts = c.params[2] * sdp_max(inventoryLevel, 0);
+  double penaltyCosts = c.params[3] * sdp_max(-inventoryLevel, 0);
+  double totalCosts = fixedCost + variableCost + holdingCosts + penaltyCosts;
+  return totalCosts;
+}
+__device__ void sdp_transition(const sdp_ctx& c, double x, double cash, double preq, double action, double randomDemand,
+                               double& nx, double& ncash, double& npreq) {
+  double nextInventory = x + action - randomDemand;
+  nextInventory = nextInventory > c.params[5] ? c.params[5] : nextInventory;
+  nextInventory = nextInventory < c.params[4] ? c.params[4] : nextInventory;
+  nx = nextInventory;
+  ncash = 0;
+  npreq = 0;
+}
+"""
+
+
+def clsp_lambda_params(w: Workload):
+    f = w.functor
+    return [f.fixedOrderingCost, f.variOrderingCost, f.holdingCost, f.penaltyCost, f.minInventory, f.maxInventory,
+            f.maxOrderQuantity]
+
+
+def custom_clsp(**kw) -> Workload:
+    """configs[1] with CLSP's lambdas handed over as user text (hipRTC) instead of the built-in F1 family."""
+    w = cfg2_clsp(**kw)
+    w.name = "custom_clsp_" + w.name[len("cfg2_clsp_"):]
+    w.note = "configs[1] through sdpgpu_create_custom (CLSP's lambdas as HIP text)"
+    w.custom_source = CLSP_LAMBDAS_HIP
+    w.custom_params = clsp_lambda_params(w)
+    return w
+
+
 def by_name(name: str, **kw) -> Workload:
     table = {"cfg1": cfg1_sS, "cfg2": cfg2_clsp, "cfg3": cfg3_cash, "cfg3t": cfg3_tenths, "cfg4": cfg4_leadtime,
-             "cfg4p": cfg4_pipeline, "target": target_grid}
+             "cfg4p": cfg4_pipeline, "target": target_grid, "f5_spl": f5_single_product_leadtime, "staff": staff_testing,
+             "custom_clsp": custom_clsp}
     if name in table:
         return table[name](**kw)
     if name == "cfg5":

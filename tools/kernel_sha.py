@@ -6,11 +6,25 @@ import os
 
 COMMON = ["sdp_device.hpp", "sdpgpu_internal.hpp"]
 WINDOW = ["sdp_window.hpp", "sdpgpu_window.hip"]   # F1 / F2 window kernels: target, cfg2, cfg4, cfg4p, cfg5
-CASH = ["sdp_cash.hpp", "sdpgpu_cash.hip"]         # uniform-shift, diagonal and cash row kernels: cfg3, cfg3t
+CASH = ["sdp_cash.hpp", "sdpgpu_cash.hip"]         # uniform-shift, diagonal and cash row kernels: cfg3, cfg3t, f5_spl
+STAFF = ["sdp_staff.hpp", "sdpgpu_staff.hip"]      # workforce.StaffRecursion's kernels
+SPARSE = ["sdpgpu_sparse.hip"]                     # the reachable-set engine of the two-product families
+CUSTOM = ["sdp_custom_src.hpp", "sdp_gather.hpp", "sdpgpu_generic.hip"]  # user lambdas (hipRTC) / generic period kernel
 
 
 def kernel_files(workload_name: str):
-    return sorted(COMMON + (CASH if workload_name.startswith("cfg3") else WINDOW))
+    n = workload_name
+    if n.startswith("cfg3") or n.startswith("f5_"):
+        fam = CASH
+    elif n.startswith("staff"):
+        fam = STAFF
+    elif n.startswith("multilead") or n.startswith("multicash") or n.startswith("multixr"):
+        return sorted(SPARSE)  # (a translation unit of its own: nothing of the grid kernels' headers)
+    elif n.startswith("custom"):
+        fam = CUSTOM
+    else:
+        fam = WINDOW  # target, cfg2, cfg4, cfg4p, cfg5, separable_*
+    return sorted(COMMON + fam)
 
 
 def kernel_source_sha(root: str, workload_name: str) -> str:

@@ -79,6 +79,9 @@ def main():
         if d.get("SQ_ACTIVE_INST_VALU") and d.get("GRBM_GUI_ACTIVE") else None,
         "lds_busy_frac": (d["SQ_LDS_IDX_ACTIVE"] / (d["GRBM_GUI_ACTIVE"] / 8.0 * 256.0))
         if d.get("SQ_LDS_IDX_ACTIVE") and d.get("GRBM_GUI_ACTIVE") else None,
+        # the reachable-set engine launches its kernels per period on sets of very different sizes: bench.py prices totals per
+        # SOLVE, and the profiled command (pmc_collect.sh: --steps 3 --no-gate) runs the first solve + 3 timed ones
+        "solves_profiled": 4 if wl.startswith("multilead") else None,
         "correction": "HBM bytes = 2 * FETCH_SIZE_KiB * 1024 + WRITE_SIZE_KiB * 1024 (gfx950: FETCH_SIZE counts half of a wide coalesced read)",
         "kernels": kernels,
         "bench_line": {k: bench[k] for k in ("value", "ms_per_step", "steps", "config", "parity_gate")} if bench else None,
