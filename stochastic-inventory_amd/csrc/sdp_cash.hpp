@@ -742,11 +742,75 @@ __global__ __launch_bounds__(256) void cash_diag_kernel(DiagParams Q, const Diag
 // keys are q(minCash), q(maxCash) (cash_key_of_bound on the host), so q(clamp(x, minCash, maxCash)) ==
 // clamp(q(x), q(minCash), q(maxCash)) for every x -- one v_med3_i32 instead of v_min_f64 + v_max_f64.  The launcher
 // only takes this kernel when |x * mult| stays far below 2^31 (cash_row_eligible), so the conversion never saturates.
+// Math.round of the quantiser (CashConstraint.java:131 `Math.round(cash * 10)`), N values at once, as ints -- TWO additions per
+// value instead of floor / subtract / compare / convert / add-with-carry.  Math.round(x) = floor(x + 1/2) in exact arithmetic
+// (ties toward +infinity).  With the fp64 rounding mode set to ROUND TOWARD MINUS INFINITY for these additions only:
+//   t  = fl_down(x + 0.5)    lies in [floor(x + 0.5), x + 0.5]: floor(x + 0.5) is representable and not above the exact sum, and
+//                            fl_down returns the largest double not above it -- so floor(t) == floor(x + 0.5), exactly, for every x
+//                            (round-to-nearest would turn 0.49999999999999994 + 0.5 into 1.0: the classic wrong floor(x + 0.5));
+//   t2 = fl_down(t + 1.5 * 2^52) = 1.5 * 2^52 + floor(t), whose low mantissa word IS the integer (two's complement), |x| < 2^31
+//                            (the launchers admit |x| < 5e8: cash_row_eligible).
+// The mode is switched and restored INSIDE one asm block (s_setreg_imm32_b32 on the double-precision round field of MODE, the
+// instruction the compiler's own mode-register pass emits), so no other fp64 operation of the wave can be scheduled into the
+// window: every accumulation keeps round-to-nearest-even.  Same result as cash_key_row's floor form on every input, bit for bit.
+#define SDP_RTN_ON "s_setreg_imm32_b32 hwreg(HW_REG_MODE, 2, 2), 2\n\t"
+#define SDP_RTN_OFF "s_setreg_imm32_b32 hwreg(HW_REG_MODE, 2, 2), 0"
+constexpr double kRoundMagic = 6755399441055744.0;  // 1.5 * 2^52
+__device__ __forceinline__ int jround_rtn(double x) {
+  double t;
+  asm volatile(SDP_RTN_ON "v_add_f64 %0, %1, 0.5\n\tv_add_f64 %0, %0, %2\n\t" SDP_RTN_OFF : "=&v"(t) : "v"(x), "s"(kRoundMagic));
+  return __double2loint(t);
+}
+__device__ __forceinline__ void jround_rtn2(const double (&x)[2], int (&k)[2]) {
+  double t0, t1;
+  asm volatile(SDP_RTN_ON
+               "v_add_f64 %0, %2, 0.5\n\tv_add_f64 %1, %3, 0.5\n\t"
+               "v_add_f64 %0, %0, %4\n\tv_add_f64 %1, %1, %4\n\t" SDP_RTN_OFF
+               : "=&v"(t0), "=&v"(t1)
+               : "v"(x[0]), "v"(x[1]), "s"(kRoundMagic));
+  k[0] = __double2loint(t0);
+  k[1] = __double2loint(t1);
+}
+__device__ __forceinline__ void jround_rtn4(const double (&x)[4], int (&k)[4]) {
+  double t0, t1, t2, t3;
+  asm volatile(SDP_RTN_ON
+               "v_add_f64 %0, %4, 0.5\n\tv_add_f64 %1, %5, 0.5\n\tv_add_f64 %2, %6, 0.5\n\tv_add_f64 %3, %7, 0.5\n\t"
+               "v_add_f64 %0, %0, %8\n\tv_add_f64 %1, %1, %8\n\tv_add_f64 %2, %2, %8\n\tv_add_f64 %3, %3, %8\n\t" SDP_RTN_OFF
+               : "=&v"(t0), "=&v"(t1), "=&v"(t2), "=&v"(t3)
+               : "v"(x[0]), "v"(x[1]), "v"(x[2]), "v"(x[3]), "s"(kRoundMagic));
+  k[0] = __double2loint(t0);
+  k[1] = __double2loint(t1);
+  k[2] = __double2loint(t2);
+  k[3] = __double2loint(t3);
+}
+__device__ __forceinline__ void jround_rtn8(const double (&x)[8], int (&k)[8]) {
+  double t0, t1, t2, t3, t4, t5, t6, t7;
+  asm volatile(SDP_RTN_ON
+               "v_add_f64 %0, %8, 0.5\n\tv_add_f64 %1, %9, 0.5\n\tv_add_f64 %2, %10, 0.5\n\tv_add_f64 %3, %11, 0.5\n\t"
+               "v_add_f64 %4, %12, 0.5\n\tv_add_f64 %5, %13, 0.5\n\tv_add_f64 %6, %14, 0.5\n\tv_add_f64 %7, %15, 0.5\n\t"
+               "v_add_f64 %0, %0, %16\n\tv_add_f64 %1, %1, %16\n\tv_add_f64 %2, %2, %16\n\tv_add_f64 %3, %3, %16\n\t"
+               "v_add_f64 %4, %4, %16\n\tv_add_f64 %5, %5, %16\n\tv_add_f64 %6, %6, %16\n\tv_add_f64 %7, %7, %16\n\t" SDP_RTN_OFF
+               : "=&v"(t0), "=&v"(t1), "=&v"(t2), "=&v"(t3), "=&v"(t4), "=&v"(t5), "=&v"(t6), "=&v"(t7)
+               : "v"(x[0]), "v"(x[1]), "v"(x[2]), "v"(x[3]), "v"(x[4]), "v"(x[5]), "v"(x[6]), "v"(x[7]), "s"(kRoundMagic));
+  k[0] = __double2loint(t0);
+  k[1] = __double2loint(t1);
+  k[2] = __double2loint(t2);
+  k[3] = __double2loint(t3);
+  k[4] = __double2loint(t4);
+  k[5] = __double2loint(t5);
+  k[6] = __double2loint(t6);
+  k[7] = __double2loint(t7);
+}
+
 template <bool INTDIV>
 __device__ __forceinline__ int cash_key_row(double next_cash, int key_lo, int key_hi, double round_mult, double round_div) {
   const double xm = next_cash * round_mult;
+#ifdef SDP_ROUND_FLOOR  // (A/B builds only: the floor form of rounds 1-3)
   const double f = floor(xm);
   int k = (int)f + ((xm - f) >= 0.5 ? 1 : 0);
+#else
+  int k = jround_rtn(xm);
+#endif
   if constexpr (INTDIV) k = (int)trunc((double)k / round_div);  // `/ 10`: long division (CashOverdraft.java:116)
   return med3_i32(k, key_lo, key_hi);
 }
@@ -785,6 +849,16 @@ struct RowTiling {
   // of consecutive rows in flight per XCD, and every XCD gets the same number of workgroups.
   int32_t colmajor;
   int32_t slots;  // cash_row_pair_kernel, in-kernel setup: entry slots per wave (cash_row_slots(D); 1 = one action per setup pass)
+  int32_t rows_real;  // cash_row_pair_kernel with four rows per workgroup (RW = 4): n_rows counts groups of four, this the rows
+  // F5, DIAGONAL ORDER (round 4; nullptr: the band numbering above).  A cell of level y = x + preQ at demand d reads row y - d of
+  // plane a at the keys  c + mult * (price * min(y, d) - v a)  (balances that pay no interest): a (level, tile) unit touches
+  // 31 planes x 40 rows x its window = 3 MB of V_{t+1} that NO other level's unit of the same tile touches -- rocprofv3 on
+  // SingleProductLeadtime's size: 34 GB per launch from beyond the L2, every trip waiting for one of those misses (VALU 58 %,
+  // TA 62 % busy).  Units on one DIAGONAL  tile_cash + price * mult * level = const  read, per (plane, row), the SAME window
+  // whatever their level: the (row group, tile) units are walked in order of that diagonal, an eighth of the order per XCD.
+  // units[u] = {row group (or row), tile}; the order is dealt to the XCDs in segments of units_seg units.  Placement only.
+  const int2* units;
+  int32_t units_seg, units_total;
   // Row order inside a band (nullptr: as numbered).  F5's state is (x, preQ) but its cells read V_{t+1} through the level
   // y = x + preQ only (SingleProductLeadtime.java:82-119): rows with equal y gather the very same entries.  Walked in order of y
   // they are in flight together and find each other's lines in L2; in (preQ, x) order the 31 rows of a level are 61 rows apart
@@ -1095,7 +1169,7 @@ __host__ __device__ inline int row_tab_block(int D) { return row_tab_head_off(D)
 // It travels in the `sal` slot of the entry, which only period T reads (and period T gathers nothing).
 __device__ __forceinline__ int row_ent_off8(const RowEnt& e) { return __double2loint(e.sal); }
 
-template <bool LAST, bool FORMULA1, bool LEAN>
+template <bool LAST, bool FORMULA1, bool LEAN, int FAM = FAM_CASH>
 __device__ __forceinline__ RowEnt row_entry(const DevParams& P, double y, double fixed, double var, double d, int k_lo_next,
                                             bool& is_uni) {
   const double revenue = P.price * jmin(y, d);
@@ -1104,7 +1178,9 @@ __device__ __forceinline__ RowEnt row_entry(const DevParams& P, double y, double
   RowEnt e;
   e.hold = P.h * pos;
   e.sal = LAST ? P.salvage * pos : 0.0;
-  if constexpr (!FORMULA1) {
+  if constexpr (FAM != FAM_CASH) {
+    e.u = revenue;  // F4 / F5: after = (before - interest) + revenue (CashOverdraft.java:99-104, SingleProductLeadtime.java:98-104)
+  } else if constexpr (!FORMULA1) {
     e.u = P.one_minus_overhead_rate * revenue;
   } else {
     double inc = revenue - fixed - var - e.hold - P.overhead;
@@ -1119,7 +1195,11 @@ __device__ __forceinline__ RowEnt row_entry(const DevParams& P, double y, double
     ninv = ninv > P.max_inventory ? P.max_inventory : ninv;
     ninv = ninv < P.min_inventory ? P.min_inventory : ninv;
     e.rowoff8 = (inv_index(P, ninv) * (int)P.next.nc - k_lo_next) * 8;
-    const double inc_u = FORMULA1 ? e.u : (LEAN ? e.u - fixed - var : e.u - fixed - var - e.hold - P.overhead);
+    // the increment with the cash balance cancelled (real arithmetic).  F4 / F5: only where the balance pays no interest
+    // (the kernel ANDs the flag with that, per tile and action): before = cash - fixed - var - overhead, after = before + revenue
+    // (`fixed` is 0 for F5, whose lambdas charge none: SingleProductLeadtime.java:88-93)
+    const double inc_u = FAM != FAM_CASH ? e.u - fixed - var - P.overhead
+                                         : (FORMULA1 ? e.u : (LEAN ? e.u - fixed - var : e.u - fixed - var - e.hold - P.overhead));
     const double dm = inc_u * P.round_mult;
     const double dn = rint(dm);
     is_uni = fabs(dm - dn) < 9.5367431640625e-07 && fabs(dn) < 1.0e9;  // 2^-20, see cash_row_kernel
@@ -1211,14 +1291,35 @@ __global__ __launch_bounds__(256) void cash_row_table_kernel(DevParams P, const 
 //     buffers per wave an action ahead.  Built and measured SLOWER than 0 (42.1 against 38.2 ms per sweep on
 //     CashConstraint.main's grid): vector loads return in order, so every first gather of an action waits behind the block
 //     load, which misses the XCD's L2 on a row's first tile.  Kept behind SDPGPU_CASH_TAB=1.
-template <bool LAST, bool FORMULA1, bool LEAN, int S, int SRC = 0>
+// FAM (round 4): FAM_CASH as above; FAM_OVERDRAFT / FAM_CASH_LEADTIME (F4 / F5: CashOverdraft, SingleProductLeadtime; SRC 0 only,
+// FORMULA1 = LEAN = false, no integer division in the quantiser).  Their increment is (before - interest(before) + revenue) - cash
+// with before = cash - fixed - var - overhead: where the piecewise interest of EVERY point of the wave's tile is zero for the
+// action (r0 == 0 and before >= -interestFreeAmount: decided per tile and action from the points' own `before`, one wave vote)
+// the balance cancels in real arithmetic exactly as in F3 and the uniform-key trips apply -- one 16-byte gather per two cells
+// on a kernel the gather unit binds (rocprofv3, SingleProductLeadtime's size: TA 84 % busy at one 8-byte gather per cell, VALU
+// 75 %); elsewhere (balances that pay interest: the shift depends on the balance) the quantiser and one gather per point.
+// F5's entries do not depend on the action (its level is x + preQ) except for the shift; the next pipeline plane (preQ' = action)
+// goes into the scalar base address.
+// RW = rows per workgroup (round 4).  1: a workgroup is ONE tile of one row, its four waves take the actions k = wave, wave + 4, ...
+// and merge through LDS.  4 (F5): a workgroup is one tile of FOUR rows consecutive in the launcher's row order, one row per wave, and
+// every wave walks ALL its row's actions and owns its arg-opt.  F5's rows are walked in order of the level x + preQ, and rows of one
+// level gather the very same entries of V_{t+1} for the same tile, action and demand: with one row per workgroup those requests come
+// from different compute units and every one is served by the L2 -- rocprofv3 on SingleProductLeadtime's size: 6.3e9 L2 requests per
+// launch = 13.7 TB/s of 128-byte lines, three quarters of what the XCDs' L2s deliver to gathers, while TA (65 %) and VALU (59 %) idle;
+// neither fewer instructions nor fewer gathers moved the time.  Four rows of a level on ONE compute unit, in step, find each other's
+// lines in its vector L1.  Placement only: every cell still issues its own gather and performs its own arithmetic.
+template <bool LAST, bool FORMULA1, bool LEAN, int S, int SRC = 0, int FAM = FAM_CASH, int RW = 1>
 __global__ __launch_bounds__(256) void cash_row_pair_kernel(DevParams P, const double* __restrict__ v_next,
                                                             double* __restrict__ v_cur, int32_t* __restrict__ pol,
                                                             const double* __restrict__ pmf_d,
                                                             const double* __restrict__ pmf_p, int64_t lo, int64_t hi,
                                                             int64_t row0, RowTiling G, const char* __restrict__ tab,
                                                             int tab_actions) {
-  constexpr int FAM = FAM_CASH;
+  constexpr bool OD = FAM != FAM_CASH;  // F4 / F5
+  static_assert(FAM == FAM_CASH || ((FAM == FAM_OVERDRAFT || FAM == FAM_CASH_LEADTIME) && SRC == 0 && !FORMULA1 && !LEAN),
+                "the overdraft families run the in-kernel setup only");
+  static_assert(RW == 1 || (RW == 4 && SRC == 0), "four rows per workgroup: in-kernel setup only");
+  constexpr int KS = RW == 4 ? 1 : 4;  // stride of a wave's actions
   constexpr int TS = 128 * S;
   constexpr int NP = 2 * S;  // cash points per lane: point p = 2 s + w is ic0 + 128 s + 2 lane + w
   constexpr bool TAB = SRC == 1, SHARE = SRC == 2, BLK = SRC != 0;
@@ -1243,7 +1344,17 @@ __global__ __launch_bounds__(256) void cash_row_pair_kernel(DevParams P, const d
   const int lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   int row_i, tile;
-  if (G.colmajor > 0) {
+  if (G.units) {
+    // segments of `units_seg` consecutive units of the order go round the XCDs: segment s to XCD s % 8 (a contiguous eighth per
+    // XCD would hand the low-cash end -- balances that pay interest: the quantiser, one gather per cell -- to XCDs 0-2 and the
+    // cheap uniform-key cells to the rest, and the launch lasts as long as its slowest XCD)
+    const int n = blockIdx.x >> 3;
+    const int64_t u = ((int64_t)(n / G.units_seg) * 8 + (blockIdx.x & 7)) * G.units_seg + n % G.units_seg;
+    if (u >= G.units_total) return;
+    const int2 ut = G.units[u];
+    row_i = ut.x;
+    tile = ut.y;
+  } else if (G.colmajor > 0) {
     const int64_t u = (int64_t)(blockIdx.x & 7) * G.colmajor + (blockIdx.x >> 3);
     if ((blockIdx.x >> 3) >= (unsigned)G.colmajor || u >= (int64_t)G.n_rows * G.tiles_per_row) return;
     tile = (int)(u / G.n_rows);
@@ -1265,6 +1376,10 @@ __global__ __launch_bounds__(256) void cash_row_pair_kernel(DevParams P, const d
   }
   __syncthreads();
 
+  if constexpr (RW == 4) {  // (G.n_rows counts GROUPS of four rows, G.rows_real the rows)
+    row_i = row_i * 4 + wave;
+    if (row_i >= G.rows_real) return;  // a wave without a row (the last group): nothing below meets a workgroup barrier
+  }
   const int64_t row = row0 + (G.perm ? G.perm[row_i] : row_i);
   const int ic0 = (SHARE ? tile * 4 + wave : tile) * TS;  // (SHARE: G counts workgroup tiles of 4 TS points, one TS per wave)
   const int nc = (int)P.cur.nc;
@@ -1333,15 +1448,25 @@ __global__ __launch_bounds__(256) void cash_row_pair_kernel(DevParams P, const d
   }
   // One action on this wave's points: the demand loop in the reference's order, then the strict-compare update of the arg-opt.
   auto consume = [&](const int k, const double fixed, const double var, [[maybe_unused]] const bool free_action) {
-    double dep[NP];
+    double dep[NP];  // F3: the deposit term; F4 / F5: cashBalanceBefore - interest
 #pragma unroll
-    for (int w = 0; w < NP; ++w) dep[w] = (s[w].cash - fixed - var) * P.one_plus_deposit;
-    const char* vbase = reinterpret_cast<const char*>(v_next);
+    for (int w = 0; w < NP; ++w) {
+      if constexpr (!OD) {
+        dep[w] = (s[w].cash - fixed - var) * P.one_plus_deposit;
+      } else {
+        const double before = FAM == FAM_OVERDRAFT ? s[w].cash - fixed - var - overhead : s[w].cash - var - overhead;
+        dep[w] = before - overdraft_interest(P, before);
+      }
+    }
+    // (F5: the plane of the next pipeline quantity, preQ' = action, in the scalar base address)
+    const char* vbase = reinterpret_cast<const char*>(v_next + ((FAM == FAM_CASH_LEADTIME && !LAST) ? (int64_t)k * P.next.nx * P.next.nc : 0));
 
     // the cash-dependent increment of one point, the reference's operations in the reference's order
     auto increment = [&](const RowEnt& e, int w) -> double {
       double inc;
-      if constexpr (FORMULA1)
+      if constexpr (OD)
+        inc = (dep[w] + e.u) - s[w].cash;  // after = before - interest + revenue; cashIncrement = after - iniCash
+      else if constexpr (FORMULA1)
         inc = e.u;
       else if constexpr (LEAN)
         inc = e.u + dep[w] - s[w].cash;
@@ -1580,9 +1705,20 @@ __global__ __launch_bounds__(256) void cash_row_pair_kernel(DevParams P, const d
     return;
   }
   [[maybe_unused]] bool next_ready = false;  // (two slots) the entries of this action were formed by the previous pass
-  for (int k = wave; k < nA_max; k += 4) {
+  // F4 / F5: "no point of this wave's tile pays interest under this order": interest(before) is a zero for before >= 0 when
+  // r0 == 0 and for -interestFreeAmount <= before < 0 (CashOverdraft.java:87-95); `before` is the points' own
+  [[maybe_unused]] auto interest_free_tile = [&](const double fixed_a, const double var_a) -> bool {
+    bool f = true;
+#pragma unroll
+    for (int w = 0; w < NP; ++w) {
+      const double before = FAM == FAM_OVERDRAFT ? s[w].cash - fixed_a - var_a - overhead : s[w].cash - var_a - overhead;
+      f = f && before >= -P.interest_free && (before < 0 || P.r0 == 0.0);
+    }
+    return __all(f) != 0;
+  };
+  for (int k = RW == 4 ? 0 : wave; k < nA_max; k += KS) {
     const double a = (double)k * P.step;
-    const double fixed = a > 0 ? P.K : 0.0;
+    const double fixed = FAM == FAM_CASH_LEADTIME ? 0.0 : (a > 0 ? P.K : 0.0);  // (F5's lambdas charge no fixed cost)
     const double var = P.v * a;
     [[maybe_unused]] bool free_action = false, has_next = false;
     [[maybe_unused]] uint4 pf[2];
@@ -1604,8 +1740,8 @@ __global__ __launch_bounds__(256) void cash_row_pair_kernel(DevParams P, const d
         }
       }
     } else if (SLOTS == 2) {
-      // ---- two actions per setup pass: lanes 0-31 form the entries of action k (slot 0), lanes 32-63 those of action k + 4
-      // (slot 1), which the NEXT trip of this loop consumes without a setup of its own.  Per lane the same row_entry()
+      // ---- two actions per setup pass: lanes 0-31 form the entries of action k (slot 0), lanes 32-63 those of the wave's next
+      // action k + KS (slot 1), which the NEXT trip of this loop consumes without a setup of its own.  Per lane the same row_entry()
       // on the same operands as the one-action pass below.
       if (next_ready) {
         next_ready = false;
@@ -1613,15 +1749,24 @@ __global__ __launch_bounds__(256) void cash_row_pair_kernel(DevParams P, const d
         uni = uni0 + NF;
       } else {
         const int half = lane >> 5, j = lane & 31;
-        const bool second = k + 4 < nA_max;
-        const double a_l = (double)(k + 4 * half) * P.step;
-        const double fixed_l = a_l > 0 ? P.K : 0.0;
+        const bool second = k + KS < nA_max;
+        const double a_l = (double)(k + KS * half) * P.step;
+        const double fixed_l = FAM == FAM_CASH_LEADTIME ? 0.0 : (a_l > 0 ? P.K : 0.0);
         const double var_l = P.v * a_l;
         const bool act = j < D && (half == 0 || second);
         bool is_uni = false, free_ = false;
+        [[maybe_unused]] bool int_free_l = true;
+        if constexpr (OD && !LAST) {
+          const double a4 = (double)(k + KS) * P.step;
+          const bool f0 = interest_free_tile(fixed, var);
+          const bool f1 = interest_free_tile(FAM == FAM_CASH_LEADTIME ? 0.0 : (a4 > 0 ? P.K : 0.0), P.v * a4);
+          int_free_l = half ? f1 : f0;
+        }
         RowEnt e{};
         if (act) {
-          e = row_entry<LAST, FORMULA1, LEAN>(P, s[0].x + a_l, fixed_l, var_l, s_d[j], k_lo_next, is_uni);
+          e = row_entry<LAST, FORMULA1, LEAN, FAM>(P, FAM == FAM_CASH_LEADTIME ? s[0].x + s[0].preq : s[0].x + a_l, fixed_l, var_l,
+                                                   s_d[j], k_lo_next, is_uni);
+          if constexpr (OD) is_uni = is_uni && int_free_l;
           if constexpr (!LAST) {
             const double dn = (double)e.dkey;
             free_ = is_uni && tile_whole && (double)key_first + dn >= (double)k_lo_next && (double)key_last + dn <= (double)k_hi_next;
@@ -1643,10 +1788,13 @@ __global__ __launch_bounds__(256) void cash_row_pair_kernel(DevParams P, const d
       }
     } else {
       // ---- wave-uniform part, lanes = demand indices (as cash_row_kernel) ---------------------------------------
-      const double y = s[0].x + a;
+      const double y = FAM == FAM_CASH_LEADTIME ? s[0].x + s[0].preq : s[0].x + a;
+      [[maybe_unused]] bool int_free = true;
+      if constexpr (OD && !LAST) int_free = interest_free_tile(fixed, var);
       for (int j = lane; j < D; j += 64) {
         bool is_uni;
-        const RowEnt e = row_entry<LAST, FORMULA1, LEAN>(P, y, fixed, var, s_d[j], k_lo_next, is_uni);
+        const RowEnt e = row_entry<LAST, FORMULA1, LEAN, FAM>(P, y, fixed, var, s_d[j], k_lo_next, is_uni);
+        if constexpr (OD) is_uni = is_uni && int_free;
         if constexpr (!LAST) {
           const double dn = (double)e.dkey;
           const bool free_ = is_uni && tile_whole && (double)key_first + dn >= (double)k_lo_next &&
@@ -1680,6 +1828,18 @@ __global__ __launch_bounds__(256) void cash_row_pair_kernel(DevParams P, const d
     }
   }
 
+  if constexpr (RW == 4) {  // a wave owns its row's tile: results go straight out
+#pragma unroll
+    for (int w = 0; w < NP; ++w) {
+      const int ic = ic0 + 128 * (w >> 1) + 2 * lane + (w & 1);
+      const int64_t idx = row * nc + ic;
+      if (ic < nc && idx >= lo && idx < hi) {
+        v_cur[idx] = best[w];
+        pol[idx] = bestk[w];
+      }
+    }
+    return;
+  }
 #pragma unroll
   for (int w = 0; w < NP; ++w) {
     s_val[wave * TS + 128 * (w >> 1) + 2 * lane + (w & 1)] = best[w];

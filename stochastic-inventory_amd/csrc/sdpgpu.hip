@@ -709,6 +709,7 @@ void sdpgpu_destroy(sdpgpu_handle* h) {
   if (h->d_diag) (void)hipFree(h->d_diag);
   if (h->d_rowtab) (void)hipFree(h->d_rowtab);
   if (h->d_rowperm) (void)hipFree(h->d_rowperm);
+  if (h->d_units) (void)hipFree(h->d_units);
   for (void* q : h->staff_owned) (void)hipFree(q);
   if (h->d_staff_val) (void)hipFree(h->d_staff_val);
   if (h->d_staff_idx) (void)hipFree(h->d_staff_idx);

@@ -313,7 +313,14 @@ hipError_t launch_cash_row(sdpgpu_handle* h, const DevParams& P, int period, con
   const bool uni = P.family == sdp::FAM_CASH && !uni_off && P.pi == 0.0 && !intdiv &&
                    (P.cash_formula == 1 || h->d.deposit_rate == 0.0);
   // two adjacent cash points per lane (cash_row_pair_kernel): rows of two 128-point tiles and more
-  const bool pair = uni && !pair_off && p.g.nc >= 256 && (last || h->per[period].g.nc >= 2);
+  const bool pair_f3 = uni && !pair_off && p.g.nc >= 256 && (last || h->per[period].g.nc >= 2);
+  // round 4: the overdraft families F4 / F5 on the same kernel (uniform-key trips wherever a tile's balances pay no interest
+  // under the order; quantiser and one gather per point elsewhere) -- not with the `/ 10` long division of CashOverdraft.main's
+  // quantiser, whose key is not the rounded balance.  SDPGPU_CASH_OD_PAIR=0: the one-point row kernel of rounds 1-3.
+  const bool od_off = std::getenv("SDPGPU_CASH_OD_PAIR") && std::atoi(std::getenv("SDPGPU_CASH_OD_PAIR")) == 0;
+  const bool od_pair = (P.family == sdp::FAM_OVERDRAFT || P.family == sdp::FAM_CASH_LEADTIME) && !intdiv && !od_off && !pair_off &&
+                       p.g.nc >= 256 && (last || h->per[period].g.nc >= 2);
+  const bool pair = pair_f3 || od_pair;
   // ... and S such tiles per wave (per-action setup and entry reads shared) where that still leaves a few thousand workgroups.
   // CashConstraint.main's grid, after the clamp-free trips became straight-line code: S = 1 / 2 -> 46.9 / 39.7 ms per sweep
   // (before: 61.7 / 63.7; S = 4 needs 260 VGPRs: 96 ms, not instantiated).  SDPGPU_CASH_PAIR_S=1|2 overrides.
@@ -333,7 +340,7 @@ hipError_t launch_cash_row(sdpgpu_handle* h, const DevParams& P, int period, con
   const bool tab_on = std::getenv("SDPGPU_CASH_TAB") && std::atoi(std::getenv("SDPGPU_CASH_TAB")) == 1;
   const size_t blk_bytes = (size_t)sdp::row_tab_block(p.nD);
   const size_t smem_share = (size_t)p.nD * 16 + 4 * blk_bytes + (size_t)p.nD * 8 + 16;
-  const bool share = pair && !share_off && !tab_on && p.g.nc > 3 * (int64_t)tile_pts && smem_share <= kLdsPerCU / 2;
+  const bool share = pair_f3 && !share_off && !tab_on && p.g.nc > 3 * (int64_t)tile_pts && smem_share <= kLdsPerCU / 2;
   const int wg_pts = share ? 4 * tile_pts : tile_pts;  // cash points per workgroup
   // F5: rows in order of the level x + preQ (RowTiling::perm); SDPGPU_CASH_ROWPERM=0 keeps the (preQ, x) order
   const bool level_order = P.family == sdp::FAM_CASH_LEADTIME && p.g.nq > 1 &&
@@ -344,6 +351,12 @@ hipError_t launch_cash_row(sdpgpu_handle* h, const DevParams& P, int period, con
   G.slots = (slots_env && std::atoi(slots_env) == 1) ? 1 : sdp::cash_row_slots(p.nD);
   G.tiles_per_row = (int32_t)((p.g.nc + wg_pts - 1) / wg_pts);
   G.n_rows = (int32_t)(row_hi - row_lo + 1);
+  // F5 on the pair kernel: a workgroup is one tile of FOUR rows consecutive in the level order, one row per wave (RW = 4, see
+  // cash_row_pair_kernel): rows of one level gather the same entries, and on one compute unit they share its vector L1.
+  // SDPGPU_CASH_RW=1: one row per workgroup.
+  const bool rw4 = od_pair && level_order && !(std::getenv("SDPGPU_CASH_RW") && std::atoi(std::getenv("SDPGPU_CASH_RW")) == 1);
+  G.rows_real = G.n_rows;
+  if (rw4) G.n_rows = (G.n_rows + 3) / 4;
   int64_t blocks = (int64_t)G.n_rows * G.tiles_per_row;
   // cash bands per XCD (see RowTiling): rows of 16 tiles and more; ~1280 cash points per band (CashConstraint.main, 313
   // 64-point tiles per row: 1 / 2 / 3 / 6 bands per XCD = 70.0 / 69.0 / 73.4 / 72.8 ms per sweep, row-major 119.8).
@@ -360,7 +373,7 @@ hipError_t launch_cash_row(sdpgpu_handle* h, const DevParams& P, int period, con
     // (F5 walks its rows in order of the level x + preQ, below: the rows of a level gather the same entries, and with bands of
     // two tiles ~130 rows are in flight on an XCD -- four levels, whose windows fit its L2.  SingleProductLeadtime's size:
     // 20 / 5 / 2 / 1 tiles per band = 293 / 220 / 185 / 185 ms per sweep; without the level order 291 / 416 / 374 / 375.)
-    const int per_band = level_order ? 2 : std::max(1, 1280 / wg_pts);  // tiles per band
+    const int per_band = level_order ? std::max(1, 128 / wg_pts) : std::max(1, 1280 / wg_pts);  // tiles per band (F5: ~128 cash points)
     G.nsub = nsub > 0 ? std::min(nsub, tpb) : std::max(1, (tpb + per_band / 2) / per_band);
     G.tps = (tpb + G.nsub - 1) / G.nsub;
     blocks = 8LL * G.nsub * G.tps * G.n_rows;
@@ -386,6 +399,52 @@ hipError_t launch_cash_row(sdpgpu_handle* h, const DevParams& P, int period, con
       std::memcpy(h->rowperm_key, key, sizeof key);
     }
     G.perm = h->d_rowperm;
+  }
+  // F5 on the pair kernel: the (row group, tile) units in DIAGONAL order (RowTiling::units).  SDPGPU_CASH_DIAG_ORDER=0: bands.
+  const bool diag_order = od_pair && level_order && !last && G.tiles_per_row >= 8 &&
+                          !(std::getenv("SDPGPU_CASH_DIAG_ORDER") && std::atoi(std::getenv("SDPGPU_CASH_DIAG_ORDER")) == 0);
+  if (diag_order) {
+    const int64_t n_units = (int64_t)G.n_rows * G.tiles_per_row;
+    double sigma = std::fabs(h->d.price) * h->d.cash_round_mult * h->d.step;  // keys per unit of level along a diagonal
+    if (const char* e = std::getenv("SDPGPU_CASH_DIAG_SIGMA")) sigma = std::atof(e);  // (experiments: 0 = tile-major, levels in order)
+    int64_t sig_bits;
+    std::memcpy(&sig_bits, &sigma, sizeof sig_bits);
+    const int64_t key[8] = {row_lo, row_hi, p.g.nx, p.g.nq, (int64_t)G.tiles_per_row, (int64_t)wg_pts, rw4 ? 4 : 1, sig_bits};
+    if (std::memcmp(key, h->units_key, sizeof key) != 0) {
+      hipError_t e = hipStreamSynchronize(st);  // (an earlier launch may still read the old order)
+      if (e != hipSuccess) return e;
+      const std::vector<int32_t>& perm = h->rowperm_host;  // rows in level order (built above)
+      const int rw = rw4 ? 4 : 1;
+      struct Unit {
+        double diag;
+        int32_t level, grp, tile;
+      };
+      std::vector<Unit> us((size_t)n_units);
+      size_t at = 0;
+      for (int32_t g = 0; g < G.n_rows; ++g) {
+        const int64_t r = row_lo + perm[(size_t)g * rw];  // the group's first row: its level stands for the group
+        const int32_t level = (int32_t)(r % p.g.nx + r / p.g.nx);
+        for (int32_t t = 0; t < G.tiles_per_row; ++t) us[at++] = Unit{(double)t * wg_pts + sigma * level, level, g, t};
+      }
+      std::stable_sort(us.begin(), us.end(), [](const Unit& a, const Unit& b) {
+        return a.diag != b.diag ? a.diag < b.diag : (a.level != b.level ? a.level < b.level : a.grp < b.grp);
+      });
+      std::vector<int2> host((size_t)n_units);
+      for (size_t i = 0; i < host.size(); ++i) host[i] = make_int2(us[i].grp, us[i].tile);
+      if (h->d_units) (void)hipFree(h->d_units);
+      h->d_units = nullptr;
+      e = hipMalloc((void**)&h->d_units, host.size() * sizeof(int2));
+      if (e == hipSuccess) e = hipMemcpy(h->d_units, host.data(), host.size() * sizeof(int2), hipMemcpyHostToDevice);
+      if (e != hipSuccess) return e;
+      std::memcpy(h->units_key, key, sizeof key);
+    }
+    G.units = h->d_units;
+    G.units_total = (int32_t)n_units;
+    int seg = 64;  // (SingleProductLeadtime's size: 8 / 64 / 256 / 1024 units per segment = 124.7 / 123.9 / 126.5 / 133.9 ms per sweep; one contiguous eighth per XCD: 160)
+    if (const char* e = std::getenv("SDPGPU_CASH_DIAG_SEG")) seg = std::max(1, std::atoi(e));
+    G.units_seg = seg;
+    const int64_t n_seg = (n_units + seg - 1) / seg;
+    blocks = 8LL * ((n_seg + 7) / 8) * seg;
   }
   if (!grid_ok(blocks)) return hipErrorInvalidValue;
   dim3 grid((unsigned)blocks);
@@ -471,8 +530,32 @@ hipError_t launch_cash_row(sdpgpu_handle* h, const DevParams& P, int period, con
       return P.cash_formula != 1 ? launch_cash_row_fam<sdp::FAM_CASH, false>(SDP_ROWARGS)
                                  : launch_cash_row_fam<sdp::FAM_CASH, true>(SDP_ROWARGS);
     }
-    case sdp::FAM_OVERDRAFT: return launch_cash_row_fam<sdp::FAM_OVERDRAFT, false>(SDP_ROWARGS);
-    case sdp::FAM_CASH_LEADTIME: return launch_cash_row_fam<sdp::FAM_CASH_LEADTIME, false>(SDP_ROWARGS);
+#define SDP_OD_GO(FM, LS, SS, RR)                                                                                                \
+  do {                                                                                                                          \
+    static LdsMark mark;                                                                                                        \
+    hipError_t ea = lds_allow(sdp::cash_row_pair_kernel<LS, false, false, SS, 0, FM, RR>, smem, &mark);                         \
+    if (ea != hipSuccess) return ea;                                                                                            \
+    hipLaunchKernelGGL((sdp::cash_row_pair_kernel<LS, false, false, SS, 0, FM, RR>), grid, dim3(256), smem, st, P, v_next,     \
+                       v_cur, pol, pmf_d, pmf_p, lo, hi, row_lo, G, (const char*)nullptr, 0);                                  \
+  } while (0)
+#define SDP_OD(FM, RR)                                                                  \
+  do {                                                                                  \
+    if (last) {                                                                         \
+      if (pair_s == 2) SDP_OD_GO(FM, true, 2, RR); else SDP_OD_GO(FM, true, 1, RR);     \
+    } else {                                                                            \
+      if (pair_s == 2) SDP_OD_GO(FM, false, 2, RR); else SDP_OD_GO(FM, false, 1, RR);   \
+    }                                                                                   \
+    return hipGetLastError();                                                           \
+  } while (0)
+    case sdp::FAM_OVERDRAFT:
+      if (od_pair) SDP_OD(sdp::FAM_OVERDRAFT, 1);
+      return launch_cash_row_fam<sdp::FAM_OVERDRAFT, false>(SDP_ROWARGS);
+    case sdp::FAM_CASH_LEADTIME:
+      if (od_pair && rw4) SDP_OD(sdp::FAM_CASH_LEADTIME, 4);
+      if (od_pair) SDP_OD(sdp::FAM_CASH_LEADTIME, 1);
+      return launch_cash_row_fam<sdp::FAM_CASH_LEADTIME, false>(SDP_ROWARGS);
+#undef SDP_OD
+#undef SDP_OD_GO
     case sdp::FAM_SURVIVAL: return launch_cash_row_fam<sdp::FAM_SURVIVAL, false>(SDP_ROWARGS);
   }
 #undef SDP_ROWARGS

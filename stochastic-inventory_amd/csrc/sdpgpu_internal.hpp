@@ -130,6 +130,8 @@ struct sdpgpu_handle {
   int32_t* d_rowperm = nullptr;  // cash row kernel, F5: rows of the launch ordered by level x + preQ (RowTiling::perm)
   std::vector<int32_t> rowperm_host;
   int64_t rowperm_key[4] = {-1, -1, -1, -1};
+  int2* d_units = nullptr;       // F5 pair kernel: (row group, tile) units in diagonal order (RowTiling::units)
+  int64_t units_key[8] = {-1, -1, -1, -1, -1, -1, -1, -1};
   char* d_rowtab = nullptr;  // cash_row_table_kernel's (row, action) blocks of the period being run (cash_row_pair_kernel<TAB>)
   size_t rowtab_bytes = 0;
   void* d_diag = nullptr;  // cash_diag_kernel: the DiagStep table of the period being run, and its padded p * gamma row

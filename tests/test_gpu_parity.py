@@ -113,6 +113,57 @@ def test_cash_row_kernel_variants(sia, oracle, monkeypatch, make, env):
     eng.close()
 
 
+def _od_cases():
+    """F4 / F5 instances for the two-point row kernel (round 4): balances on both sides of zero (uniform-key trips where a
+    tile pays no interest under the order, the quantiser elsewhere), deposit interest on positive balances (r0 != 0: no tile is
+    ever interest-free above zero), an interest-free overdraft band, a fixed order cost (F4), half-grid prices (tie steps)."""
+    import copy
+    out = []
+    w = cases.f5_cash_leadtime()
+    out.append(("f5_spl_shape", w))
+    w = cases.f5_cash_leadtime()
+    w.functor.r0 = 0.02
+    out.append(("f5_deposit_interest", w))
+    w = cases.f5_cash_leadtime()
+    w.functor.interestFreeAmount = 3.0
+    w.functor.price = 4.5
+    out.append(("f5_interest_free_band_half_grid_price", w))
+    w = cases.f5_cash_leadtime()
+    w.functor.price = 3.333
+    out.append(("f5_off_grid_price", w))
+    w = cases.f4_overdraft()
+    w.functor.cashRoundIntDiv = False  # tenths grid, no long division: the two-point kernel's quantiser
+    w.functor.r0 = 0.0
+    out.append(("f4_tenths", w))
+    w = cases.f4_overdraft()
+    w.functor.cashRoundIntDiv = False
+    w.functor.fixOrderCost = 2.5
+    w.functor.cashRoundMult = w.functor.cashRoundDiv = 100.0
+    w.functor.minCashState, w.functor.maxCashState = -20.0, 30.0
+    out.append(("f4_hundredths_fixed_cost_deposit", w))
+    return out
+
+
+@pytest.mark.parametrize("env", [{}, {"SDPGPU_CASH_OD_PAIR": "0"}, {"SDPGPU_CASH_RW": "1"}, {"SDPGPU_CASH_DIAG_ORDER": "0"},
+                                 {"SDPGPU_CASH_PAIR_S": "1"}, {"SDPGPU_CASH_PAIR_S": "2"}, {"SDPGPU_CASH_DIAG_SEG": "3"},
+                                 {"SDPGPU_CASH_SLOTS": "1"}, {"SDPGPU_CASH_SLOTS": "1", "SDPGPU_CASH_RW": "1", "SDPGPU_CASH_PAIR_S": "2"},
+                                 {"SDPGPU_CASH_BANDS": "0", "SDPGPU_CASH_DIAG_ORDER": "0"}],
+                         ids=lambda e: ",".join(f"{k[12:]}={v}" for k, v in e.items()) or "default")
+@pytest.mark.parametrize("name", [n for n, _ in _od_cases()])
+def test_overdraft_pair_kernel_variants(sia, oracle, monkeypatch, name, env):
+    """F4 / F5 on cash_row_pair_kernel (round 4) in every launch form -- one / two tiles per wave, one row per workgroup or four
+    rows of a level (RW), diagonal unit order with odd segment sizes or the band numbering, one or two setup slots, and the
+    one-point row kernel of rounds 1-3 (OD_PAIR=0) -- against the oracle, every table bit for bit."""
+    for k, v in env.items():
+        monkeypatch.setenv(k, v)
+    w = dict(_od_cases())[name]
+    eng, P, V, pol, _ = _solve_both(sia, oracle, w)
+    assert eng.stats().kernel_used == 2
+    for period in range(1, w.T + 1):
+        _assert_tables(eng.values(period), eng.policy(period), V[period - 1], pol[period - 1], f"{name} t={period}")
+    eng.close()
+
+
 @pytest.mark.parametrize("pair_s", ["2", "1", None], ids=["two-tiles-per-wave", "one-tile", "planned"])
 def test_cash_row_wide_pmf_above_64KiB_of_lds(sia, oracle, monkeypatch, pair_s):
     """A 345-point pmf on CashConstraint.main's tenths grid: 152 B of per-wave entries per demand point + the read-out
