@@ -843,6 +843,10 @@ struct RowTiling {
   int32_t n_rows;  // inventory(/preQ) rows launched
   int32_t tps;     // tiles per band; 0 = plain row-major numbering (short rows)
   int32_t nsub;    // bands per XCD
+  // 1: XCD i walks the bands i, i + 8, i + 16, ... instead of the contiguous run i * nsub ...: the cost of a tile varies ALONG the
+  // cash axis (action counts grow with the balance, trips clamp near the ends, balances below zero pay interest), a contiguous
+  // eighth per XCD hands the dear end to one XCD and the launch lasts as long as its slowest XCD
+  int32_t band_interleave;
   // colmajor > 0 (the shared-block form, whose workgroup tiles are few and wide -- 20 per row on CashConstraint.main's grid, which
   // whole-column bands would deal 3, 3, 3, 3, 3, 3, 2, 0 to the eight XCDs): the (tile, row) units in column-major order,
   // unit u = tile * n_rows + row, are cut into eight equal runs of `colmajor` units, XCD i walks run i.  Still one narrow band
@@ -904,7 +908,7 @@ __global__ __launch_bounds__(256) void cash_row_kernel(DevParams P, const double
     const int per_band = G.n_rows * G.tps;
     const int sub = n / per_band, rem = n - sub * per_band;
     row_i = rem / G.tps;
-    tile = (xcd * G.nsub + sub) * G.tps + (rem - row_i * G.tps);
+    tile = (G.band_interleave ? sub * 8 + xcd : xcd * G.nsub + sub) * G.tps + (rem - row_i * G.tps);
     if (tile >= G.tiles_per_row) return;  // the bands cover a little more than the row (whole workgroup leaves)
   }
   for (int j = tid; j < D; j += 256) {
@@ -1367,7 +1371,7 @@ __global__ __launch_bounds__(256) void cash_row_pair_kernel(DevParams P, const d
     const int per_band = G.n_rows * G.tps;
     const int sub = n / per_band, rem = n - sub * per_band;
     row_i = rem / G.tps;
-    tile = (xcd * G.nsub + sub) * G.tps + (rem - row_i * G.tps);
+    tile = (G.band_interleave ? sub * 8 + xcd : xcd * G.nsub + sub) * G.tps + (rem - row_i * G.tps);
     if (tile >= G.tiles_per_row) return;
   }
   for (int j = tid; j < D; j += 256) {

@@ -376,6 +376,11 @@ hipError_t launch_cash_row(sdpgpu_handle* h, const DevParams& P, int period, con
     const int per_band = level_order ? std::max(1, 128 / wg_pts) : std::max(1, 1280 / wg_pts);  // tiles per band (F5: ~128 cash points)
     G.nsub = nsub > 0 ? std::min(nsub, tpb) : std::max(1, (tpb + per_band / 2) / per_band);
     G.tps = (tpb + G.nsub - 1) / G.nsub;
+    // bands i, i + 8, ... per XCD for the families whose cells below a zero balance cost twice the others' (F4 / F5 / F6:
+    // SingleProductLeadtime's size on the band numbering 177.7 -> 131.3 ms per sweep); F3's tiles cost about the same along the
+    // axis and neighbouring bands share window lines in the XCD's L2 (CashConstraint.main: 36.4 contiguous, 37.1 interleaved)
+    G.band_interleave = P.family != sdp::FAM_CASH;
+    if (const char* e = std::getenv("SDPGPU_CASH_BAND_INTERLEAVE")) G.band_interleave = std::atoi(e) != 0;
     blocks = 8LL * G.nsub * G.tps * G.n_rows;
   }
   if (level_order) {
