@@ -402,6 +402,70 @@ __global__ __launch_bounds__(256) void lattice_list_kernel(Lattice L, const unsi
 }
 
 // ---- backward: one workgroup per state ------------------------------------------------------------
+// The lead-time family's actions of one state (model 0), NI actions per lane (a = tid + 256 i), demand pairs in the OUTER loop: a
+// pair's terms are read from LDS once per lane instead of once per cell (round 3: three LDS instructions per cell beside ~10
+// vector ones -- 17.6 instructions per cell on the recorded instances, whose cells are almost all period T's), and every
+// accumulator still takes its addends in the reference's order, demand index ascending (CashRecursionMultiLead.java:72-80):
+// thisActionsValue of action a is acc[i], and trip j of the outer loop adds pair j's two terms to each of them.  Per cell in
+// period T: the three additions of cash_increment, the product with p, the accumulation.
+constexpr int kActPerLane = 10;  // Qbound up to 50 (2560 pairs)
+template <int NI>
+__device__ __forceinline__ void lead_actions(const MLParams& P, const Tuple& st, int64_t s, int tid, int NA, const DemandTerms* s_t,
+                                             const double* s_p, const int* __restrict__ uid, const double* __restrict__ v_next,
+                                             double* s_q) {
+  double bi[NI], acc[NI];
+  const int* urow[NI];
+  // (i, j) of the lane's actions without a division per action (an emulated 32-bit division is ~25 instructions, more than the
+  // 20 a four-pair action's cells take): one division for a = tid, then steps of 256
+  const int step1 = 256 / P.qb, step2 = 256 - step1 * P.qb;
+  int a1 = tid / P.qb, a2 = tid - a1 * P.qb;
+  const int* urow0 = P.is_last ? nullptr : uid + (int64_t)s * NA * P.nd;  // (period T reads no successor)
+#pragma unroll
+  for (int i = 0; i < NI; ++i) {
+    const int a = tid + 256 * i;
+    const double oc = P.vari[0] * (double)a1 + P.vari[1] * (double)a2;
+    const double before = st.cash - oc - P.overhead;
+    bi[i] = before - ml_interest(P, before);
+    acc[i] = 0.0;  // thisActionsValue, CashRecursionMultiLead.java:72-80
+    // (ids are non-negative 32-bit ranks: zero-extended byte offsets from the table's base instead of sign-extended 64-bit
+    // index arithmetic per cell)
+    urow[i] = urow0 + (a < NA ? a : 0) * P.nd;
+    a1 += step1;
+    a2 += step2;
+    if (a2 >= P.qb) {
+      a2 -= P.qb;
+      ++a1;
+    }
+  }
+  const char* vb = reinterpret_cast<const char*>(v_next);
+  if (P.is_last) {
+    for (int j = 0; j < P.nd; ++j) {
+      const DemandTerms t = s_t[j];
+      const double p = s_p[j];
+#pragma unroll
+      for (int i = 0; i < NI; ++i) acc[i] += p * cash_increment(st, bi[i], t);
+    }
+  } else {
+    for (int j = 0; j < P.nd; ++j) {
+      const DemandTerms t = s_t[j];
+      const double p = s_p[j];
+      const double pg = p * P.discount;
+      double v[NI];
+#pragma unroll
+      for (int i = 0; i < NI; ++i)
+        v[i] = tid + 256 * i < NA ? *reinterpret_cast<const double*>(vb + ((uint64_t)(uint32_t)urow[i][j] << 3)) : 0.0;
+#pragma unroll
+      for (int i = 0; i < NI; ++i) {
+        acc[i] += p * cash_increment(st, bi[i], t);
+        acc[i] += pg * v[i];
+      }
+    }
+  }
+#pragma unroll
+  for (int i = 0; i < NI; ++i)
+    if (tid + 256 * i < NA) s_q[tid + 256 * i] = acc[i];
+}
+
 __global__ __launch_bounds__(256) void backward_kernel(MLParams P, const Tuple* __restrict__ states, int64_t s_first,
                                                        int64_t n_states,
                                                        const double2* __restrict__ dem, const double* __restrict__ prob,
@@ -485,14 +549,27 @@ __global__ __launch_bounds__(256) void backward_kernel(MLParams P, const Tuple* 
     }
     s_q[a] = acc;
   }
-  for (int a = tid; a < NA && P.model == 0; a += 256) {
+  if (P.model == 0 && NA <= 256 * kActPerLane) {
+    // (the lane's action count is a template argument: straight-line code per demand pair, no per-action guards)
+    switch ((NA + 255) / 256) {
+      case 1: lead_actions<1>(P, st, s, tid, NA, s_t, s_p, uid, v_next, s_q); break;
+      case 2: lead_actions<2>(P, st, s, tid, NA, s_t, s_p, uid, v_next, s_q); break;
+      case 3: lead_actions<3>(P, st, s, tid, NA, s_t, s_p, uid, v_next, s_q); break;
+      case 4: lead_actions<4>(P, st, s, tid, NA, s_t, s_p, uid, v_next, s_q); break;
+      case 5: lead_actions<5>(P, st, s, tid, NA, s_t, s_p, uid, v_next, s_q); break;
+      case 6: lead_actions<6>(P, st, s, tid, NA, s_t, s_p, uid, v_next, s_q); break;
+      case 7: lead_actions<7>(P, st, s, tid, NA, s_t, s_p, uid, v_next, s_q); break;
+      case 8: lead_actions<8>(P, st, s, tid, NA, s_t, s_p, uid, v_next, s_q); break;
+      case 9: lead_actions<9>(P, st, s, tid, NA, s_t, s_p, uid, v_next, s_q); break;
+      default: lead_actions<10>(P, st, s, tid, NA, s_t, s_p, uid, v_next, s_q); break;
+    }
+  } else
+  for (int a = tid; a < NA && P.model == 0; a += 256) {  // (more than 256 * kActPerLane actions: one action at a time)
     const int a1 = a / P.qb, a2 = a - a1 * P.qb;
     const double oc = P.vari[0] * (double)a1 + P.vari[1] * (double)a2;
     const double before = st.cash - oc - P.overhead;
     const double bi = before - ml_interest(P, before);
     double acc = 0.0;  // thisActionsValue, CashRecursionMultiLead.java:72-80
-    // (ids are non-negative 32-bit ranks: zero-extended byte offsets from the table's base instead of sign-extended
-    // 64-bit index arithmetic per cell)
     const int* urow = uid + ((int64_t)s * NA + a) * P.nd;
     const char* vb = reinterpret_cast<const char*>(v_next);
     if (P.is_last) {
@@ -534,6 +611,107 @@ __global__ __launch_bounds__(256) void backward_kernel(MLParams P, const Tuple* 
       v_out[s] = val;
       act_out[s] = best;
     }
+  }
+}
+
+// ---- backward, lead-time family (model 0): ONE WAVE per state ------------------------------------------------------------
+// Round 3's form -- a 256-thread workgroup per state, Q(s, .) in LDS, two barriers, then the first wave alone scanning the 2500
+// action values while three waves hold their registers -- ran the recorded instances (1.7e7 period-T states x 2500 order pairs x
+// 4-9 demand pairs) at 40 % of the vector issue rate: the 5 operations a period-T cell costs were under half of what a state
+// executed.  Here a wave owns a state: lane l holds the order pairs a = l + 64 i, so chunk i of the `> val + 0.1` scan
+// (CashRecursionMultiLead.java:82, serial in action order) IS the 64 lanes' accumulators acc[i] -- no Q array, no LDS traffic, no
+// workgroup barrier, no idle wave.  The action range is walked in passes of kLeadChunks chunks (registers), the scan's `val`
+// carried from pass to pass.  Per (lane, chunk) the order quantities step by 64 without a division.  Every accumulator takes its
+// addends demand index ascending, exactly as before.
+constexpr int kLeadChunks = 10;
+template <bool LAST>
+__global__ __launch_bounds__(256) void backward_lead_wave_kernel(MLParams P, const Tuple* __restrict__ states, int64_t s_first,
+                                                                int64_t n_states, const double2* __restrict__ dem,
+                                                                const double* __restrict__ prob, const double* __restrict__ v_next,
+                                                                const int* __restrict__ uid, double* __restrict__ v_out,
+                                                                int* __restrict__ act_out) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int NA = P.qb * P.qb;
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  DemandTerms* s_t = reinterpret_cast<DemandTerms*>(smem) + (size_t)wave * P.nd;  // this wave's state: per demand pair
+  double* s_p = reinterpret_cast<double*>(reinterpret_cast<DemandTerms*>(smem) + (size_t)4 * P.nd);
+  const int64_t s = s_first + (int64_t)blockIdx.x * 4 + wave;
+  // (the pmf is the same for the four states: every wave writes the same values, nobody waits for anybody)
+  for (int j = lane; j < P.nd; j += 64) s_p[j] = prob[j];
+  if (s >= n_states) return;
+  const Tuple st = states[s];
+  for (int j = lane; j < P.nd; j += 64) s_t[j] = demand_terms(P, st, dem[j].x, dem[j].y);
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_s_waitcnt(0xC07F);  // lgkmcnt(0): the wave's own LDS writes have landed
+  const int step1 = 64 / P.qb, step2 = 64 - step1 * P.qb;
+  int a1 = lane / P.qb, a2 = lane - a1 * P.qb;
+  [[maybe_unused]] const int* urow0 = LAST ? nullptr : uid + (int64_t)s * NA * P.nd;  // (period T reads no successor)
+  const char* vb = reinterpret_cast<const char*>(v_next);
+  double val = -1.7976931348623157e308;
+  int best = 0;  // new Actions(0, 0)
+  for (int c0 = 0; c0 * 64 < NA; c0 += kLeadChunks) {
+    double bi[kLeadChunks], acc[kLeadChunks];
+    [[maybe_unused]] const int* urow[kLeadChunks];
+#pragma unroll
+    for (int i = 0; i < kLeadChunks; ++i) {
+      [[maybe_unused]] const int a = (c0 + i) * 64 + lane;
+      const double oc = P.vari[0] * (double)a1 + P.vari[1] * (double)a2;
+      const double before = st.cash - oc - P.overhead;
+      bi[i] = before - ml_interest(P, before);
+      acc[i] = 0.0;  // thisActionsValue, CashRecursionMultiLead.java:72-80
+      if constexpr (!LAST) urow[i] = urow0 + (a < NA ? a : 0) * P.nd;
+      a1 += step1;
+      a2 += step2;
+      if (a2 >= P.qb) {
+        a2 -= P.qb;
+        ++a1;
+      }
+    }
+    if constexpr (LAST) {
+      for (int j = 0; j < P.nd; ++j) {
+        const DemandTerms t = s_t[j];
+        const double p = s_p[j];
+#pragma unroll
+        for (int i = 0; i < kLeadChunks; ++i) acc[i] += p * cash_increment(st, bi[i], t);
+      }
+    } else {
+      for (int j = 0; j < P.nd; ++j) {
+        const DemandTerms t = s_t[j];
+        const double p = s_p[j];
+        const double pg = p * P.discount;
+        double v[kLeadChunks];
+#pragma unroll
+        for (int i = 0; i < kLeadChunks; ++i)
+          v[i] = (c0 + i) * 64 + lane < NA ? *reinterpret_cast<const double*>(vb + ((uint64_t)(uint32_t)urow[i][j] << 3)) : 0.0;
+#pragma unroll
+        for (int i = 0; i < kLeadChunks; ++i) {
+          acc[i] += p * cash_increment(st, bi[i], t);
+          acc[i] += pg * v[i];
+        }
+      }
+    }
+    // `if (actionValues[i] > val + 0.1)` in action order (:82): chunk by chunk, each pass of the inner loop jumps to the next
+    // improvement of the chunk
+#pragma unroll
+    for (int i = 0; i < kLeadChunks; ++i) {
+      const int base = (c0 + i) * 64;
+      const bool live = base + lane < NA;  // (a chunk past the last action: no lane is live, the first ballot is empty)
+      const double q = acc[i];
+      int from = 0;
+      while (true) {
+        const unsigned long long m = __ballot(live && lane >= from && q > val + 0.1);
+        if (!m) break;
+        const int first = __ffsll((long long)m) - 1;
+        val = __shfl(q, first, 64);
+        best = base + first;
+        from = first + 1;
+      }
+    }
+  }
+  if (lane == 0) {
+    v_out[s] = val;
+    act_out[s] = best;
   }
 }
 
@@ -794,6 +972,21 @@ int sparse_solve(const SparseProblem& sp, double* final_value, int32_t* q1, int3
       }
       if (smem > 64 * 1024)  // above the legacy limit of a launch: raise the kernel's dynamic-LDS limit
         ML_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(backward_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
+      // the lead-time family: a wave per state (backward_lead_wave_kernel); SDPGPU_MULTI_WAVE=0: round 3's workgroup per state
+      const bool lead_wave = P.model == 0 && NA <= 4096 && !(std::getenv("SDPGPU_MULTI_WAVE") && std::atoi(std::getenv("SDPGPU_MULTI_WAVE")) == 0);
+      if (lead_wave) {
+        const size_t smem_w = (size_t)nd * (4 * sizeof(DemandTerms) + 8);
+        for (int64_t first = 0; first < n_states[t]; first += (int64_t)1 << 24) {  // 4M workgroups of four states
+          const int64_t ns = std::min<int64_t>((int64_t)1 << 24, n_states[t] - first);
+          if (P.is_last)
+            hipLaunchKernelGGL(backward_lead_wave_kernel<true>, dim3((unsigned)((ns + 3) / 4)), dim3(256), smem_w, 0, P, d_states[t], first,
+                               n_states[t], d_dem + sp.off[(size_t)t], d_prob + sp.off[(size_t)t], d_vnext, d_uid[t], d_vcur, d_act);
+          else
+            hipLaunchKernelGGL(backward_lead_wave_kernel<false>, dim3((unsigned)((ns + 3) / 4)), dim3(256), smem_w, 0, P, d_states[t], first,
+                               n_states[t], d_dem + sp.off[(size_t)t], d_prob + sp.off[(size_t)t], d_vnext, d_uid[t], d_vcur, d_act);
+          ML_TRY(hipGetLastError());
+        }
+      } else
       // a dispatch carries at most 2^32 work-items: batches of 4M workgroups (2^30 lanes)
       for (int64_t first = 0; first < n_states[t]; first += (int64_t)1 << 22) {
         const int64_t nb = std::min<int64_t>((int64_t)1 << 22, n_states[t] - first);
