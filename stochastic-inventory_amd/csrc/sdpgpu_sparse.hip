@@ -614,6 +614,243 @@ __global__ __launch_bounds__(256) void backward_kernel(MLParams P, const Tuple* 
   }
 }
 
+// ---- backward, the two cash-constrained families (models 1 and 2) with a FACTORED demand list --------------------------------
+// What a cell of these families computes splits by product: endInventory_k, revenue_k, the salvage term and the successor's
+// inventory of product k read the k-th order quantity and the k-th demand only (MultiItemCash.java:79-118,
+// MultiItemCashXR.java:108-148).  With the period's pair list factored into its distinct first and second demands (the lists
+// GetPmfMulti builds are products of two marginals: 22 x 16 values for MultiItemCashXR.main's 352 pairs), a state's workgroup
+// tabulates them once per (order quantity, distinct demand) -- 50 x (22 + 16) entries against 2500 x 352 cells -- and a cell is
+// two table reads, the additions that join the two products, and the accumulation: 7 vector operations in period T where round
+// 3's kernel executed the whole lambda per cell (17.6 instructions per cell; MultiItemCashXR with four periods: 11.4 s).  Every
+// table entry is formed by the reference's expressions on the reference's operands, and a cell joins them in the reference's
+// order, so the values are the same doubles.
+struct FactSide {  // per (order index of one product, distinct demand of that product)
+  double rev;      // price_k * (level_k - endInventory_k)
+  double w;        // period T: salvage_k * endInventory_k; earlier: variCost_k * nextInventory_k (model 2's next R)
+  long long lat;   // the successor's lattice-index share of this product (see lattice_index)
+};
+struct FactList {
+  const double* u1;  // distinct first demands, distinct second demands
+  const double* u2;
+  const int* idx;    // per pair j: k1 | k2 << 16
+  int nu1, nu2;
+};
+
+// V_{t+1} on the lattice: vdense[lattice index of state k] = v[k].  The backward pass of the bitmap path ranks every successor
+// (a gather of the bitmap word and its prefix) and then gathers the value by that rank: two dependent reads per cell, which is
+// what binds the long horizons (MultiItemCashXR with four periods: the 1.5e12 cells of period 3 took 8 of 11.4 s).  Where the
+// lattice's box is small enough for 8 bytes per POINT (<= SDPGPU_MULTI_DENSE_GB, default 16 GB of the 288), the values are laid
+// out by lattice index and a cell reads its successor's value directly.  Only reachable points are ever written or read.
+__global__ __launch_bounds__(256) void dense_scatter_kernel(Lattice L, const Tuple* __restrict__ states, int64_t n,
+                                                           const double* __restrict__ v, double* __restrict__ vdense) {
+  const int64_t k = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (k < n) vdense[lattice_index(L, states[k])] = v[k];
+}
+
+constexpr int kFactThreads = 512;  // eight waves share a state's tables: twice the waves per compute unit for the same LDS
+template <int MODEL, bool LAST>
+__global__ __launch_bounds__(kFactThreads) void backward_fact_kernel(MLParams P, const Tuple* __restrict__ states, int64_t s_first,
+                                                           int64_t n_states, FactList F, const double* __restrict__ prob,
+                                                           const double* __restrict__ v_next, const int* __restrict__ uid,
+                                                           double* __restrict__ v_out, int* __restrict__ act_out,
+                                                           unsigned long long* __restrict__ cell_count, Lattice L,
+                                                           const uint2* __restrict__ lat_rank, const double* __restrict__ vdense) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int NA = P.qb * P.qb;
+  double* s_q = reinterpret_cast<double*>(smem);  // Q(s, a)
+  double* s_p = s_q + NA;
+  // the tables as separate arrays, [distinct demand][order index]: the lanes of a wave are consecutive second order quantities
+  // (and at most two first ones), so a read of a pair's entries is 64 consecutive 8-byte words -- as [order][demand] records of
+  // 24 bytes the lanes were 384 bytes apart, two LDS banks for 64 lanes (measured: 6x slower than round 3's kernel)
+  const int n_e = P.qb * (F.nu1 + F.nu2);
+  double* s_rev = s_p + P.nd;            // [nu1][qb] then [nu2][qb]
+  double* s_w = s_rev + n_e;
+  long long* s_lat = reinterpret_cast<long long*>(s_w + n_e);
+  int* s_idx = reinterpret_cast<int*>(s_lat + (LAST ? 0 : n_e));
+  int* s_off = s_idx + P.nd;
+  const int64_t s = s_first + blockIdx.x;
+  if (s >= n_states) return;
+  const Tuple st = states[s];
+  const int tid = threadIdx.x;
+  for (int j = tid; j < P.nd; j += kFactThreads) {
+    s_p[j] = prob[j];
+    s_idx[j] = F.idx[j];
+  }
+  for (int e = tid; e < P.qb * (F.nu1 + F.nu2); e += kFactThreads) {
+    const bool first = e < P.qb * F.nu1;
+    const int ee = first ? e : e - P.qb * F.nu1;
+    const int nu = first ? F.nu1 : F.nu2;
+    const int ai = ee / nu, k = ee - ai * nu;
+    const double d = first ? F.u1[k] : F.u2[k];
+    const double x = first ? st.i1 : st.i2;
+    // the level the demand meets: model 1 x_k + action_k (MultiItemCash.java:84-85), model 2 the order-up-to level
+    // y_k = (int) x_k + i (MultiItemCashXR.java:95-103, :113-114)
+    const double level = MODEL == 2 ? (double)((int)x + ai) : x + (double)ai;
+    const double end = jmax(0.0, level - d);
+    FactSide t;
+    t.rev = P.price[first ? 0 : 1] * (level - end);
+    t.lat = 0;
+    const int slot = (first ? 0 : P.qb * F.nu1) + k * P.qb + ai;
+    if constexpr (LAST) {
+      t.w = P.sal[first ? 0 : 1] * end;
+    } else {
+      // the transition's own end inventory: upper clamp on product 1 only, lower clamp on product 2 only, (int) cast
+      double n = end;
+      if (first)
+        n = n > P.max_inventory ? P.max_inventory : n;
+      else
+        n = n < P.min_inventory ? P.min_inventory : n;
+      n = (double)(int)n;
+      t.w = P.vari[first ? 0 : 1] * n;  // (model 2: nextR = (int) nextCash + variCost[0] * n1 + variCost[1] * n2)
+      const long long i = (long long)n;
+      t.lat = first ? (i * L.nr + L.skew1 * i) * L.n2 : L.skew2 * i * L.n2 + i;
+    }
+    s_rev[slot] = t.rev;
+    s_w[slot] = t.w;
+    if constexpr (!LAST) s_lat[slot] = t.lat;
+  }
+  __syncthreads();
+  int n_offered = NA;
+  if constexpr (MODEL == 1) {  // the offered prefix of every row of the action box (see backward_kernel)
+    if (tid < P.qb) {
+      int n2 = 0;
+      while (n2 < P.qb && mc_feasible(P, st, tid, n2)) ++n2;
+      s_off[tid + 1] = n2;
+    }
+    __syncthreads();
+    if (tid == 0) {
+      s_off[0] = 0;
+      for (int i = 0; i < P.qb; ++i) s_off[i + 1] += s_off[i];
+    }
+    __syncthreads();
+    n_offered = s_off[P.qb];
+    if (tid == 0 && cell_count) atomicAdd(cell_count, (unsigned long long)n_offered * (unsigned long long)P.nd);
+  }
+  auto offered_pair = [&](int k, int& a1, int& a2) {
+    int lo_r = 0, hi_r = P.qb - 1;
+    while (lo_r < hi_r) {
+      const int mid = (lo_r + hi_r + 1) >> 1;
+      if (s_off[mid] <= k) lo_r = mid; else hi_r = mid - 1;
+    }
+    a1 = lo_r;
+    a2 = k - s_off[lo_r];
+  };
+  const double ini_cash = MODEL == 2 ? st.cash - P.vari[0] * st.i1 - P.vari[1] * st.i2 : st.cash;  // (model 2: initialCash)
+  const double pdisc = P.discount;
+  // NI actions of a lane at a time (k = tid + 256 i), demand pairs in the outer loop: the pair's index word and probability are
+  // read once per lane, every accumulator takes its addends demand index ascending
+  constexpr int NI = 5;  // (512 threads x 5: the 2500 order pairs of Qbound 50 in one pass)
+  for (int k0 = 0; k0 < n_offered; k0 += kFactThreads * NI) {
+    int r1[NI], r2[NI];  // slot of (distinct demand 0, this action's order index): + k * qb per pair
+    double base[NI], acc[NI];
+    const int* urow[NI];
+#pragma unroll
+    for (int i = 0; i < NI; ++i) {
+      const int k = k0 + tid + kFactThreads * i;
+      int a1 = 0, a2 = 0;
+      if (k < n_offered) {
+        if constexpr (MODEL == 1) {
+          offered_pair(k, a1, a2);
+        } else {
+          a1 = k / P.qb;
+          a2 = k - a1 * P.qb;
+        }
+      }
+      r1[i] = a1;
+      r2[i] = P.qb * F.nu1 + a2;
+      if constexpr (MODEL == 1) {
+        const double orderingCost1 = P.vari[0] * (double)a1, orderingCost2 = P.vari[1] * (double)a2;
+        base[i] = orderingCost1 + orderingCost2;  // orderingCosts
+      } else {
+        const double y1 = (double)((int)st.i1 + a1), y2 = (double)((int)st.i2 + a2);
+        const double orderingCostY1 = P.vari[0] * y1, orderingCostY2 = P.vari[1] * y2;
+        base[i] = P.one_minus_deposit * (st.cash - (orderingCostY1 + orderingCostY2));
+      }
+      acc[i] = 0.0;
+      urow[i] = uid ? uid + ((int64_t)s * NA + (a1 * P.qb + a2)) * P.nd : nullptr;
+    }
+#pragma unroll 2
+    for (int j = 0; j < P.nd; ++j) {
+      const int kk = s_idx[j];
+      const double p = s_p[j];
+      const int o1 = (kk & 0xffff) * P.qb, o2 = (kk >> 16) * P.qb;
+#pragma unroll
+      for (int i = 0; i < NI; ++i) {
+        FactSide e1, e2;
+        e1.rev = s_rev[r1[i] + o1];
+        e2.rev = s_rev[r2[i] + o2];
+        e1.w = s_w[r1[i] + o1];
+        e2.w = s_w[r2[i] + o2];
+        const double revenue = e1.rev + e2.rev;
+        double imm;
+        if constexpr (MODEL == 1) {
+          const double sal = LAST ? e1.w + e2.w : 0.0;
+          imm = revenue - base[i] + sal;  // MultiItemCash.java:98
+        } else {
+          const double sal = LAST ? e1.w + e2.w : 0.0;
+          imm = revenue + base[i] + sal - ini_cash;  // MultiItemCashXR.java:127
+        }
+        acc[i] += p * imm;
+        if constexpr (!LAST) {
+          int id;
+          if (lat_rank) {
+            double nc = ini_cash + imm;  // (model 1: s.cash + immediate; model 2: initialCash + immediate)
+            nc = nc > P.max_cash ? P.max_cash : nc;
+            nc = nc < P.min_cash ? P.min_cash : nc;
+            long long r;
+            if constexpr (MODEL == 2)
+              r = (long long)(int)((double)(int)nc + e1.w + e2.w);  // nextR (inside the lattice's box: below 2^31)
+            else
+              r = (long long)(int)nc;
+            const long long li = s_lat[r1[i] + o1] + s_lat[r2[i] + o2] +
+                                 (long long)((unsigned long long)(unsigned)(r - L.r0) * (unsigned)L.n2);
+            if (vdense) {  // V_{t+1} laid out on the lattice itself: one gather instead of rank word, then value
+              acc[i] += p * pdisc * vdense[li];
+              continue;
+            }
+            id = lattice_rank(lat_rank, li);
+          } else {
+            id = urow[i][j];
+          }
+          acc[i] += p * pdisc * v_next[id];
+        }
+      }
+    }
+#pragma unroll
+    for (int i = 0; i < NI; ++i) {
+      const int k = k0 + tid + kFactThreads * i;
+      if (k < n_offered) s_q[k] = acc[i];
+    }
+  }
+  __syncthreads();
+  if (tid < 64) {  // `if (actionValues[i] > val + 0.1)` in action order, as in backward_kernel
+    double val = -1.7976931348623157e308;
+    int best = 0;
+    for (int base_k = 0; base_k < n_offered; base_k += 64) {
+      const int a = base_k + tid;
+      const double q = a < n_offered ? s_q[a] : -1.7976931348623157e308;
+      int from = 0;
+      while (true) {
+        const unsigned long long m = __ballot(a < n_offered && tid >= from && q > val + 0.1);
+        if (!m) break;
+        const int first = __ffsll((long long)m) - 1;
+        val = __shfl(q, first, 64);
+        best = base_k + first;
+        from = first + 1;
+      }
+    }
+    if (tid == 0) {
+      if constexpr (MODEL == 1) {
+        int a1, a2;
+        offered_pair(best, a1, a2);
+        best = a1 * P.qb + a2;
+      }
+      v_out[s] = val;
+      act_out[s] = best;
+    }
+  }
+}
+
 // ---- backward, lead-time family (model 0): ONE WAVE per state ------------------------------------------------------------
 // Round 3's form -- a 256-thread workgroup per state, Q(s, .) in LDS, two barriers, then the first wave alone scanning the 2500
 // action values while three waves hold their registers -- ran the recorded instances (1.7e7 period-T states x 2500 order pairs x
@@ -719,7 +956,7 @@ __global__ __launch_bounds__(256) void backward_lead_wave_kernel(MLParams P, con
   do {                                                                                   \
     hipError_t e_ = (expr);                                                              \
     if (e_ != hipSuccess) {                                                              \
-      g_ml_error = std::string(#expr) + ": " + hipGetErrorString(e_);                    \
+      g_ml_error = std::string(#expr) + " (sdpgpu_sparse.hip:" + std::to_string(__LINE__) + "): " + hipGetErrorString(e_); \
       goto fail;                                                                         \
     }                                                                                    \
   } while (0)
@@ -805,6 +1042,8 @@ int sparse_solve(const SparseProblem& sp, double* final_value, int32_t* q1, int3
   double *d_vcur = nullptr, *d_vnext = nullptr;
   int* d_act = nullptr;
   unsigned long long* d_cells = nullptr;
+  double* d_vdense = nullptr;  // backward_fact_kernel: V_{t+1} by lattice index (dense_scatter_kernel)
+  char* d_fact = nullptr;  // backward_fact_kernel: the period's distinct demands and the pairs' index words
   hipEvent_t ev0 = nullptr, ev1 = nullptr;
   int64_t total_cells = 0;
   int rc = SDPGPU_ERR_DEVICE;
@@ -959,6 +1198,7 @@ int sparse_solve(const SparseProblem& sp, double* final_value, int32_t* q1, int3
       if (d_act) (void)hipFree(d_act);
       d_act = nullptr;
       ML_TRY(hipMalloc((void**)&d_act, (size_t)n_states[t] * 4));
+      bool fact_done = false;
       const size_t smem = (size_t)NA * 8 + (size_t)nd * (sizeof(DemandTerms) + 8) + (size_t)(P.qb + 1) * 4;
       // (Q(s, a) of every action pair of a state sits in LDS: Qbound up to ~140 within the 160 KiB of a compute unit)
       constexpr size_t kLdsPerCU = 160 * 1024;  // (gfx950; sdpgpu_internal.hpp has the same figure for the grid kernels)
@@ -972,8 +1212,76 @@ int sparse_solve(const SparseProblem& sp, double* final_value, int32_t* q1, int3
       }
       if (smem > 64 * 1024)  // above the legacy limit of a launch: raise the kernel's dynamic-LDS limit
         ML_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(backward_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
+      // models 1 / 2: the factored kernel when the period's pair list has few distinct first / second demands and the tables
+      // fit the LDS (backward_fact_kernel); SDPGPU_MULTI_FACT=0: the per-cell lambdas of round 3
+      if (P.model != 0 && !(std::getenv("SDPGPU_MULTI_FACT") && std::atoi(std::getenv("SDPGPU_MULTI_FACT")) == 0)) {
+        std::vector<double> u1, u2;
+        std::vector<int> idx((size_t)nd);
+        bool ok = true;
+        for (int j = 0; j < nd && ok; ++j) {
+          const double2 d = h_dem[(size_t)sp.off[(size_t)t] + j];
+          size_t k1 = 0, k2 = 0;
+          while (k1 < u1.size() && u1[k1] != d.x) ++k1;
+          if (k1 == u1.size()) u1.push_back(d.x);
+          while (k2 < u2.size() && u2[k2] != d.y) ++k2;
+          if (k2 == u2.size()) u2.push_back(d.y);
+          ok = u1.size() <= 4096 && u2.size() <= 4096;
+          idx[(size_t)j] = (int)k1 | ((int)k2 << 16);
+        }
+        const size_t smem_f = (size_t)NA * 8 + (size_t)nd * 12 + (size_t)P.qb * (u1.size() + u2.size()) * (P.is_last ? 16 : 24) +
+                              (size_t)(P.qb + 1) * 4 + 16;
+        if (ok && smem_f <= kLdsPerCU) {
+          if (d_fact) (void)hipFree(d_fact);
+          d_fact = nullptr;
+          const size_t bytes = (u1.size() + u2.size()) * 8 + (size_t)nd * 4;
+          ML_TRY(hipMalloc((void**)&d_fact, bytes));
+          ML_TRY(hipMemcpy(d_fact, u1.data(), u1.size() * 8, hipMemcpyHostToDevice));
+          ML_TRY(hipMemcpy(d_fact + u1.size() * 8, u2.data(), u2.size() * 8, hipMemcpyHostToDevice));
+          ML_TRY(hipMemcpy(d_fact + (u1.size() + u2.size()) * 8, idx.data(), (size_t)nd * 4, hipMemcpyHostToDevice));
+          if (d_vdense) (void)hipFree(d_vdense);
+          d_vdense = nullptr;
+          if (!P.is_last && d_lat_rank[t]) {
+            double cap_gb = 16.0;
+            if (const char* e = std::getenv("SDPGPU_MULTI_DENSE_GB")) cap_gb = std::atof(e);
+            if ((double)sp.lat.bits * 8.0 <= cap_gb * 1e9 && hipMalloc((void**)&d_vdense, (size_t)sp.lat.bits * 8) == hipSuccess) {
+              hipLaunchKernelGGL(dense_scatter_kernel, dim3((unsigned)((n_states[t + 1] + 255) / 256)), dim3(256), 0, 0, sp.lat,
+                                 d_states[t + 1], n_states[t + 1], d_vnext, d_vdense);
+              ML_TRY(hipGetLastError());
+            } else {
+              (void)hipGetLastError();  // (no room: ranks and values, as before)
+              d_vdense = nullptr;
+            }
+          }
+          FactList F;
+          F.u1 = reinterpret_cast<const double*>(d_fact);
+          F.u2 = F.u1 + u1.size();
+          F.idx = reinterpret_cast<const int*>(F.u2 + u2.size());
+          F.nu1 = (int)u1.size();
+          F.nu2 = (int)u2.size();
+#define ML_FACT(MD, LS)                                                                                                      \
+  do {                                                                                                                      \
+    if (smem_f > 64 * 1024)                                                                                                 \
+      ML_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(backward_fact_kernel<MD, LS>),                              \
+                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem_f));                                \
+    for (int64_t first = 0; first < n_states[t]; first += (int64_t)1 << 21) {                                               \
+      const int64_t nb = std::min<int64_t>((int64_t)1 << 21, n_states[t] - first);                                          \
+      hipLaunchKernelGGL((backward_fact_kernel<MD, LS>), dim3((unsigned)nb), dim3(kFactThreads), smem_f, 0, P, d_states[t], first, \
+                         n_states[t], F, d_prob + sp.off[(size_t)t], d_vnext, d_uid[t], d_vcur, d_act, d_cells, sp.lat,     \
+                         d_lat_rank[t], d_vdense);                                                                          \
+      ML_TRY(hipGetLastError());                                                                                            \
+    }                                                                                                                       \
+  } while (0)
+          if (P.model == 1) {
+            if (P.is_last) ML_FACT(1, true); else ML_FACT(1, false);
+          } else {
+            if (P.is_last) ML_FACT(2, true); else ML_FACT(2, false);
+          }
+#undef ML_FACT
+          fact_done = true;
+        }
+      }
       // the lead-time family: a wave per state (backward_lead_wave_kernel); SDPGPU_MULTI_WAVE=0: round 3's workgroup per state
-      const bool lead_wave = P.model == 0 && NA <= 4096 && !(std::getenv("SDPGPU_MULTI_WAVE") && std::atoi(std::getenv("SDPGPU_MULTI_WAVE")) == 0);
+      const bool lead_wave = !fact_done && P.model == 0 && NA <= 4096 && !(std::getenv("SDPGPU_MULTI_WAVE") && std::atoi(std::getenv("SDPGPU_MULTI_WAVE")) == 0);
       if (lead_wave) {
         const size_t smem_w = (size_t)nd * (4 * sizeof(DemandTerms) + 8);
         for (int64_t first = 0; first < n_states[t]; first += (int64_t)1 << 24) {  // 4M workgroups of four states
@@ -986,7 +1294,7 @@ int sparse_solve(const SparseProblem& sp, double* final_value, int32_t* q1, int3
                                n_states[t], d_dem + sp.off[(size_t)t], d_prob + sp.off[(size_t)t], d_vnext, d_uid[t], d_vcur, d_act);
           ML_TRY(hipGetLastError());
         }
-      } else
+      } else if (!fact_done)
       // a dispatch carries at most 2^32 work-items: batches of 4M workgroups (2^30 lanes)
       for (int64_t first = 0; first < n_states[t]; first += (int64_t)1 << 22) {
         const int64_t nb = std::min<int64_t>((int64_t)1 << 22, n_states[t] - first);
@@ -1075,6 +1383,7 @@ fail:
   if (d_vnext) (void)hipFree(d_vnext);
   if (d_act) (void)hipFree(d_act);
   if (d_cells) (void)hipFree(d_cells);
+  if (d_fact) (void)hipFree(d_fact);
   if (ev0) (void)hipEventDestroy(ev0);
   if (ev1) (void)hipEventDestroy(ev1);
   return rc;
