@@ -69,6 +69,20 @@ def test_headline_is_the_target_grid_with_secondaries():
     names = [s["workload"] for s in r["secondary"]]
     assert any(n.startswith("cfg2_clsp_10000x200x100x52") for n in names) and any(n.startswith("cfg3_cash") for n in names)
     assert any(n.startswith("cfg3t_cash_tenths") for n in names) and any(n.startswith("cfg4_leadtime") for n in names)
+    # round 4: configs[4] at full width, the SURVEY 8(f)-3 families at the sizes of the reference's slowest drivers, the 8(f)-4 mode
+    for prefix in ("cfg5_f1_100000000x500x200x3", "f5_spl_", "staff_testing0", "custom_clsp_10000x200x100x52", "multilead_kat2",
+                   "separable_target_f1_1000000x500x200x6"):
+        assert any(n.startswith(prefix) for n in names), (prefix, names)
     for s in r["secondary"]:
-        assert s["parity_gate"]["status"] == "ok"
-        _check_roofline(s["roofline"])
+        assert s["parity_gate"]["status"] == "ok", s["workload"]
+        assert s["value"] > 0 and s["ms_per_step"] > 0
+        if s["workload"].startswith("multilead"):  # (a solve, not a sweep of launches: its own roofline block)
+            rf = s["roofline"]
+            assert rf["bound"] == "valu-issue" and (rf["frac"] is None or 0.0 < rf["frac"] <= 1.0)
+            assert s["parity_gate"]["final_cash"] == -76.56 and s["parity_gate"]["first_order"] == [30, 15]
+        else:
+            _check_roofline(s["roofline"])
+    sep = [s for s in r["secondary"] if s["workload"].startswith("separable_target")][0]
+    assert sep["speedup_over_brute_force"] > 3 and abs(sep["ms_per_sweep"] - sep["ms_per_step"]) < 1e-9
+    assert sep["parity_gate"]["worst_relative_difference"] <= 1e-9
+    assert r["build"]["match"] is True and len(r["build"]["build_id"]) == 16
