@@ -54,11 +54,12 @@ FAMILY_NAME = {"target": "F1 backorder (capacitated.CLSP.f lambdas)", "cfg2": "F
                "f5_spl": "F5 cash + lead time (SingleProductLeadtime.main via CashLeadtimeRecursion)",
                "staff": "F7 workforce (WorkforceTesting.main[0] via StaffRecursion, level-dependent pmf)",
                "custom_clsp": "user lambdas as HIP text (CLSP's, through sdpgpu_create_custom / hipRTC)",
+               "custom_clsp_level": "user lambdas of the declared LEVEL SHAPE (CLSP's cost functions as HIP text, tabulated, on the F1 window kernel)",
                "separable_target": "F1 backorder, OPT-IN separable mode (values to 1e-9, not the bit-exact path)",
                "multilead_kat2": "two-product overdraft with lead time (MultiProductLeadtime via CashRecursionMultiLead)"}
 REFERENCE_FLOPS_PER_CELL = {"target": 14, "cfg2": 14, "cfg5": 14, "cfg4": 14, "cfg4p": 14, "cfg3": 25, "cfg3t": 25}
 # the entries of `secondary` beyond the BASELINE configs: configs[4] at full width and the SURVEY 8(f)-3 / 8(f)-4 rows
-FAMILY_WORKLOADS = ("f5_spl", "staff", "custom_clsp", "separable_target", "multilead_kat2")
+FAMILY_WORKLOADS = ("f5_spl", "staff", "custom_clsp", "custom_clsp_level", "separable_target", "multilead_kat2")
 
 
 def parse_args():
@@ -68,7 +69,7 @@ def parse_args():
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--workload", default="target",
                     help="target (default: 1e6 x 500 x 200, T = 6) | cfg2 | cfg3 | cfg3t | cfg4 | cfg4p | cfg5 (1e8 states) | "
-                         "f5_spl | staff | custom_clsp | separable_target | multilead_kat2 (N = 1 only)")
+                         "f5_spl | staff | custom_clsp | custom_clsp_level | separable_target | multilead_kat2 (N = 1 only)")
     ap.add_argument("--states", type=int, default=0, help="override the state count of the F1 grids (target/cfg2/cfg5)")
     ap.add_argument("--periods", type=int, default=0, help="override the horizon")
     ap.add_argument("--weak", action="store_true",
@@ -555,7 +556,8 @@ def run_single(sia, torch, dev, name, w, steps, warmup, kernel, gate_cells, no_g
     if ping_pong:
         out["tables"] = "two ping-pong value tables (store_all_values = 0), as the full 100-period horizon runs"
     if getattr(w, "custom_source", None):
-        out["kernel"] = "user lambdas compiled with hipRTC around the generic period loop"
+        out["kernel"] = ("user cost functions compiled with hipRTC, tabulated per period; the library's F1 window kernel reads the tables"
+                         if int(st.kernel_used) == 2 else "user lambdas compiled with hipRTC around the generic period loop")
     if name == "separable_target":
         out["value_is"] = ("brute-force-equivalent cells/s: the cells of the (state x action x demand) grid / time -- the mode "
                            "evaluates O((S + A) D + S A) terms instead; compare `ms_per_step` with the headline's")
@@ -764,7 +766,8 @@ def main():
             # the sizes of the reference's slowest drivers and the 8(f)-4 mode -- each gated like the rest
             sec.append(run_single(sia, torch, dev, "cfg5", make_workload("cfg5", 1, periods=3), 1, 1, 0, args.gate_cells / 8,
                                   args.no_gate, ping_pong=True, min_warmup=1))
-            for name, st_, wu_ in (("f5_spl", 3, 1), ("staff", 20, 2), ("custom_clsp", 10, 2), ("multilead_kat2", 3, 0)):
+            for name, st_, wu_ in (("f5_spl", 3, 1), ("staff", 20, 2), ("custom_clsp", 10, 2), ("custom_clsp_level", 100, 10),
+                                   ("multilead_kat2", 3, 0)):
                 ws = None if name == "multilead_kat2" else make_workload(name, 1)
                 sec.append(run_single(sia, torch, dev, name, ws, st_, wu_, 0, args.gate_cells / 6, args.no_gate))
             sep = run_single(sia, torch, dev, "separable_target", make_workload("separable_target", 1), 5, 1, 0,

@@ -277,6 +277,22 @@ void sdpgpu_destroy(sdpgpu_handle* h);
  * sdp_transition are still required (the reachable-set pass and sdpgpu_eval_states' host twins use them); the
  * natural way to write them is as calls of sdp_cell.
  *
+ * ABI 6, optional -- the LEVEL SHAPE: a text that says `#define SDP_SHAPE_LEVEL 1` and defines, INSTEAD of the three lambdas,
+ *   __device__ double sdp_action_cost(const sdp_ctx& c, double action);
+ *   __device__ double sdp_level_cost(const sdp_ctx& c, double level);
+ * declares its lambdas to be
+ *   immediateValue  = sdp_action_cost(action) + sdp_level_cost(x + action - demand)      (one addition of the two terms),
+ *   stateTransition = x + action - demand, clamped to [min_inventory, max_inventory] as the descriptor says (upper, then lower),
+ *   feasible actions = every order 0, step, ... max_order_quantity in every state
+ * -- the shape of capacitated.CLSP's lambdas (CLSP.java:251-272) and of the period-1-special second Recursion of CLSPforDraw
+ * (CLSPforDraw.java:146-169), with any piecewise, period-dependent costs inside the two functions.  desc->family must be
+ * BACKORDER.  The library compiles the two functions with hipRTC, lets them tabulate M(level) and c(action) for every period
+ * once (kernel sdp_custom_tabulate), and runs its F1 window kernel from the tables: arbitrary cost closures at the built-in
+ * family's speed, and -- each table entry being the user's function of the very level / action the reference would hand it,
+ * joined by the one declared addition -- the tables' values are the reference's doubles.  kernel = SDPGPU_KERNEL_GATHER (and
+ * sdpgpu_eval_states, sdpgpu_reachable) run the same text through the generic loop; the library forms the three lambdas from
+ * the two functions as stated above.
+ *
  * with `struct sdp_ctx { int period; int T; double step; const double* params; }` (period = state.getPeriod(),
  * params = the n_params doubles given here: the constants the Java lambdas close over) and the helpers
  * sdp_max / sdp_min / sdp_round / sdp_trunc (java.lang.Math.max / min / round and the (int) cast).

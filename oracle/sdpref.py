@@ -348,6 +348,26 @@ using std::fmax; using std::fmin; using std::floor; using std::trunc; using std:
 #line 1 "user_functor"
 """
 _HOST_WRAPPERS = r"""
+#ifdef SDP_SHAPE_LEVEL
+// a text of the LEVEL SHAPE (sdp_action_cost + sdp_level_cost, include/sdpgpu.h): the three lambdas of the generic loop are
+// formed from it exactly as the product's engine source forms them (csrc/sdp_custom_src.hpp); SDP_LEVEL_* come from the
+// descriptor (custom_functor(..., level=desc))
+static inline int sdp_feasible_count(const sdp_ctx& c, double x, double cash, double preq) { return SDP_LEVEL_NACT; }
+static inline double sdp_immediate(const sdp_ctx& c, double x, double cash, double preq, double action, double randomDemand) {
+  return sdp_action_cost(c, action) + sdp_level_cost(c, x + action - randomDemand);
+}
+static inline void sdp_transition(const sdp_ctx& c, double x, double cash, double preq, double action, double randomDemand,
+                                  double& nx, double& ncash, double& npreq) {
+  double n = x + action - randomDemand;
+  if (SDP_LEVEL_CLAMP) {
+    n = n > SDP_LEVEL_MAX ? SDP_LEVEL_MAX : n;
+    n = n < SDP_LEVEL_MIN ? SDP_LEVEL_MIN : n;
+  }
+  nx = n;
+  ncash = 0;
+  npreq = 0;
+}
+#endif
 extern "C" int sdpref_user_count(const sdp_ctx* c, double x, double cash, double preq) {
   return sdp_feasible_count(*c, x, cash, preq);
 }
@@ -377,10 +397,16 @@ extern "C" void sdpref_user_trans(const sdp_ctx* c, double x, double cash, doubl
 class custom_functor:
     """Context manager: compile `source` for the host and make it the oracle's lambdas while the block runs."""
 
-    def __init__(self, source: str, params=()):
+    def __init__(self, source: str, params=(), level=None):
+        """level: the descriptor of a text that declares SDP_SHAPE_LEVEL (its action count and clamp are the descriptor's)."""
         import hashlib
         import tempfile
-        text = _HOST_PRELUDE + source + "\n" + _HOST_WRAPPERS
+        defs = ""
+        if level is not None:
+            nact = int(level.max_order_quantity / level.step) + 1
+            defs = (f"#define SDP_LEVEL_NACT {nact}\n#define SDP_LEVEL_CLAMP {1 if level.clamp_inventory else 0}\n"
+                    f"#define SDP_LEVEL_MIN {float(level.min_inventory).hex()}\n#define SDP_LEVEL_MAX {float(level.max_inventory).hex()}\n")
+        text = defs + _HOST_PRELUDE + source + "\n" + _HOST_WRAPPERS
         tag = hashlib.sha1(text.encode()).hexdigest()[:16]
         d = os.path.join(tempfile.gettempdir(), "sdpref_custom")
         os.makedirs(d, exist_ok=True)

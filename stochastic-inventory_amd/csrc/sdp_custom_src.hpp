@@ -74,6 +74,27 @@ static_assert(sizeof(CParams) == 168, "CParams layout is mirrored in sdp_custom_
 
 struct CState { double x, cash, preq; };
 
+#ifdef SDP_SHAPE_LEVEL
+// The user declared the LEVEL SHAPE: immediate value = sdp_action_cost(action) + sdp_level_cost(x + action - demand) -- one
+// addition of two separately formed terms -- every order quantity 0 .. maxOrderQuantity on offer in every state, and the
+// (clamped, as the descriptor says) level as the next inventory.  The three lambdas of the generic loop are these:
+__device__ inline int sdp_feasible_count(const sdp_ctx& c, double x, double cash, double preq) { return SDP_LEVEL_NACT; }
+__device__ inline double sdp_immediate(const sdp_ctx& c, double x, double cash, double preq, double action, double randomDemand) {
+  return sdp_action_cost(c, action) + sdp_level_cost(c, x + action - randomDemand);
+}
+__device__ inline void sdp_transition(const sdp_ctx& c, double x, double cash, double preq, double action, double randomDemand,
+                                      double& nx, double& ncash, double& npreq) {
+  double n = x + action - randomDemand;
+  if (SDP_LEVEL_CLAMP) {  // CLSP.java:257-258: upper clamp, then lower clamp
+    n = n > SDP_LEVEL_MAX ? SDP_LEVEL_MAX : n;
+    n = n < SDP_LEVEL_MIN ? SDP_LEVEL_MIN : n;
+  }
+  nx = n;
+  ncash = 0;
+  npreq = 0;
+}
+#endif
+
 __device__ inline void c_decode(const CParams& P, sdp_i64 idx, CState& s) {
   sdp_i64 ic = idx % P.cur.nc;
   sdp_i64 r = idx / P.cur.nc;
@@ -243,6 +264,26 @@ __device__ inline void custom_period_body(
     if (tid == 0 && cells) atomicAdd(cells, c);
   }
 }
+
+#ifdef SDP_SHAPE_LEVEL
+// M(m) = sdp_level_cost(lev0 + m step) for the n_m window levels of a period starting at m_min, c(a) = sdp_action_cost(a step):
+// what the library's F1 window kernel reads in place of its built-in costs (sdp_window.hpp: WinParams::m_tab / c_tab).
+extern "C" __global__ __launch_bounds__(256) void sdp_custom_tabulate(CParams P, double lev0, int m_min, int n_m,
+                                                                     double* __restrict__ m_tab, int n_a,
+                                                                     double* __restrict__ c_tab) {
+  double prm[SDP_NP];
+#pragma unroll
+  for (int i = 0; i < SDP_NP; ++i) prm[i] = P.user[i];
+  sdp_ctx U;
+  U.period = P.period;
+  U.T = P.T;
+  U.step = P.step;
+  U.params = prm;
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i < n_m) m_tab[i] = sdp_level_cost(U, lev0 + (double)(m_min + i) * P.step);
+  if (i < n_a) c_tab[i] = sdp_action_cost(U, (double)i * P.step);
+}
+#endif
 
 #define SDP_CUSTOM_PERIOD(SX)                                                                                        \
   extern "C" __global__ __launch_bounds__(256) void sdp_custom_period_##SX(                                          \

@@ -49,6 +49,15 @@ struct WinParams {
   int32_t pad0;
   int64_t partial_stride; // elements between chunk rows of the partial tables
   int64_t pol_lo, pol_hi; // states whose action index may be stored (all of them when the rows are chunk rows)
+  // USER LAMBDAS OF THE LEVEL SHAPE (sdpgpu_create_custom with SDP_SHAPE_LEVEL; nullptr: the built-in CLSP costs above).
+  // The driver declared its immediate value as  sdp_action_cost(action) + sdp_level_cost(x + action - demand)  and its
+  // transition as the (clamped) level: everything this kernel needs from the lambdas is one number per level m and one per
+  // action, tabulated for the period by the user's own compiled functions (sdp_custom_tabulate):
+  // M(m) = m_tab[m - m_tab_min], c(a) = c_tab[a].  An index outside a table is a padded cell (probability 0, or a lane
+  // beyond the tile): clamped onto the table so that what it multiplies by zero is finite.
+  const double* m_tab;
+  const double* c_tab;
+  int32_t m_tab_min, m_tab_n;
 };
 
 // LDS of a workgroup of window_f1_kernel: one window per wave (span entries of 16 B) and ONE copy of the probabilities
@@ -74,11 +83,17 @@ __device__ __forceinline__ double f64_unkey(unsigned long long k) {
 template <bool FUTURE, bool KEYED_IN>
 __device__ __forceinline__ double2 window_entry(const WinParams& W, const double* __restrict__ v_next,
                                                 const unsigned long long* __restrict__ k_next, int m) {
-  double l = W.lev0 + (double)m * W.step;
-  double hold = W.h * jmax(l, 0.0);
-  double pen = W.pi * jmax(-l, 0.0);
   double2 e;
-  e.x = hold + pen;  // one of the two is +-0: c0 + e.x == (c0 + hold) + pen bit for bit
+  if (W.m_tab) {  // (wave-uniform; staging only: once per window entry, not per cell)
+    int i = m - W.m_tab_min;
+    i = i < 0 ? 0 : (i >= W.m_tab_n ? W.m_tab_n - 1 : i);
+    e.x = W.m_tab[i];
+  } else {
+    double l = W.lev0 + (double)m * W.step;
+    double hold = W.h * jmax(l, 0.0);
+    double pen = W.pi * jmax(-l, 0.0);
+    e.x = hold + pen;  // one of the two is +-0: c0 + e.x == (c0 + hold) + pen bit for bit
+  }
   e.y = 0.0;
   if constexpr (FUTURE) {
     // CLSP.java:257-258: upper clamp, then lower clamp.  In the unclamped variant every real cell
@@ -192,7 +207,10 @@ __global__ __launch_bounds__(256) void window_f1_kernel(WinParams W, const doubl
 #pragma unroll
     for (int r = 0; r < R; ++r) {
       double a = (double)(k0 + r) * W.step;
-      c0[r] = (a > 0 ? W.K : 0.0) + W.v * a;  // fixedCost + variableCost (wave-uniform)
+      if (W.c_tab)  // (user lambdas of the level shape: the action's own cost, tabulated; a padded action reads the last entry)
+        c0[r] = W.c_tab[k0 + r < W.n_actions ? k0 + r : W.n_actions - 1];
+      else
+        c0[r] = (a > 0 ? W.K : 0.0) + W.v * a;  // fixedCost + variableCost (wave-uniform)
     }
     // slot of (lane, s, r, j):  S*lane + s + (k0 - kA) + r - j + d_pad;  window entry q at step j: base - j + q
     const int base = S * lane + (k0 - kA) + W.d_pad;

@@ -238,6 +238,11 @@ int allocate(sdpgpu_handle* h) {
     HIP_TRY(h, hipMemset(h->d_custom_cells, 0, (size_t)h->T * sizeof(unsigned long long)));
     HIP_TRY(h, hipMalloc((void**)&h->d_custom_err, sizeof(int)));
     HIP_TRY(h, hipMemset(h->d_custom_err, 0, sizeof(int)));
+    if (h->level_shape) {
+      HIP_TRY(h, hipModuleGetFunction(&h->custom_tabulate, h->custom_mod, "sdp_custom_tabulate"));
+      int rc_t = fill_level_tables(h);
+      if (rc_t) return rc_t;
+    }
   }
   h->allocated = true;
   return SDPGPU_OK;
@@ -293,7 +298,7 @@ DevParams make_params(const sdpgpu_handle* h, int period) {
 // cells of one period: sum over states of nA(s) * D  (host arithmetic, no device work)
 void count_cells(sdpgpu_handle* h, int period) {
   PeriodInfo& p = h->per[period - 1];
-  if (h->custom) return;  // counted on the device (sdpgpu_stats_get)
+  if (h->custom && !h->level_shape) return;  // counted on the device (sdpgpu_stats_get); the level shape offers every order everywhere
   if (p.cells_counted) return;  // once per handle and period: the sums below are O(S) host loops for some families
   p.cells_counted = true;
   const sdpgpu_desc& d = h->d;
@@ -384,7 +389,7 @@ int run_period_impl(sdpgpu_handle* h, int period, int part, int64_t range_lo, in
   }
   const bool ranged = range_lo >= 0;
   if (ranged) {
-    const bool f1_window = !h->custom && h->d.family == SDPGPU_FAMILY_BACKORDER &&
+    const bool f1_window = f1_like(h) && h->d.family == SDPGPU_FAMILY_BACKORDER &&
                            (h->d.kernel == SDPGPU_KERNEL_AUTO || h->d.kernel == SDPGPU_KERNEL_WINDOW) &&
                            window_eligible(h, period);
     if (!f1_window) return fail(h, SDPGPU_ERR_UNSUPPORTED, "run_period_range: only the backorder family on the window kernel has a bounded footprint");
@@ -408,7 +413,11 @@ int run_period_impl(sdpgpu_handle* h, int period, int part, int64_t range_lo, in
     if (!h->d.store_all_values && period + 2 <= h->T) h->period_done[period + 1] = 0;
     return SDPGPU_OK;
   }
-  if (h->custom) {
+  // user lambdas of the level shape run on the F1 window kernel wherever the built-in family would (tables in place of the
+  // built-in costs); anything else about them -- kernel = GATHER, a period no window plan fits -- is the generic loop below
+  const bool level_win = h->level_shape && h->d.kernel != SDPGPU_KERNEL_GATHER && window_eligible(h, period) &&
+                         ((h->win_r || h->win_s || h->win_nch) || plan_window(h, period, p.lo, p.hi).R);
+  if (h->custom && !level_win) {
     if (part == SDPGPU_PART_INTERIOR) return SDPGPU_OK;  // no bounded footprint is known for user lambdas
     if ((size_t)p.nD * 16 + 4 * 64 * 12 > kLdsLegacy)  // (a hipRTC module function keeps the 64 KiB launch limit)
       return fail(h, SDPGPU_ERR_UNSUPPORTED, "a user functor takes pmfs of at most 3900 points (period %d has %d)", period, p.nD);
@@ -545,7 +554,10 @@ bool keys_needed(sdpgpu_handle* h) {
 }
 
 int flush_api(sdpgpu_handle* h) {
-  if (h->custom) return custom_check(h);
+  if (h->custom) {
+    int rc_c = custom_check(h);
+    if (rc_c || !h->level_shape) return rc_c;  // (the level shape's window periods leave pending rows like the built-in family's)
+  }
   if (h->n_pending == 0) return SDPGPU_OK;
   int rc = ensure_device(h);
   if (rc) return rc;
@@ -639,7 +651,13 @@ int sdpgpu_create_custom(const sdpgpu_desc* desc, const char* functor_source, co
   *out = nullptr;
   if (desc->family == SDPGPU_FAMILY_STAFF) return fail(nullptr, SDPGPU_ERR_UNSUPPORTED, "a user functor takes one pmf per period; the staff family's level-dependent pmf is a built-in shape");
   if (desc->lead_time == 2) return fail(nullptr, SDPGPU_ERR_UNSUPPORTED, "a user functor has one pipeline quantity at most (lead_time 2 is a built-in shape)");
-  if (desc->kernel != SDPGPU_KERNEL_AUTO && desc->kernel != SDPGPU_KERNEL_GATHER) return fail(nullptr, SDPGPU_ERR_UNSUPPORTED, "a user functor runs on the generic kernel only");
+  // SDP_SHAPE_LEVEL in the text: the lambdas are sdp_action_cost + sdp_level_cost (see include/sdpgpu.h), evaluated from tables by
+  // the F1 window kernel; the generic loop around them stays available (kernel = GATHER, off-grid queries, the reachable set)
+  const bool level_shape = std::strstr(functor_source, "#define SDP_SHAPE_LEVEL") != nullptr;
+  if (level_shape && desc->family != SDPGPU_FAMILY_BACKORDER)
+    return fail(nullptr, SDPGPU_ERR_ARG, "SDP_SHAPE_LEVEL is the backorder family's state shape (one inventory level)");
+  if (desc->kernel != SDPGPU_KERNEL_AUTO && desc->kernel != SDPGPU_KERNEL_GATHER && !(level_shape && desc->kernel == SDPGPU_KERNEL_WINDOW))
+    return fail(nullptr, SDPGPU_ERR_UNSUPPORTED, "a user functor runs on the generic kernel only (or, with SDP_SHAPE_LEVEL, on the window kernel)");
   // compile: prelude + the user's three device functions + the engine kernels, strict fp64 (no FMA)
   std::string src = std::string(sdp::kCustomPrelude) + functor_source + "\n" + sdp::kCustomEngine;
   hiprtcProgram prog = nullptr;
@@ -653,10 +671,17 @@ int sdpgpu_create_custom(const sdpgpu_desc* desc, const char* functor_source, co
       std::string("-DSDP_SURVIVAL=") + (desc->family == SDPGPU_FAMILY_SURVIVAL ? "1" : "0"),
       std::string("-DSDP_MAXDIR=") + (desc->direction == SDPGPU_MAX ? "1" : "0"),
       std::string("-DSDP_CASH_INT_DIV=") + (desc->cash_round_int_div ? "1" : "0")};
+  // (the level shape's generic lambdas read the descriptor's action count and clamp as constants; hex floats are exact)
+  char hexbuf[2][64];
+  std::snprintf(hexbuf[0], sizeof hexbuf[0], "-DSDP_LEVEL_MIN=%a", desc->min_inventory);
+  std::snprintf(hexbuf[1], sizeof hexbuf[1], "-DSDP_LEVEL_MAX=%a", desc->max_inventory);
+  const std::string level_defs[2] = {
+      "-DSDP_LEVEL_NACT=" + std::to_string(desc->step > 0 ? (int)(desc->max_order_quantity / desc->step) + 1 : 1),
+      std::string("-DSDP_LEVEL_CLAMP=") + (desc->clamp_inventory ? "1" : "0")};
   const char* opts[] = {"--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fno-fast-math", np_def.c_str(),
                         shape_defs[0].c_str(), shape_defs[1].c_str(), shape_defs[2].c_str(), shape_defs[3].c_str(),
-                        shape_defs[4].c_str()};
-  hiprtcResult cr = hiprtcCompileProgram(prog, 11, opts);
+                        shape_defs[4].c_str(), level_defs[0].c_str(), level_defs[1].c_str(), hexbuf[0], hexbuf[1]};
+  hiprtcResult cr = hiprtcCompileProgram(prog, 15, opts);
   if (cr != HIPRTC_SUCCESS) {
     size_t n = 0;
     (void)hiprtcGetProgramLogSize(prog, &n);
@@ -676,6 +701,7 @@ int sdpgpu_create_custom(const sdpgpu_desc* desc, const char* functor_source, co
   if (rc) return rc;
   sdpgpu_handle* h = *out;
   h->custom = true;
+  h->level_shape = level_shape;
   h->custom_code.swap(code);
   h->custom_params.assign(params, params + n_params);
   return SDPGPU_OK;
@@ -720,6 +746,7 @@ void sdpgpu_destroy(sdpgpu_handle* h) {
   if (h->d_custom_params) (void)hipFree(h->d_custom_params);
   if (h->d_custom_cells) (void)hipFree(h->d_custom_cells);
   if (h->d_custom_err) (void)hipFree(h->d_custom_err);
+  if (h->d_level_tabs) (void)hipFree(h->d_level_tabs);
   if (h->custom_mod) (void)hipModuleUnload(h->custom_mod);
   comm_release(h);
   if (h->stream && h->own_stream) (void)hipStreamDestroy(h->stream);
@@ -1005,7 +1032,7 @@ int sdpgpu_plan_period(const sdpgpu_handle* hc, int32_t period, sdpgpu_plan* out
   out->kernel = SDPGPU_KERNEL_GATHER;
   // (the launcher's own predicate: an AUTO handle with action counts of the caller's for this period runs the generic kernel)
   const bool own_counts = !h->counts[(size_t)period - 1].empty();
-  const bool f1_window = !h->custom && h->d.family == SDPGPU_FAMILY_BACKORDER && window_eligible(h, period) &&
+  const bool f1_window = f1_like(h) && h->d.kernel != SDPGPU_KERNEL_GATHER && h->d.family == SDPGPU_FAMILY_BACKORDER && window_eligible(h, period) &&
                          (h->d.kernel == SDPGPU_KERNEL_WINDOW || (h->d.kernel == SDPGPU_KERNEL_AUTO && !own_counts));
   if (!f1_window) return SDPGPU_OK;
   const PeriodInfo& p = h->per[period - 1];
@@ -1037,7 +1064,7 @@ int sdpgpu_footprint(const sdpgpu_handle* hc, int32_t period, int64_t* left, int
   if (rc) return rc;
   // (clamped grids only: with per-period boxes the slabs of consecutive periods are different index ranges and a
   // widened slab is not simply "the same slab plus a margin")
-  if (h->custom || h->d.family != SDPGPU_FAMILY_BACKORDER || !h->d.clamp_inventory || h->d.kernel == SDPGPU_KERNEL_GATHER ||
+  if (!f1_like(h) || h->d.family != SDPGPU_FAMILY_BACKORDER || !h->d.clamp_inventory || h->d.kernel == SDPGPU_KERNEL_GATHER ||
       h->d.kernel == SDPGPU_KERNEL_SEPARABLE || !window_eligible(h, period))
     return fail(h, SDPGPU_ERR_UNSUPPORTED, "footprint: unbounded (only the backorder family on the window kernel reads a bounded neighbourhood)");
   int64_t l = 0, r = 0;
@@ -1428,7 +1455,7 @@ int sdpgpu_stats_get(sdpgpu_handle* h, sdpgpu_stats* out) {
   if (!modelled) out->fp64_ops_executed = 0;
   out->graph_replays = h->graph_replays;
   out->kernel_used = h->per[0].kernel_used;
-  if (!h->custom && h->d.family == SDPGPU_FAMILY_BACKORDER && h->per[0].kernel_used == SDPGPU_KERNEL_WINDOW &&
+  if (f1_like(h) && h->d.family == SDPGPU_FAMILY_BACKORDER && h->per[0].kernel_used == SDPGPU_KERNEL_WINDOW &&
       window_eligible(h, 1)) {
     const WinPlan pl = plan_window(h, 1, h->per[0].lo, h->per[0].hi);
     out->window_r = pl.R;
@@ -1436,7 +1463,7 @@ int sdpgpu_stats_get(sdpgpu_handle* h, sdpgpu_stats* out) {
   }
   if (h->allocated) {
     (void)ensure_device(h);
-    if (h->custom && h->d_custom_cells && hipStreamSynchronize(h->stream) == hipSuccess) {
+    if (h->custom && !h->level_shape && h->d_custom_cells && hipStreamSynchronize(h->stream) == hipSuccess) {
       // the action count of a user functor is only known on the device: the kernel counted its cells
       std::vector<unsigned long long> c((size_t)h->T, 0);
       if (hipMemcpy(c.data(), h->d_custom_cells, c.size() * sizeof(unsigned long long), hipMemcpyDeviceToHost) == hipSuccess) {

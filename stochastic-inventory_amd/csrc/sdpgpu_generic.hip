@@ -74,6 +74,40 @@ hipError_t launch_custom_reach(sdpgpu_handle* h, int period, const uint8_t* mcur
   return hipModuleLaunchKernel(h->custom_reach, (unsigned)blocks, 1, 1, 256, 1, 1, 0, h->stream, args, nullptr);
 }
 
+// User lambdas of the LEVEL SHAPE: per period the table M(m) = sdp_level_cost(lev0 + m step) over every level index the F1
+// window kernel may stage (cells: m = state + action - demand step in [-(D - 1), nx + A - 2]; padded steps, padded actions and
+// tail lanes reach further and are clamped onto the table by the kernel) and c(a) = sdp_action_cost(a step), a < A -- filled by
+// the user's own compiled functions, once (the lambdas' constants are fixed at create; the period is an argument).
+int fill_level_tables(sdpgpu_handle* h) {
+  const int A = h->n_actions_full;
+  h->level_tab_off.assign((size_t)h->T, 0);
+  h->level_m_min.assign((size_t)h->T, 0);
+  h->level_m_n.assign((size_t)h->T, 0);
+  size_t total = 0;
+  for (int t = 0; t < h->T; ++t) {
+    const PeriodInfo& p = h->per[(size_t)t];
+    const int D = std::max<int>(p.nD_win, p.nD);
+    h->level_m_min[(size_t)t] = -(D + 64);
+    h->level_m_n[(size_t)t] = (int32_t)std::min<int64_t>(p.g.nx + A + 2 * (int64_t)D + 1024, 2000000000LL);
+    h->level_tab_off[(size_t)t] = total;
+    total += (size_t)h->level_m_n[(size_t)t] + (size_t)A;
+  }
+  HIP_TRY(h, hipMalloc((void**)&h->d_level_tabs, total * sizeof(double)));
+  for (int t = 0; t < h->T; ++t) {
+    const PeriodInfo& p = h->per[(size_t)t];
+    sdp::CustomParams C = make_custom_params(h, t + 1);
+    double lev0 = p.g.x_lo - h->pmf_d[(size_t)t][0];  // level of m = 0: launch_window's W.lev0
+    int m_min = h->level_m_min[(size_t)t], n_m = h->level_m_n[(size_t)t], n_a = A;
+    double* m_tab = h->d_level_tabs + h->level_tab_off[(size_t)t];
+    double* c_tab = m_tab + n_m;
+    void* args[] = {&C, &lev0, &m_min, &n_m, &m_tab, &n_a, &c_tab};
+    const int64_t blocks = ((int64_t)std::max(n_m, n_a) + 255) / 256;
+    if (!grid_ok(blocks)) return fail(h, SDPGPU_ERR_UNSUPPORTED, "level tables: the grid of period %d is too long", t + 1);
+    HIP_TRY(h, hipModuleLaunchKernel(h->custom_tabulate, (unsigned)blocks, 1, 1, 256, 1, 1, 0, h->stream, args, nullptr));
+  }
+  return SDPGPU_OK;
+}
+
 // After a synchronisation point: did a user transition return a state that is not a grid point?
 int custom_check(sdpgpu_handle* h) {
   if (!h->custom || !h->d_custom_err) return SDPGPU_OK;

@@ -152,6 +152,13 @@ struct sdpgpu_handle {
   hipModule_t custom_mod = nullptr;
   hipFunction_t custom_period[3] = {nullptr, nullptr, nullptr};  // 64 / 16 / 4 states per workgroup
   hipFunction_t custom_reach = nullptr;
+  // user lambdas of the LEVEL SHAPE (SDP_SHAPE_LEVEL in the text): the F1 window kernel runs them from per-period tables
+  // M(m), c(a) filled once by the user's own compiled functions (sdp_custom_tabulate)
+  bool level_shape = false;
+  hipFunction_t custom_tabulate = nullptr;
+  double* d_level_tabs = nullptr;             // per period: [m_tab (n_m)] [c_tab (n_a)]
+  std::vector<size_t> level_tab_off;          // element offset of period t's m_tab
+  std::vector<int32_t> level_m_min, level_m_n;
   double* d_custom_params = nullptr;
   unsigned long long* d_custom_cells = nullptr;  // [T]
   int* d_custom_err = nullptr;
@@ -273,6 +280,10 @@ inline hipError_t lds_allow(K kernel, size_t smem, LdsMark* mark) {
   return e;
 }
 
+// the handle evaluates the backorder family's loop shape on the F1 window kernel: the built-in family, or user lambdas that
+// declared the level shape
+inline bool f1_like(const sdpgpu_handle* h) { return !h->custom || h->level_shape; }
+
 // ---- sdpgpu.hip ----------------------------------------------------------------------------------------
 int run_period_impl(sdpgpu_handle* h, int period, int part = SDPGPU_PART_ALL, int64_t range_lo = -1, int64_t range_hi = -1);
 void graph_drop(sdpgpu_handle* h);  // forget the captured sweep (the next sdpgpu_solve runs eagerly, the one after captures again)
@@ -296,6 +307,7 @@ hipError_t launch_custom_period(sdpgpu_handle* h, int period, const double* v_ne
                                 int64_t lo, int64_t hi, const double* qx, const double* qcash, const double* qpreq,
                                 bool count);
 int custom_check(sdpgpu_handle* h);
+int fill_level_tables(sdpgpu_handle* h);  // user lambdas of the level shape: M(m), c(a) of every period (sdp_custom_tabulate)
 int compute_reachable(sdpgpu_handle* h);
 hipError_t launch_simulate(sdpgpu_handle* h, const sdp::SimPeriod* d_per, const double* d_dem, const double* d_disc,
                            int64_t n_paths, int64_t idx0, double ini_x, double ini_cash, double ini_preq,

@@ -10,7 +10,7 @@ namespace sdpgpu_detail {
 
 // F1 / F2 on a unit-stride demand grid d_j = d_0 + j*step (supports with gaps are laid out on one, see PeriodInfo).
 bool window_eligible(const sdpgpu_handle* h, int period) {
-  if (h->custom) return false;
+  if (h->custom && !h->level_shape) return false;  // (user lambdas of the level shape run on the F1 window kernel from tables)
   if (!h->counts[(size_t)period - 1].empty()) return false;  // caller-supplied action counts: generic kernel
   if (h->d.family != SDPGPU_FAMILY_BACKORDER && h->d.family != SDPGPU_FAMILY_LEADTIME) return false;
   const PeriodInfo& p = h->per[period - 1];
@@ -466,6 +466,12 @@ hipError_t launch_window(sdpgpu_handle* h, const DevParams& P, int period, const
   if (future) {
     W.idx_off = (int32_t)((W.lev0 - h->per[period].g.x_lo) / h->d.step);
     W.next_last = (int32_t)(h->per[period].g.nx - 1);
+  }
+  if (h->level_shape) {  // user lambdas of the level shape: this period's tables (filled at allocate: sdp_custom_tabulate)
+    W.m_tab = h->d_level_tabs + h->level_tab_off[(size_t)period - 1];
+    W.c_tab = W.m_tab + h->level_m_n[(size_t)period - 1];
+    W.m_tab_min = h->level_m_min[(size_t)period - 1];
+    W.m_tab_n = h->level_m_n[(size_t)period - 1];
   }
   W.n_actions = h->n_actions_full;
   W.d_pad = pl.d_pad;

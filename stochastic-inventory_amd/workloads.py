@@ -208,6 +208,24 @@ __device__ void sdp_transition(const sdp_ctx& c, double x, double cash, double p
 """
 
 
+# The same lambdas with the LEVEL SHAPE declared (include/sdpgpu.h, SDP_SHAPE_LEVEL): immediate value = the action's cost + the
+# cost of the level the demand leaves, next inventory = that level, clamped.  The engine tabulates the two functions per period
+# with the driver's own compiled code and runs the F1 window kernel from the tables.
+CLSP_LAMBDAS_LEVEL_HIP = r"""
+#define SDP_SHAPE_LEVEL 1
+__device__ double sdp_action_cost(const sdp_ctx& c, double action) {
+  double fixedCost = action > 0 ? c.params[0] : 0;
+  double variableCost = c.params[1] * action;
+  return fixedCost + variableCost;
+}
+__device__ double sdp_level_cost(const sdp_ctx& c, double inventoryLevel) {
+  double holdingCosts = c.params[2] * sdp_max(inventoryLevel, 0);
+  double penaltyCosts = c.params[3] * sdp_max(-inventoryLevel, 0);
+  return holdingCosts + penaltyCosts;
+}
+"""
+
+
 def clsp_lambda_params(w: Workload):
     f = w.functor
     return [f.fixedOrderingCost, f.variOrderingCost, f.holdingCost, f.penaltyCost, f.minInventory, f.maxInventory,
@@ -224,10 +242,21 @@ def custom_clsp(**kw) -> Workload:
     return w
 
 
+def custom_clsp_level(**kw) -> Workload:
+    """configs[1] with CLSP's lambdas as user text of the level shape: hipRTC compiles the two cost functions, the F1 window
+    kernel runs them from tables."""
+    w = cfg2_clsp(**kw)
+    w.name = "custom_clsp_level_" + w.name[len("cfg2_clsp_"):]
+    w.note = "configs[1] through sdpgpu_create_custom, lambdas of the declared level shape"
+    w.custom_source = CLSP_LAMBDAS_LEVEL_HIP
+    w.custom_params = clsp_lambda_params(w)
+    return w
+
+
 def by_name(name: str, **kw) -> Workload:
     table = {"cfg1": cfg1_sS, "cfg2": cfg2_clsp, "cfg3": cfg3_cash, "cfg3t": cfg3_tenths, "cfg4": cfg4_leadtime,
              "cfg4p": cfg4_pipeline, "target": target_grid, "f5_spl": f5_single_product_leadtime, "staff": staff_testing,
-             "custom_clsp": custom_clsp}
+             "custom_clsp": custom_clsp, "custom_clsp_level": custom_clsp_level}
     if name in table:
         return table[name](**kw)
     if name == "cfg5":

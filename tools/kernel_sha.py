@@ -20,6 +20,8 @@ def kernel_files(workload_name: str):
         fam = STAFF
     elif n.startswith("multilead") or n.startswith("multicash") or n.startswith("multixr"):
         return sorted(SPARSE)  # (a translation unit of its own: nothing of the grid kernels' headers)
+    elif n.startswith("custom_clsp_level"):
+        fam = CUSTOM + WINDOW  # (the user's cost functions tabulated, the F1 window kernel reading the tables)
     elif n.startswith("custom"):
         fam = CUSTOM
     else:
