@@ -56,10 +56,11 @@ FAMILY_NAME = {"target": "F1 backorder (capacitated.CLSP.f lambdas)", "cfg2": "F
                "custom_clsp": "user lambdas as HIP text (CLSP's, through sdpgpu_create_custom / hipRTC)",
                "custom_clsp_level": "user lambdas of the declared LEVEL SHAPE (CLSP's cost functions as HIP text, tabulated, on the F1 window kernel)",
                "separable_target": "F1 backorder, OPT-IN separable mode (values to 1e-9, not the bit-exact path)",
+               "separable_f5": "F5 cash + lead time, OPT-IN separable mode (one row per level x + preQ; exact)",
                "multilead_kat2": "two-product overdraft with lead time (MultiProductLeadtime via CashRecursionMultiLead)"}
 REFERENCE_FLOPS_PER_CELL = {"target": 14, "cfg2": 14, "cfg5": 14, "cfg4": 14, "cfg4p": 14, "cfg3": 25, "cfg3t": 25}
 # the entries of `secondary` beyond the BASELINE configs: configs[4] at full width and the SURVEY 8(f)-3 / 8(f)-4 rows
-FAMILY_WORKLOADS = ("f5_spl", "staff", "custom_clsp", "custom_clsp_level", "separable_target", "multilead_kat2")
+FAMILY_WORKLOADS = ("f5_spl", "staff", "custom_clsp", "custom_clsp_level", "separable_target", "separable_f5", "multilead_kat2")
 
 
 def parse_args():
@@ -69,7 +70,7 @@ def parse_args():
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--workload", default="target",
                     help="target (default: 1e6 x 500 x 200, T = 6) | cfg2 | cfg3 | cfg3t | cfg4 | cfg4p | cfg5 (1e8 states) | "
-                         "f5_spl | staff | custom_clsp | custom_clsp_level | separable_target | multilead_kat2 (N = 1 only)")
+                         "f5_spl | staff | custom_clsp | custom_clsp_level | separable_target | separable_f5 | multilead_kat2 (N = 1 only)")
     ap.add_argument("--states", type=int, default=0, help="override the state count of the F1 grids (target/cfg2/cfg5)")
     ap.add_argument("--periods", type=int, default=0, help="override the horizon")
     ap.add_argument("--weak", action="store_true",
@@ -117,6 +118,10 @@ def make_workload(name: str, world: int, states: int = 0, periods: int = 0, weak
         raise SystemExit(f"--weak is defined for the F1 grids only (target/cfg2/cfg5), not {name}")
     if name == "separable_target":
         w = workloads.target_grid(**kw)
+        w.name = "separable_" + w.name
+        return w
+    if name == "separable_f5":
+        w = workloads.by_name("f5_spl", **kw)
         w.name = "separable_" + w.name
         return w
     return workloads.by_name(name, **kw)
@@ -493,7 +498,7 @@ def run_single(sia, torch, dev, name, w, steps, warmup, kernel, gate_cells, no_g
         return run_multilead(steps, no_gate)
     d = w.desc()
     d.device = dev.index
-    d.kernel = 3 if name == "separable_target" else kernel
+    d.kernel = 3 if name in ("separable_target", "separable_f5") else kernel
     if ping_pong:
         d.store_all_values = 0
     T = w.T
@@ -561,6 +566,10 @@ def run_single(sia, torch, dev, name, w, steps, warmup, kernel, gate_cells, no_g
     if name == "separable_target":
         out["value_is"] = ("brute-force-equivalent cells/s: the cells of the (state x action x demand) grid / time -- the mode "
                            "evaluates O((S + A) D + S A) terms instead; compare `ms_per_step` with the headline's")
+    if name == "separable_f5":
+        out["value_is"] = ("brute-force-equivalent cells/s: the dense grid's cells / time -- the mode evaluates one row per level "
+                           "x + preQ (the rows of a level hold identical tables) cell by cell and copies it to the others: EXACT, "
+                           "values and policy bit-identical; compare `ms_per_step` with the f5_spl entry's")
     return out
 
 
@@ -776,6 +785,13 @@ def main():
             sep["speedup_over_brute_force"] = head["ms_per_step"] / sep["ms_per_step"]
             sep["brute_force_ms_per_sweep"] = head["ms_per_step"]
             sec.append(sep)
+            f5 = [e for e in sec if e["workload"].startswith("f5_spl")][0]
+            sep5 = run_single(sia, torch, dev, "separable_f5", make_workload("separable_f5", 1), 5, 1, 0, args.gate_cells / 6,
+                              args.no_gate)
+            sep5["ms_per_sweep"] = sep5["ms_per_step"]
+            sep5["speedup_over_brute_force"] = f5["ms_per_step"] / sep5["ms_per_step"]
+            sep5["brute_force_ms_per_sweep"] = f5["ms_per_step"]
+            sec.append(sep5)
             out["secondary"] = sec
         if not args.no_cpu_baseline and args.workload not in FAMILY_WORKLOADS:
             out["cpu_baseline"] = cpu_baseline(w, args.cpu_seconds)

@@ -131,7 +131,12 @@ typedef enum sdpgpu_direction { SDPGPU_MIN = 0, SDPGPU_MAX = 1 } sdpgpu_directio
                                      F2 (lead time 1 or 2): V_t and the arg-min depend on (x + preQ[, q2]) only: one
                                      evaluation per level in the reference's operation order, O(A (nx+nq) D [nq]) for
                                      that table + one write per state.  EXACT: values and policy bit-identical to the
-                                     cell-by-cell kernels (tests/test_gpu_separable.py). */
+                                     cell-by-cell kernels (tests/test_gpu_separable.py).
+                                     F5 (cash + lead time, ABI 6): SingleProductLeadtime's lambdas read x and preQ through
+                                     x + preQ only (SingleProductLeadtime.java:82-119), so every row of a level holds the same
+                                     tables: one representative row per level through the cash row kernel, cell by cell in the
+                                     reference's order, then one copy per state -- (nx + nq - 1) rows evaluated instead of
+                                     nx nq.  EXACT; one rank only. */
 
 /*
  * Problem descriptor: everything the reference's lambdas close over.  Field names

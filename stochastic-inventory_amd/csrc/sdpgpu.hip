@@ -452,8 +452,30 @@ int run_period_impl(sdpgpu_handle* h, int period, int part, int64_t range_lo, in
     if (!h->d.store_all_values && period + 2 <= h->T) h->period_done[period + 1] = 0;
     return SDPGPU_OK;
   }
+  if (h->d.kernel == SDPGPU_KERNEL_SEPARABLE && h->d.family == SDPGPU_FAMILY_CASH_LEADTIME) {
+    // F5 (SingleProductLeadtime.java:72-119): the lambdas read the inventory and the pipeline quantity through x + preQ only, so
+    // the rows of one level hold the same values and the same arg-max: one representative row per level through the row
+    // kernel, every cell in the reference's operation order, then one copy per state.  EXACT; opt-in like the F2 mode.
+    if (h->d.world_size != 1 || p.lo != 0 || p.hi != p.S) return fail(h, SDPGPU_ERR_UNSUPPORTED, "the separable mode of the cash + lead-time family runs on one rank");
+    if (p.g.nq < 2 || !cash_row_eligible(h, period))
+      return fail(h, SDPGPU_ERR_UNSUPPORTED, "separable mode (cash + lead-time family): the grid does not fit the cash row kernel");
+    if (part == SDPGPU_PART_INTERIOR) return SDPGPU_OK;
+    hipError_t es = flush_pending(h);
+    if (es == hipSuccess) es = launch_cash_row(h, P, period, v_next, v_cur, pol, pd, pp, p.lo, p.hi, h->stream, true);
+    if (es == hipSuccess) es = launch_level_fill(h, period, v_cur, pol, h->stream);
+    if (es != hipSuccess) return fail(h, SDPGPU_ERR_DEVICE, "period %d separable kernel (cash + lead-time family): %s", period, hipGetErrorString(es));
+    p.kernel_used = SDPGPU_KERNEL_SEPARABLE;
+    if (h->profiling) {
+      HIP_TRY(h, hipEventRecord(p.ev1, h->stream));
+      p.timed = true;
+    }
+    h->period_done[period - 1] = 1;
+    h->policy_done[period - 1] = 1;
+    if (!h->d.store_all_values && period + 2 <= h->T) h->period_done[period + 1] = 0;
+    return SDPGPU_OK;
+  }
   if (h->d.kernel == SDPGPU_KERNEL_SEPARABLE) {
-    if (h->d.family != SDPGPU_FAMILY_BACKORDER) return fail(h, SDPGPU_ERR_UNSUPPORTED, "the separable mode exists for the backorder and lead-time families only");
+    if (h->d.family != SDPGPU_FAMILY_BACKORDER) return fail(h, SDPGPU_ERR_UNSUPPORTED, "the separable mode exists for the backorder, lead-time and cash + lead-time families only");
     if (h->n_actions_full > 6000) return fail(h, SDPGPU_ERR_UNSUPPORTED, "separable mode: action range exceeds the LDS tile");
     if (part == SDPGPU_PART_INTERIOR) return SDPGPU_OK;
     bool too_big = false;

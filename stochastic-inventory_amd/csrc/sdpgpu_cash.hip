@@ -301,7 +301,8 @@ hipError_t launch_cash_row_fam(const DevParams& P, bool last, bool intdiv, const
 }
 
 hipError_t launch_cash_row(sdpgpu_handle* h, const DevParams& P, int period, const double* v_next, double* v_cur,
-                           int32_t* pol, const double* pmf_d, const double* pmf_p, int64_t lo, int64_t hi, hipStream_t st) {
+                           int32_t* pol, const double* pmf_d, const double* pmf_p, int64_t lo, int64_t hi, hipStream_t st,
+                           bool levels_only) {
   if (hi <= lo) return hipSuccess;
   const PeriodInfo& p = h->per[period - 1];
   const int64_t row_lo = lo / p.g.nc, row_hi = (hi - 1) / p.g.nc;
@@ -355,6 +356,10 @@ hipError_t launch_cash_row(sdpgpu_handle* h, const DevParams& P, int period, con
   // cash_row_pair_kernel): rows of one level gather the same entries, and on one compute unit they share its vector L1.
   // SDPGPU_CASH_RW=1: one row per workgroup.
   const bool rw4 = od_pair && level_order && !(std::getenv("SDPGPU_CASH_RW") && std::atoi(std::getenv("SDPGPU_CASH_RW")) == 1);
+  if (levels_only) {  // (the caller has checked: F5, the whole grid in one slab) one representative row per level x + preQ
+    if (!level_order || row_lo != 0 || row_hi != p.g.nx * p.g.nq - 1) return hipErrorInvalidValue;
+    G.n_rows = (int32_t)(p.g.nx + p.g.nq - 1);
+  }
   G.rows_real = G.n_rows;
   if (rw4) G.n_rows = (G.n_rows + 3) / 4;
   int64_t blocks = (int64_t)G.n_rows * G.tiles_per_row;
@@ -384,18 +389,26 @@ hipError_t launch_cash_row(sdpgpu_handle* h, const DevParams& P, int period, con
     blocks = 8LL * G.nsub * G.tps * G.n_rows;
   }
   if (level_order) {
-    const int64_t key[4] = {row_lo, row_hi, p.g.nx, p.g.nq};
+    const int64_t key[4] = {row_lo, levels_only ? -2 - row_hi : row_hi, p.g.nx, p.g.nq};
     if (std::memcmp(key, h->rowperm_key, sizeof key) != 0) {
-      const int64_t n = row_hi - row_lo + 1;
+      const int64_t n = levels_only ? p.g.nx + p.g.nq - 1 : row_hi - row_lo + 1;
       std::vector<int32_t>& perm = h->rowperm_host;
       hipError_t e = hipStreamSynchronize(st);  // (an earlier launch may still read the old order)
       if (e != hipSuccess) return e;
       perm.resize((size_t)n);
-      for (int64_t i = 0; i < n; ++i) perm[(size_t)i] = (int32_t)i;
-      std::stable_sort(perm.begin(), perm.end(), [&](int32_t a, int32_t b) {
-        const int64_t ra = row_lo + a, rb = row_lo + b;
-        return ra % p.g.nx + ra / p.g.nx < rb % p.g.nx + rb / p.g.nx;
-      });
+      if (levels_only) {  // level y's representative: the row (preQ index, inventory index) = (max(0, y - (nx - 1)), y - that)
+        for (int64_t y = 0; y < n; ++y) {
+          const int64_t iq = std::max<int64_t>(0, y - (p.g.nx - 1));
+          perm[(size_t)y] = (int32_t)(iq * p.g.nx + (y - iq));
+        }
+      } else {
+        for (int64_t i = 0; i < n; ++i) perm[(size_t)i] = (int32_t)i;
+        std::stable_sort(perm.begin(), perm.end(), [&](int32_t a, int32_t b) {
+          const int64_t ra = row_lo + a, rb = row_lo + b;
+          return ra % p.g.nx + ra / p.g.nx < rb % p.g.nx + rb / p.g.nx;
+        });
+      }
+      h->units_key[0] = -1;  // (the diagonal unit order is built from this row order)
       if (h->d_rowperm) (void)hipFree(h->d_rowperm);
       h->d_rowperm = nullptr;
       e = hipMalloc((void**)&h->d_rowperm, (size_t)n * sizeof(int32_t));
@@ -565,6 +578,31 @@ hipError_t launch_cash_row(sdpgpu_handle* h, const DevParams& P, int period, con
   }
 #undef SDP_ROWARGS
   return hipErrorInvalidValue;
+}
+
+namespace {
+// every row (iq, ix) of the F5 grid takes the tables of its level's representative row (launch_cash_row, levels_only)
+__global__ __launch_bounds__(256) void level_fill_kernel(double* __restrict__ v, int32_t* __restrict__ pol, int64_t nx, int64_t nq,
+                                                         int64_t nc) {
+  const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (i >= nx * nq * nc) return;
+  const int64_t row = i / nc, ic = i - row * nc;
+  const int64_t iq = row / nx, ix = row - iq * nx, y = ix + iq;
+  const int64_t rq = y - (nx - 1) > 0 ? y - (nx - 1) : 0;
+  const int64_t rep = rq * nx + (y - rq);
+  if (rep == row) return;
+  v[i] = v[rep * nc + ic];
+  pol[i] = pol[rep * nc + ic];
+}
+}  // namespace
+
+hipError_t launch_level_fill(sdpgpu_handle* h, int period, double* v_cur, int32_t* pol, hipStream_t st) {
+  const PeriodInfo& p = h->per[period - 1];
+  const int64_t n = p.g.nx * p.g.nq * p.g.nc;
+  if (!grid_ok((n + 255) / 256)) return hipErrorInvalidValue;
+  hipLaunchKernelGGL(level_fill_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, v_cur, pol, (int64_t)p.g.nx,
+                     (int64_t)p.g.nq, (int64_t)p.g.nc);
+  return hipGetLastError();
 }
 
 }  // namespace sdpgpu_detail

@@ -327,7 +327,10 @@ hipError_t launch_cash_shift(sdpgpu_handle* h, const DevParams& P, int period, c
 bool cash_row_eligible(const sdpgpu_handle* h, int period);
 size_t cash_row_lds(int nD, int tile_pts);
 hipError_t launch_cash_row(sdpgpu_handle* h, const DevParams& P, int period, const double* v_next, double* v_cur,
-                           int32_t* pol, const double* pmf_d, const double* pmf_p, int64_t lo, int64_t hi, hipStream_t st);
+                           int32_t* pol, const double* pmf_d, const double* pmf_p, int64_t lo, int64_t hi, hipStream_t st, bool levels_only = false);
+// F5, OPT-IN separable mode: the rows of one level x + preQ hold identical tables; launch_cash_row(levels_only) evaluates one
+// representative row per level, this copies it to the level's other rows
+hipError_t launch_level_fill(sdpgpu_handle* h, int period, double* v_cur, int32_t* pol, hipStream_t st);
 
 // ---- sdpgpu_window.hip -------------------------------------------------------------------------------------
 bool window_eligible(const sdpgpu_handle* h, int period);

@@ -105,3 +105,33 @@ def test_separable_f1_above_64KiB_of_lds(sia, oracle):
     w = workloads.cfg5_scaled(S=1500, T=2, A=3000, D=400)
     worst, mismatches, states = _compare_with_oracle(sia, oracle, w)
     assert worst <= REL_TOL and mismatches <= 0.02 * states
+
+
+@pytest.mark.parametrize("wide", [False, True], ids=["row-kernel", "pair-kernel"])
+def test_separable_f5_level_collapse_is_exact(sia, oracle, wide):
+    """The cash + lead-time family (SingleProductLeadtime's lambdas) reads the state through x + preQ only: the opt-in mode
+    evaluates ONE row per level (cell by cell, the reference's order) and copies it to the level's other rows -- values and
+    policy of every state bit-identical to the oracle's dense sweep, on the one-point row kernel (short cash rows) and on the
+    two-point pair kernel with the diagonal unit order (rows of 256 cash points and more)."""
+    w = cases.f5_cash_leadtime()
+    if not wide:
+        w.functor.minCashState, w.functor.maxCashState = -1.0, 1.2  # 221 cash points: below the pair kernel's 256
+    sep = w.desc()
+    sep.kernel = sia._abi.KERNEL_SEPARABLE
+    V, pol, cells = oracle.Problem(w.desc(), w.pmf, w.overhead()).solve(nthreads=8)
+    with sia.SdpEngine(sep, w.pmf, w.overhead()) as s:
+        s.solve()
+        st = s.stats()
+        assert st.kernel_used == 3 and st.cells_evaluated == cells  # (charged the dense count; executed: one row per level)
+        for period in range(1, w.T + 1):
+            assert np.array_equal(s.values(period), V[period - 1]), period
+            assert np.array_equal(s.policy(period), pol[period - 1]), period
+
+
+def test_separable_f5_refuses_slabs(sia):
+    w = cases.f5_cash_leadtime()
+    d = w.desc()
+    d.kernel, d.rank, d.world_size = sia._abi.KERNEL_SEPARABLE, 0, 2
+    with sia.SdpEngine(d, w.pmf, w.overhead()) as s:
+        with pytest.raises(sia.SdpgpuError, match="one rank"):
+            s.run_period(w.T)  # (a sharded handle runs period by period)
