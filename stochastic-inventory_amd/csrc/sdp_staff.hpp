@@ -318,8 +318,12 @@ __global__ __launch_bounds__(64) void staff_pair_kernel(StaffParams P, const dou
 // enters an accumulator is the reference's, in the reference's order (j ascending; zero-probability steps beyond a
 // row's length add +0.0).
 // ---------------------------------------------------------------------------------------------
+// Three waves per SIMD: the (4, 4) block takes 207 VGPRs left alone (two waves); capped at 168 it spills 31 dwords to scratch and
+// runs WorkforceTesting.main's instance 3 % faster (3.86 against 3.75e12 cells/s, two runs each, same box) -- the launches of
+// that instance are short (0.2-1.4 ms, 28 tiles of states x action groups), which is what holds it, not the registers.
+// -DSDP_STAFF_WIN_ATTR= (empty) rebuilds the two-wave form.
 #ifndef SDP_STAFF_WIN_ATTR
-#define SDP_STAFF_WIN_ATTR
+#define SDP_STAFF_WIN_ATTR __attribute__((amdgpu_waves_per_eu(3, 3)))
 #endif
 template <int R, int S, bool FUTURE>
 __global__ __launch_bounds__(64) SDP_STAFF_WIN_ATTR void staff_window_kernel(StaffParams P, const double* __restrict__ pT0,
