@@ -14,7 +14,7 @@ CUSTOM = ["sdp_custom_src.hpp", "sdp_gather.hpp", "sdpgpu_generic.hip"]  # user 
 
 def kernel_files(workload_name: str):
     n = workload_name
-    if n.startswith("cfg3") or n.startswith("f5_"):
+    if n.startswith("cfg3") or n.startswith("f5_") or n.startswith("separable_f5"):
         fam = CASH
     elif n.startswith("staff"):
         fam = STAFF

@@ -19,6 +19,8 @@ from kernel_sha import kernel_source_sha  # noqa: E402  (same digest as bench.py
 
 
 def short(name):
+    if name.startswith("void "):  # (templated kernels carry their return type)
+        name = name[len("void "):]
     if name.startswith("(anonymous namespace)::"):  # the reachable-set engine's kernels (sdpgpu_sparse.hip)
         name = "sparse::" + name[len("(anonymous namespace)::"):]
     return name.split("(")[0].replace("void ", "").strip()
@@ -85,7 +87,7 @@ def main():
         "correction": "HBM bytes = 2 * FETCH_SIZE_KiB * 1024 + WRITE_SIZE_KiB * 1024 (gfx950: FETCH_SIZE counts half of a wide coalesced read)",
         "kernels": kernels,
         "bench_line": {k: bench[k] for k in ("value", "ms_per_step", "steps", "config", "parity_gate")} if bench else None,
-        "bench_per_launch_ms_events": bench["roofline"]["per_launch_ms_events"] if bench else None,
+        "bench_per_launch_ms_events": bench["roofline"].get("per_launch_ms_events") if bench else None,
         "command": "tools/pmc_collect.sh (separate rocprofv3 --pmc passes with --kernel-trace only; --kernel-trace --stats in its own run)",
     }
     # In-run calibration of the two traffic counters on byte counts this code knows exactly: key_fill_kernel
@@ -111,8 +113,12 @@ def main():
     lines = [f"{rnd} {name}: dominant kernel {dom}"]
     if bench:
         rf = bench["roofline"]
-        lines.append(f"bench line: {bench['value']:.4g} cells/s, {bench['ms_per_step']:.4f} ms per sweep, avg launch {rf['avg_launch_ms'] * 1e3:.2f} us (HIP events, un-profiled); "
-                     f"sum of per-launch events {sum(rf['per_launch_ms_events']):.4f} ms; roofline {rf['bound']} frac {rf['frac']}")
+        if "per_launch_ms_events" in rf:
+            lines.append(f"bench line: {bench['value']:.4g} cells/s, {bench['ms_per_step']:.4f} ms per sweep, avg launch {rf['avg_launch_ms'] * 1e3:.2f} us (HIP events, un-profiled); "
+                         f"sum of per-launch events {sum(rf['per_launch_ms_events']):.4f} ms; roofline {rf['bound']} frac {rf['frac']}")
+        else:  # (the reachable-set engine: a step is a whole solve)
+            lines.append(f"bench line: {bench['value']:.4g} cells/s, {bench['ms_per_step']:.4f} ms per solve (wall), device "
+                         f"{rf.get('device_ms_per_solve')} ms per solve (HIP events); roofline {rf['bound']} frac {rf['frac']}")
     for k, r in sorted(kernels.items(), key=lambda kv: -kv[1].get("rocprof", {}).get("total_ms", 0.0)):
         rp = r.get("rocprof")
         lines.append(f"-- {k}" + (f": {rp['calls']} calls, avg {rp['avg_us']:.2f} us under rocprofv3 ({rp['pct']:.1f} % of kernel time)" if rp else ""))
