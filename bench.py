@@ -389,7 +389,7 @@ def load_pmc(workload_name: str):
     return None
 
 
-def roofline_block(w, st, T, cells_rank, states_rank, dev_ms_per_sweep, per_launch_ms):
+def roofline_block(w, st, T, cells_rank, states_rank, dev_ms_per_sweep, per_launch_ms, per_launch_cells=None):
     """`dev_ms_per_sweep`: HIP-event time of one timed sweep on the launch stream (average over the timed steps)."""
     launches = T
     avg_launch_ms = dev_ms_per_sweep / launches
@@ -451,7 +451,11 @@ def roofline_block(w, st, T, cells_rank, states_rank, dev_ms_per_sweep, per_laun
             "achieved": lane_ops / 1e12, "peak": VALU_PEAK_LANE_OPS / 1e12, "unit": "T lane-op/s",
             "frac": lane_ops / VALU_PEAK_LANE_OPS,
             "dominant_launch_ms": dom_ms,
-            "valu_insts_per_cell": float(pmc["valu_insts_per_launch"]) * 64.0 / max(cells_rank / launches, 1),
+            # (the counted kernel's launches are the periods before T: priced against THEIR cells -- period T of a family may
+            # offer fewer orders, e.g. none in SingleProductLeadtime's last period)
+            "valu_insts_per_cell": float(pmc["valu_insts_per_launch"]) * 64.0 / max(
+                (sum(c for c in per_launch_cells[1:] if c > 0) / max(1, sum(1 for c in per_launch_cells[1:] if c > 0)))
+                if per_launch_cells and any(c > 0 for c in per_launch_cells[1:]) else cells_rank / launches, 1),
             "ta_busy_frac": pmc.get("ta_busy_frac"),
             "note": f"SQ_INSTS_VALU x 64 lanes per launch ({pmc['_file']}) / HIP-event launch time; every wave64 VALU "
                     "instruction holds its SIMD four cycles",
@@ -546,10 +550,11 @@ def run_single(sia, torch, dev, name, w, steps, warmup, kernel, gate_cells, no_g
         eng.set_profiling(True)
         eng.solve(sync=True)
         per_launch = [eng.period_ms(p) for p in range(T, 0, -1)]
+        per_launch_cells = [eng.period_cells(p) for p in range(T, 0, -1)]
         eng.set_profiling(False)
         cells = int(st.cells_evaluated)
         states = int(st.states_total)
-        rf = roofline_block(w, st, T, cells, states, dev_ms, per_launch)
+        rf = roofline_block(w, st, T, cells, states, dev_ms, per_launch, per_launch_cells)
         rf["sweep_issue"] = ("one hipGraphLaunch per sweep (captured inside sdpgpu_solve)" if replays >= steps
                              else "eager: one launch per period")
         rf["wall_over_device"] = (elapsed / steps * 1e3) / dev_ms if dev_ms > 0 else None

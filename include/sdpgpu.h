@@ -624,6 +624,10 @@ int sdpgpu_multixr_solve(const sdpgpu_multicash* k, double deposit_rate, double*
                          int64_t* states_per_period, int64_t* cells, double* gpu_ms);
 /* Kernel time of period t of the last solve (ms), needs sdpgpu_set_profiling(h, 1). */
 double sdpgpu_period_ms(sdpgpu_handle* h, int32_t period);
+/* ABI 6: (state, action, demand) cells of period t on this rank's slab, as sdpgpu_stats.cells_evaluated sums them over the periods
+ * run (bench.py prices a kernel's counters against the cells of ITS launches: period T of a family may offer fewer orders).  -1:
+ * not counted yet (the period has not run) or not known per period. */
+int64_t sdpgpu_period_cells(sdpgpu_handle* h, int32_t period);
 
 #if defined(__GNUC__)
 #pragma GCC visibility pop

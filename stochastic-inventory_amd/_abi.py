@@ -269,6 +269,7 @@ EXPORTS = {
                                   C.POINTER(C.c_uint8)]),
     "sdpgpu_stats_get": (C.c_int, [_P, C.POINTER(SdpgpuStats)]),
     "sdpgpu_period_ms": (C.c_double, [_P, C.c_int32]),
+    "sdpgpu_period_cells": (C.c_int64, [_P, C.c_int32]),
     "sdpgpu_plan_period": (C.c_int, [_P, C.c_int32, C.POINTER(SdpgpuPlan)]),
     "sdpgpu_multilead_solve": (C.c_int, [C.POINTER(SdpgpuMultilead), _DP, _IP, _IP, _LP, _LP, _DP]),
     "sdpgpu_multilead_last_error": (C.c_char_p, []),

@@ -1521,4 +1521,19 @@ double sdpgpu_period_ms(sdpgpu_handle* h, int32_t period) {
   return ms;
 }
 
+int64_t sdpgpu_period_cells(sdpgpu_handle* h, int32_t period) {
+  if (!h || period < 1 || period > h->T) return -1;
+  const PeriodInfo& p = h->per[period - 1];
+  if (h->custom && !h->level_shape) {  // counted on the device, one counter per period
+    if (!h->d_custom_cells || !h->period_done[period - 1]) return -1;
+    (void)ensure_device(h);
+    unsigned long long c = 0;
+    if (hipStreamSynchronize(h->stream) != hipSuccess ||
+        hipMemcpy(&c, h->d_custom_cells + (period - 1), sizeof c, hipMemcpyDeviceToHost) != hipSuccess)
+      return -1;
+    return (int64_t)c;
+  }
+  return p.cells_counted ? p.cells_rank : -1;
+}
+
 }  // extern "C"

@@ -321,3 +321,7 @@ class SdpEngine:
 
     def period_ms(self, period: int) -> float:
         return float(self._lib.sdpgpu_period_ms(self._h, period))
+
+    def period_cells(self, period: int) -> int:
+        """Cells of `period` on this rank's slab (-1: not counted)."""
+        return int(self._lib.sdpgpu_period_cells(self._h, period))
