@@ -648,13 +648,24 @@ __global__ __launch_bounds__(256) void dense_scatter_kernel(Lattice L, const Tup
 }
 
 constexpr int kFactThreads = 512;  // eight waves share a state's tables: twice the waves per compute unit for the same LDS
-template <int MODEL, bool LAST>
+// LK: where a successor's value comes from in the periods before T -- 0: the rank stored per candidate by the sorted-candidates
+// forward pass (uid), 1: the lattice's rank word, then the value by rank, 2: V_{t+1} laid out on the lattice itself.  A template
+// argument, and the loop below forms the NI actions' reads of a demand pair first, issues them together and consumes them
+// afterwards: with the three forms behind run-time branches every cell was its own basic block, one gather and one full wait
+// each -- the not-last periods of the long horizons ran at 0.27e12 cells/s on dependent reads.
+template <int MODEL, bool LAST, int LK = 0>
 __global__ __launch_bounds__(kFactThreads) void backward_fact_kernel(MLParams P, const Tuple* __restrict__ states, int64_t s_first,
                                                            int64_t n_states, FactList F, const double* __restrict__ prob,
                                                            const double* __restrict__ v_next, const int* __restrict__ uid,
                                                            double* __restrict__ v_out, int* __restrict__ act_out,
                                                            unsigned long long* __restrict__ cell_count, Lattice L,
-                                                           const uint2* __restrict__ lat_rank, const double* __restrict__ vdense) {
+                                                           const uint2* __restrict__ lat_rank, const double* __restrict__ vdense,
+                                                           unsigned int* __restrict__ mark_words, int* __restrict__ mark_oob) {
+  // LK == 3: the FORWARD pass on the lattice with the same tables -- no values, no probabilities: every (state, offered action,
+  // demand pair) marks its successor's bit (lattice_mark_kernel evaluates the whole transition lambda per cell: 3.5 of the 7.5 s
+  // of MultiItemCashXR's four periods)
+  constexpr bool MARK = LK == 3;
+  static_assert(!MARK || !LAST, "the forward pass has no period T");
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int NA = P.qb * P.qb;
   double* s_q = reinterpret_cast<double*>(smem);  // Q(s, a)
@@ -773,55 +784,84 @@ __global__ __launch_bounds__(kFactThreads) void backward_fact_kernel(MLParams P,
     for (int j = 0; j < P.nd; ++j) {
       const int kk = s_idx[j];
       const double p = s_p[j];
+      const double pg = p * pdisc;
       const int o1 = (kk & 0xffff) * P.qb, o2 = (kk >> 16) * P.qb;
+      [[maybe_unused]] long long li[NI];
 #pragma unroll
       for (int i = 0; i < NI; ++i) {
-        FactSide e1, e2;
-        e1.rev = s_rev[r1[i] + o1];
-        e2.rev = s_rev[r2[i] + o2];
-        e1.w = s_w[r1[i] + o1];
-        e2.w = s_w[r2[i] + o2];
-        const double revenue = e1.rev + e2.rev;
+        const double rev1 = s_rev[r1[i] + o1], rev2 = s_rev[r2[i] + o2];
+        const double w1 = s_w[r1[i] + o1], w2 = s_w[r2[i] + o2];
+        const double revenue = rev1 + rev2;
+        const double sal = LAST ? w1 + w2 : 0.0;
         double imm;
-        if constexpr (MODEL == 1) {
-          const double sal = LAST ? e1.w + e2.w : 0.0;
+        if constexpr (MODEL == 1)
           imm = revenue - base[i] + sal;  // MultiItemCash.java:98
-        } else {
-          const double sal = LAST ? e1.w + e2.w : 0.0;
+        else
           imm = revenue + base[i] + sal - ini_cash;  // MultiItemCashXR.java:127
-        }
-        acc[i] += p * imm;
-        if constexpr (!LAST) {
-          int id;
-          if (lat_rank) {
-            double nc = ini_cash + imm;  // (model 1: s.cash + immediate; model 2: initialCash + immediate)
-            nc = nc > P.max_cash ? P.max_cash : nc;
-            nc = nc < P.min_cash ? P.min_cash : nc;
-            long long r;
-            if constexpr (MODEL == 2)
-              r = (long long)(int)((double)(int)nc + e1.w + e2.w);  // nextR (inside the lattice's box: below 2^31)
-            else
-              r = (long long)(int)nc;
-            const long long li = s_lat[r1[i] + o1] + s_lat[r2[i] + o2] +
-                                 (long long)((unsigned long long)(unsigned)(r - L.r0) * (unsigned)L.n2);
-            if (vdense) {  // V_{t+1} laid out on the lattice itself: one gather instead of rank word, then value
-              acc[i] += p * pdisc * vdense[li];
-              continue;
-            }
-            id = lattice_rank(lat_rank, li);
-          } else {
-            id = urow[i][j];
-          }
-          acc[i] += p * pdisc * v_next[id];
+        if constexpr (!MARK) acc[i] += p * imm;
+        if constexpr (!LAST && LK != 0) {
+          double nc = ini_cash + imm;  // (model 1: s.cash + immediate; model 2: initialCash + immediate)
+          nc = nc > P.max_cash ? P.max_cash : nc;
+          nc = nc < P.min_cash ? P.min_cash : nc;
+          int r;
+          if constexpr (MODEL == 2)
+            r = (int)((double)(int)nc + w1 + w2);  // nextR (inside the lattice's box: below 2^31)
+          else
+            r = (int)nc;
+          if constexpr (MARK)  // (the forward pass also has to notice a successor outside the box: signed arithmetic)
+            li[i] = (r < L.r0 || r - L.r0 >= L.nr) ? -1 : s_lat[r1[i] + o1] + s_lat[r2[i] + o2] + (long long)(r - L.r0) * L.n2;
+          else
+            li[i] = s_lat[r1[i] + o1] + s_lat[r2[i] + o2] +
+                    (long long)((unsigned long long)(unsigned)(r - (int)L.r0) * (unsigned)L.n2);
         }
       }
-    }
+      if constexpr (MARK) {
+        // (the words of the NI successors are read together, then tested: most candidates are already marked)
+        unsigned int wd[NI];
+        bool in_box[NI];
 #pragma unroll
-    for (int i = 0; i < NI; ++i) {
-      const int k = k0 + tid + kFactThreads * i;
-      if (k < n_offered) s_q[k] = acc[i];
+        for (int i = 0; i < NI; ++i) {
+          const bool offered = k0 + tid + kFactThreads * i < n_offered;
+          in_box[i] = offered && li[i] >= 0 && li[i] < L.bits;
+          if (offered && !in_box[i]) *mark_oob = 1;  // the host's box was too small: reported, never silently dropped
+          wd[i] = in_box[i] ? mark_words[li[i] >> 5] : 0xffffffffu;
+        }
+#pragma unroll
+        for (int i = 0; i < NI; ++i) {
+          const unsigned int bit = 1u << (li[i] & 31);
+          if (in_box[i] && !(wd[i] & bit)) atomicOr(&mark_words[li[i] >> 5], bit);
+        }
+      } else if constexpr (!LAST) {
+        double v[NI];
+        if constexpr (LK == 2) {
+#pragma unroll
+          for (int i = 0; i < NI; ++i) v[i] = vdense[li[i]];
+        } else if constexpr (LK == 1) {
+          uint2 wp[NI];
+#pragma unroll
+          for (int i = 0; i < NI; ++i) wp[i] = lat_rank[li[i] >> 5];
+#pragma unroll
+          for (int i = 0; i < NI; ++i) {
+            const unsigned int below = wp[i].x & ((1u << (li[i] & 31)) - 1u);
+            v[i] = v_next[(int)(wp[i].y + __popc(below))];
+          }
+        } else {
+#pragma unroll
+          for (int i = 0; i < NI; ++i) v[i] = v_next[urow[i][j]];
+        }
+#pragma unroll
+        for (int i = 0; i < NI; ++i) acc[i] += pg * v[i];
+      }
+    }
+    if constexpr (!MARK) {
+#pragma unroll
+      for (int i = 0; i < NI; ++i) {
+        const int k = k0 + tid + kFactThreads * i;
+        if (k < n_offered) s_q[k] = acc[i];
+      }
     }
   }
+  if constexpr (MARK) return;
   __syncthreads();
   if (tid < 64) {  // `if (actionValues[i] > val + 0.1)` in action order, as in backward_kernel
     double val = -1.7976931348623157e308;
@@ -998,6 +1038,8 @@ int ml_guard(const char* who, Body&& body) {
   }
 }
 
+constexpr size_t kLdsPerCUSparse = 160 * 1024;  // (gfx950; sdpgpu_internal.hpp has the same figure for the grid kernels)
+
 struct SparseProblem {
   int T = 0;
   MLParams P{};
@@ -1085,9 +1127,58 @@ int sparse_solve(const SparseProblem& sp, double* final_value, int32_t* q1, int3
           ML_TRY(hipMalloc((void**)&d_oob, 4));
           ML_TRY(hipMemset(d_oob, 0, 4));
         }
+        // the factored form of the marking pass (backward_fact_kernel, LK = 3) where the pair list factors and the tables fit
+        bool marked = false;
+        if (!(std::getenv("SDPGPU_MULTI_FACT") && std::atoi(std::getenv("SDPGPU_MULTI_FACT")) == 0)) {
+          std::vector<double> u1, u2;
+          std::vector<int> idx((size_t)nd);
+          bool ok = true;
+          for (int j = 0; j < nd && ok; ++j) {
+            const double2 d = h_dem[(size_t)sp.off[(size_t)t] + j];
+            size_t k1 = 0, k2 = 0;
+            while (k1 < u1.size() && u1[k1] != d.x) ++k1;
+            if (k1 == u1.size()) u1.push_back(d.x);
+            while (k2 < u2.size() && u2[k2] != d.y) ++k2;
+            if (k2 == u2.size()) u2.push_back(d.y);
+            ok = u1.size() <= 4096 && u2.size() <= 4096;
+            idx[(size_t)j] = (int)k1 | ((int)k2 << 16);
+          }
+          const size_t smem_m = (size_t)NA * 8 + (size_t)nd * 12 + (size_t)P.qb * (u1.size() + u2.size()) * 24 + (size_t)(P.qb + 1) * 4 + 16;
+          if (ok && smem_m <= kLdsPerCUSparse) {
+            if (d_fact) (void)hipFree(d_fact);
+            d_fact = nullptr;
+            ML_TRY(hipMalloc((void**)&d_fact, (u1.size() + u2.size()) * 8 + (size_t)nd * 4));
+            ML_TRY(hipMemcpy(d_fact, u1.data(), u1.size() * 8, hipMemcpyHostToDevice));
+            ML_TRY(hipMemcpy(d_fact + u1.size() * 8, u2.data(), u2.size() * 8, hipMemcpyHostToDevice));
+            ML_TRY(hipMemcpy(d_fact + (u1.size() + u2.size()) * 8, idx.data(), (size_t)nd * 4, hipMemcpyHostToDevice));
+            FactList F;
+            F.u1 = reinterpret_cast<const double*>(d_fact);
+            F.u2 = F.u1 + u1.size();
+            F.idx = reinterpret_cast<const int*>(F.u2 + u2.size());
+            F.nu1 = (int)u1.size();
+            F.nu2 = (int)u2.size();
+#define ML_MARK(MD)                                                                                                            \
+  do {                                                                                                                        \
+    if (smem_m > 64 * 1024)                                                                                                   \
+      ML_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(backward_fact_kernel<MD, false, 3>),                          \
+                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem_m));                                  \
+    for (int64_t first = 0; first < n_states[t]; first += (int64_t)1 << 21) {                                                 \
+      const int64_t nb = std::min<int64_t>((int64_t)1 << 21, n_states[t] - first);                                            \
+      hipLaunchKernelGGL((backward_fact_kernel<MD, false, 3>), dim3((unsigned)nb), dim3(kFactThreads), smem_m, 0, P, d_states[t], \
+                         first, n_states[t], F, d_prob + sp.off[(size_t)t], (const double*)nullptr, (const int*)nullptr,      \
+                         (double*)nullptr, (int*)nullptr, (unsigned long long*)nullptr, L, (const uint2*)nullptr,             \
+                         (const double*)nullptr, d_lat_words, d_oob);                                                         \
+      ML_TRY(hipGetLastError());                                                                                              \
+    }                                                                                                                         \
+  } while (0)
+            if (P.model == 1) ML_MARK(1); else ML_MARK(2);
+#undef ML_MARK
+            marked = true;
+          }
+        }
         // a dispatch carries at most 2^32 work-items: batches of states
         const int64_t per_batch = std::max<int64_t>(1, ((int64_t)1 << 30) / NA);
-        for (int64_t first = 0; first < n_states[t]; first += per_batch) {
+        for (int64_t first = 0; !marked && first < n_states[t]; first += per_batch) {
           const int64_t ns = std::min<int64_t>(per_batch, n_states[t] - first);
           hipLaunchKernelGGL(lattice_mark_kernel, dim3((unsigned)((ns * NA + 255) / 256)), dim3(256), 0, 0, P, L,
                              d_states[t] + first, ns, dem_t, d_lat_words, d_oob);
@@ -1258,23 +1349,30 @@ int sparse_solve(const SparseProblem& sp, double* final_value, int32_t* q1, int3
           F.idx = reinterpret_cast<const int*>(F.u2 + u2.size());
           F.nu1 = (int)u1.size();
           F.nu2 = (int)u2.size();
-#define ML_FACT(MD, LS)                                                                                                      \
+#define ML_FACT(MD, LS, LKK)                                                                                                    \
   do {                                                                                                                      \
     if (smem_f > 64 * 1024)                                                                                                 \
-      ML_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(backward_fact_kernel<MD, LS>),                              \
+      ML_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(backward_fact_kernel<MD, LS, LKK>),                              \
                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem_f));                                \
     for (int64_t first = 0; first < n_states[t]; first += (int64_t)1 << 21) {                                               \
       const int64_t nb = std::min<int64_t>((int64_t)1 << 21, n_states[t] - first);                                          \
-      hipLaunchKernelGGL((backward_fact_kernel<MD, LS>), dim3((unsigned)nb), dim3(kFactThreads), smem_f, 0, P, d_states[t], first, \
+      hipLaunchKernelGGL((backward_fact_kernel<MD, LS, LKK>), dim3((unsigned)nb), dim3(kFactThreads), smem_f, 0, P, d_states[t], first, \
                          n_states[t], F, d_prob + sp.off[(size_t)t], d_vnext, d_uid[t], d_vcur, d_act, d_cells, sp.lat,     \
-                         d_lat_rank[t], d_vdense);                                                                          \
+                         d_lat_rank[t], d_vdense, (unsigned int*)nullptr, (int*)nullptr);                                   \
       ML_TRY(hipGetLastError());                                                                                            \
     }                                                                                                                       \
   } while (0)
+          const int lk = d_vdense ? 2 : (d_lat_rank[t] ? 1 : 0);
           if (P.model == 1) {
-            if (P.is_last) ML_FACT(1, true); else ML_FACT(1, false);
+            if (P.is_last) ML_FACT(1, true, 0);
+            else if (lk == 2) ML_FACT(1, false, 2);
+            else if (lk == 1) ML_FACT(1, false, 1);
+            else ML_FACT(1, false, 0);
           } else {
-            if (P.is_last) ML_FACT(2, true); else ML_FACT(2, false);
+            if (P.is_last) ML_FACT(2, true, 0);
+            else if (lk == 2) ML_FACT(2, false, 2);
+            else if (lk == 1) ML_FACT(2, false, 1);
+            else ML_FACT(2, false, 0);
           }
 #undef ML_FACT
           fact_done = true;
