@@ -901,12 +901,20 @@ __global__ __launch_bounds__(kFactThreads) void backward_fact_kernel(MLParams P,
 // carried from pass to pass.  Per (lane, chunk) the order quantities step by 64 without a division.  Every accumulator takes its
 // addends demand index ascending, exactly as before.
 constexpr int kLeadChunks = 10;
+// orderingCosts of every order pair (see backward_lead_wave_kernel)
+__global__ __launch_bounds__(256) void order_cost_kernel(MLParams P, double* __restrict__ oc_tab) {
+  const int a = blockIdx.x * 256 + threadIdx.x;
+  if (a >= P.qb * P.qb) return;
+  const int a1 = a / P.qb, a2 = a - a1 * P.qb;
+  oc_tab[a] = P.vari[0] * (double)a1 + P.vari[1] * (double)a2;
+}
+
 template <bool LAST>
 __global__ __launch_bounds__(256) void backward_lead_wave_kernel(MLParams P, const Tuple* __restrict__ states, int64_t s_first,
                                                                 int64_t n_states, const double2* __restrict__ dem,
                                                                 const double* __restrict__ prob, const double* __restrict__ v_next,
                                                                 const int* __restrict__ uid, double* __restrict__ v_out,
-                                                                int* __restrict__ act_out) {
+                                                                int* __restrict__ act_out, const double* __restrict__ oc_tab) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int NA = P.qb * P.qb;
   const int lane = threadIdx.x & 63;
@@ -921,8 +929,9 @@ __global__ __launch_bounds__(256) void backward_lead_wave_kernel(MLParams P, con
   for (int j = lane; j < P.nd; j += 64) s_t[j] = demand_terms(P, st, dem[j].x, dem[j].y);
   __builtin_amdgcn_wave_barrier();
   __builtin_amdgcn_s_waitcnt(0xC07F);  // lgkmcnt(0): the wave's own LDS writes have landed
-  const int step1 = 64 / P.qb, step2 = 64 - step1 * P.qb;
-  int a1 = lane / P.qb, a2 = lane - a1 * P.qb;
+  // oc_tab[a] = variCost[0] * i + variCost[1] * j of order pair a = i * Qbound + j (MultiProductLeadtime.java:184), formed once
+  // per solve by order_cost_kernel with these very operations: a state's setup per order pair is then one coalesced load instead
+  // of two conversions, two products, a sum and the stepping of (i, j) -- a third of the ~30 instructions it took
   [[maybe_unused]] const int* urow0 = LAST ? nullptr : uid + (int64_t)s * NA * P.nd;  // (period T reads no successor)
   const char* vb = reinterpret_cast<const char*>(v_next);
   double val = -1.7976931348623157e308;
@@ -932,18 +941,12 @@ __global__ __launch_bounds__(256) void backward_lead_wave_kernel(MLParams P, con
     [[maybe_unused]] const int* urow[kLeadChunks];
 #pragma unroll
     for (int i = 0; i < kLeadChunks; ++i) {
-      [[maybe_unused]] const int a = (c0 + i) * 64 + lane;
-      const double oc = P.vari[0] * (double)a1 + P.vari[1] * (double)a2;
+      const int a = (c0 + i) * 64 + lane;
+      const double oc = oc_tab[a < NA ? a : NA - 1];
       const double before = st.cash - oc - P.overhead;
       bi[i] = before - ml_interest(P, before);
       acc[i] = 0.0;  // thisActionsValue, CashRecursionMultiLead.java:72-80
       if constexpr (!LAST) urow[i] = urow0 + (a < NA ? a : 0) * P.nd;
-      a1 += step1;
-      a2 += step2;
-      if (a2 >= P.qb) {
-        a2 -= P.qb;
-        ++a1;
-      }
     }
     if constexpr (LAST) {
       for (int j = 0; j < P.nd; ++j) {
@@ -1084,6 +1087,7 @@ int sparse_solve(const SparseProblem& sp, double* final_value, int32_t* q1, int3
   double *d_vcur = nullptr, *d_vnext = nullptr;
   int* d_act = nullptr;
   unsigned long long* d_cells = nullptr;
+  double* d_oc = nullptr;      // backward_lead_wave_kernel: orderingCosts of every order pair
   double* d_vdense = nullptr;  // backward_fact_kernel: V_{t+1} by lattice index (dense_scatter_kernel)
   char* d_fact = nullptr;  // backward_fact_kernel: the period's distinct demands and the pairs' index words
   hipEvent_t ev0 = nullptr, ev1 = nullptr;
@@ -1381,15 +1385,20 @@ int sparse_solve(const SparseProblem& sp, double* final_value, int32_t* q1, int3
       // the lead-time family: a wave per state (backward_lead_wave_kernel); SDPGPU_MULTI_WAVE=0: round 3's workgroup per state
       const bool lead_wave = !fact_done && P.model == 0 && NA <= 4096 && !(std::getenv("SDPGPU_MULTI_WAVE") && std::atoi(std::getenv("SDPGPU_MULTI_WAVE")) == 0);
       if (lead_wave) {
+        if (!d_oc) {
+          ML_TRY(hipMalloc((void**)&d_oc, (size_t)NA * 8));
+          hipLaunchKernelGGL(order_cost_kernel, dim3((unsigned)((NA + 255) / 256)), dim3(256), 0, 0, P, d_oc);
+          ML_TRY(hipGetLastError());
+        }
         const size_t smem_w = (size_t)nd * (4 * sizeof(DemandTerms) + 8);
         for (int64_t first = 0; first < n_states[t]; first += (int64_t)1 << 24) {  // 4M workgroups of four states
           const int64_t ns = std::min<int64_t>((int64_t)1 << 24, n_states[t] - first);
           if (P.is_last)
             hipLaunchKernelGGL(backward_lead_wave_kernel<true>, dim3((unsigned)((ns + 3) / 4)), dim3(256), smem_w, 0, P, d_states[t], first,
-                               n_states[t], d_dem + sp.off[(size_t)t], d_prob + sp.off[(size_t)t], d_vnext, d_uid[t], d_vcur, d_act);
+                               n_states[t], d_dem + sp.off[(size_t)t], d_prob + sp.off[(size_t)t], d_vnext, d_uid[t], d_vcur, d_act, d_oc);
           else
             hipLaunchKernelGGL(backward_lead_wave_kernel<false>, dim3((unsigned)((ns + 3) / 4)), dim3(256), smem_w, 0, P, d_states[t], first,
-                               n_states[t], d_dem + sp.off[(size_t)t], d_prob + sp.off[(size_t)t], d_vnext, d_uid[t], d_vcur, d_act);
+                               n_states[t], d_dem + sp.off[(size_t)t], d_prob + sp.off[(size_t)t], d_vnext, d_uid[t], d_vcur, d_act, d_oc);
           ML_TRY(hipGetLastError());
         }
       } else if (!fact_done)
