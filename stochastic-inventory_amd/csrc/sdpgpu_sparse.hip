@@ -751,15 +751,22 @@ __global__ __launch_bounds__(kFactThreads) void backward_fact_kernel(MLParams P,
   // NI actions of a lane at a time (k = tid + 256 i), demand pairs in the outer loop: the pair's index word and probability are
   // read once per lane, every accumulator takes its addends demand index ascending
   constexpr int NI = 5;  // (512 threads x 5: the 2500 order pairs of Qbound 50 in one pass)
-  for (int k0 = 0; k0 < n_offered; k0 += kFactThreads * NI) {
+  // Model 2's action box is regular (a = i * Qbound + j): with the lanes' actions a multiple of Qbound apart (TS = the largest
+  // multiple of Qbound that fits the workgroup; lanes beyond it idle: 12 of 512 at Qbound 50) a lane's NI actions share the SECOND
+  // order index, so the second product's table entries of a demand pair are read once per lane instead of once per cell -- 12
+  // LDS reads per pair and lane instead of 20 in period T, where those reads are what binds (2.5e12 cells/s at four per cell).
+  constexpr bool SAME2 = MODEL == 2;
+  const int TS = (SAME2 && P.qb <= kFactThreads) ? (kFactThreads / P.qb) * P.qb : kFactThreads;
+  const bool lane_on = tid < TS;
+  for (int k0 = 0; k0 < n_offered; k0 += TS * NI) {
     int r1[NI], r2[NI];  // slot of (distinct demand 0, this action's order index): + k * qb per pair
     double base[NI], acc[NI];
     const int* urow[NI];
 #pragma unroll
     for (int i = 0; i < NI; ++i) {
-      const int k = k0 + tid + kFactThreads * i;
+      const int k = k0 + tid + TS * i;
       int a1 = 0, a2 = 0;
-      if (k < n_offered) {
+      if (k < n_offered && lane_on) {
         if constexpr (MODEL == 1) {
           offered_pair(k, a1, a2);
         } else {
@@ -787,10 +794,14 @@ __global__ __launch_bounds__(kFactThreads) void backward_fact_kernel(MLParams P,
       const double pg = p * pdisc;
       const int o1 = (kk & 0xffff) * P.qb, o2 = (kk >> 16) * P.qb;
       [[maybe_unused]] long long li[NI];
+      // (SAME2: r2[i] is the same slot for every i -- except past the last action, where it is slot 0's: harmless, unused)
+      [[maybe_unused]] const double rev2_c = s_rev[r2[0] + o2], w2_c = s_w[r2[0] + o2];
+      [[maybe_unused]] long long lat2_c = 0;
+      if constexpr (SAME2 && !LAST && LK != 0) lat2_c = s_lat[r2[0] + o2];
 #pragma unroll
       for (int i = 0; i < NI; ++i) {
-        const double rev1 = s_rev[r1[i] + o1], rev2 = s_rev[r2[i] + o2];
-        const double w1 = s_w[r1[i] + o1], w2 = s_w[r2[i] + o2];
+        const double rev1 = s_rev[r1[i] + o1], rev2 = SAME2 ? rev2_c : s_rev[r2[i] + o2];
+        const double w1 = s_w[r1[i] + o1], w2 = SAME2 ? w2_c : s_w[r2[i] + o2];
         const double revenue = rev1 + rev2;
         const double sal = LAST ? w1 + w2 : 0.0;
         double imm;
@@ -809,9 +820,9 @@ __global__ __launch_bounds__(kFactThreads) void backward_fact_kernel(MLParams P,
           else
             r = (int)nc;
           if constexpr (MARK)  // (the forward pass also has to notice a successor outside the box: signed arithmetic)
-            li[i] = (r < L.r0 || r - L.r0 >= L.nr) ? -1 : s_lat[r1[i] + o1] + s_lat[r2[i] + o2] + (long long)(r - L.r0) * L.n2;
+            li[i] = (r < L.r0 || r - L.r0 >= L.nr) ? -1 : s_lat[r1[i] + o1] + (SAME2 ? lat2_c : s_lat[r2[i] + o2]) + (long long)(r - L.r0) * L.n2;
           else
-            li[i] = s_lat[r1[i] + o1] + s_lat[r2[i] + o2] +
+            li[i] = s_lat[r1[i] + o1] + (SAME2 ? lat2_c : s_lat[r2[i] + o2]) +
                     (long long)((unsigned long long)(unsigned)(r - (int)L.r0) * (unsigned)L.n2);
         }
       }
@@ -821,7 +832,7 @@ __global__ __launch_bounds__(kFactThreads) void backward_fact_kernel(MLParams P,
         bool in_box[NI];
 #pragma unroll
         for (int i = 0; i < NI; ++i) {
-          const bool offered = k0 + tid + kFactThreads * i < n_offered;
+          const bool offered = lane_on && k0 + tid + TS * i < n_offered;
           in_box[i] = offered && li[i] >= 0 && li[i] < L.bits;
           if (offered && !in_box[i]) *mark_oob = 1;  // the host's box was too small: reported, never silently dropped
           wd[i] = in_box[i] ? mark_words[li[i] >> 5] : 0xffffffffu;
@@ -856,8 +867,8 @@ __global__ __launch_bounds__(kFactThreads) void backward_fact_kernel(MLParams P,
     if constexpr (!MARK) {
 #pragma unroll
       for (int i = 0; i < NI; ++i) {
-        const int k = k0 + tid + kFactThreads * i;
-        if (k < n_offered) s_q[k] = acc[i];
+        const int k = k0 + tid + TS * i;
+        if (lane_on && k < n_offered) s_q[k] = acc[i];
       }
     }
   }
