@@ -177,6 +177,58 @@ def test_random_wide_cash_rows_bit_exact(sia, oracle, monkeypatch):
 
 
 # ---------------------------------------------------------------------------------------------------------------
+# Round 4: F5 (cash + lead time) at large balances on the two-point kernel -- the two-addition rounding of the quantiser and the
+# uniform-key trips of tiles that pay no interest, at magnitudes where one ulp of the balance is 2e-10
+# ---------------------------------------------------------------------------------------------------------------
+def make_large_magnitude_f5_instance(seed):
+    """SingleProductLeadtime's shape with cash in hundredths on rows of 1500-4000 points whose balances sit around +-1e6:
+    positive rows pay no interest (uniform-key trips when r0 = 0), negative rows pay the piecewise interest beyond the limit
+    (the quantiser on every cell), rows across zero mix the two inside one launch.  bound * mult stays below the 5e8 the
+    launcher admits (the bound multiplies the balance by 1 + r3)."""
+    rng = np.random.default_rng(7300 + seed)
+    T = int(rng.integers(2, 4))
+    mult = 100.0
+    nc = int(rng.integers(1500, 4000))
+    where = seed % 3  # 0: positive balances, 1: negative, 2: across zero
+    mag = float(rng.uniform(0.5, 0.9)) * 5.0e8 / mult / 3.05
+    base = {0: mag, 1: -mag - nc / mult, 2: -0.5 * nc / mult}[where]
+    base = float(np.floor(base * mult) / mult)
+    on_grid = bool(rng.integers(0, 3))
+    money = (lambda lo, hi: float(round(rng.uniform(lo, hi) * mult) / mult)) if on_grid else \
+            (lambda lo, hi: float(round(rng.uniform(lo, hi), 3) + 0.0005))
+    f = CashLeadtimeFunctor(price=money(0.3, 2.0), variCost=max(0.01, money(0.05, 0.6)), salvageValue=money(0, 0.2),
+                            maxOrderQuantity=float(rng.integers(2, 6)), minInventoryState=0.0,
+                            maxInventoryState=float(rng.integers(2, 7)), minCashState=base, maxCashState=base + (nc - 1) / mult,
+                            iniInventory=0.0, iniCash=base + 3.0, cashRoundMult=mult, cashRoundDiv=mult, cashRoundIntDiv=False,
+                            r0=float(rng.choice([0, 0, 0.01])), r2=0.1, r3=2.0, limit=float(rng.integers(5, 20)),
+                            interestFreeAmount=float(rng.integers(0, 4)), iniPreQ=0.0,
+                            overheadCosts=[money(0, 1.0) for _ in range(T)])
+    return Workload(f"fuzz_big_f5_{seed}", f, OptDirection.MAX, _pmf(rng, T, d_max=8))
+
+
+def test_large_magnitude_f5_bit_exact(sia, oracle, monkeypatch):
+    """Automatic kernel (two-point kernel, four rows of a level per workgroup, diagonal order), the one-point row kernel and the
+    generic kernel against the oracle, every table bit for bit."""
+    n = int(os.environ.get("SDP_FUZZ_N", "9"))
+    for seed in range(n):
+        w = make_large_magnitude_f5_instance(seed)
+        V, pol, cells = oracle.Problem(w.desc(), w.pmf, w.overhead()).solve(nthreads=8)
+        for variant in ("auto", "one-point", "generic"):
+            monkeypatch.delenv("SDPGPU_CASH_OD_PAIR", raising=False)
+            if variant == "one-point":
+                monkeypatch.setenv("SDPGPU_CASH_OD_PAIR", "0")
+            d = w.desc()
+            d.kernel = 1 if variant == "generic" else 0
+            with sia.SdpEngine(d, w.pmf, w.overhead()) as eng:
+                eng.solve()
+                assert eng.stats().kernel_used == (1 if variant == "generic" else 2), f"{w.name} {variant}"
+                assert eng.stats().cells_evaluated == cells, w.name
+                for period in range(1, w.T + 1):
+                    assert np.array_equal(eng.policy(period), pol[period - 1]), f"{w.name} {variant} t={period}: policy"
+                    assert np.array_equal(eng.values(period), V[period - 1]), f"{w.name} {variant} t={period}: values"
+
+
+# ---------------------------------------------------------------------------------------------------------------
 # Large magnitudes: the proof-carrying shortcuts of the cash kernels near their admission limit
 # ---------------------------------------------------------------------------------------------------------------
 def make_large_magnitude_cash_instance(seed, past_limit=False):
