@@ -86,6 +86,8 @@ static int fill_desc(JNIEnv* env, jintArray ints, jdoubleArray dbls, sdpgpu_desc
 
 JNIEXPORT void JNICALL Java_sdp_gpu_SdpGpu_destroy(JNIEnv* env, jclass cls, jlong h) { sdpgpu_destroy(H(h)); }
 
+JNIEXPORT jstring JNICALL Java_sdp_gpu_SdpGpu_buildId(JNIEnv* env, jclass cls) { return (*env)->NewStringUTF(env, sdpgpu_build_id()); }
+
 JNIEXPORT void JNICALL Java_sdp_gpu_SdpGpu_setPmf(JNIEnv* env, jclass cls, jlong h, jint t, jdoubleArray dem, jdoubleArray prob) {
   if (!dem || !prob) {
     throw_state(env, "setPmf: null array");

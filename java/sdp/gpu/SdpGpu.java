@@ -42,6 +42,12 @@ public final class SdpGpu {
 
 	public static native void destroy(long handle);
 
+	/**
+	 * sdpgpu_build_id (ABI 6): the 16-hex-digit digest of the sources libsdpgpu.so was built from. A JVM runs the classes it
+	 * was given; the native half is a separate artefact -- log this next to the version of the jar.
+	 */
+	public static native String buildId();
+
 	public static native void setPmf(long handle, int t, double[] demand, double[] prob);
 
 	/**

@@ -37,6 +37,7 @@ struct JNINativeInterface_ {
   void (*DeleteLocalRef)(JNIEnv*, jobject);
   const char* (*GetStringUTFChars)(JNIEnv*, jstring, jboolean*);
   void (*ReleaseStringUTFChars)(JNIEnv*, jstring, const char*);
+  jstring (*NewStringUTF)(JNIEnv*, const char*);
   jsize (*GetArrayLength)(JNIEnv*, jarray);
   jobjectArray (*NewObjectArray)(JNIEnv*, jsize, jclass, jobject);
   void (*SetObjectArrayElement)(JNIEnv*, jobjectArray, jsize, jobject);
