@@ -86,3 +86,16 @@ def test_headline_is_the_target_grid_with_secondaries():
     assert sep["speedup_over_brute_force"] > 3 and abs(sep["ms_per_sweep"] - sep["ms_per_step"]) < 1e-9
     assert sep["parity_gate"]["worst_relative_difference"] <= 1e-9
     assert r["build"]["match"] is True and len(r["build"]["build_id"]) == 16
+
+
+def test_a_failing_secondary_entry_does_not_take_the_headline_down(monkeypatch):
+    """A secondary workload whose gate fails (injected) is recorded in its place -- no value, the reason -- and the line, whose
+    headline has passed its own gate, is still printed with the other entries intact."""
+    monkeypatch.setenv("SDP_BENCH_ONLY_SECONDARY", "cfg2,staff,custom_clsp_level")
+    monkeypatch.setenv("SDP_BENCH_TEST_FAIL_SECONDARY", "staff")
+    r = _run("--steps", "2")
+    assert r["parity_gate"]["status"] == "ok" and r["value"] > 1e12
+    by = {s["workload"].split("_")[0]: s for s in r["secondary"]}
+    assert set(by) == {"cfg2", "staff", "custom"}
+    assert by["staff"]["value"] is None and by["staff"]["parity_gate"]["status"] == "FAILED" and "injected" in by["staff"]["error"]
+    assert by["cfg2"]["parity_gate"]["status"] == "ok" and by["custom"]["parity_gate"]["status"] == "ok"
