@@ -72,6 +72,27 @@ static_assert(sizeof(CParams) == 168, "CParams layout is mirrored in sdp_custom_
 #define SDP_CASH_INT_DIV P.cash_int_div
 #endif
 
+// SDP_BAKE (sdpgpu_create_custom, clamped grids): the grid every period shares, the step and the user's constants as
+// compile-time constants -- the index arithmetic of c_next_index folds (one axis: no 64-bit products), the user's formulas are
+// specialised to their constants.
+#ifdef SDP_BAKE
+#define C_STEP (SDP_B_STEP)
+#define C_INV_STEP (SDP_B_INV_STEP)
+#define C_NEXT_XLO (SDP_B_XLO)
+#define C_NEXT_NX ((sdp_i64)(SDP_B_NX))
+#define C_NEXT_NC ((sdp_i64)(SDP_B_NC))
+#define C_NEXT_NQ ((sdp_i64)(SDP_B_NQ))
+#define C_NEXT_KLO ((sdp_i64)(SDP_B_KLO))
+#else
+#define C_STEP P.step
+#define C_INV_STEP P.inv_step
+#define C_NEXT_XLO P.next.x_lo
+#define C_NEXT_NX P.next.nx
+#define C_NEXT_NC P.next.nc
+#define C_NEXT_NQ P.next.nq
+#define C_NEXT_KLO P.next.k_lo
+#endif
+
 struct CState { double x, cash, preq; };
 
 #ifdef SDP_SHAPE_LEVEL
@@ -112,9 +133,9 @@ __device__ inline void c_decode(const CParams& P, sdp_i64 idx, CState& s) {
 __device__ inline sdp_i64 c_next_index(const CParams& P, double nx, double ncash, double npreq, bool& bad) {
   // (32-bit conversions: every axis is shorter than 2^31 points and cash keys fit 32 bits, checked at create;
   // a value out of int range saturates and fails the range test)
-  const double fx = (nx - P.next.x_lo) * P.inv_step;
+  const double fx = (nx - C_NEXT_XLO) * C_INV_STEP;
   const int ix = (int)fx;
-  bool ok = (double)ix == fx && ix >= 0 && ix < (int)P.next.nx;
+  bool ok = (double)ix == fx && ix >= 0 && ix < (int)C_NEXT_NX;
   int ic = 0, iq = 0;
   if (SDP_HAS_CASH) {
     int k;
@@ -126,19 +147,19 @@ __device__ inline sdp_i64 c_next_index(const CParams& P, double nx, double ncash
       k = (int)sdp_round(ncash * P.round_mult);
       back = (double)k / P.round_div;
     }
-    ic = k - (int)P.next.k_lo;
-    ok = ok && back == ncash && ic >= 0 && ic < (int)P.next.nc;
+    ic = k - (int)C_NEXT_KLO;
+    ok = ok && back == ncash && ic >= 0 && ic < (int)C_NEXT_NC;
   }
   if (SDP_HAS_PREQ) {
-    const double fq = npreq * P.inv_step;
+    const double fq = npreq * C_INV_STEP;
     iq = (int)fq;
-    ok = ok && (double)iq == fq && iq >= 0 && iq < (int)P.next.nq;
+    ok = ok && (double)iq == fq && iq >= 0 && iq < (int)C_NEXT_NQ;
   }
   if (!ok) {
     bad = true;
     return 0;
   }
-  return ((sdp_i64)iq * P.next.nx + ix) * P.next.nc + ic;
+  return ((sdp_i64)iq * C_NEXT_NX + ix) * C_NEXT_NC + ic;
 }
 
 __device__ inline bool c_better(bool maxdir, double v2, int k2, double v, int k) {
@@ -179,13 +200,17 @@ __device__ inline void custom_period_body(
   // The user's constants are copied into a private array first: constant indices then become registers, a
   // period-dependent index one hoisted load -- read through the global pointer, every use inside a branch of the
   // user's code would be a scalar load with a full wait in the demand loop (the compiler may not speculate it).
+#ifdef SDP_BAKE
+  const double prm[SDP_NP] = SDP_B_PARAMS;
+#else
   double prm[SDP_NP];
 #pragma unroll
   for (int i = 0; i < SDP_NP; ++i) prm[i] = P.user[i];
+#endif
   sdp_ctx U;
   U.period = P.period;
   U.T = P.T;
-  U.step = P.step;
+  U.step = C_STEP;
   U.params = prm;
   const int nA = live ? sdp_feasible_count(U, s.x, s.cash, s.preq) : 0;
   const int nD = P.n_demand;
@@ -194,7 +219,7 @@ __device__ inline void custom_period_body(
   int bestk = 0;
   bool bad = false;
   for (int k = as; k < nA; k += AS) {
-    const double a = (double)k * P.step;
+    const double a = (double)k * C_STEP;
     double acc = 0.0;
     for (int j = 0; j < nD; ++j) {
       const double2 dp = s_pmf[j];

@@ -700,10 +700,47 @@ int sdpgpu_create_custom(const sdpgpu_desc* desc, const char* functor_source, co
   const std::string level_defs[2] = {
       "-DSDP_LEVEL_NACT=" + std::to_string(desc->step > 0 ? (int)(desc->max_order_quantity / desc->step) + 1 : 1),
       std::string("-DSDP_LEVEL_CLAMP=") + (desc->clamp_inventory ? "1" : "0")};
-  const char* opts[] = {"--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fno-fast-math", np_def.c_str(),
-                        shape_defs[0].c_str(), shape_defs[1].c_str(), shape_defs[2].c_str(), shape_defs[3].c_str(),
-                        shape_defs[4].c_str(), level_defs[0].c_str(), level_defs[1].c_str(), hexbuf[0], hexbuf[1]};
-  hiprtcResult cr = hiprtcCompileProgram(prog, 15, opts);
+  std::vector<const char*> opts = {"--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fno-fast-math", np_def.c_str(),
+                                   shape_defs[0].c_str(), shape_defs[1].c_str(), shape_defs[2].c_str(), shape_defs[3].c_str(),
+                                   shape_defs[4].c_str(), level_defs[0].c_str(), level_defs[1].c_str(), hexbuf[0], hexbuf[1]};
+  // Specialise instead of interpret (round 4): on a CLAMPED grid every period has the same box, known from the descriptor alone
+  // (layout(): inventory bounds, cash keys of the bounds, pipeline quantities 0 .. maxOrderQuantity) -- the grid, the step and
+  // the user's constants go into the generated source as compile-time constants (exact: hex floats).  The successor's index
+  // arithmetic folds (one axis: no 64-bit products) and the compiler specialises the user's formulas to their constants:
+  // configs[1] through CLSP's three lambdas 0.94e12 -> 1.26e12 cells/s.  Constant folding is IEEE round-to-nearest, no
+  // contraction: the same doubles.  SDPGPU_CUSTOM_BAKE=0: everything read from the parameter block, as in rounds 1-3.
+  std::vector<std::string> bake;
+  bool finite = std::isfinite(desc->step) && std::isfinite(desc->min_inventory) && std::isfinite(desc->max_inventory) &&
+                std::isfinite(desc->min_cash) && std::isfinite(desc->max_cash) && std::isfinite(desc->max_order_quantity) &&
+                std::isfinite(desc->cash_round_mult) && std::isfinite(desc->cash_round_div) && desc->cash_round_div != 0;
+  for (int i = 0; i < n_params; ++i) finite = finite && std::isfinite(params[i]);  // (a NaN / infinity has no literal: read at run time then)
+  if (!(std::getenv("SDPGPU_CUSTOM_BAKE") && std::atoi(std::getenv("SDPGPU_CUSTOM_BAKE")) == 0) && desc->clamp_inventory && finite &&
+      desc->step > 0 && desc->max_inventory >= desc->min_inventory) {
+    char b[96];
+    long long nc = 1, k_lo = 0, nq = 1;
+    if (has_cash(desc->family)) {
+      k_lo = cash_key_of_bound(*desc, desc->min_cash);
+      nc = cash_key_of_bound(*desc, desc->max_cash) - k_lo + 1;
+    }
+    if (has_preq(desc->family)) nq = java_d2i(desc->max_order_quantity / desc->step) + 1;
+    bake.push_back("-DSDP_BAKE=1");
+    std::snprintf(b, sizeof b, "-DSDP_B_STEP=%a", desc->step); bake.push_back(b);
+    std::snprintf(b, sizeof b, "-DSDP_B_INV_STEP=%a", 1.0 / desc->step); bake.push_back(b);
+    std::snprintf(b, sizeof b, "-DSDP_B_XLO=%a", desc->min_inventory); bake.push_back(b);
+    std::snprintf(b, sizeof b, "-DSDP_B_NX=%lld", (long long)((desc->max_inventory - desc->min_inventory) / desc->step) + 1); bake.push_back(b);
+    std::snprintf(b, sizeof b, "-DSDP_B_NC=%lld", nc); bake.push_back(b);
+    std::snprintf(b, sizeof b, "-DSDP_B_NQ=%lld", nq); bake.push_back(b);
+    std::snprintf(b, sizeof b, "-DSDP_B_KLO=%lld", k_lo); bake.push_back(b);
+    std::string pl = "-DSDP_B_PARAMS={";
+    for (int i = 0; i < std::max(1, (int)n_params); ++i) {
+      std::snprintf(b, sizeof b, "%s%a", i ? "," : "", i < n_params ? params[i] : 0.0);
+      pl += b;
+    }
+    pl += "}";
+    bake.push_back(pl);
+    for (const std::string& o : bake) opts.push_back(o.c_str());
+  }
+  hiprtcResult cr = hiprtcCompileProgram(prog, (int)opts.size(), opts.data());
   if (cr != HIPRTC_SUCCESS) {
     size_t n = 0;
     (void)hiprtcGetProgramLogSize(prog, &n);
