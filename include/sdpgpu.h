@@ -300,7 +300,9 @@ void sdpgpu_destroy(sdpgpu_handle* h);
  *
  * with `struct sdp_ctx { int period; int T; double step; const double* params; }` (period = state.getPeriod(),
  * params = the n_params doubles given here: the constants the Java lambdas close over) and the helpers
- * sdp_max / sdp_min / sdp_round / sdp_trunc (java.lang.Math.max / min / round and the (int) cast).
+ * sdp_max / sdp_min / sdp_round / sdp_trunc (java.lang.Math.max / min / round and the (int) cast) and, ABI 6, sdp_ldiv(a, b)
+ * (Java's `long / int` on an integer-valued double below 2^31, e.g. `Math.round(cash * 10) / 10`, CashOverdraft.java:116: truncating
+ * integer division -- a few integer instructions with a literal divisor, where sdp_trunc(a / b) is an fp64 division per cell).
  *
  * `desc->family` selects the STATE SHAPE and the loop, not the formulas: BACKORDER = (x) under Recursion,
  * LEADTIME = (x, preQ) under LeadtimeRecursion, CASH / OVERDRAFT = (x, cash) under CashRecursion (discounted),

@@ -344,6 +344,7 @@ static inline double sdp_max(double a, double b) { if (a != a) return a; if (a =
 static inline double sdp_min(double a, double b) { if (a != a) return a; if (a == 0 && b == 0) return std::signbit(a) ? a : b; return a < b ? a : b; }
 static inline double sdp_round(double x) { double f = std::floor(x); return (x - f >= 0.5) ? f + 1.0 : f; }
 static inline double sdp_trunc(double x) { return std::trunc(x); }
+static inline double sdp_ldiv(double a, int b) { return (double)((long long)a / b); }  // Java long / int: truncating
 using std::fmax; using std::fmin; using std::floor; using std::trunc; using std::fabs;
 #line 1 "user_functor"
 """

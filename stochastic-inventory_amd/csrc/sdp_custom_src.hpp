@@ -43,6 +43,10 @@ __device__ inline double sdp_max(double a, double b) { return fmax(a, b); }
 __device__ inline double sdp_min(double a, double b) { return fmin(a, b); }
 __device__ inline double sdp_round(double x) { double f = floor(x); return (x - f >= 0.5) ? f + 1.0 : f; }
 __device__ inline double sdp_trunc(double x) { return trunc(x); }  // (int) / (long) casts, long division
+// Java's `long / int` on an integer-valued double, e.g. `Math.round(cash * 10) / 10` (CashOverdraft.java:116): truncating integer
+// division, done in integers (|a| < 2^31: cash keys fit 32 bits, checked at create) -- with a literal divisor a few integer
+// instructions, where sdp_trunc(a / b) costs a correctly rounded fp64 division per cell
+__device__ inline double sdp_ldiv(double a, int b) { return (double)((int)a / b); }
 #line 1 "user_functor"
 )SDPSRC";
 

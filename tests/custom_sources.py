@@ -143,3 +143,10 @@ __device__ void sdp_transition(const sdp_ctx& c, double x, double cash, double p
 
 # a transition that forgets to clamp: leaves the grid
 BROKEN_TRANSITION = BACKORDER.replace("nextInventory = nextInventory < c.params[4] ? c.params[4] : nextInventory;", "")
+
+
+# the same two texts with the long division `Math.round(nextCash * 10) / 10` written through the prelude's integer helper
+# (sdp_ldiv: truncating integer division, a few integer instructions with a literal divisor) instead of an fp64 division
+OVERDRAFT_LIMIT_LDIV = OVERDRAFT_LIMIT.replace("sdp_trunc(sdp_round(nextCash * 10) / 10)", "sdp_ldiv(sdp_round(nextCash * 10), 10)")
+OVERDRAFT_LIMIT_FUSED_LDIV = OVERDRAFT_LIMIT_FUSED.replace("sdp_trunc(sdp_round(nextCash * 10) / 10)", "sdp_ldiv(sdp_round(nextCash * 10), 10)")
+assert "sdp_ldiv" in OVERDRAFT_LIMIT_LDIV and "sdp_ldiv" in OVERDRAFT_LIMIT_FUSED_LDIV

@@ -53,7 +53,8 @@ def _overdraft_limit_case(sia, T=4):
     return shape, params, pmf
 
 
-@pytest.mark.parametrize("source", ["OVERDRAFT_LIMIT", "OVERDRAFT_LIMIT_FUSED"], ids=["three-functions", "fused-sdp_cell"])
+@pytest.mark.parametrize("source", ["OVERDRAFT_LIMIT", "OVERDRAFT_LIMIT_FUSED", "OVERDRAFT_LIMIT_LDIV", "OVERDRAFT_LIMIT_FUSED_LDIV"],
+                         ids=["three-functions", "fused-sdp_cell", "three-functions-sdp_ldiv", "fused-sdp_ldiv"])
 def test_driver_outside_the_builtin_families(sia, oracle, source):
     """CashOverdraftLimit's lambdas as user text, written as the reference's three lambdas and with the fused per-cell callback
     (ABI 5: `#define SDP_USER_CELL 1` + sdp_cell, one evaluation of the increment per cell): tables, reachable sets, off-grid

@@ -31,11 +31,12 @@ params = [6, 2, 1, 0.25, 0.1, 0.0, 0.5, 59, 0, 199, -500, 1500] + [9.0, 12.0, 7.
 pmf = [truncated_poisson_tile(18.0, 40) for _ in range(T)]
 desc = shape.to_desc(T, sia.OptDirection.MAX)
 ref = None
-for name, text in (("three functions", cs.OVERDRAFT_LIMIT), ("fused sdp_cell", cs.OVERDRAFT_LIMIT_FUSED)):
+for name, text in (("three functions", cs.OVERDRAFT_LIMIT), ("fused sdp_cell", cs.OVERDRAFT_LIMIT_FUSED),
+                   ("three fns, sdp_ldiv", cs.OVERDRAFT_LIMIT_LDIV), ("fused, sdp_ldiv", cs.OVERDRAFT_LIMIT_FUSED_LDIV)):
     e = sia.SdpEngine(desc, pmf, custom_source=text, custom_params=params)
     e.solve(); e.solve()
     s_ = e.stats()
-    print(f"CashOverdraftLimit, {name:16s} {s_.cells_evaluated / s_.solve_ms / 1e9 * 1e3:8.1f} Gcells/s  ({s_.solve_ms:.2f} ms per sweep, {s_.cells_evaluated:.3g} cells)")
+    print(f"CashOverdraftLimit, {name:20s} {s_.cells_evaluated / s_.solve_ms / 1e9 * 1e3:8.1f} Gcells/s  ({s_.solve_ms:.2f} ms per sweep, {s_.cells_evaluated:.3g} cells)")
     v = e.values(1)
     if ref is not None:
         print("fused tables == three-function tables:", bool(np.array_equal(ref, v)))
