@@ -43,3 +43,24 @@ def test_a_fraction_above_one_is_withheld(capsys):
     assert rf["frac"] is None and rf["achieved"] is None and "withheld" in rf["error"]
     assert "withheld" in capsys.readouterr().err
     assert rf["avg_launch_ms"] == 0.005 and len(rf["per_launch_ms_events"]) == 2  # the measured times stay
+
+
+def test_every_bench_workload_has_a_kernel_source_digest():
+    """tools/kernel_sha.py maps every --workload of bench.py to the files its kernels are built from (a counter summary in
+    profiles/ is used only when that digest matches): each family to its own files, all of them present."""
+    import os
+    from tools.kernel_sha import kernel_files, kernel_source_sha, build_source_sha
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    csrc = os.path.join(root, "stochastic-inventory_amd", "csrc")
+    names = {"target_f1_1000000x500x200x6": "sdp_window.hpp", "cfg2_clsp_x": "sdp_window.hpp", "cfg5_f1_x": "sdp_window.hpp",
+             "cfg3_cash_x": "sdp_cash.hpp", "cfg3t_cash_tenths_x": "sdp_cash.hpp", "f5_spl_x": "sdp_cash.hpp",
+             "separable_f5_spl_x": "sdp_cash.hpp", "separable_target_f1_x": "sdp_window.hpp", "cfg4_leadtime_x": "sdp_window.hpp",
+             "staff_testing0_x": "sdp_staff.hpp", "multilead_kat2_T3_Q50": "sdpgpu_sparse.hip", "custom_clsp_x": "sdp_custom_src.hpp",
+             "custom_clsp_level_x": "sdp_window.hpp"}
+    for name, must in names.items():
+        files = kernel_files(name)
+        assert must in files, (name, files)
+        assert all(os.path.exists(os.path.join(csrc, f)) for f in files)
+        assert len(kernel_source_sha(root, name)) == 16
+    assert "sdp_custom_src.hpp" in kernel_files("custom_clsp_level_x")
+    assert len(build_source_sha(root)) == 16

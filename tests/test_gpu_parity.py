@@ -918,3 +918,20 @@ def test_dyadic_cash_grid_with_gapped_demand_support(sia, oracle, monkeypatch, e
     for period in range(1, w.T + 1):
         _assert_tables(eng.values(period), eng.policy(period), V[period - 1], pol[period - 1], f"{w.name} {env} t={period}")
     eng.close()
+
+
+@pytest.mark.parametrize("make", [cases.f1_small, cases.f3_grid_prices, cases.f5_cash_leadtime, cases.f2_clamped], ids=lambda f: f.__name__)
+def test_period_cells_add_up_to_the_sweep(sia, oracle, make):
+    """sdpgpu_period_cells (ABI 6): the cells of every period, as the oracle counts them, and their sum = stats.cells_evaluated
+    (F5's last period offers one order only: what bench.py prices a kernel's counters against)."""
+    w = make()
+    P = oracle.Problem(w.desc(), w.pmf, w.overhead())
+    with sia.SdpEngine(w.desc(), w.pmf, w.overhead()) as eng:
+        assert eng.period_cells(1) == -1  # nothing has run
+        eng.solve()
+        per = [eng.period_cells(p) for p in range(1, w.T + 1)]
+        assert sum(per) == eng.stats().cells_evaluated
+        v = None
+        for period in range(w.T, 0, -1):
+            v, _, cells = P.period(period, v)
+            assert per[period - 1] == cells, period
