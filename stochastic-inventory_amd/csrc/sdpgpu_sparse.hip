@@ -33,6 +33,7 @@
 #include <stdexcept>
 #include <string>
 #include <vector>
+#include <type_traits>
 
 namespace {
 
@@ -634,7 +635,16 @@ struct FactList {
   const double* u2;
   const int* idx;    // per pair j: k1 | k2 << 16
   int nu1, nu2;
+  int grouped;       // the list's length is a multiple of four and every aligned group of four pairs shares k1 (fact_grouped)
 };
+
+inline int fact_grouped(const std::vector<int>& idx) {
+  if (idx.empty() || idx.size() % 4 != 0) return 0;
+  for (size_t j = 0; j < idx.size(); j += 4)
+    for (size_t c = 1; c < 4; ++c)
+      if ((idx[j + c] & 0xffff) != (idx[j] & 0xffff)) return 0;
+  return 1;
+}
 
 // V_{t+1} on the lattice: vdense[lattice index of state k] = v[k].  The backward pass of the bitmap path ranks every successor
 // (a gather of the bitmap word and its prefix) and then gathers the value by that rank: two dependent reads per cell, which is
@@ -653,7 +663,10 @@ constexpr int kFactThreads = 512;  // eight waves share a state's tables: twice 
 // argument, and the loop below forms the NI actions' reads of a demand pair first, issues them together and consumes them
 // afterwards: with the three forms behind run-time branches every cell was its own basic block, one gather and one full wait
 // each -- the not-last periods of the long horizons ran at 0.27e12 cells/s on dependent reads.
-template <int MODEL, bool LAST, int LK = 0>
+// I32: the lattice has fewer than 2^32 - 1 points and its R and i2 extents are below 2^24 (the recorded instances: 4.4e8 points):
+// the successor's index is formed in 32-bit words -- 4-byte table entries, a 24-bit multiply-add -- where the 64-bit form costs
+// a quarter-rate v_mad_u64_u32, two 2-word additions and 8-byte LDS reads per cell.
+template <int MODEL, bool LAST, int LK = 0, bool I32 = false>
 __global__ __launch_bounds__(kFactThreads) void backward_fact_kernel(MLParams P, const Tuple* __restrict__ states, int64_t s_first,
                                                            int64_t n_states, FactList F, const double* __restrict__ prob,
                                                            const double* __restrict__ v_next, const int* __restrict__ uid,
@@ -666,6 +679,8 @@ __global__ __launch_bounds__(kFactThreads) void backward_fact_kernel(MLParams P,
   // of MultiItemCashXR's four periods)
   constexpr bool MARK = LK == 3;
   static_assert(!MARK || !LAST, "the forward pass has no period T");
+  static_assert(!I32 || (!LAST && LK != 0), "the index width only matters where a lattice index is formed");
+  using LI = std::conditional_t<I32, unsigned int, long long>;
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int NA = P.qb * P.qb;
   double* s_q = reinterpret_cast<double*>(smem);  // Q(s, a)
@@ -676,7 +691,7 @@ __global__ __launch_bounds__(kFactThreads) void backward_fact_kernel(MLParams P,
   const int n_e = P.qb * (F.nu1 + F.nu2);
   double* s_rev = s_p + P.nd;            // [nu1][qb] then [nu2][qb]
   double* s_w = s_rev + n_e;
-  long long* s_lat = reinterpret_cast<long long*>(s_w + n_e);
+  LI* s_lat = reinterpret_cast<LI*>(s_w + n_e);
   int* s_idx = reinterpret_cast<int*>(s_lat + (LAST ? 0 : n_e));
   int* s_off = s_idx + P.nd;
   const int64_t s = s_first + blockIdx.x;
@@ -718,7 +733,7 @@ __global__ __launch_bounds__(kFactThreads) void backward_fact_kernel(MLParams P,
     }
     s_rev[slot] = t.rev;
     s_w[slot] = t.w;
-    if constexpr (!LAST) s_lat[slot] = t.lat;
+    if constexpr (!LAST) s_lat[slot] = (LI)t.lat;  // (I32: modulo 2^32 -- the sum of the three shares is below it)
   }
   __syncthreads();
   int n_offered = NA;
@@ -787,21 +802,47 @@ __global__ __launch_bounds__(kFactThreads) void backward_fact_kernel(MLParams P,
       acc[i] = 0.0;
       urow[i] = uid ? uid + ((int64_t)s * NA + (a1 * P.qb + a2)) * P.nd : nullptr;
     }
-#pragma unroll 2
-    for (int j = 0; j < P.nd; ++j) {
-      const int kk = s_idx[j];
-      const double p = s_p[j];
-      const double pg = p * pdisc;
-      const int o1 = (kk & 0xffff) * P.qb, o2 = (kk >> 16) * P.qb;
-      [[maybe_unused]] long long li[NI];
-      // (SAME2: r2[i] is the same slot for every i -- except past the last action, where it is slot 0's: harmless, unused)
-      [[maybe_unused]] const double rev2_c = s_rev[r2[0] + o2], w2_c = s_w[r2[0] + o2];
-      [[maybe_unused]] long long lat2_c = 0;
-      if constexpr (SAME2 && !LAST && LK != 0) lat2_c = s_lat[r2[0] + o2];
+    // A product's table entries of a demand pair depend on that product's distinct demand only, and the lists GetPmfMulti builds
+    // run through the second product's demands under every first one (22 x 16: the first index changes every 16th pair).  The
+    // first product's entries are kept in registers and read again only when a pair's first index differs from the previous
+    // pair's -- a wave-uniform test; in period T, where the LDS reads were what bound the kernel (12 reads of 8 bytes per pair
+    // and five cells: 6.07e12 cells in 1.84 s), a pair then costs the reads of the second product's entries alone.  The pairs
+    // are taken CH at a time: where the CH pairs share their first index (always, inside a run of such a list) their index
+    // words, probabilities and second-product entries are read together, ahead of the arithmetic -- one LDS round trip per CH
+    // pairs instead of two per pair; any other group of pairs goes one by one.  The pairs are walked, and every accumulator fed,
+    // in list order either way.
+    constexpr int N2 = SAME2 ? 1 : NI;       // (SAME2: r2[i] is the same slot for every i -- except past the last action,
+    constexpr int CH = SAME2 ? 4 : 2;        //  where it is slot 0's: harmless, unused)
+    int cur1 = -1;
+    double c_rev1[NI], c_w1[NI];
+    [[maybe_unused]] LI c_lat1[NI];
+    auto load1 = [&](int k1) {
+      cur1 = k1;
+      const int o1 = k1 * P.qb;
 #pragma unroll
       for (int i = 0; i < NI; ++i) {
-        const double rev1 = s_rev[r1[i] + o1], rev2 = SAME2 ? rev2_c : s_rev[r2[i] + o2];
-        const double w1 = s_w[r1[i] + o1], w2 = SAME2 ? w2_c : s_w[r2[i] + o2];
+        c_rev1[i] = s_rev[r1[i] + o1];
+        c_w1[i] = s_w[r1[i] + o1];
+        if constexpr (!LAST && LK != 0) c_lat1[i] = s_lat[r1[i] + o1];
+      }
+    };
+    auto load2 = [&](int k2, double (&rev2)[N2], double (&w2)[N2], LI (&lat2)[N2]) {
+      const int o2 = k2 * P.qb;
+#pragma unroll
+      for (int i = 0; i < N2; ++i) {
+        rev2[i] = s_rev[r2[i] + o2];
+        w2[i] = s_w[r2[i] + o2];
+        if constexpr (!LAST && LK != 0) lat2[i] = s_lat[r2[i] + o2]; else lat2[i] = 0;
+      }
+    };
+    // the NI cells of demand pair j
+    auto pair_body = [&](int j, double p, const double (&c_rev2)[N2], const double (&c_w2)[N2], const LI (&c_lat2)[N2]) {
+      [[maybe_unused]] const double pg = p * pdisc;
+      [[maybe_unused]] LI li[NI];
+#pragma unroll
+      for (int i = 0; i < NI; ++i) {
+        const double rev1 = c_rev1[i], rev2 = c_rev2[SAME2 ? 0 : i];
+        const double w1 = c_w1[i], w2 = c_w2[SAME2 ? 0 : i];
         const double revenue = rev1 + rev2;
         const double sal = LAST ? w1 + w2 : 0.0;
         double imm;
@@ -812,18 +853,25 @@ __global__ __launch_bounds__(kFactThreads) void backward_fact_kernel(MLParams P,
         if constexpr (!MARK) acc[i] += p * imm;
         if constexpr (!LAST && LK != 0) {
           double nc = ini_cash + imm;  // (model 1: s.cash + immediate; model 2: initialCash + immediate)
-          nc = nc > P.max_cash ? P.max_cash : nc;
-          nc = nc < P.min_cash ? P.min_cash : nc;
+          // `nextCash > maxCash ? maxCash : nextCash`, then the lower bound the same way: v_min_f64 / v_max_f64 give the same
+          // doubles for finite operands (a +-0 tie is the only difference, and the (int) cast below maps both to 0)
+          nc = __builtin_fmax(__builtin_fmin(nc, P.max_cash), P.min_cash);
           int r;
           if constexpr (MODEL == 2)
             r = (int)((double)(int)nc + w1 + w2);  // nextR (inside the lattice's box: below 2^31)
           else
             r = (int)nc;
-          if constexpr (MARK)  // (the forward pass also has to notice a successor outside the box: signed arithmetic)
-            li[i] = (r < L.r0 || r - L.r0 >= L.nr) ? -1 : s_lat[r1[i] + o1] + (SAME2 ? lat2_c : s_lat[r2[i] + o2]) + (long long)(r - L.r0) * L.n2;
-          else
-            li[i] = s_lat[r1[i] + o1] + (SAME2 ? lat2_c : s_lat[r2[i] + o2]) +
-                    (long long)((unsigned long long)(unsigned)(r - (int)L.r0) * (unsigned)L.n2);
+          const LI lat12 = c_lat1[i] + c_lat2[SAME2 ? 0 : i];
+          if constexpr (I32) {
+            const unsigned int dr = (unsigned int)(r - (int)L.r0);  // (a successor below r0 wraps to a large value)
+            const unsigned int idx = lat12 + __umul24(dr, (unsigned int)L.n2);
+            // (the forward pass also has to notice a successor outside the box: no index, the all-ones word)
+            li[i] = (MARK && dr >= (unsigned int)L.nr) ? 0xffffffffu : idx;
+          } else if constexpr (MARK) {
+            li[i] = (r < L.r0 || r - L.r0 >= L.nr) ? -1 : lat12 + (long long)(r - L.r0) * L.n2;
+          } else {
+            li[i] = lat12 + (long long)((unsigned long long)(unsigned)(r - (int)L.r0) * (unsigned)L.n2);
+          }
         }
       }
       if constexpr (MARK) {
@@ -833,7 +881,10 @@ __global__ __launch_bounds__(kFactThreads) void backward_fact_kernel(MLParams P,
 #pragma unroll
         for (int i = 0; i < NI; ++i) {
           const bool offered = lane_on && k0 + tid + TS * i < n_offered;
-          in_box[i] = offered && li[i] >= 0 && li[i] < L.bits;
+          if constexpr (I32)
+            in_box[i] = offered && li[i] < (unsigned int)L.bits;
+          else
+            in_box[i] = offered && li[i] >= 0 && li[i] < L.bits;
           if (offered && !in_box[i]) *mark_oob = 1;  // the host's box was too small: reported, never silently dropped
           wd[i] = in_box[i] ? mark_words[li[i] >> 5] : 0xffffffffu;
         }
@@ -862,6 +913,33 @@ __global__ __launch_bounds__(kFactThreads) void backward_fact_kernel(MLParams P,
         }
 #pragma unroll
         for (int i = 0; i < NI; ++i) acc[i] += pg * v[i];
+      }
+    };
+    if (F.grouped) {  // (the host's test of the list: every aligned group of four pairs shares its first index)
+      for (int j = 0; j < P.nd; j += CH) {
+        int kk[CH];
+        double pp[CH];
+#pragma unroll
+        for (int c = 0; c < CH; ++c) {
+          kk[c] = __builtin_amdgcn_readfirstlane(s_idx[j + c]);
+          pp[c] = s_p[j + c];
+        }
+        if ((kk[0] & 0xffff) != cur1) load1(kk[0] & 0xffff);
+        double rev2[CH][N2], w2[CH][N2];
+        LI lat2[CH][N2];
+#pragma unroll
+        for (int c = 0; c < CH; ++c) load2(kk[c] >> 16, rev2[c], w2[c], lat2[c]);
+#pragma unroll
+        for (int c = 0; c < CH; ++c) pair_body(j + c, pp[c], rev2[c], w2[c], lat2[c]);
+      }
+    } else {
+      for (int j = 0; j < P.nd; ++j) {
+        const int kk = __builtin_amdgcn_readfirstlane(s_idx[j]);
+        if ((kk & 0xffff) != cur1) load1(kk & 0xffff);
+        double rev2[N2], w2[N2];
+        LI lat2[N2];
+        load2(kk >> 16, rev2, w2, lat2);
+        pair_body(j, s_p[j], rev2, w2, lat2);
       }
     }
     if constexpr (!MARK) {
@@ -1097,6 +1175,9 @@ int sparse_solve(const SparseProblem& sp, double* final_value, int32_t* q1, int3
   void* d_tmp = nullptr;
   double *d_vcur = nullptr, *d_vnext = nullptr;
   int* d_act = nullptr;
+  // backward_fact_kernel's 32-bit index form (SDPGPU_MULTI_I32=0: the 64-bit form everywhere)
+  const bool lat_i32 = sp.lattice_ok && sp.lat.bits < (1LL << 31) && sp.lat.nr < (1LL << 24) && sp.lat.n2 < (1LL << 24) &&
+                       !(std::getenv("SDPGPU_MULTI_I32") && std::atoi(std::getenv("SDPGPU_MULTI_I32")) == 0);
   unsigned long long* d_cells = nullptr;
   double* d_oc = nullptr;      // backward_lead_wave_kernel: orderingCosts of every order pair
   double* d_vdense = nullptr;  // backward_fact_kernel: V_{t+1} by lattice index (dense_scatter_kernel)
@@ -1172,21 +1253,26 @@ int sparse_solve(const SparseProblem& sp, double* final_value, int32_t* q1, int3
             F.idx = reinterpret_cast<const int*>(F.u2 + u2.size());
             F.nu1 = (int)u1.size();
             F.nu2 = (int)u2.size();
-#define ML_MARK(MD)                                                                                                            \
+            F.grouped = fact_grouped(idx);
+#define ML_MARK(MD, W32)                                                                                                       \
   do {                                                                                                                        \
     if (smem_m > 64 * 1024)                                                                                                   \
-      ML_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(backward_fact_kernel<MD, false, 3>),                          \
+      ML_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(backward_fact_kernel<MD, false, 3, W32>),                          \
                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem_m));                                  \
     for (int64_t first = 0; first < n_states[t]; first += (int64_t)1 << 21) {                                                 \
       const int64_t nb = std::min<int64_t>((int64_t)1 << 21, n_states[t] - first);                                            \
-      hipLaunchKernelGGL((backward_fact_kernel<MD, false, 3>), dim3((unsigned)nb), dim3(kFactThreads), smem_m, 0, P, d_states[t], \
+      hipLaunchKernelGGL((backward_fact_kernel<MD, false, 3, W32>), dim3((unsigned)nb), dim3(kFactThreads), smem_m, 0, P, d_states[t], \
                          first, n_states[t], F, d_prob + sp.off[(size_t)t], (const double*)nullptr, (const int*)nullptr,      \
                          (double*)nullptr, (int*)nullptr, (unsigned long long*)nullptr, L, (const uint2*)nullptr,             \
                          (const double*)nullptr, d_lat_words, d_oob);                                                         \
       ML_TRY(hipGetLastError());                                                                                              \
     }                                                                                                                         \
   } while (0)
-            if (P.model == 1) ML_MARK(1); else ML_MARK(2);
+            if (P.model == 1) {
+              if (lat_i32) ML_MARK(1, true); else ML_MARK(1, false);
+            } else {
+              if (lat_i32) ML_MARK(2, true); else ML_MARK(2, false);
+            }
 #undef ML_MARK
             marked = true;
           }
@@ -1364,30 +1450,36 @@ int sparse_solve(const SparseProblem& sp, double* final_value, int32_t* q1, int3
           F.idx = reinterpret_cast<const int*>(F.u2 + u2.size());
           F.nu1 = (int)u1.size();
           F.nu2 = (int)u2.size();
-#define ML_FACT(MD, LS, LKK)                                                                                                    \
+          F.grouped = fact_grouped(idx);
+#define ML_FACT(MD, LS, LKK, W32)                                                                                               \
   do {                                                                                                                      \
     if (smem_f > 64 * 1024)                                                                                                 \
-      ML_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(backward_fact_kernel<MD, LS, LKK>),                              \
+      ML_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(backward_fact_kernel<MD, LS, LKK, W32>),                              \
                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem_f));                                \
     for (int64_t first = 0; first < n_states[t]; first += (int64_t)1 << 21) {                                               \
       const int64_t nb = std::min<int64_t>((int64_t)1 << 21, n_states[t] - first);                                          \
-      hipLaunchKernelGGL((backward_fact_kernel<MD, LS, LKK>), dim3((unsigned)nb), dim3(kFactThreads), smem_f, 0, P, d_states[t], first, \
+      hipLaunchKernelGGL((backward_fact_kernel<MD, LS, LKK, W32>), dim3((unsigned)nb), dim3(kFactThreads), smem_f, 0, P, d_states[t], first, \
                          n_states[t], F, d_prob + sp.off[(size_t)t], d_vnext, d_uid[t], d_vcur, d_act, d_cells, sp.lat,     \
                          d_lat_rank[t], d_vdense, (unsigned int*)nullptr, (int*)nullptr);                                   \
       ML_TRY(hipGetLastError());                                                                                            \
     }                                                                                                                       \
   } while (0)
           const int lk = d_vdense ? 2 : (d_lat_rank[t] ? 1 : 0);
+          const bool w32 = lat_i32 && lk != 0;
           if (P.model == 1) {
-            if (P.is_last) ML_FACT(1, true, 0);
-            else if (lk == 2) ML_FACT(1, false, 2);
-            else if (lk == 1) ML_FACT(1, false, 1);
-            else ML_FACT(1, false, 0);
+            if (P.is_last) ML_FACT(1, true, 0, false);
+            else if (lk == 2 && w32) ML_FACT(1, false, 2, true);
+            else if (lk == 2) ML_FACT(1, false, 2, false);
+            else if (lk == 1 && w32) ML_FACT(1, false, 1, true);
+            else if (lk == 1) ML_FACT(1, false, 1, false);
+            else ML_FACT(1, false, 0, false);
           } else {
-            if (P.is_last) ML_FACT(2, true, 0);
-            else if (lk == 2) ML_FACT(2, false, 2);
-            else if (lk == 1) ML_FACT(2, false, 1);
-            else ML_FACT(2, false, 0);
+            if (P.is_last) ML_FACT(2, true, 0, false);
+            else if (lk == 2 && w32) ML_FACT(2, false, 2, true);
+            else if (lk == 2) ML_FACT(2, false, 2, false);
+            else if (lk == 1 && w32) ML_FACT(2, false, 1, true);
+            else if (lk == 1) ML_FACT(2, false, 1, false);
+            else ML_FACT(2, false, 0, false);
           }
 #undef ML_FACT
           fact_done = true;
