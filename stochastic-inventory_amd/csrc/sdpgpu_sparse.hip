@@ -844,12 +844,22 @@ __global__ __launch_bounds__(kFactThreads) void backward_fact_kernel(MLParams P,
         const double rev1 = c_rev1[i], rev2 = c_rev2[SAME2 ? 0 : i];
         const double w1 = c_w1[i], w2 = c_w2[SAME2 ? 0 : i];
         const double revenue = rev1 + rev2;
-        const double sal = LAST ? w1 + w2 : 0.0;
+        // Before period T the salvage term the reference adds is the constant 0.0, and x + 0.0 is x for every x but -0.0, which
+        // it turns into +0.0: the sign of a zero immediate value reaches neither the accumulator (it starts at +0.0, and
+        // +0.0 + -0.0 = +0.0) nor the successor (a zero of either sign casts to 0) -- the addition is left out there.
         double imm;
-        if constexpr (MODEL == 1)
-          imm = revenue - base[i] + sal;  // MultiItemCash.java:98
-        else
-          imm = revenue + base[i] + sal - ini_cash;  // MultiItemCashXR.java:127
+        if constexpr (LAST) {
+          const double sal = w1 + w2;
+          if constexpr (MODEL == 1)
+            imm = revenue - base[i] + sal;  // MultiItemCash.java:98
+          else
+            imm = revenue + base[i] + sal - ini_cash;  // MultiItemCashXR.java:127
+        } else {
+          if constexpr (MODEL == 1)
+            imm = revenue - base[i];
+          else
+            imm = revenue + base[i] - ini_cash;
+        }
         if constexpr (!MARK) acc[i] += p * imm;
         if constexpr (!LAST && LK != 0) {
           double nc = ini_cash + imm;  // (model 1: s.cash + immediate; model 2: initialCash + immediate)
@@ -857,10 +867,14 @@ __global__ __launch_bounds__(kFactThreads) void backward_fact_kernel(MLParams P,
           // doubles for finite operands (a +-0 tie is the only difference, and the (int) cast below maps both to 0)
           nc = __builtin_fmax(__builtin_fmin(nc, P.max_cash), P.min_cash);
           int r;
-          if constexpr (MODEL == 2)
-            r = (int)((double)(int)nc + w1 + w2);  // nextR (inside the lattice's box: below 2^31)
-          else
+          if constexpr (MODEL == 2) {
+            // nextR = (int) nextCash + variCost . nextInventory (inside the lattice's box: below 2^31).  I32 (the cash bounds are
+            // below 2^31 too): (double)(int) nc is trunc(nc) but for the sign of a zero, which the additions and the cast absorb
+            const double whole = I32 ? __builtin_trunc(nc) : (double)(int)nc;
+            r = (int)(whole + w1 + w2);
+          } else {
             r = (int)nc;
+          }
           const LI lat12 = c_lat1[i] + c_lat2[SAME2 ? 0 : i];
           if constexpr (I32) {
             const unsigned int dr = (unsigned int)(r - (int)L.r0);  // (a successor below r0 wraps to a large value)
@@ -1177,6 +1191,7 @@ int sparse_solve(const SparseProblem& sp, double* final_value, int32_t* q1, int3
   int* d_act = nullptr;
   // backward_fact_kernel's 32-bit index form (SDPGPU_MULTI_I32=0: the 64-bit form everywhere)
   const bool lat_i32 = sp.lattice_ok && sp.lat.bits < (1LL << 31) && sp.lat.nr < (1LL << 24) && sp.lat.n2 < (1LL << 24) &&
+                       std::fabs(P.min_cash) < 2147483648.0 && std::fabs(P.max_cash) < 2147483648.0 &&
                        !(std::getenv("SDPGPU_MULTI_I32") && std::atoi(std::getenv("SDPGPU_MULTI_I32")) == 0);
   unsigned long long* d_cells = nullptr;
   double* d_oc = nullptr;      // backward_lead_wave_kernel: orderingCosts of every order pair

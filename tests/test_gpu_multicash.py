@@ -107,11 +107,15 @@ def test_whole_memo_matches_the_oracle(sia, oracle, kind, seed):
     assert (r.table == want).all()
 
 
+@pytest.mark.parametrize("index_words", ["32-bit", "64-bit"])
 @pytest.mark.parametrize("kind", ["multicash", "multixr"])
-def test_lattice_path_whole_memo(sia, oracle, kind, monkeypatch):
+def test_lattice_path_whole_memo(sia, oracle, kind, index_words, monkeypatch):
     """The bitmap / rank path of the reachable-set engine (chosen by itself when states x actions x demand pairs
-    outgrow 32-bit candidate indices), forced on small instances: every visited state, value and action pair."""
+    outgrow 32-bit candidate indices), forced on small instances: every visited state, value and action pair -- with the
+    successor's lattice index formed in 32-bit words (the default where the box allows it) and in 64-bit words."""
     monkeypatch.setenv("SDPGPU_MULTI_LATTICE", "1")
+    if index_words == "64-bit":
+        monkeypatch.setenv("SDPGPU_MULTI_I32", "0")
     done = 0
     for seed in range(24):
         if kind == "multicash":
