@@ -310,6 +310,14 @@ void sdpgpu_destroy(sdpgpu_handle* h);
  * (step, inventory bounds and clamp flag, cash bounds and rounding, max_order_quantity = longest pipeline
  * quantity, ini_*) keep their meaning; the cost fields are ignored.  sdpgpu_simulate is not available (the
  * lambdas also exist on the host, where the reference's simulators call them).
+ *
+ * How the text is compiled: -O3, no contraction, no fast-math.  On a CLAMPED grid with finite constants the grid, the step and
+ * params[] are baked into the generated source as exact literals (SDPGPU_CUSTOM_BAKE=0: read at run time, as before ABI 6), and
+ * that compile additionally assumes the lambdas' arithmetic produces no NaN (-fno-honor-nans; SDPGPU_CUSTOM_NNAN=0 turns it
+ * off): a clamp the Java source spells `x > c ? c : x` against a non-zero constant then costs one v_min_f64 instead of a compare
+ * and two selects.  For lambdas whose values are numbers the results are the same doubles either way
+ * (tests/test_gpu_custom_functor.py runs the three modes against each other); what a lambda that does produce a NaN returns is
+ * unspecified in the default mode.
  */
 int sdpgpu_create_custom(const sdpgpu_desc* desc, const char* functor_source, const double* params, int32_t n_params,
                          sdpgpu_handle** out);

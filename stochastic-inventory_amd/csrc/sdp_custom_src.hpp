@@ -132,37 +132,40 @@ __device__ inline void c_decode(const CParams& P, sdp_i64 idx, CState& s) {
 }
 
 // Flat index of the state the user's transition returned, which must be a grid point of period + 1 (the Java
-// lambda clamps and rounds itself).  Anything else sets `bad` and reads index 0.  (`bad` is a register: an atomic
-// inside the demand loop would make the compiler reload the user's parameters after every cell.)
+// lambda clamps and rounds itself).  Anything else sets `bad`; the index read is then some point of the grid (every axis
+// index is clamped into its range: a safe address, no branch) and the solve fails with the flag.  A coordinate is a grid
+// point exactly when its clamped integer index converts back to it -- one test for "integer" and "in range" together.
+// (`bad` is a register: an atomic inside the demand loop would make the compiler reload the user's parameters after every cell.)
+__device__ inline int c_clamp_index(int i, int n) {  // (max, then min: one v_med3_i32)
+  const int t = i > 0 ? i : 0;
+  return t < n - 1 ? t : n - 1;
+}
 __device__ inline sdp_i64 c_next_index(const CParams& P, double nx, double ncash, double npreq, bool& bad) {
   // (32-bit conversions: every axis is shorter than 2^31 points and cash keys fit 32 bits, checked at create;
-  // a value out of int range saturates and fails the range test)
+  // a value out of int range saturates and fails the test)
   const double fx = (nx - C_NEXT_XLO) * C_INV_STEP;
-  const int ix = (int)fx;
-  bool ok = (double)ix == fx && ix >= 0 && ix < (int)C_NEXT_NX;
+  const int ix = c_clamp_index((int)fx, (int)C_NEXT_NX);
+  bool ok = (double)ix == fx;
   int ic = 0, iq = 0;
   if (SDP_HAS_CASH) {
     int k;
     double back;
     if (SDP_CASH_INT_DIV) {
-      k = (int)ncash;
+      k = c_clamp_index((int)((unsigned)(int)ncash - (unsigned)(int)C_NEXT_KLO), (int)C_NEXT_NC) + (int)C_NEXT_KLO;
       back = (double)k;
     } else {
-      k = (int)sdp_round(ncash * P.round_mult);
+      k = c_clamp_index((int)((unsigned)(int)sdp_round(ncash * P.round_mult) - (unsigned)(int)C_NEXT_KLO), (int)C_NEXT_NC) + (int)C_NEXT_KLO;
       back = (double)k / P.round_div;
     }
     ic = k - (int)C_NEXT_KLO;
-    ok = ok && back == ncash && ic >= 0 && ic < (int)C_NEXT_NC;
+    ok = ok && back == ncash;
   }
   if (SDP_HAS_PREQ) {
     const double fq = npreq * C_INV_STEP;
-    iq = (int)fq;
-    ok = ok && (double)iq == fq && iq >= 0 && iq < (int)C_NEXT_NQ;
+    iq = c_clamp_index((int)fq, (int)C_NEXT_NQ);
+    ok = ok && (double)iq == fq;
   }
-  if (!ok) {
-    bad = true;
-    return 0;
-  }
+  bad = bad || !ok;
   return ((sdp_i64)iq * C_NEXT_NX + ix) * C_NEXT_NC + ic;
 }
 

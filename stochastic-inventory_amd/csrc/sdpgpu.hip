@@ -724,6 +724,7 @@ int sdpgpu_create_custom(const sdpgpu_desc* desc, const char* functor_source, co
     }
     if (has_preq(desc->family)) nq = java_d2i(desc->max_order_quantity / desc->step) + 1;
     bake.push_back("-DSDP_BAKE=1");
+    if (!(std::getenv("SDPGPU_CUSTOM_NNAN") && std::atoi(std::getenv("SDPGPU_CUSTOM_NNAN")) == 0)) bake.push_back("-fno-honor-nans");
     std::snprintf(b, sizeof b, "-DSDP_B_STEP=%a", desc->step); bake.push_back(b);
     std::snprintf(b, sizeof b, "-DSDP_B_INV_STEP=%a", 1.0 / desc->step); bake.push_back(b);
     std::snprintf(b, sizeof b, "-DSDP_B_XLO=%a", desc->min_inventory); bake.push_back(b);
@@ -756,6 +757,12 @@ int sdpgpu_create_custom(const sdpgpu_desc* desc, const char* functor_source, co
   hiprtcResult gr = hiprtcGetCode(prog, code.data());
   (void)hiprtcDestroyProgram(&prog);
   if (gr != HIPRTC_SUCCESS || code.empty()) return fail(nullptr, SDPGPU_ERR_DEVICE, "hiprtcGetCode failed");
+  if (const char* dump = std::getenv("SDPGPU_CUSTOM_DUMP")) {  // the code object, for llvm-objdump -d (tools/custom_functor_isa.py)
+    if (FILE* f = std::fopen(dump, "wb")) {
+      (void)std::fwrite(code.data(), 1, code.size(), f);
+      (void)std::fclose(f);
+    }
+  }
   int rc = sdpgpu_create(desc, out);
   if (rc) return rc;
   sdpgpu_handle* h = *out;

@@ -142,6 +142,36 @@ def test_mirror_class_over_user_lambdas(sia, oracle):
     assert rec.getExpectedValue(s1) == order[(2, s1.getIniInventory(), s1.getIniCash())]
 
 
+@pytest.mark.parametrize("env", [{"SDPGPU_CUSTOM_NNAN": "0"}, {"SDPGPU_CUSTOM_BAKE": "0"}], ids=["honor-nans", "not-baked"])
+def test_compile_modes_give_the_same_tables(sia, oracle, env, monkeypatch):
+    """The generated source with the grid and the user's constants baked in and NaN-free arithmetic assumed (the default on a
+    clamped grid: `x > c ? c : x` against a non-zero constant becomes one v_min_f64), with NaNs honoured, and with everything
+    read at run time: the same tables, bit for bit, for a built-in family as text and for CashOverdraftLimit's lambdas."""
+    w = cases.f1_clsp_main()
+    shape, params, pmf = _overdraft_limit_case(sia)
+    desc = shape.to_desc(len(pmf), sia.OptDirection.MAX)
+
+    def tables():
+        out = []
+        for d, pm, src, prm in ((w.desc(), w.pmf, cs.BACKORDER, _params_backorder(w.functor)), (desc, pmf, cs.OVERDRAFT_LIMIT, params)):
+            e = sia.SdpEngine(d, pm, custom_source=src, custom_params=prm)
+            e.solve()
+            out.append([(e.values(t).copy(), e.policy(t).copy()) for t in range(1, len(pm) + 1)])
+            e.close()
+        return out
+
+    default = tables()
+    for k, v in env.items():
+        monkeypatch.setenv(k, v)
+    other = tables()
+    for a, b in zip(default, other):
+        for (va, pa), (vb, pb) in zip(a, b):
+            assert np.array_equal(va, vb) and np.array_equal(pa, pb)
+    V, pol, _ = oracle.Problem(w.desc(), w.pmf).solve()
+    for t, (va, pa) in enumerate(default[0]):
+        assert np.array_equal(va, V[t]) and np.array_equal(pa, pol[t])
+
+
 def test_transition_that_leaves_the_grid_is_reported(sia):
     w = cases.f1_small()
     eng = sia.SdpEngine(w.desc(), w.pmf, custom_source=cs.BROKEN_TRANSITION, custom_params=_params_backorder(w.functor))
