@@ -707,7 +707,7 @@ int sdpgpu_create_custom(const sdpgpu_desc* desc, const char* functor_source, co
   // (layout(): inventory bounds, cash keys of the bounds, pipeline quantities 0 .. maxOrderQuantity) -- the grid, the step and
   // the user's constants go into the generated source as compile-time constants (exact: hex floats).  The successor's index
   // arithmetic folds (one axis: no 64-bit products) and the compiler specialises the user's formulas to their constants:
-  // configs[1] through CLSP's three lambdas 0.94e12 -> 1.26e12 cells/s.  Constant folding is IEEE round-to-nearest, no
+  // configs[1] through CLSP's three lambdas 0.94e12 -> 1.26e12 cells/s (1.53e12 with the NaN-free compile below).  Constant folding is IEEE round-to-nearest, no
   // contraction: the same doubles.  SDPGPU_CUSTOM_BAKE=0: everything read from the parameter block, as in rounds 1-3.
   std::vector<std::string> bake;
   bool finite = std::isfinite(desc->step) && std::isfinite(desc->min_inventory) && std::isfinite(desc->max_inventory) &&
