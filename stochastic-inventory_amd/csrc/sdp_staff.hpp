@@ -94,6 +94,83 @@ __global__ __launch_bounds__(64) void staff_period_kernel(StaffParams P, const d
   out_idx[at] = bestk;
 }
 
+// A handful of states (period 1 of a run from one initial staff number is ONE state): with lanes = states a wave of the kernels
+// below holds one live lane and walks maxHireNum + 1 actions x a row of realisations serially -- 0.22 ms for the single state
+// of WorkforceTesting.main's instance, 3 % of its sweep.  Here the lanes of a wave are 64 consecutive ACTIONS of one state,
+// hence 64 consecutive levels: the same coalesced reads of the transposed table and of V_{t+1}, every cell's arithmetic as in
+// staff_period_kernel, the realisations of a lane summed serially in the reference's order.  The wave's strict-compare arg-min
+// in ascending action order (:110-113) is the minimum with the lowest action among equals, or the initial (Double.MAX_VALUE,
+// 0) when no value is below it; the waves of a state are the `groups` combine_staff_kernel scans.
+template <bool FUTURE>
+__global__ __launch_bounds__(64) void staff_action_kernel(StaffParams P, const double* __restrict__ pT,
+                                                          const int32_t* __restrict__ row_len,
+                                                          const double* __restrict__ v_next,
+                                                          double* __restrict__ out_val, int32_t* __restrict__ out_idx,
+                                                          int64_t lo, int64_t hi) {
+  const int64_t tile = blockIdx.x / P.n_groups;
+  const int group = (int)(blockIdx.x - tile * P.n_groups);
+  const int64_t idx = lo + tile;
+  if (idx >= hi) return;
+  const int x = P.x_lo + (int)idx;
+  const int a = group * 64 + (int)threadIdx.x;
+  double acc = 1.7976931348623157e308;
+  if (a < P.n_actions) {
+    const int y = x + a;
+    const int row = y >= P.n_rows - 1 ? P.n_rows - 1 : y;
+    const int nj = row_len[row];
+    const double fixHire = a > 0 ? P.K : 0.0;
+    const double variHire = P.v * (double)a;
+    const double fv = fixHire + variHire;
+    const double* prow = pT + row;
+    acc = 0.0;
+    // four realisations a trip, their reads issued together (a lane's chain is otherwise one dependent load per step); the steps
+    // past the row's end read the zeros the table holds there (kStaffPadJ rows behind j = maxj - 1) and add +0.0, as in the
+    // window kernel
+    constexpr int U = 4;
+    static_assert(U - 1 <= kStaffPadJ, "table padding behind the last row of realisations");
+    for (int j0 = 0; j0 < nj; j0 += U) {
+      double p[U], vn[U];
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+        const int n = y - (j0 + u);
+        p[u] = prow[(size_t)(j0 + u) * (size_t)P.n_rows];
+        if constexpr (FUTURE) {
+          int nn = n > P.nn_hi ? P.nn_hi : n;
+          nn = nn < P.nn_lo ? P.nn_lo : nn;
+          vn[u] = v_next[nn - P.next_x_lo];
+        }
+      }
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+        const int n = y - (j0 + u);
+        const double salaryCost = P.salary * (double)n;
+        const double penalty = n > P.min_staff ? 0.0 : P.pen * (double)(P.min_staff - n);
+        const double imm = fv + salaryCost + penalty;
+        acc += p[u] * imm;
+        if constexpr (FUTURE) acc += p[u] * vn[u];
+      }
+    }
+  }
+  // (an action beyond the range holds MAX_VALUE and a higher index than every real one: it never wins)
+  double best = acc;
+  int bestk = a;
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) {
+    const double ov = __shfl_xor(best, off, 64);
+    const int ok = __shfl_xor(bestk, off, 64);
+    if (ov < best || (ov == best && ok < bestk)) {
+      best = ov;
+      bestk = ok;
+    }
+  }
+  if (threadIdx.x == 0) {
+    const int64_t at = (int64_t)group * P.part_stride + idx;
+    const bool none = !(best < 1.7976931348623157e308);  // `totalCosts < val` never held: val and bestHireQty as initialised
+    out_val[at] = none ? 1.7976931348623157e308 : best;
+    out_idx[at] = none ? 0 : bestk;
+  }
+}
+
 // The register-blocked form described at the top (pT0 = address of the j = 0 row inside the padded table).
 template <int R, bool FUTURE>
 __global__ __launch_bounds__(64) void staff_block_kernel(StaffParams P, const double* __restrict__ pT0,

@@ -89,18 +89,33 @@ hipError_t launch_staff(sdpgpu_handle* h, int period, const double* v_next, doub
   // (the pair kernel addresses the table and V_{t+1} by 32-bit byte offsets from scalar bases)
   const bool small_tables = ((int64_t)S.n_rows + 2 * sdp::kStaffPadJ) * S.n_rows * 8 < 2147483647LL &&
                             (period == h->T || (int64_t)h->per[period].g.nx * 8 < 2147483647LL);
-  const bool pair = !pair_off && !plain && staff_block() == 4 && S.n_rows >= 2 && (period == h->T || S.nn_hi > S.nn_lo) &&
-                    small_tables && (roomy || std::getenv("SDPGPU_STAFF_PAIR"));
-  // window form (staff_window_kernel: S adjacent states per lane, one probability per LEVEL instead of one per cell) on staff
-  // ranges of a thousand numbers and more; SDPGPU_STAFF_WIN=0 turns it off, =2 / =4 picks the states per lane
+  const bool pair_ok = !pair_off && !plain && staff_block() == 4 && S.n_rows >= 2 && (period == h->T || S.nn_hi > S.nn_lo) && small_tables;
+  // window form (staff_window_kernel: S adjacent states per lane, one probability per LEVEL instead of one per cell).  Which
+  // form serves a period is its staff range's size -- measured per period on WorkforceTesting.main's instance (1, 1001, 2001,
+  // ... 7001 states from period 1 to 8; tools/staff_variants.py): four states per lane from ~1500 numbers up (2001 states:
+  // 0.60 ms against 0.65 with two per lane and 1.10 on the block kernel), two per lane from a few hundred (1001 states: 0.39
+  // against 0.42 and 0.59), the block kernel below (one state: 0.22 against 0.30-0.37).  Until late in round 4 the window form
+  // waited for 4096 tile-blocks, and the two smallest multi-state periods of that instance ran on the block kernel: 1.7 of the
+  // sweep's 7.0 ms.  SDPGPU_STAFF_WIN=0 turns the form off, =2 / =4 forces the states per lane.
   int win_s = 0;
-  if (pair && hi - lo >= 1024) win_s = 4;
+  if (pair_ok && hi - lo >= 1536) win_s = 4;
+  else if (pair_ok && hi - lo >= 256) win_s = 2;
   if (const char* e = std::getenv("SDPGPU_STAFF_WIN")) {
     const int v = std::atoi(e);
-    win_s = (v == 2 || v == 4) && pair ? v : 0;
+    win_s = (v == 2 || v == 4) && pair_ok ? v : 0;
   }
-  const int tile_states = win_s ? 64 * win_s : (pair ? 128 : 64);
-  staff_groups(h, hi - lo, tile_states, &S.n_groups, &S.group_actions);
+  // (without the window form: two adjacent states per lane only where 128-state tiles x action blocks still fill the chip)
+  const bool pair = win_s != 0 || (pair_ok && (roomy || std::getenv("SDPGPU_STAFF_PAIR")));
+  // a handful of states: lanes = actions (staff_action_kernel); SDPGPU_STAFF_LANES=0 never, =1 for any number of states
+  bool by_action = hi - lo <= 16 && !plain;
+  if (const char* e = std::getenv("SDPGPU_STAFF_LANES")) by_action = std::atoi(e) != 0;
+  const int tile_states = by_action ? 1 : (win_s ? 64 * win_s : (pair ? 128 : 64));
+  if (by_action) {
+    S.group_actions = 64;
+    S.n_groups = (h->n_actions_full + 63) / 64;
+  } else {
+    staff_groups(h, hi - lo, tile_states, &S.n_groups, &S.group_actions);
+  }
   const int64_t tiles = (hi - lo + tile_states - 1) / tile_states;
   const int64_t blocks = tiles * S.n_groups;
   if (blocks * 64 >= 4294967296LL) return hipErrorInvalidValue;
@@ -126,7 +141,14 @@ hipError_t launch_staff(sdpgpu_handle* h, int period, const double* v_next, doub
   }
   const double* pT = h->d_lvl_p[period - 1];
   const int32_t* len = h->d_lvl_len[period - 1];
-  if (win_s) {
+  if (by_action) {
+    if (period < h->T)
+      hipLaunchKernelGGL((sdp::staff_action_kernel<true>), dim3((unsigned)blocks), dim3(64), 0, st, S, pT, len, v_next, out_val,
+                         out_idx, lo, hi);
+    else
+      hipLaunchKernelGGL((sdp::staff_action_kernel<false>), dim3((unsigned)blocks), dim3(64), 0, st, S, pT, len, v_next, out_val,
+                         out_idx, lo, hi);
+  } else if (win_s) {
 #define SDP_SW(SS, FU) \
   hipLaunchKernelGGL((sdp::staff_window_kernel<4, SS, FU>), dim3((unsigned)blocks), dim3(64), 0, st, S, pT, len, v_next, out_val, out_idx, lo, hi)
     if (win_s == 4) { if (period < h->T) SDP_SW(4, true); else SDP_SW(4, false); }

@@ -253,6 +253,55 @@ def test_window_kernel_on_every_case(sia, staffref, monkeypatch, win):
                 assert np.array_equal(eng.values(c.T)[lo:hi], V[c.T - 1][lo:hi]) and np.array_equal(eng.policy(c.T), pol[c.T - 1][lo:hi])
 
 
+def test_lanes_are_actions_kernel_on_every_case(sia, staffref, monkeypatch):
+    """staff_action_kernel (the lanes of a wave are 64 consecutive actions of ONE state; chosen by itself for periods of at most 16
+    states, period 1 of every run from one initial staff number) forced on every named case and on random ones: the wave's
+    arg-min with the reference's first-best rule, action ranges that are not multiples of 64, rows of unequal lengths, the
+    table's last row, both clamps -- and on slabs."""
+    monkeypatch.setenv("SDPGPU_STAFF_LANES", "1")
+    cases = [m() for m in staff_cases.ALL] + [_random_case(s) for s in range(300, 340)]
+    for c in cases:
+        V, pol, cells = c.oracle_problem(staffref).solve()
+        with _engine(sia, c) as eng:
+            eng.solve(sync=True)
+            assert eng.stats().cells_evaluated == cells, c.name
+            for period in range(1, c.T + 1):
+                assert np.array_equal(eng.values(period), V[period - 1]), (c.name, period)
+                assert np.array_equal(eng.policy(period), pol[period - 1]), (c.name, period)
+    c = staff_cases.staff_wide_actions()
+    V, pol, _ = c.oracle_problem(staffref).solve()
+    for world in (2, 3):
+        for rank in range(world):
+            with _engine(sia, c, rank, world) as eng:
+                eng.run_period(c.T)
+                _, lo, hi = eng.slab(c.T)
+                assert np.array_equal(eng.values(c.T)[lo:hi], V[c.T - 1][lo:hi]) and np.array_equal(eng.policy(c.T), pol[c.T - 1][lo:hi])
+
+
+def test_kernel_forms_chosen_by_range_size(sia, staffref, monkeypatch):
+    """Left alone the launcher picks the form by the period's staff range (one state: lanes = actions; a few hundred numbers: two
+    states per lane from a window; ~1500 and more: four) -- a run whose periods cross all of them, against the oracle, and against
+    the same run with the window form and the lanes-are-actions form switched off."""
+    T = 4  # staff ranges of 1, 601, 1201 and 1801 numbers
+    f = staff_cases.StaffFunctor(fixCost=50, unitVariCost=20, salary=5, unitPenalty=250, minStaffNum=[40, 90, 60, 30], maxHireNum=600,
+                                 clampStaff=False, iniStaffNum=0)
+    c = staff_cases.StaffCase("staff_forms", f, staff_cases.staff_level_pmf([0.3] * T, 601))
+    V, pol, cells = c.oracle_problem(staffref).solve()
+    assert [len(v) for v in V] == [1, 601, 1201, 1801]
+    with _engine(sia, c) as eng:
+        eng.solve(sync=True)
+        got = [(eng.values(t).copy(), eng.policy(t).copy()) for t in range(1, c.T + 1)]
+        assert eng.stats().cells_evaluated == cells
+    for t in range(c.T):
+        assert np.array_equal(got[t][0], V[t]) and np.array_equal(got[t][1], pol[t])
+    monkeypatch.setenv("SDPGPU_STAFF_WIN", "0")
+    monkeypatch.setenv("SDPGPU_STAFF_LANES", "0")
+    with _engine(sia, c) as eng:
+        eng.solve(sync=True)
+        for t in range(1, c.T + 1):
+            assert np.array_equal(eng.values(t), got[t - 1][0]) and np.array_equal(eng.policy(t), got[t - 1][1])
+
+
 def test_ping_pong_tables(sia, staffref):
     """store_all_values = 0: two value rows reused period after period; V_1 (and the policy of every period) must not
     care."""
