@@ -582,17 +582,33 @@ __global__ __launch_bounds__(256) void combine_staff_kernel(const double* __rest
                                                             int32_t* __restrict__ pol, int64_t lo, int64_t hi) {
   const int64_t idx = lo + (int64_t)blockIdx.x * 256 + threadIdx.x;
   if (idx >= hi) return;
+  // The scan keeps the winning GROUP and reads that group's action afterwards: with the action read inside the compare, every
+  // step was a dependent load (251 groups of WorkforceTesting.main's instance: 61 us a period, 8 % of its sweep); the values
+  // alone are independent reads, eight in flight per trip.
   double best = 1.7976931348623157e308;
-  int bestk = 0;
-  for (int g = 0; g < n_groups; ++g) {
+  int bestg = -1;
+  constexpr int U = 8;
+  int g = 0;
+  for (; g + U <= n_groups; g += U) {
+    double v[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) v[u] = part_val[(int64_t)(g + u) * part_stride + idx];
+#pragma unroll
+    for (int u = 0; u < U; ++u)
+      if (v[u] < best) {
+        best = v[u];
+        bestg = g + u;
+      }
+  }
+  for (; g < n_groups; ++g) {
     const double v = part_val[(int64_t)g * part_stride + idx];
     if (v < best) {
       best = v;
-      bestk = part_idx[(int64_t)g * part_stride + idx];
+      bestg = g;
     }
   }
   v_cur[idx] = best;
-  pol[idx] = bestk;
+  pol[idx] = bestg >= 0 ? part_idx[(int64_t)bestg * part_stride + idx] : 0;  // (no value below Double.MAX_VALUE: bestHireQty = 0)
 }
 
 }  // namespace sdp
