@@ -28,6 +28,8 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include <type_traits>
+
 namespace sdp {
 
 constexpr int kStaffPadJ = 8;  // zero rows before j = 0 and after j = maxj - 1 of the transposed table (>= R - 1)
@@ -43,6 +45,7 @@ struct StaffParams {
   int32_t nn_lo, nn_hi;  // bounds of the next staff number: [minX, maxX] when clamped, else the next period's box
   int32_t n_groups, group_actions;
   int64_t part_stride;  // elements between the partial rows of two groups
+  int32_t uni_rows;     // staff_window_kernel: the scalar-probability form for blocks beyond the table's last row (0: never)
 };
 
 template <bool FUTURE>
@@ -502,57 +505,86 @@ __global__ __launch_bounds__(64) SDP_STAFF_WIN_ATTR void staff_window_kernel(Sta
         s_p[buf][w_slot[c] + H] = tmp[c].y;
       }
     };
-    __builtin_amdgcn_wave_barrier();  // (the previous block's reads of the buffers are done)
-    row_load(0);
-    row_store(0);
-    __builtin_amdgcn_wave_barrier();
-    int cur = 0;
-    for (int jb = 0; jb < ksteps; jb += NW) {
+    // UNI: every level of the block sits on or beyond the table's last row (pmfs[t][min(y, rows - 1)], :93-94) -- all of a run's
+    // staff numbers from rows - 1 up, six tiles of seven in the last period of WorkforceTesting.main's instance.  Every lane of
+    // every level then reads the SAME probability p(rows - 1, j): one scalar load a step, a step ahead -- no row piece, no LDS
+    // staging, no barriers, no fold selects; the cells' arithmetic is the same, on the same values.
+    auto run_steps = [&](auto uni_tag) {
+      constexpr bool UNI = decltype(uni_tag)::value;
+      const char* p_last = pb + (int64_t)last_row * 8;
+      [[maybe_unused]] double p_ahead = 0.0;
+      if constexpr (UNI) {
+        p_ahead = *reinterpret_cast<const double*>(p_last);
+      } else {
+        __builtin_amdgcn_wave_barrier();  // (the previous block's reads of the buffers are done)
+        row_load(0);
+        row_store(0);
+        __builtin_amdgcn_wave_barrier();
+      }
+      int cur = 0;
+      for (int jb = 0; jb < ksteps; jb += NW) {
 #pragma unroll
-      for (int t = 0; t < NW; ++t) {
-        const int j = jb + t;
-        row_load(j + 1);
-        double vnew = 0.0;
-        if constexpr (FUTURE) vnew = v_of(Yl - (j + 1));
-        // by level (anti-diagonal u = r + s): one probability read and one product p V per level, used by its cells at once
-        double imm0[R];
+        for (int t = 0; t < NW; ++t) {
+          const int j = jb + t;
+          [[maybe_unused]] double p_now = 0.0;
+          if constexpr (UNI) {
+            p_now = p_ahead;
+            p_ahead = *reinterpret_cast<const double*>(p_last + (int64_t)(j + 1) * row_bytes);
+          } else {
+            row_load(j + 1);
+          }
+          double vnew = 0.0;
+          if constexpr (FUTURE) vnew = v_of(Yl - (j + 1));
+          // by level (anti-diagonal u = r + s): one probability read and one product p V per level, used by its cells at once
+          double imm0[R];
 #pragma unroll
-        for (int r = 0; r < R; ++r) {
-          const int w0 = (r - t + NW) % NW;
-          imm0[r] = fv[r] + salw[w0] + penw[w0];
-        }
+          for (int r = 0; r < R; ++r) {
+            const int w0 = (r - t + NW) % NW;
+            imm0[r] = fv[r] + salw[w0] + penw[w0];
+          }
 #pragma unroll
-        for (int u = 0; u < NW; ++u) {
-          const double pu = s_p[cur][(u % S) * H + lane + u / S];
-          double pvu = 0.0;
-          if constexpr (FUTURE) pvu = pu * vw[(u - t + NW) % NW];
+          for (int u = 0; u < NW; ++u) {
+            double pu;
+            if constexpr (UNI) pu = p_now; else pu = s_p[cur][(u % S) * H + lane + u / S];
+            double pvu = 0.0;
+            if constexpr (FUTURE) pvu = pu * vw[(u - t + NW) % NW];
 #pragma unroll
-          for (int s2 = 0; s2 < S; ++s2) {
-            const int r = u - s2;
-            if (r >= 0 && r < R) {
-              acc[s2][r] += pu * (s2 == 0 ? imm0[r] : immc[s2][r]);
-              if constexpr (FUTURE) acc[s2][r] += pvu;
+            for (int s2 = 0; s2 < S; ++s2) {
+              const int r = u - s2;
+              if (r >= 0 && r < R) {
+                acc[s2][r] += pu * (s2 == 0 ? imm0[r] : immc[s2][r]);
+                if constexpr (FUTURE) acc[s2][r] += pvu;
+              }
             }
           }
-        }
 #pragma unroll
-        for (int r = 0; r < R; ++r) {
+          for (int r = 0; r < R; ++r) {
 #pragma unroll
-          for (int s2 = S - 1; s2 > 1; --s2) immc[s2][r] = immc[s2 - 1][r];
-          if constexpr (S > 1) immc[1][r] = imm0[r];
+            for (int s2 = S - 1; s2 > 1; --s2) immc[s2][r] = immc[s2 - 1][r];
+            if constexpr (S > 1) immc[1][r] = imm0[r];
+          }
+          // slide: the entry of level Yl at step j + 1 replaces the one of level Yl + NW - 1 just used
+          const int nn = Yl - (j + 1);
+          vw[(NW - 1 - t) % NW] = vnew;
+          salw[(NW - 1 - t) % NW] = salary_of(nn);
+          penw[(NW - 1 - t) % NW] = penalty_of(nn);
+          if constexpr (!UNI) {
+            __builtin_amdgcn_wave_barrier();
+            row_store(cur ^ 1);
+            __builtin_amdgcn_wave_barrier();
+            cur ^= 1;
+          }
+          __builtin_amdgcn_sched_barrier(0);  // (one step at a time: left alone, the scheduler hoists the loads of all NW steps -- 330 VGPRs)
         }
-        // slide: the entry of level Yl at step j + 1 replaces the one of level Yl + NW - 1 just used
-        const int nn = Yl - (j + 1);
-        vw[(NW - 1 - t) % NW] = vnew;
-        salw[(NW - 1 - t) % NW] = salary_of(nn);
-        penw[(NW - 1 - t) % NW] = penalty_of(nn);
-        __builtin_amdgcn_wave_barrier();
-        row_store(cur ^ 1);
-        __builtin_amdgcn_wave_barrier();
-        cur ^= 1;
-        __builtin_amdgcn_sched_barrier(0);  // (one step at a time: left alone, the scheduler hoists the loads of all NW steps -- 330 VGPRs)
       }
-    }
+    };
+    // (one kernel, two branches: as two launches over the same grid -- each form with its own registers, the staged one without
+    // the 58 extra spilled dwords it carries here -- the two partially filled launches ran one after the other and the sweep took
+    // 6.5 ms against 4.4)
+    if (Y0 >= last_row && P.uni_rows)
+      run_steps(std::true_type{});
+    else
+      run_steps(std::false_type{});
 #pragma unroll
     for (int r = 0; r < R; ++r)
       if (a0 + r < P.n_actions) {

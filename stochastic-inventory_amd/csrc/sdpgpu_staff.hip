@@ -69,6 +69,7 @@ hipError_t launch_staff(sdpgpu_handle* h, int period, const double* v_next, doub
   S.min_staff = (int32_t)p.overhead;
   S.n_actions = h->n_actions_full;
   S.n_rows = h->lvl_rows[period - 1];
+  S.uni_rows = !(std::getenv("SDPGPU_STAFF_UNI") && std::atoi(std::getenv("SDPGPU_STAFF_UNI")) == 0);
   S.clamp = d.clamp_inventory;
   S.min_x = (int32_t)d.min_inventory;
   S.max_x = (int32_t)d.max_inventory;
@@ -121,8 +122,9 @@ hipError_t launch_staff(sdpgpu_handle* h, int period, const double* v_next, doub
   if (blocks * 64 >= 4294967296LL) return hipErrorInvalidValue;
   double* out_val = v_cur;
   int32_t* out_idx = pol;
-  if (S.n_groups > 1) {
-    const size_t need = (size_t)S.n_groups * (size_t)(hi - lo);
+  const int part_rows = S.n_groups;
+  if (part_rows > 1) {
+    const size_t need = (size_t)part_rows * (size_t)(hi - lo);
     if (need > h->staff_part_elems) {
       if (h->d_staff_val) (void)hipFree(h->d_staff_val);
       if (h->d_staff_idx) (void)hipFree(h->d_staff_idx);
@@ -183,9 +185,9 @@ hipError_t launch_staff(sdpgpu_handle* h, int period, const double* v_next, doub
                        out_val, out_idx, lo, hi);
   }
   hipError_t e = hipGetLastError();
-  if (e != hipSuccess || S.n_groups == 1) return e;
+  if (e != hipSuccess || part_rows == 1) return e;
   hipLaunchKernelGGL(sdp::combine_staff_kernel, dim3((unsigned)((hi - lo + 255) / 256)), dim3(256), 0, st, out_val,
-                     out_idx, S.n_groups, S.part_stride, v_cur, pol, lo, hi);
+                     out_idx, part_rows, S.part_stride, v_cur, pol, lo, hi);
   return hipGetLastError();
 }
 

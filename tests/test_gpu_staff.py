@@ -294,6 +294,13 @@ def test_kernel_forms_chosen_by_range_size(sia, staffref, monkeypatch):
         assert eng.stats().cells_evaluated == cells
     for t in range(c.T):
         assert np.array_equal(got[t][0], V[t]) and np.array_equal(got[t][1], pol[t])
+    # (the window kernel's blocks beyond the table's last row -- here every tile from staff number 600 up -- read one scalar
+    # probability a step instead of a staged row piece: switched off, the same tables)
+    monkeypatch.setenv("SDPGPU_STAFF_UNI", "0")
+    with _engine(sia, c) as eng:
+        eng.solve(sync=True)
+        for t in range(1, c.T + 1):
+            assert np.array_equal(eng.values(t), got[t - 1][0]) and np.array_equal(eng.policy(t), got[t - 1][1])
     monkeypatch.setenv("SDPGPU_STAFF_WIN", "0")
     monkeypatch.setenv("SDPGPU_STAFF_LANES", "0")
     with _engine(sia, c) as eng:
