@@ -653,12 +653,17 @@ def self_launch(args, argv) -> int:
     for t in pumps:
         t.join(timeout=5.0)
 
-    records = []
+    records, dec = [], json.JSONDecoder()
     for line in out_lines:
         if line.startswith("{"):
-            try:
-                records.append(json.loads(line))
-                continue
+            try:  # (one record a line; two ranks' writes that met in the pipe are taken apart)
+                pos, found = 0, []
+                while line.startswith("{", pos):
+                    rec, pos = dec.raw_decode(line, pos)
+                    found.append(rec)
+                if pos == len(line.rstrip()):
+                    records.extend(found)
+                    continue
             except ValueError:
                 pass
         if line.strip():

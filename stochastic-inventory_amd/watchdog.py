@@ -89,7 +89,15 @@ class PhaseWatchdog:
         rec.update(self.context)
         line = json.dumps(rec)
         try:
-            print(line, file=sys.stderr, flush=True)
-            print(line, flush=True)
+            # one write() per stream, record and newline together: the ranks of a job share the launcher's pipe, and on an
+            # unbuffered stream print() hands over the text and the newline separately -- two ranks firing in the same instant
+            # then put two records on one line (seen once in round 4: a JSONDecodeError in the reader, not a lost record)
+            data = (line + "\n").encode()
+            for stream in (sys.stderr, sys.stdout):
+                try:
+                    stream.flush()
+                    os.write(stream.fileno(), data)
+                except Exception:
+                    print(line, file=stream, flush=True)
         finally:
             os._exit(self.exit_code)
