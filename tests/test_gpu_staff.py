@@ -229,7 +229,7 @@ def test_two_states_per_lane_kernel_on_every_case(sia, staffref, monkeypatch):
 @pytest.mark.parametrize("win", ["4", "2"], ids=["S4", "S2"])
 def test_window_kernel_on_every_case(sia, staffref, monkeypatch, win):
     """staff_window_kernel (S adjacent states per lane, one probability per LEVEL from an LDS-staged piece of the table row,
-    immediate costs handed down the diagonal) is chosen by itself on staff ranges of 1024 numbers and more; forced here on
+    immediate costs handed down the diagonal) is chosen by itself on staff ranges of 256 numbers and more (two or four states per lane by size); forced here on
     every named case and on random ones -- the fold at the table's last row, clamped and unclamped staff ranges, penalties,
     truncated rows, tiles and action blocks with ragged ends -- and on slabs with odd lengths."""
     monkeypatch.setenv("SDPGPU_STAFF_PAIR", "1")
