@@ -635,15 +635,20 @@ struct FactList {
   const double* u2;
   const int* idx;    // per pair j: k1 | k2 << 16
   int nu1, nu2;
-  int grouped;       // the list's length is a multiple of four and every aligned group of four pairs shares k1 (fact_grouped)
+  int run;           // the list is made of runs of `run` pairs with one first index each (fact_run); 0: any other list
 };
 
-inline int fact_grouped(const std::vector<int>& idx) {
-  if (idx.empty() || idx.size() % 4 != 0) return 0;
-  for (size_t j = 0; j < idx.size(); j += 4)
-    for (size_t c = 1; c < 4; ++c)
+// The length of the list's runs of one first index, when the list is made of runs of equal length (the product lists GetPmfMulti
+// builds: the second product's demands under every first one); 0 otherwise.
+inline int fact_run(const std::vector<int>& idx) {
+  if (idx.empty()) return 0;
+  size_t run = 1;
+  while (run < idx.size() && (idx[run] & 0xffff) == (idx[0] & 0xffff)) ++run;
+  if (idx.size() % run != 0) return 0;
+  for (size_t j = 0; j < idx.size(); j += run)
+    for (size_t c = 1; c < run; ++c)
       if ((idx[j + c] & 0xffff) != (idx[j] & 0xffff)) return 0;
-  return 1;
+  return (int)run;
 }
 
 // V_{t+1} on the lattice: vdense[lattice index of state k] = v[k].  The backward pass of the bitmap path ranks every successor
@@ -689,9 +694,11 @@ __global__ __launch_bounds__(kFactThreads) void backward_fact_kernel(MLParams P,
   // (and at most two first ones), so a read of a pair's entries is 64 consecutive 8-byte words -- as [order][demand] records of
   // 24 bytes the lanes were 384 bytes apart, two LDS banks for 64 lanes (measured: 6x slower than round 3's kernel)
   const int n_e = P.qb * (F.nu1 + F.nu2);
-  double* s_rev = s_p + P.nd;            // [nu1][qb] then [nu2][qb]
-  double* s_w = s_rev + n_e;
-  LI* s_lat = reinterpret_cast<LI*>(s_w + n_e);
+  // (rev and w of an entry side by side: one 16-byte read and one address per entry -- as two arrays the second product's entries
+  // of model 1, read per cell, cost three address operations and two reads each: 12.6 vector operations per period-T cell
+  // counted where the arithmetic is 7)
+  double2* s_rw = reinterpret_cast<double2*>(s_p + ((P.nd + NA + 1) & ~1) - NA);  // [nu1][qb] then [nu2][qb], 16-byte aligned
+  LI* s_lat = reinterpret_cast<LI*>(s_rw + n_e);
   int* s_idx = reinterpret_cast<int*>(s_lat + (LAST ? 0 : n_e));
   int* s_off = s_idx + P.nd;
   const int64_t s = s_first + blockIdx.x;
@@ -731,8 +738,7 @@ __global__ __launch_bounds__(kFactThreads) void backward_fact_kernel(MLParams P,
       const long long i = (long long)n;
       t.lat = first ? (i * L.nr + L.skew1 * i) * L.n2 : L.skew2 * i * L.n2 + i;
     }
-    s_rev[slot] = t.rev;
-    s_w[slot] = t.w;
+    s_rw[slot] = make_double2(t.rev, t.w);
     if constexpr (!LAST) s_lat[slot] = (LI)t.lat;  // (I32: modulo 2^32 -- the sum of the three shares is below it)
   }
   __syncthreads();
@@ -740,13 +746,37 @@ __global__ __launch_bounds__(kFactThreads) void backward_fact_kernel(MLParams P,
   if constexpr (MODEL == 1) {  // the offered prefix of every row of the action box (see backward_kernel)
     if (tid < P.qb) {
       int n2 = 0;
-      while (n2 < P.qb && mc_feasible(P, st, tid, n2)) ++n2;
+      if (P.vari[1] >= 0) {
+        // the first second order quantity the row does not offer, by bisection: with a non-negative unit cost the ordering cost
+        // fl(fl(c1 a1) + fl(c2 a2)) never decreases in a2 (rounding is monotone), so the offered quantities are a prefix and
+        // the walk below stops at the same one -- in 7 tests instead of up to Qbound (MultiItemCash.main: 100)
+        int lo_f = 0, hi_f = P.qb;
+        while (lo_f < hi_f) {
+          const int mid = (lo_f + hi_f) >> 1;
+          if (mc_feasible(P, st, tid, mid)) lo_f = mid + 1; else hi_f = mid;
+        }
+        n2 = lo_f;
+      } else {
+        while (n2 < P.qb && mc_feasible(P, st, tid, n2)) ++n2;
+      }
       s_off[tid + 1] = n2;
     }
     __syncthreads();
-    if (tid == 0) {
-      s_off[0] = 0;
-      for (int i = 0; i < P.qb; ++i) s_off[i + 1] += s_off[i];
+    if (tid < 64) {  // running sum of the rows' counts: the first wave, 64 rows a step (one thread adding Qbound entries one
+                     // after the other was a chain of Qbound dependent LDS round trips per state)
+      int carry = 0;
+      for (int base_r = 0; base_r < P.qb; base_r += 64) {
+        const int r = base_r + tid;
+        int v = r < P.qb ? s_off[r + 1] : 0;
+#pragma unroll
+        for (int off = 1; off < 64; off <<= 1) {
+          const int u = __shfl_up(v, off, 64);
+          if (tid >= off) v += u;
+        }
+        if (r < P.qb) s_off[r + 1] = carry + v;
+        carry += __shfl(v, 63, 64);
+      }
+      if (tid == 0) s_off[0] = 0;
     }
     __syncthreads();
     n_offered = s_off[P.qb];
@@ -812,7 +842,7 @@ __global__ __launch_bounds__(kFactThreads) void backward_fact_kernel(MLParams P,
     // pairs instead of two per pair; any other group of pairs goes one by one.  The pairs are walked, and every accumulator fed,
     // in list order either way.
     constexpr int N2 = SAME2 ? 1 : NI;       // (SAME2: r2[i] is the same slot for every i -- except past the last action,
-    constexpr int CH = SAME2 ? 4 : 2;        //  where it is slot 0's: harmless, unused)
+    constexpr int CH = 4;                    //  where it is slot 0's: harmless, unused)
     int cur1 = -1;
     double c_rev1[NI], c_w1[NI];
     [[maybe_unused]] LI c_lat1[NI];
@@ -821,8 +851,9 @@ __global__ __launch_bounds__(kFactThreads) void backward_fact_kernel(MLParams P,
       const int o1 = k1 * P.qb;
 #pragma unroll
       for (int i = 0; i < NI; ++i) {
-        c_rev1[i] = s_rev[r1[i] + o1];
-        c_w1[i] = s_w[r1[i] + o1];
+        const double2 e = s_rw[r1[i] + o1];
+        c_rev1[i] = e.x;
+        c_w1[i] = e.y;
         if constexpr (!LAST && LK != 0) c_lat1[i] = s_lat[r1[i] + o1];
       }
     };
@@ -830,8 +861,9 @@ __global__ __launch_bounds__(kFactThreads) void backward_fact_kernel(MLParams P,
       const int o2 = k2 * P.qb;
 #pragma unroll
       for (int i = 0; i < N2; ++i) {
-        rev2[i] = s_rev[r2[i] + o2];
-        w2[i] = s_w[r2[i] + o2];
+        const double2 e = s_rw[r2[i] + o2];
+        rev2[i] = e.x;
+        w2[i] = e.y;
         if constexpr (!LAST && LK != 0) lat2[i] = s_lat[r2[i] + o2]; else lat2[i] = 0;
       }
     };
@@ -929,22 +961,34 @@ __global__ __launch_bounds__(kFactThreads) void backward_fact_kernel(MLParams P,
         for (int i = 0; i < NI; ++i) acc[i] += pg * v[i];
       }
     };
-    if (F.grouped) {  // (the host's test of the list: every aligned group of four pairs shares its first index)
-      for (int j = 0; j < P.nd; j += CH) {
-        int kk[CH];
-        double pp[CH];
+    if (F.run > 0) {  // (the host's test of the list: runs of F.run pairs, each with one first index)
+      for (int j0 = 0; j0 < P.nd; j0 += F.run) {
+        load1(__builtin_amdgcn_readfirstlane(s_idx[j0]) & 0xffff);
+        int jj = 0;
+        for (; jj + CH <= F.run; jj += CH) {
+          const int j = j0 + jj;
+          int kk[CH];
+          double pp[CH];
 #pragma unroll
-        for (int c = 0; c < CH; ++c) {
-          kk[c] = __builtin_amdgcn_readfirstlane(s_idx[j + c]);
-          pp[c] = s_p[j + c];
+          for (int c = 0; c < CH; ++c) {
+            kk[c] = __builtin_amdgcn_readfirstlane(s_idx[j + c]);
+            pp[c] = s_p[j + c];
+          }
+          double rev2[CH][N2], w2[CH][N2];
+          LI lat2[CH][N2];
+#pragma unroll
+          for (int c = 0; c < CH; ++c) load2(kk[c] >> 16, rev2[c], w2[c], lat2[c]);
+#pragma unroll
+          for (int c = 0; c < CH; ++c) pair_body(j + c, pp[c], rev2[c], w2[c], lat2[c]);
         }
-        if ((kk[0] & 0xffff) != cur1) load1(kk[0] & 0xffff);
-        double rev2[CH][N2], w2[CH][N2];
-        LI lat2[CH][N2];
-#pragma unroll
-        for (int c = 0; c < CH; ++c) load2(kk[c] >> 16, rev2[c], w2[c], lat2[c]);
-#pragma unroll
-        for (int c = 0; c < CH; ++c) pair_body(j + c, pp[c], rev2[c], w2[c], lat2[c]);
+        for (; jj < F.run; ++jj) {  // (a run that is not a multiple of CH pairs long: its last pairs one by one)
+          const int j = j0 + jj;
+          const int kk = __builtin_amdgcn_readfirstlane(s_idx[j]);
+          double rev2[N2], w2[N2];
+          LI lat2[N2];
+          load2(kk >> 16, rev2, w2, lat2);
+          pair_body(j, s_p[j], rev2, w2, lat2);
+        }
       }
     } else {
       for (int j = 0; j < P.nd; ++j) {
@@ -966,20 +1010,51 @@ __global__ __launch_bounds__(kFactThreads) void backward_fact_kernel(MLParams P,
   }
   if constexpr (MARK) return;
   __syncthreads();
-  if (tid < 64) {  // `if (actionValues[i] > val + 0.1)` in action order, as in backward_kernel
+  // `if (actionValues[i] > val + 0.1)` in action order (as in backward_kernel), in two steps.  `val` only grows, so a chunk of
+  // 64 action values whose largest is not above val + 0.1 when the scan reaches it holds no value that is: every wave forms the
+  // maxima of its share of the chunks (in the tables' LDS, which nobody reads any more), and the first wave then walks the
+  // CHUNKS in order -- 64 maxima a step -- opening only those that can move `val`.  Opening every chunk, as before, had one wave
+  // walk all the action values while seven waited: a third of a state's time at MultiItemCash.main's 10000 order pairs.
+  double* s_max = reinterpret_cast<double*>(s_rw);  // (ceil(Qbound^2 / 64) doubles; the tables hold 2 Qbound (nu1 + nu2) >= 4 Qbound)
+  const int n_chunks = (n_offered + 63) >> 6;
+  {
+    const int wave_id = tid >> 6, lane_id = tid & 63;
+    for (int c = wave_id; c < n_chunks; c += kFactThreads / 64) {
+      const int a = c * 64 + lane_id;
+      double m = a < n_offered ? s_q[a] : -1.7976931348623157e308;
+#pragma unroll
+      for (int off = 32; off > 0; off >>= 1) {
+        const double o = __shfl_xor(m, off, 64);
+        m = o > m ? o : m;
+      }
+      if (lane_id == 0) s_max[c] = m;
+    }
+  }
+  __syncthreads();
+  if (tid < 64) {
     double val = -1.7976931348623157e308;
     int best = 0;
-    for (int base_k = 0; base_k < n_offered; base_k += 64) {
-      const int a = base_k + tid;
-      const double q = a < n_offered ? s_q[a] : -1.7976931348623157e308;
-      int from = 0;
+    for (int base_c = 0; base_c < n_chunks; base_c += 64) {
+      const int cc = base_c + tid;
+      const double mc = cc < n_chunks ? s_max[cc] : -1.7976931348623157e308;
+      int from_c = 0;
       while (true) {
-        const unsigned long long m = __ballot(a < n_offered && tid >= from && q > val + 0.1);
-        if (!m) break;
-        const int first = __ffsll((long long)m) - 1;
-        val = __shfl(q, first, 64);
-        best = base_k + first;
-        from = first + 1;
+        const unsigned long long open = __ballot(cc < n_chunks && tid >= from_c && mc > val + 0.1);
+        if (!open) break;
+        const int first_c = __ffsll((long long)open) - 1;
+        const int base_k = (base_c + first_c) * 64;
+        const int a = base_k + tid;
+        const double q = a < n_offered ? s_q[a] : -1.7976931348623157e308;
+        int from = 0;
+        while (true) {
+          const unsigned long long m = __ballot(a < n_offered && tid >= from && q > val + 0.1);
+          if (!m) break;
+          const int first = __ffsll((long long)m) - 1;
+          val = __shfl(q, first, 64);
+          best = base_k + first;
+          from = first + 1;
+        }
+        from_c = first_c + 1;
       }
     }
     if (tid == 0) {
@@ -1268,7 +1343,7 @@ int sparse_solve(const SparseProblem& sp, double* final_value, int32_t* q1, int3
             F.idx = reinterpret_cast<const int*>(F.u2 + u2.size());
             F.nu1 = (int)u1.size();
             F.nu2 = (int)u2.size();
-            F.grouped = fact_grouped(idx);
+            F.run = fact_run(idx);
 #define ML_MARK(MD, W32)                                                                                                       \
   do {                                                                                                                        \
     if (smem_m > 64 * 1024)                                                                                                   \
@@ -1465,7 +1540,7 @@ int sparse_solve(const SparseProblem& sp, double* final_value, int32_t* q1, int3
           F.idx = reinterpret_cast<const int*>(F.u2 + u2.size());
           F.nu1 = (int)u1.size();
           F.nu2 = (int)u2.size();
-          F.grouped = fact_grouped(idx);
+          F.run = fact_run(idx);
 #define ML_FACT(MD, LS, LKK, W32)                                                                                               \
   do {                                                                                                                      \
     if (smem_f > 64 * 1024)                                                                                                 \
