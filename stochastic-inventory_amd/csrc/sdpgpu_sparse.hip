@@ -640,6 +640,16 @@ struct FactList {
 
 // The length of the list's runs of one first index, when the list is made of runs of equal length (the product lists GetPmfMulti
 // builds: the second product's demands under every first one); 0 otherwise.
+constexpr int kFactThreads = 512;  // eight waves share a state's tables: twice the waves per compute unit for the same LDS
+constexpr int kFactNI = 5;         // order pairs a lane carries through a pass of the demand list
+// LDS of a backward_fact_kernel workgroup (its carve-up): one pass of Q(s, .), the pmf and the pairs' index words, the tables
+// (16 bytes an entry; before period T up to 8 more for the lattice share), the rows' offsets, the chunk maxima; slack for alignment
+inline size_t fact_lds_bytes(int NA, int nd, int qb, size_t n_distinct, bool last) {
+  const size_t qn = (size_t)std::min(NA, kFactThreads * kFactNI);
+  return qn * 8 + (size_t)nd * 12 + (size_t)qb * n_distinct * (last ? 16 : 24) + (size_t)(qb + 1) * 4 +
+         (size_t)(kFactThreads * kFactNI / 64) * 8 + 32;
+}
+
 inline int fact_run(const std::vector<int>& idx) {
   if (idx.empty()) return 0;
   size_t run = 1;
@@ -662,7 +672,6 @@ __global__ __launch_bounds__(256) void dense_scatter_kernel(Lattice L, const Tup
   if (k < n) vdense[lattice_index(L, states[k])] = v[k];
 }
 
-constexpr int kFactThreads = 512;  // eight waves share a state's tables: twice the waves per compute unit for the same LDS
 // LK: where a successor's value comes from in the periods before T -- 0: the rank stored per candidate by the sorted-candidates
 // forward pass (uid), 1: the lattice's rank word, then the value by rank, 2: V_{t+1} laid out on the lattice itself.  A template
 // argument, and the loop below forms the NI actions' reads of a demand pair first, issues them together and consumes them
@@ -672,7 +681,7 @@ constexpr int kFactThreads = 512;  // eight waves share a state's tables: twice 
 // the successor's index is formed in 32-bit words -- 4-byte table entries, a 24-bit multiply-add -- where the 64-bit form costs
 // a quarter-rate v_mad_u64_u32, two 2-word additions and 8-byte LDS reads per cell.
 template <int MODEL, bool LAST, int LK = 0, bool I32 = false>
-__global__ __launch_bounds__(kFactThreads) void backward_fact_kernel(MLParams P, const Tuple* __restrict__ states, int64_t s_first,
+__global__ __launch_bounds__(kFactThreads, 4) void backward_fact_kernel(MLParams P, const Tuple* __restrict__ states, int64_t s_first,
                                                            int64_t n_states, FactList F, const double* __restrict__ prob,
                                                            const double* __restrict__ v_next, const int* __restrict__ uid,
                                                            double* __restrict__ v_out, int* __restrict__ act_out,
@@ -688,8 +697,12 @@ __global__ __launch_bounds__(kFactThreads) void backward_fact_kernel(MLParams P,
   using LI = std::conditional_t<I32, unsigned int, long long>;
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int NA = P.qb * P.qb;
-  double* s_q = reinterpret_cast<double*>(smem);  // Q(s, a)
-  double* s_p = s_q + NA;
+  // Q(s, a) of ONE pass of the action range (kFactThreads x NI order pairs); the tolerance scan runs behind every pass, its `val`
+  // carried on.  Held for the whole range (8 B x Qbound^2: 80 KB at MultiItemCash.main's Qbound 100) the array left room for one
+  // workgroup a compute unit -- two waves per SIMD, the vector unit 0.60 busy.
+  const int QN = NA < kFactThreads * kFactNI ? NA : kFactThreads * kFactNI;
+  double* s_q = reinterpret_cast<double*>(smem);
+  double* s_p = s_q + QN;
   // the tables as separate arrays, [distinct demand][order index]: the lanes of a wave are consecutive second order quantities
   // (and at most two first ones), so a read of a pair's entries is 64 consecutive 8-byte words -- as [order][demand] records of
   // 24 bytes the lanes were 384 bytes apart, two LDS banks for 64 lanes (measured: 6x slower than round 3's kernel)
@@ -697,10 +710,12 @@ __global__ __launch_bounds__(kFactThreads) void backward_fact_kernel(MLParams P,
   // (rev and w of an entry side by side: one 16-byte read and one address per entry -- as two arrays the second product's entries
   // of model 1, read per cell, cost three address operations and two reads each: 12.6 vector operations per period-T cell
   // counted where the arithmetic is 7)
-  double2* s_rw = reinterpret_cast<double2*>(s_p + ((P.nd + NA + 1) & ~1) - NA);  // [nu1][qb] then [nu2][qb], 16-byte aligned
+  double2* s_rw = reinterpret_cast<double2*>(s_p + ((P.nd + QN + 1) & ~1) - QN);  // [nu1][qb] then [nu2][qb], 16-byte aligned
   LI* s_lat = reinterpret_cast<LI*>(s_rw + n_e);
   int* s_idx = reinterpret_cast<int*>(s_lat + (LAST ? 0 : n_e));
   int* s_off = s_idx + P.nd;
+  // maxima of a pass's 64-value chunks (see the scan): kFactThreads * kFactNI / 64 doubles, 8-byte aligned
+  double* s_max = reinterpret_cast<double*>((reinterpret_cast<uintptr_t>(s_off + P.qb + 1) + 7) & ~(uintptr_t)7);
   const int64_t s = s_first + blockIdx.x;
   if (s >= n_states) return;
   const Tuple st = states[s];
@@ -795,7 +810,7 @@ __global__ __launch_bounds__(kFactThreads) void backward_fact_kernel(MLParams P,
   const double pdisc = P.discount;
   // NI actions of a lane at a time (k = tid + 256 i), demand pairs in the outer loop: the pair's index word and probability are
   // read once per lane, every accumulator takes its addends demand index ascending
-  constexpr int NI = 5;  // (512 threads x 5: the 2500 order pairs of Qbound 50 in one pass)
+  constexpr int NI = kFactNI;  // (512 threads x 5: the 2500 order pairs of Qbound 50 in one pass)
   // Model 2's action box is regular (a = i * Qbound + j): with the lanes' actions a multiple of Qbound apart (TS = the largest
   // multiple of Qbound that fits the workgroup; lanes beyond it idle: 12 of 512 at Qbound 50) a lane's NI actions share the SECOND
   // order index, so the second product's table entries of a demand pair are read once per lane instead of once per cell -- 12
@@ -803,6 +818,8 @@ __global__ __launch_bounds__(kFactThreads) void backward_fact_kernel(MLParams P,
   constexpr bool SAME2 = MODEL == 2;
   const int TS = (SAME2 && P.qb <= kFactThreads) ? (kFactThreads / P.qb) * P.qb : kFactThreads;
   const bool lane_on = tid < TS;
+  double scan_val = -1.7976931348623157e308;  // (the first wave's: `val` and the best action so far of the tolerance scan)
+  int scan_best = 0;
   for (int k0 = 0; k0 < n_offered; k0 += TS * NI) {
     int r1[NI], r2[NI];  // slot of (distinct demand 0, this action's order index): + k * qb per pair
     double base[NI], acc[NI];
@@ -1004,59 +1021,62 @@ __global__ __launch_bounds__(kFactThreads) void backward_fact_kernel(MLParams P,
 #pragma unroll
       for (int i = 0; i < NI; ++i) {
         const int k = k0 + tid + TS * i;
-        if (lane_on && k < n_offered) s_q[k] = acc[i];
+        if (lane_on && k < n_offered) s_q[k - k0] = acc[i];
       }
+      __syncthreads();
+      // `if (actionValues[i] > val + 0.1)` in action order (as in backward_kernel) over this pass's values, in two steps.  `val`
+      // only grows, so a chunk of 64 values whose largest is not above val + 0.1 when the scan reaches it holds no value that is:
+      // every wave forms the maxima of its share of the chunks, and the first wave then walks the CHUNKS in order -- 64 maxima a
+      // step -- opening only those that can move `val`.  (Opening every chunk had one wave walk all the action values while
+      // seven waited: a third of a state's time at MultiItemCash.main's 10000 order pairs.)
+      const int n_pass = (n_offered - k0) < TS * NI ? (n_offered - k0) : TS * NI;
+      const int n_chunks = (n_pass + 63) >> 6;
+      {
+        const int wave_id = tid >> 6, lane_id = tid & 63;
+        for (int c = wave_id; c < n_chunks; c += kFactThreads / 64) {
+          const int a = c * 64 + lane_id;
+          double m = a < n_pass ? s_q[a] : -1.7976931348623157e308;
+#pragma unroll
+          for (int off = 32; off > 0; off >>= 1) {
+            const double o = __shfl_xor(m, off, 64);
+            m = o > m ? o : m;
+          }
+          if (lane_id == 0) s_max[c] = m;
+        }
+      }
+      __syncthreads();
+      if (tid < 64) {
+        for (int base_c = 0; base_c < n_chunks; base_c += 64) {
+          const int cc = base_c + tid;
+          const double mc = cc < n_chunks ? s_max[cc] : -1.7976931348623157e308;
+          int from_c = 0;
+          while (true) {
+            const unsigned long long open = __ballot(cc < n_chunks && tid >= from_c && mc > scan_val + 0.1);
+            if (!open) break;
+            const int first_c = __ffsll((long long)open) - 1;
+            const int base_k = (base_c + first_c) * 64;
+            const int a = base_k + tid;
+            const double q = a < n_pass ? s_q[a] : -1.7976931348623157e308;
+            int from = 0;
+            while (true) {
+              const unsigned long long m = __ballot(a < n_pass && tid >= from && q > scan_val + 0.1);
+              if (!m) break;
+              const int first = __ffsll((long long)m) - 1;
+              scan_val = __shfl(q, first, 64);
+              scan_best = k0 + base_k + first;
+              from = first + 1;
+            }
+            from_c = first_c + 1;
+          }
+        }
+      }
+      __syncthreads();  // (the next pass writes s_q and s_max again)
     }
   }
   if constexpr (MARK) return;
-  __syncthreads();
-  // `if (actionValues[i] > val + 0.1)` in action order (as in backward_kernel), in two steps.  `val` only grows, so a chunk of
-  // 64 action values whose largest is not above val + 0.1 when the scan reaches it holds no value that is: every wave forms the
-  // maxima of its share of the chunks (in the tables' LDS, which nobody reads any more), and the first wave then walks the
-  // CHUNKS in order -- 64 maxima a step -- opening only those that can move `val`.  Opening every chunk, as before, had one wave
-  // walk all the action values while seven waited: a third of a state's time at MultiItemCash.main's 10000 order pairs.
-  double* s_max = reinterpret_cast<double*>(s_rw);  // (ceil(Qbound^2 / 64) doubles; the tables hold 2 Qbound (nu1 + nu2) >= 4 Qbound)
-  const int n_chunks = (n_offered + 63) >> 6;
-  {
-    const int wave_id = tid >> 6, lane_id = tid & 63;
-    for (int c = wave_id; c < n_chunks; c += kFactThreads / 64) {
-      const int a = c * 64 + lane_id;
-      double m = a < n_offered ? s_q[a] : -1.7976931348623157e308;
-#pragma unroll
-      for (int off = 32; off > 0; off >>= 1) {
-        const double o = __shfl_xor(m, off, 64);
-        m = o > m ? o : m;
-      }
-      if (lane_id == 0) s_max[c] = m;
-    }
-  }
-  __syncthreads();
   if (tid < 64) {
-    double val = -1.7976931348623157e308;
-    int best = 0;
-    for (int base_c = 0; base_c < n_chunks; base_c += 64) {
-      const int cc = base_c + tid;
-      const double mc = cc < n_chunks ? s_max[cc] : -1.7976931348623157e308;
-      int from_c = 0;
-      while (true) {
-        const unsigned long long open = __ballot(cc < n_chunks && tid >= from_c && mc > val + 0.1);
-        if (!open) break;
-        const int first_c = __ffsll((long long)open) - 1;
-        const int base_k = (base_c + first_c) * 64;
-        const int a = base_k + tid;
-        const double q = a < n_offered ? s_q[a] : -1.7976931348623157e308;
-        int from = 0;
-        while (true) {
-          const unsigned long long m = __ballot(a < n_offered && tid >= from && q > val + 0.1);
-          if (!m) break;
-          const int first = __ffsll((long long)m) - 1;
-          val = __shfl(q, first, 64);
-          best = base_k + first;
-          from = first + 1;
-        }
-        from_c = first_c + 1;
-      }
-    }
+    const double val = scan_val;
+    int best = scan_best;
     if (tid == 0) {
       if constexpr (MODEL == 1) {
         int a1, a2;
@@ -1329,7 +1349,7 @@ int sparse_solve(const SparseProblem& sp, double* final_value, int32_t* q1, int3
             ok = u1.size() <= 4096 && u2.size() <= 4096;
             idx[(size_t)j] = (int)k1 | ((int)k2 << 16);
           }
-          const size_t smem_m = (size_t)NA * 8 + (size_t)nd * 12 + (size_t)P.qb * (u1.size() + u2.size()) * 24 + (size_t)(P.qb + 1) * 4 + 16;
+          const size_t smem_m = fact_lds_bytes(NA, nd, P.qb, u1.size() + u2.size(), false);
           if (ok && smem_m <= kLdsPerCUSparse) {
             if (d_fact) (void)hipFree(d_fact);
             d_fact = nullptr;
@@ -1510,8 +1530,7 @@ int sparse_solve(const SparseProblem& sp, double* final_value, int32_t* q1, int3
           ok = u1.size() <= 4096 && u2.size() <= 4096;
           idx[(size_t)j] = (int)k1 | ((int)k2 << 16);
         }
-        const size_t smem_f = (size_t)NA * 8 + (size_t)nd * 12 + (size_t)P.qb * (u1.size() + u2.size()) * (P.is_last ? 16 : 24) +
-                              (size_t)(P.qb + 1) * 4 + 16;
+        const size_t smem_f = fact_lds_bytes(NA, nd, P.qb, u1.size() + u2.size(), P.is_last != 0);
         if (ok && smem_f <= kLdsPerCU) {
           if (d_fact) (void)hipFree(d_fact);
           d_fact = nullptr;
