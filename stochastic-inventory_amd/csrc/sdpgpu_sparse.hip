@@ -644,8 +644,8 @@ constexpr int kFactThreads = 512;  // eight waves share a state's tables: twice 
 constexpr int kFactNI = 5;         // order pairs a lane carries through a pass of the demand list
 // LDS of a backward_fact_kernel workgroup (its carve-up): one pass of Q(s, .), the pmf and the pairs' index words, the tables
 // (16 bytes an entry; before period T up to 8 more for the lattice share), the rows' offsets, the chunk maxima; slack for alignment
-inline size_t fact_lds_bytes(int NA, int nd, int qb, size_t n_distinct, bool last) {
-  const size_t qn = (size_t)std::min(NA, kFactThreads * kFactNI);
+inline size_t fact_lds_bytes(int NA, int nd, int qb, size_t n_distinct, bool last, bool mark = false) {
+  const size_t qn = mark ? 0 : (size_t)std::min(NA, kFactThreads * kFactNI);
   return qn * 8 + (size_t)nd * 12 + (size_t)qb * n_distinct * (last ? 16 : 24) + (size_t)(qb + 1) * 4 +
          (size_t)(kFactThreads * kFactNI / 64) * 8 + 32;
 }
@@ -700,7 +700,7 @@ __global__ __launch_bounds__(kFactThreads, 4) void backward_fact_kernel(MLParams
   // Q(s, a) of ONE pass of the action range (kFactThreads x NI order pairs); the tolerance scan runs behind every pass, its `val`
   // carried on.  Held for the whole range (8 B x Qbound^2: 80 KB at MultiItemCash.main's Qbound 100) the array left room for one
   // workgroup a compute unit -- two waves per SIMD, the vector unit 0.60 busy.
-  const int QN = NA < kFactThreads * kFactNI ? NA : kFactThreads * kFactNI;
+  const int QN = (LK == 3) ? 0 : (NA < kFactThreads * kFactNI ? NA : kFactThreads * kFactNI);  // (the forward pass keeps no values)
   double* s_q = reinterpret_cast<double*>(smem);
   double* s_p = s_q + QN;
   // the tables as separate arrays, [distinct demand][order index]: the lanes of a wave are consecutive second order quantities
@@ -1349,7 +1349,7 @@ int sparse_solve(const SparseProblem& sp, double* final_value, int32_t* q1, int3
             ok = u1.size() <= 4096 && u2.size() <= 4096;
             idx[(size_t)j] = (int)k1 | ((int)k2 << 16);
           }
-          const size_t smem_m = fact_lds_bytes(NA, nd, P.qb, u1.size() + u2.size(), false);
+          const size_t smem_m = fact_lds_bytes(NA, nd, P.qb, u1.size() + u2.size(), false, true);
           if (ok && smem_m <= kLdsPerCUSparse) {
             if (d_fact) (void)hipFree(d_fact);
             d_fact = nullptr;
