@@ -445,6 +445,15 @@ def roofline_block(w, st, T, cells_rank, states_rank, dev_ms_per_sweep, per_laun
         # the cheaper period-T launch would flatter)
         dom = [m for m in per_launch_ms[1:] if m > 0] or [avg_launch_ms]
         dom_ms = sum(dom) / len(dom)
+        priced = "HIP-event launch time"
+        # A sweep whose periods run DIFFERENT kernels or very different grids (the workforce family: staff ranges of 1 to 7001
+        # numbers, four kernel forms) has no "the launch" to divide the counted kernel's instructions by: the mean of its
+        # launches is not that kernel's duration (priced so, round 4's staff entry read 0.96 where the unit was 0.78 busy).
+        # Told apart by the counted kernel's own duration in the profile; its instructions are then priced against THAT.
+        prof_us = ((pmc.get("kernels") or {}).get(pmc.get("dominant_kernel") or "", {}).get("rocprof") or {}).get("avg_us")
+        if prof_us and abs(prof_us * 1e-3 - dom_ms) > 0.15 * dom_ms:
+            dom_ms = float(prof_us) * 1e-3
+            priced = "the counted kernel's own rocprofv3 duration (the sweep's launches run different kernels / grids)"
         lane_ops = float(pmc["valu_insts_per_launch"]) * 64.0 / (dom_ms * 1e-3)
         out.update({
             "bound": "valu-issue",
@@ -457,7 +466,7 @@ def roofline_block(w, st, T, cells_rank, states_rank, dev_ms_per_sweep, per_laun
                 (sum(c for c in per_launch_cells[1:] if c > 0) / max(1, sum(1 for c in per_launch_cells[1:] if c > 0)))
                 if per_launch_cells and any(c > 0 for c in per_launch_cells[1:]) else cells_rank / launches, 1),
             "ta_busy_frac": pmc.get("ta_busy_frac"),
-            "note": f"SQ_INSTS_VALU x 64 lanes per launch ({pmc['_file']}) / HIP-event launch time; every wave64 VALU "
+            "note": f"SQ_INSTS_VALU x 64 lanes per launch ({pmc['_file']}) / {priced}; every wave64 VALU "
                     "instruction holds its SIMD four cycles",
         })
     else:

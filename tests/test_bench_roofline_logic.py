@@ -64,3 +64,22 @@ def test_every_bench_workload_has_a_kernel_source_digest():
         assert len(kernel_source_sha(root, name)) == 16
     assert "sdp_custom_src.hpp" in kernel_files("custom_clsp_level_x")
     assert len(build_source_sha(root)) == 16
+
+
+def test_a_sweep_of_different_kernels_is_priced_against_the_counted_kernels_own_duration(monkeypatch):
+    """The workforce family's periods run different kernel forms on staff ranges of 1 to 7001 numbers: the mean of the sweep's
+    launches is not the counted kernel's duration.  The counted instructions are then divided by that kernel's own duration in
+    the profile (and the note says so); a sweep of like launches keeps the HIP-event time."""
+    insts = 3.1e8  # wave instructions of the counted kernel per launch
+    pmc = {"_file": "profiles/x.json", "dominant_kernel": "k<4, 4, true>", "valu_insts_per_launch": insts,
+           "kernels": {"k<4, 4, true>": {"rocprof": {"calls": 35, "avg_us": 663.0}}}}
+    monkeypatch.setattr(bench, "load_pmc", lambda name: dict(pmc))
+    per_launch = [0.66, 0.87, 0.83, 0.72, 0.46, 0.44, 0.29, 0.07]
+    rf = bench.roofline_block(_workload("staff_x"), _stats(), 8, 2.7e10, 3e4, sum(per_launch), per_launch)
+    assert rf["bound"] == "valu-issue" and abs(rf["dominant_launch_ms"] - 0.663) < 1e-9 and "own rocprofv3 duration" in rf["note"]
+    assert abs(rf["frac"] - insts * 64 / 0.663e-3 / bench.VALU_PEAK_LANE_OPS) < 1e-12 and 0.7 < rf["frac"] < 0.8
+    like = [0.74, 41.6, 41.7, 41.7]
+    pmc["kernels"]["k<4, 4, true>"]["rocprof"]["avg_us"] = 41990.0
+    pmc["valu_insts_per_launch"] = 2.0e10
+    rf = bench.roofline_block(_workload("f5_x"), _stats(), 4, 3.56e11, 1e8, sum(like), like)
+    assert abs(rf["dominant_launch_ms"] - sum(like[1:]) / 3) < 1e-9 and "HIP-event launch time" in rf["note"]
