@@ -402,6 +402,63 @@ __global__ __launch_bounds__(256) void lattice_list_kernel(Lattice L, const unsi
   }
 }
 
+// ---- forward on the lattice, XR family with exact data: marking through the POST-ORDER triples -------------------------
+// MultiItemCashXR's transition reads its state through three numbers only when its arithmetic is exact: the order-up-to
+// levels y1, y2 and W = R - c . y.  initialCash = R - c . x; immediate = revenue + 1.0 (R - c . y) - initialCash; nextCash =
+// initialCash + immediate (MultiItemCashXR.java:108-148) -- with no deposit rate, integer unit costs, R and x integers (lattice
+// states are), prices and demands on a 1/8 grid and everything far below 2^53, every one of those operations is exact, so
+// nextCash = revenue + W whatever initialCash was, and the end inventories read y and the demand alone.  The host checks those
+// conditions (xr_exact_data).  Every (state, order) pair then marks its triple in a bitmap of its own, and the successors are
+// marked from the DISTINCT triples -- each as the stand-in state (x = y, R = W + c . y) ordering up to its own level, through the
+// same xr_successor -- instead of from every (state, order, demand pair): 4.4e9 pairs fold onto a few 1e7 triples in period 3 of
+// MultiItemCashXR's four-period run, whose marking pass was 1.08 of 3.45 s.
+__global__ __launch_bounds__(256) void xr_triple_mark_kernel(MLParams P, Lattice B, long long w0, const Tuple* __restrict__ states,
+                                                             int64_t n_states, unsigned int* __restrict__ words,
+                                                             int* __restrict__ oob) {
+  const int NA = P.qb * P.qb;
+  const int64_t g = (int64_t)blockIdx.x * 256 + threadIdx.x;  // (s, a)
+  if (g >= n_states * NA) return;
+  const int64_t s = g / NA;
+  const int a = (int)(g - s * NA);
+  const Tuple st = states[s];
+  const int a1 = a / P.qb, a2 = a - a1 * P.qb;
+  const long long y1 = (long long)((int)st.i1 + a1), y2 = (long long)((int)st.i2 + a2);
+  const long long w = (long long)st.cash - (long long)P.vari[0] * y1 - (long long)P.vari[1] * y2 - w0;
+  if (y1 < 0 || y2 < 0 || y2 >= B.nr || w < 0 || w >= B.n2) {
+    *oob = 1;
+    return;
+  }
+  const long long idx = (y1 * B.nr + y2) * B.n2 + w;  // (the triples' box as a Lattice: i1 = y1, R - r0 = y2, i2 = W - w0)
+  if (idx >= B.bits) {
+    *oob = 1;
+    return;
+  }
+  const unsigned int bit = 1u << (idx & 31);
+  if (!(words[idx >> 5] & bit)) atomicOr(&words[idx >> 5], bit);
+}
+
+__global__ __launch_bounds__(256) void xr_triple_succ_kernel(MLParams P, Lattice L, long long w0, const Tuple* __restrict__ triples,
+                                                             int64_t n_triples, const double2* __restrict__ dem,
+                                                             unsigned int* __restrict__ words, int* __restrict__ oob) {
+  const int64_t g = (int64_t)blockIdx.x * 256 + threadIdx.x;  // (triple, demand pair)
+  if (g >= n_triples * P.nd) return;
+  const int64_t k = g / P.nd;
+  const int j = (int)(g - k * P.nd);
+  const Tuple tr = triples[k];  // (lattice_tuple of the triples' box: i1 = y1, cash = y2, i2 = W - w0)
+  Tuple st;
+  st.i1 = tr.i1;
+  st.i2 = tr.cash;
+  st.q1 = st.q2 = 0.0;
+  st.cash = (tr.i2 + (double)w0) + P.vari[0] * tr.i1 + P.vari[1] * tr.cash;
+  const long long idx = lattice_index(L, xr_successor(P, st, st.i1, st.i2, dem[j].x, dem[j].y));
+  if (idx < 0 || idx >= L.bits) {
+    *oob = 1;
+    return;
+  }
+  const unsigned int bit = 1u << (idx & 31);
+  if (!(words[idx >> 5] & bit)) atomicOr(&words[idx >> 5], bit);
+}
+
 // ---- backward: one workgroup per state ------------------------------------------------------------
 // The lead-time family's actions of one state (model 0), NI actions per lane (a = tid + 256 i), demand pairs in the OUTER loop: a
 // pair's terms are read from LDS once per lane instead of once per cell (round 3: three LDS instructions per cell beside ~10
@@ -1272,6 +1329,9 @@ int sparse_solve(const SparseProblem& sp, double* final_value, int32_t* q1, int3
   // lattice path: bitmap and rank prefix of S_{t+1}, kept for the backward pass of period t
   std::vector<uint2*> d_lat_rank((size_t)T, nullptr);
   unsigned int *d_lat_words = nullptr, *d_lat_prefix = nullptr, *d_lat_counts = nullptr;
+  unsigned int *d_tw = nullptr, *d_tc = nullptr, *d_tp = nullptr;  // the XR family's post-order triples: bitmap, counts, prefix
+  uint2* d_tr_rank = nullptr;
+  Tuple* d_triples = nullptr;
   int* d_oob = nullptr;
   const char* lat_env = std::getenv("SDPGPU_MULTI_LATTICE");
   const bool lat_force = lat_env && std::atoi(lat_env) == 1, lat_never = lat_env && std::atoi(lat_env) == 0;
@@ -1284,6 +1344,15 @@ int sparse_solve(const SparseProblem& sp, double* final_value, int32_t* q1, int3
   void* d_tmp = nullptr;
   double *d_vcur = nullptr, *d_vnext = nullptr;
   int* d_act = nullptr;
+  // the XR family's marking pass through post-order triples: exact data only (see xr_triple_mark_kernel)
+  auto on_grid8 = [](double v) { return std::isfinite(v) && std::fabs(v) < 1048576.0 && v * 8.0 == std::floor(v * 8.0); };
+  auto whole = [](double v) { return std::isfinite(v) && std::fabs(v) < 2147483648.0 && v == std::floor(v); };
+  bool xr_exact = sp.lattice_ok && P.model == 2 && P.one_minus_deposit == 1.0 && on_grid8(P.price[0]) && on_grid8(P.price[1]) &&
+                  whole(P.vari[0]) && whole(P.vari[1]) && P.vari[0] >= 0 && P.vari[1] >= 0 && whole(ini.i1) && whole(ini.i2) &&
+                  whole(ini.cash) && ini.i1 >= 0 && ini.i2 >= 0;
+  for (int j = 0; xr_exact && j < nd_all; ++j) xr_exact = whole(h_dem[(size_t)j].x) && whole(h_dem[(size_t)j].y);
+  const char* tr_env = std::getenv("SDPGPU_MULTI_TRIPLES");
+  const bool triples_force = tr_env && std::atoi(tr_env) == 1, triples_never = tr_env && std::atoi(tr_env) == 0;
   // backward_fact_kernel's 32-bit index form (SDPGPU_MULTI_I32=0: the 64-bit form everywhere)
   const bool lat_i32 = sp.lattice_ok && sp.lat.bits < (1LL << 31) && sp.lat.nr < (1LL << 24) && sp.lat.n2 < (1LL << 24) &&
                        std::fabs(P.min_cash) < 2147483648.0 && std::fabs(P.max_cash) < 2147483648.0 &&
@@ -1333,9 +1402,74 @@ int sparse_solve(const SparseProblem& sp, double* final_value, int32_t* q1, int3
           ML_TRY(hipMalloc((void**)&d_oob, 4));
           ML_TRY(hipMemset(d_oob, 0, 4));
         }
-        // the factored form of the marking pass (backward_fact_kernel, LK = 3) where the pair list factors and the tables fit
         bool marked = false;
-        if (!(std::getenv("SDPGPU_MULTI_FACT") && std::atoi(std::getenv("SDPGPU_MULTI_FACT")) == 0)) {
+        // the XR family with exact data: the distinct post-order triples mark the successors (xr_triple_*_kernel);
+        // SDPGPU_MULTI_TRIPLES=0 never, =1 whenever the data allow it (default: periods of 2e10 candidates and more)
+        if (xr_exact && !triples_never && (triples_force || (double)nc >= 2e10)) {
+          const long long n1 = L.bits / (L.nr * L.n2);
+          const long long ny1 = n1 + P.qb, ny2 = L.n2 + P.qb;
+          const long long cmax = (long long)P.vari[0] * (ny1 - 1) + (long long)P.vari[1] * (ny2 - 1);
+          const long long w0 = L.r0 - cmax;
+          Lattice B;
+          B.n2 = L.nr + cmax;  // W - w0
+          B.nr = ny2;          // y2
+          B.r0 = 0;
+          B.skew1 = B.skew2 = 0;
+          const double tb = (double)ny1 * (double)ny2 * (double)B.n2;
+          B.bits = tb < 1.6e10 ? (long long)tb : 0;
+          if (B.bits > 0) {
+            const long long n_tw = (B.bits + 31) / 32;
+            {
+              ML_TRY(hipMalloc((void**)&d_tw, (size_t)n_tw * 4));
+              ML_TRY(hipMemset(d_tw, 0, (size_t)n_tw * 4));
+              ML_TRY(hipMalloc((void**)&d_tc, (size_t)n_tw * 4));
+              ML_TRY(hipMalloc((void**)&d_tp, (size_t)n_tw * 4));
+              const int64_t per_batch_s = std::max<int64_t>(1, ((int64_t)1 << 30) / NA);
+              for (int64_t first = 0; first < n_states[t]; first += per_batch_s) {
+                const int64_t ns = std::min<int64_t>(per_batch_s, n_states[t] - first);
+                hipLaunchKernelGGL(xr_triple_mark_kernel, dim3((unsigned)((ns * NA + 255) / 256)), dim3(256), 0, 0, P, B, w0,
+                                   d_states[t] + first, ns, d_tw, d_oob);
+                ML_TRY(hipGetLastError());
+              }
+              const unsigned gtw = (unsigned)((n_tw + 255) / 256);
+              hipLaunchKernelGGL(lattice_popc_kernel, dim3(gtw), dim3(256), 0, 0, d_tw, n_tw, d_tc);
+              ML_TRY(hipGetLastError());
+              size_t tmp_b = 0;
+              ML_TRY(hipcub::DeviceScan::ExclusiveSum(nullptr, tmp_b, d_tc, d_tp, (int)n_tw));
+              ML_TRY(hipMalloc(&d_tmp, tmp_b));
+              ML_TRY(hipcub::DeviceScan::ExclusiveSum(d_tmp, tmp_b, d_tc, d_tp, (int)n_tw));
+              ML_TRY(hipFree(d_tmp));
+              d_tmp = nullptr;
+              unsigned int lp = 0, lc = 0;
+              ML_TRY(hipMemcpy(&lp, d_tp + (n_tw - 1), 4, hipMemcpyDeviceToHost));
+              ML_TRY(hipMemcpy(&lc, d_tc + (n_tw - 1), 4, hipMemcpyDeviceToHost));
+              const int64_t n_tr = (int64_t)lp + lc;
+              ML_TRY(hipMalloc((void**)&d_triples, (size_t)std::max<int64_t>(n_tr, 1) * sizeof(Tuple)));
+              ML_TRY(hipMalloc((void**)&d_tr_rank, (size_t)n_tw * 8));
+              hipLaunchKernelGGL(lattice_list_kernel, dim3(gtw), dim3(256), 0, 0, B, d_tw, d_tp, n_tw, d_triples, d_tr_rank);
+              ML_TRY(hipGetLastError());
+              const int64_t per_batch_t = std::max<int64_t>(1, ((int64_t)1 << 30) / nd);
+              for (int64_t first = 0; first < n_tr; first += per_batch_t) {
+                const int64_t nt = std::min<int64_t>(per_batch_t, n_tr - first);
+                hipLaunchKernelGGL(xr_triple_succ_kernel, dim3((unsigned)((nt * nd + 255) / 256)), dim3(256), 0, 0, P, L, w0,
+                                   d_triples + first, nt, dem_t, d_lat_words, d_oob);
+                ML_TRY(hipGetLastError());
+              }
+              ML_TRY(hipDeviceSynchronize());
+              marked = true;
+            }
+            (void)hipFree(d_tw);
+            (void)hipFree(d_tc);
+            (void)hipFree(d_tp);
+            (void)hipFree(d_tr_rank);
+            (void)hipFree(d_triples);
+            d_tw = d_tc = d_tp = nullptr;
+            d_tr_rank = nullptr;
+            d_triples = nullptr;
+          }
+        }
+        // the factored form of the marking pass (backward_fact_kernel, LK = 3) where the pair list factors and the tables fit
+        if (!marked && !(std::getenv("SDPGPU_MULTI_FACT") && std::atoi(std::getenv("SDPGPU_MULTI_FACT")) == 0)) {
           std::vector<double> u1, u2;
           std::vector<int> idx((size_t)nd);
           bool ok = true;
@@ -1688,6 +1822,11 @@ fail:
   if (d_lat_words) (void)hipFree(d_lat_words);
   if (d_lat_prefix) (void)hipFree(d_lat_prefix);
   if (d_lat_counts) (void)hipFree(d_lat_counts);
+  if (d_tw) (void)hipFree(d_tw);
+  if (d_tc) (void)hipFree(d_tc);
+  if (d_tp) (void)hipFree(d_tp);
+  if (d_tr_rank) (void)hipFree(d_tr_rank);
+  if (d_triples) (void)hipFree(d_triples);
   if (d_oob) (void)hipFree(d_oob);
   if (d_dem) (void)hipFree(d_dem);
   if (d_prob) (void)hipFree(d_prob);

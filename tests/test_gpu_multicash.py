@@ -135,6 +135,29 @@ def test_lattice_path_whole_memo(sia, oracle, kind, index_words, monkeypatch):
     assert done == 24
 
 
+def test_xr_marking_through_post_order_triples(sia, oracle, monkeypatch):
+    """MultiItemCashXR's forward pass with exact data (no deposit rate, integer unit costs and demands, prices on a 1/8 grid):
+    the successors are marked from the distinct post-order triples (y1, y2, R - c . y) instead of from every (state, order, demand
+    pair) -- chosen by itself on periods of 2e10 candidates and more, forced here on small instances: the same visited states,
+    values and actions as the oracle's memoised recursion, and as the run with the form switched off."""
+    monkeypatch.setenv("SDPGPU_MULTI_LATTICE", "1")
+    done = 0
+    for seed in range(40):
+        _, kw = multicash_cases.xr_random_instance(seed)
+        kw["vari_cost"] = [float(int(c) + 1) for c in kw["vari_cost"]]
+        monkeypatch.setenv("SDPGPU_MULTI_TRIPLES", "1")
+        r = sia.multixr_solve(0.0, table=True, **kw)
+        (fv, q1, q2, states, cells), want = oracle.memo_table("multixr", 0.0, **kw)
+        assert r.finalValue == fv and (r.firstAction, r.secondAction) == (q1, q2), seed
+        assert r.statesPerPeriod == states and r.cells == cells, seed
+        assert r.table.shape == want.shape and (r.table == want).all(), seed
+        monkeypatch.setenv("SDPGPU_MULTI_TRIPLES", "0")
+        r0 = sia.multixr_solve(0.0, table=True, **kw)
+        assert (r0.table == r.table).all() and r0.statesPerPeriod == r.statesPerPeriod
+        done += 1
+    assert done == 40
+
+
 def test_mirror_classes_read_like_the_reference_mains(sia, oracle):
     """MultiItemCash.main (:120-133) / MultiItemCashXR.main (:150-164) / MultiProductLeadtime.main (:225-239) through
     the mirror classes: construct, getExpectedValue(iniState), getAction(iniState), getOptTable(variCost)."""
