@@ -1444,6 +1444,11 @@ int sparse_solve(const SparseProblem& sp, double* final_value, int32_t* q1, int3
               ML_TRY(hipMemcpy(&lp, d_tp + (n_tw - 1), 4, hipMemcpyDeviceToHost));
               ML_TRY(hipMemcpy(&lc, d_tc + (n_tw - 1), 4, hipMemcpyDeviceToHost));
               const int64_t n_tr = (int64_t)lp + lc;
+              // (nothing has touched the successors' bitmap yet: where the triples do not fold the pairs at least four to one, or
+              // their list would not fit comfortably, the per-cell marking pass below serves the period)
+              const bool worth = n_tr < 2000000000LL && (double)n_tr * 4.0 <= (double)n_states[t] * (double)NA &&
+                                 (double)n_tr * sizeof(Tuple) <= 64e9;
+              if (!worth && !triples_force) goto triples_done;
               ML_TRY(hipMalloc((void**)&d_triples, (size_t)std::max<int64_t>(n_tr, 1) * sizeof(Tuple)));
               ML_TRY(hipMalloc((void**)&d_tr_rank, (size_t)n_tw * 8));
               hipLaunchKernelGGL(lattice_list_kernel, dim3(gtw), dim3(256), 0, 0, B, d_tw, d_tp, n_tw, d_triples, d_tr_rank);
@@ -1458,6 +1463,7 @@ int sparse_solve(const SparseProblem& sp, double* final_value, int32_t* q1, int3
               ML_TRY(hipDeviceSynchronize());
               marked = true;
             }
+          triples_done:
             (void)hipFree(d_tw);
             (void)hipFree(d_tc);
             (void)hipFree(d_tp);
